@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def _load(name):
+        return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    return _load
+
+
+def ref_round_equal(a, b, decimals=5, count=10):
+    """The reference's own pass criterion (test/_test_functions.py:15-20): the first `count`
+    entries agree after round(., 5)."""
+    a = [round(float(v), decimals) for v in np.asarray(a).reshape(-1)[:count]]
+    b = [round(float(v), decimals) for v in np.asarray(b).reshape(-1)[:count]]
+    return a == b

@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""Generate the committed golden fixtures under tests/golden/ (run in the BUILD container only).
+
+Imports, by file path and with PYTHONDONTWRITEBYTECODE=1, the pieces of the reference that run
+without gpytorch/faiss/torch_sparse:
+  * /root/reference/test/_dense_operators.py      (graph_laplacian, matern_* dense twins)
+  * /root/reference/manifold_gp/utils/torch_utils.py   (bump_function)
+  * /root/reference/manifold_gp/utils/load_dataset.py  (get_data, groundtruth_from_samples)
+and evaluates them on the configuration of the reference's live test
+(test/test_laplacian.py:18-50: dumbbell, seed-1337 split with 10 held-out points, k=50, nu=1,
+20 modes, eps=kappa=0.5, bump 3.0/1.0) plus a k=10 / self-loop variant that matches the kernel
+defaults (riemann_kernel.py:30-35,115).
+
+The k-NN graph fed to the reference code comes from oracle/knn.py (faiss is absent: parity
+unpinned for the k-NN row); everything downstream of (idx, val) is reference arithmetic.
+The eigen/feature/out-of-sample expectations restate riemann_kernel.py:121-136 and
+test/_test_functions.py:134-150 with the same torch calls on top of the imported dense
+Laplacian (those two files import gpytorch and cannot be imported here).
+
+Only DATA is written (inputs + expected outputs, npz); no reference source text is stored.
+"""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.dont_write_bytecode = True
+
+from oracle import knn as oknn  # noqa: E402
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def main():
+    dense = _load("ref_dense_operators", f"{REF}/test/_dense_operators.py")
+    tu = _load("ref_torch_utils", f"{REF}/manifold_gp/utils/torch_utils.py")
+    ld = _load("ref_load_dataset", f"{REF}/manifold_gp/utils/load_dataset.py")
+
+    # ---- dataset (load_dataset.py:10-18 without the importlib.resources lookup) ----
+    data = ld.get_data(f"{REF}/manifold_gp/data/dumbbell.msh", "Nodes", "Elements")
+    vertices = data["Nodes"][:, 1:-1]
+    edges = data["Elements"][:, -2:].astype(int) - 1
+    truth, _ = ld.groundtruth_from_samples(vertices, edges)
+    sampled_x = torch.from_numpy(vertices).float()
+    sampled_y = torch.from_numpy(truth).float()
+    np.savez_compressed(os.path.join(HERE, "dumbbell.npz"),
+                        x=sampled_x.numpy(), y=sampled_y.numpy(), segments=edges.astype(np.int32))
+
+    # ---- split (test_laplacian.py:20-23) ----
+    torch.manual_seed(1337)
+    num_test = 10
+    test_idx = torch.zeros(sampled_x.shape[0]).scatter_(0, torch.randperm(sampled_x.shape[0])[:num_test], 1).bool()
+    train_x, test_x = sampled_x[~test_idx].contiguous(), sampled_x[test_idx].contiguous()
+    train_y, test_y = sampled_y[~test_idx].contiguous(), sampled_y[test_idx].contiguous()
+    n = train_x.shape[0]
+    torch.manual_seed(7)
+    probes = torch.randn(n, 4)
+
+    for tag, k, self_loops, eps, kappa, nu_list, modes, bump in [
+        ("k50_noloop", 50, False, 0.5, 0.5, (1, 2, 3), 20, (3.0, 1.0)),   # test_laplacian.py:31-50
+        ("k10_loop", 10, True, 0.05, 0.5, (1, 2), 50, (1.0, 0.01)),       # kernel defaults, data-scaled eps
+    ]:
+        D, I = oknn.knn_search(train_x.numpy(), train_x.numpy(), k)
+        idx_np, val_np = oknn.knn_graph_from_search(D, I, n)
+        Dt, It = oknn.knn_search(train_x.numpy(), test_x.numpy(), k)
+        idx, val = torch.from_numpy(idx_np), torch.from_numpy(val_np)
+        gb = torch.tensor([[eps]], dtype=torch.float32)
+        ls = torch.tensor([[kappa]], dtype=torch.float32)
+        out = dict(train_x=train_x.numpy(), train_y=train_y.numpy(), test_x=test_x.numpy(), test_y=test_y.numpy(),
+                   test_mask=test_idx.numpy(), knn_D=D, knn_I=I.astype(np.int32), knn_test_D=Dt,
+                   knn_test_I=It.astype(np.int32), edge_index=idx_np.astype(np.int32), edge_value=val_np,
+                   probes=probes.numpy(), eps=np.float32(eps), kappa=np.float32(kappa), k=np.int32(k),
+                   self_loops=np.bool_(self_loops), modes=np.int32(modes), bump=np.float32(bump))
+        for norm in ("symmetric", "randomwalk"):
+            L, adj_un, deg_un, adj, deg = dense.graph_laplacian(idx, val, gb, n, normalization=norm,
+                                                                self_loops=self_loops)
+            p = f"{norm}_"
+            out[p + "degree_unnorm"] = deg_un.numpy()
+            out[p + "degree"] = deg.numpy()
+            out[p + "diag"] = L.diag().numpy()
+            out[p + "mv"] = torch.mv(L, train_y).numpy()                    # _test_functions.py:13
+            out[p + "mvT"] = torch.mv(L.T, train_y).numpy()                 # :25
+            out[p + "mm"] = torch.mm(L, probes).numpy()
+            out[p + "mmT"] = torch.mm(L.T, probes).numpy()
+            r, c = idx[0, :64], idx[1, :64]
+            out[p + "offdiag64"] = L[r, c].numpy()
+            for nu in nu_list:
+                Q = dense.matern_precision(L, nu, ls, deg if norm == "randomwalk" else None)
+                out[p + f"Q{nu}_mv"] = torch.mv(Q, train_y).numpy()
+                out[p + f"Q{nu}_mm"] = torch.mm(Q, probes).numpy()
+                if nu == nu_list[0]:
+                    noise = torch.tensor(1e-2)
+                    outputscale = torch.tensor(0.7)
+                    out[p + "Qscaled_mv"] = torch.mv(dense.matern_scaled_precision(Q, outputscale), train_y).numpy()
+                    out[p + "Qnoisy_mv"] = torch.mv(dense.matern_noisy_precision(Q, noise), train_y).numpy()
+                    torch.manual_seed(11)
+                    mask = torch.zeros(n).scatter_(0, torch.randperm(n)[: n // 10], 1).bool()
+                    S = dense.matern_labeled_precision(Q.double(), mask)
+                    out[p + "schur_mask"] = mask.numpy()
+                    out[p + "schur_mv"] = (S @ train_y[mask].double()).float().numpy()
+                    out[p + "solve"] = torch.linalg.solve(Q.double(), train_y.double()).float().numpy()
+            # ---- spectrum / features (riemann_kernel.py:121-136 on the reference's dense L_sym) ----
+            if norm == "symmetric":
+                Lsym, deg_sym, deg_un_sym = L, deg, deg_un
+            evals, evecs = torch.linalg.eigh(Lsym)
+            evals, evecs = evals[:modes].clone(), evecs[:, :modes].clone()
+            out[p + "evals_raw"] = evals.numpy().copy()
+            evals[0] = 0.0
+            evecs = evecs * deg_sym.pow(-0.5).view(-1, 1)
+            evecs = torch.nn.functional.normalize(evecs, p=2, dim=0)
+            nu = nu_list[0]
+            sd = (2 * nu / ls.square() + evals).pow(-nu)
+            sd = sd / sd.sum()
+            Z = (sd * n).sqrt() * evecs
+            out[p + "evals"] = evals.numpy()
+            out[p + "features_gram_64"] = (Z[:64] @ Z[:64].T).numpy()
+            out[p + "features_diag"] = (Z * Z).sum(-1).numpy()
+            # ---- out of sample (test/_test_functions.py:134-150, dense) ----
+            ev, ei = torch.from_numpy(Dt), torch.from_numpy(It)
+            T = ei.shape[0]
+            rows = torch.arange(T).repeat_interleave(ei.shape[1])
+            cols = ei.reshape(-1)
+            adj_ext_un = torch.sparse_coo_tensor(torch.stack([rows, cols]), ev.reshape(-1).div(-4 * gb.square()).exp().squeeze(),
+                                                 (T, n)).to_dense()
+            deg_ext_un = adj_ext_un.sum(dim=1)
+            adj_ext = torch.mm(deg_ext_un.pow(-1).diag(), torch.mm(adj_ext_un, deg_un.pow(-1).diag()))
+            deg_ext = adj_ext.sum(dim=1)
+            if norm == "symmetric":
+                ext = torch.mm(deg_ext.pow(-0.5).diag(), torch.mm(adj_ext, deg.pow(-0.5).diag()))
+            else:
+                ext = torch.mm(deg_ext.pow(-1.0).diag(), adj_ext)
+            sd2 = (2 * nu / ls.square() + evals).pow(-nu)
+            sd2 = sd2 / (1 - evals * gb.square()).square()
+            sd2 = sd2 / sd2.sum()
+            sd2 = sd2 * n
+            Zext = sd2.sqrt() * torch.mm(ext, evecs)
+            d1 = ev[:, 0].sqrt()
+            b = tu.bump_function(d1, torch.tensor(bump[0] * eps), bump[1])
+            out[p + "oos_gram"] = (Zext @ Z[:64].T).numpy()           # rotation-invariant
+            out[p + "oos_bump"] = b.numpy()
+            out[p + "oos_features_abs_col1"] = Zext[:, 1].abs().numpy()
+        np.savez_compressed(os.path.join(HERE, f"dumbbell_{tag}.npz"), **out)
+
+    # ---- bump function known answers (torch_utils.py:38-41) ----
+    xs = torch.linspace(0, 1.2, 25)
+    bumps = {f"a{a}_b{b}": tu.bump_function(xs, torch.tensor(a), b).numpy() for a in (0.5, 1.0) for b in (0.01, 1.0)}
+    np.savez_compressed(os.path.join(HERE, "bump.npz"), x=xs.numpy(), **bumps)
+
+    # ---- trained hyper-parameters (models/*.pth -> constrained values via softplus) ----
+    hp = {}
+    for f in ("srmnist_manifold_semisupervised", "srmnist_manifold_supervised", "1D_manifold_semisupervised"):
+        sd = torch.load(f"{REF}/models/{f}.pth", weights_only=True, map_location="cpu")
+        sp = torch.nn.functional.softplus
+        lb = sd["covar_module.base_kernel.raw_graphbandwidth_constraint.lower_bound"]
+        hp[f] = dict(
+            graphbandwidth=float(sp(sd["covar_module.base_kernel.raw_graphbandwidth"]).item() + lb.item()),
+            lengthscale=float(sp(sd["covar_module.base_kernel.raw_lengthscale"]).item()),
+            outputscale=float(sp(sd["covar_module.raw_outputscale"]).item()),
+            noise=float(sp(sd["likelihood.noise_covar.raw_noise"]).item() + sd["likelihood.noise_covar.raw_noise_constraint.lower_bound"].item()),
+        )
+    with open(os.path.join(HERE, "hyperparameters.json"), "w") as fh:
+        json.dump(hp, fh, indent=1)
+    print(json.dumps(hp, indent=1))
+
+
+if __name__ == "__main__":
+    main()
