@@ -1,0 +1,263 @@
+/*
+ * mgp_hip.h -- C-ABI of libmgp_hip.so: the MI355X (gfx950) implementation of manifold-gp's
+ * sparse graph-Laplacian GP hot path.
+ *
+ * Boundary contract (every entry point):
+ *   - extern "C", plain device pointers + sizes + a hipStream_t passed as void*; no torch types;
+ *   - returns int: 0 = ok, <0 = argument error (MGP_ERR_*), >0 = hipError_t from the runtime;
+ *   - never allocates or frees caller memory: scratch comes from an explicit `work` buffer whose
+ *     size the matching *_workspace_bytes() query returns;
+ *   - asynchronous on `stream` unless the comment says it synchronises (graph-build calls that
+ *     must report a data-dependent size do);
+ *   - all matrices of right-hand sides are row-major [N, C] fp32, indices int32, values fp32.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * nash169/manifold-gp checkout; third-party call sites are the reference's, the arithmetic
+ * lived in faiss / torch_sparse / linear_operator / ATen).
+ */
+#ifndef MGP_HIP_H
+#define MGP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGP_OK 0
+#define MGP_ERR_ARG (-1)        /* null pointer / bad size / bad enum */
+#define MGP_ERR_WORKSPACE (-2)  /* work buffer too small */
+#define MGP_ERR_UNSUPPORTED (-3)
+#define MGP_ERR_NOT_CONVERGED (-4)
+#define MGP_ERR_KNN_AMBIGUOUS (-5)
+
+#define MGP_PAD 4 /* CSR rows are padded to a multiple of 4 entries (16-byte vector loads) */
+
+/* library / device probes ------------------------------------------------------------------ */
+int mgp_version(void);                       /* 100*major + minor */
+int mgp_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes); /* hipGetDeviceProperties */
+
+/* ---------------------------------------------------------------------------------------------
+ * k-NN: exact brute-force squared-L2 top-k, ascending (d2, index).
+ * Replaces faiss IndexFlatL2 / IndexIVFFlat(nlist=1) / Gpu* `search` as called at
+ * manifold_gp/utils/nearest_neighbors.py:35-37 (index built at :17-33).
+ *   db [N,d] f32 row-major (the indexed points), q [n,d] f32 (queries), k <= min(N, 1024)
+ *   D [n,k] f32 = (float) of the fp64 distance, I [n,k] i32
+ * Distances/ties follow the rule in oracle/knn_oracle.c (fp64 sum in ascending feature order,
+ * no FMA contraction, lower index wins exact ties): fp32 tiles select a padded candidate set,
+ * an fp64 re-rank orders it, a per-row bound check proves the set sufficient, rows that fail
+ * are redone with a wider set and finally by an exact fp64 scan.  Synchronises `stream`.
+ * stats (nullable, host int64[4]): rows redone wide, rows redone exact, chunks, candidates K'. */
+size_t mgp_knn_workspace_bytes(int64_t N, int64_t n, int d, int k);
+int mgp_knn_search(const float* db, int64_t N, int d, const float* q, int64_t n, int k,
+                   float* D, int32_t* I, void* work, size_t work_bytes, int64_t* stats,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Graph: k-NN lists -> symmetrised graph.  Replaces NearestNeighbors.graph
+ * (manifold_gp/utils/nearest_neighbors.py:39-55: drop column 0, orient row<col,
+ * torch_sparse.coalesce(op='mean')).
+ * Outputs (caller allocates the upper bounds, actual sizes returned through host pointers):
+ *   reference view: tri_row/tri_col i32 [<= n(k-1)], tri_val f32 -- sorted unique (row<=col) COO,
+ *                   value = fp32 mean of the duplicates;  *M = number of undirected edges
+ *   kernel view   : full symmetric padded CSR of the same graph: rowptr i32 [n+1] (every row
+ *                   start a multiple of MGP_PAD), col i32 / d2 f32 / eid i32 [<= 2n(k-1)+4n]
+ *                   (eid = index into tri_*; padding entries: col = own row, d2 = +inf, eid = -1)
+ *                   *nnz = rowptr[n].  A (i,i) edge (duplicate points) appears twice in row i,
+ *                   exactly as the reference scatters it twice.
+ * Synchronises `stream` (needs M on the host). */
+size_t mgp_graph_workspace_bytes(int64_t n, int k);
+int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int k,
+                    int32_t* tri_row, int32_t* tri_col, float* tri_val, int64_t* M,
+                    int32_t* rowptr, int32_t* col, float* d2, int32_t* eid, int64_t* nnz,
+                    void* work, size_t work_bytes, void* stream);
+/* same CSR from an existing reference-style edge list (idx[2,M] given as two i32 arrays) */
+size_t mgp_graph_coo_workspace_bytes(int64_t n, int64_t M);
+int mgp_graph_from_coo(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val,
+                       int64_t M, int64_t n, int32_t* rowptr, int32_t* col, float* d2,
+                       int32_t* eid, int64_t* nnz, void* work, size_t work_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Laplacian build: diffusion-maps normalisation of the kernel weights, fused row passes.
+ * Replaces the cached properties adjacency_unnorm_mat / degree_unnorm_mat / adjacency_mat /
+ * degree_mat / laplacian_diag / laplacian_triu of
+ * manifold_gp/operators/graph_laplacian_operator.py:52-106.
+ *   in : padded CSR (rowptr, col, d2), eps (graph bandwidth), self_loops
+ *   out: degree_unnorm D~ [n], degree D [n], diag [n], dsqrt = sqrt(D) [n], dinvsqrt [n],
+ *        vals [nnz] = S_ij = A_ij / (sqrt(D_i) sqrt(D_j)) / eps^2  (positive; L_ij = -S_ij) */
+int mgp_laplacian_build(int64_t n, const int32_t* rowptr, const int32_t* col, const float* d2,
+                        float eps, int self_loops, float* degree_unnorm, float* degree,
+                        float* diag, float* dsqrt, float* dinvsqrt, float* vals, void* stream);
+/* per-edge values in the reference's COO order: which = 0 W (adjacency_unnorm_mat :54-56),
+ * 1 A (adjacency_mat :73-75), 2 S (laplacian_triu :104-106) */
+int mgp_edge_values(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val,
+                    int64_t M, const float* degree_unnorm, const float* degree, float eps,
+                    int which, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The hot kernel: fused CSR SpMV / SpMM with the symmetric Laplacian.
+ *   xs_j = pre ? pre[j] * X[j,:] : X[j,:]
+ *   lx_i = diag[i] * xs_i - sum_j vals[ij] * xs_j
+ *   t_i  = (post ? post[i] : 1) * (a * xs_i + b * lx_i)
+ *   Y[i,:] = (base ? cb * base[i,:] : 0) + co * t_i
+ *   dot_partials (nullable) [dot_blocks, C]: per-workgroup partial sums of dotw[i,:] * Y[i,:]
+ * Replaces GraphLaplacianOperator._matmul (graph_laplacian_operator.py:108-124: two
+ * torch_sparse.spmm calls + diagonal + random-walk scalings) and is the building block of the
+ * precision / wrapper operators below.  pre/post/base/dotw/dot_partials may be NULL. */
+typedef struct {
+  int64_t n;
+  const int32_t* rowptr;
+  const int32_t* col;
+  const float* vals;
+  const float* diag;
+} mgp_csr_t;
+
+int mgp_spmm_dot_blocks(int64_t n, int C);   /* workgroups that write dot partials */
+int mgp_spmm_set_group_hint(int lanes);      /* C == 1: lanes per row, one of 4,8,16,32,64 */
+int mgp_spmm_fused(const mgp_csr_t* L, const float* X, int C, float* Y, float a, float b,
+                   const float* pre, const float* post, const float* base, float cb, float co,
+                   const float* dotw, float* dot_partials, void* stream);
+
+/* L @ X in the three flavours of graph_laplacian_operator.py:108-124:
+ * mode 0 symmetric, 1 randomwalk (D^-1/2 L_sym D^1/2), 2 randomwalk transposed */
+int mgp_laplacian_matmul(const mgp_csr_t* L, const float* dsqrt, const float* dinvsqrt, int mode,
+                         const float* X, int C, float* Y, float* work_nc, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Precision-side operator family, applied matrix-free as a chain of fused SpMMs:
+ *   Q2  = scale * diag(post) (tau I + L_sym)^nu diag(pre)          tau = 2 nu / kappa^2
+ *         - symmetric normalisation: pre = post = NULL
+ *           (PrecisionMaternOperator._matmul, precision_matern_operator.py:26-37)
+ *         - random walk: pre = post = sqrt(D), because
+ *           D (tau I + L_rw)^nu = D^1/2 (tau I + L_sym)^nu D^1/2   (same file, :36-37)
+ *         - scale = outputscale or 1/outputscale (ScaleWrapperOperator,
+ *           scale_wrapper_operator.py:27)
+ *         - a 0/1 mask multiplied into pre / post gives the MaskedLinearOperator blocks
+ *           Q_ll, Q_lu, Q_ul, Q_uu of schur_complement_operator.py:26-30 on full-length
+ *           zero-padded vectors
+ *   A   = form 0: Q2
+ *         form 1: Q2 - s Q2^2 + s^2 Q2^3   (NoiseWrapperOperator, noise_wrapper_operator.py:22,
+ *                                           evaluated as Q2(v - s Q2(v - s Q2 v)))
+ *         form 2: I + s Q2                 ((K + s I) in precision form with K = Q2^-1:
+ *                                           K (K + s I)^-1 y = (I + s Q2)^-1 y) */
+typedef struct {
+  mgp_csr_t L;
+  const float* pre;   /* nullable [n] */
+  const float* post;  /* nullable [n] */
+  int32_t nu;
+  float kappa;        /* lengthscale */
+  float scale;        /* 1 = none */
+  int32_t form;       /* 0, 1, 2 above */
+  float noise;        /* s */
+} mgp_operator_t;
+
+size_t mgp_operator_workspace_bytes(const mgp_operator_t* op, int C);
+int mgp_operator_apply(const mgp_operator_t* op, const float* X, int C, float* Y, void* work,
+                       size_t work_bytes, void* stream);
+/* as above, additionally writing per-workgroup partials of dotw . Y (used by CG/Lanczos) */
+int mgp_operator_apply_dot(const mgp_operator_t* op, const float* X, int C, float* Y,
+                           const float* dotw, float* dot_partials, void* work, size_t work_bytes,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (Preconditioned) conjugate gradients on A x = b, multi right-hand side, single-reduction
+ * (Chronopoulos-Gear) recurrence, whole iterations captured in a hipGraph.
+ * Replaces linear_operator.utils.linear_cg as reached from
+ * precision_matern_operator.py:53 (`inv_quad_logdet`), schur_complement_operator.py:28
+ * (`.solve`) and train_model.py:68.
+ *   B [n,C] rhs, X [n,C] solution (in: ignored, start from 0), minv (nullable) Jacobi 1/diag(A)
+ *   stop: mode 0 = linear_cg's rule (rhs columns normalised; >= min_iter(10) iterations; stop
+ *         when the mean over columns of ||r||_2 < tol; columns with ||r|| < 1e-10 freeze),
+ *         mode 1 = every column ||r||_2 <= tol * ||b||_2
+ *   out (host): iters, resid[C] relative residual norms (recurrence residual).
+ * Synchronises `stream`. */
+typedef struct {
+  float tol;
+  int32_t max_iter;
+  int32_t min_iter;
+  int32_t stop_mode;
+  int32_t check_every; /* iterations per graph launch / host convergence poll (0 = default) */
+  int32_t use_graph;   /* 1 = hipGraph replay (default), 0 = eager launches */
+} mgp_cg_params_t;
+
+size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);
+/* reusable solver: owns the captured iteration graph; `work` must outlive the plan */
+int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
+                       const mgp_cg_params_t* params, void* work, size_t work_bytes, void* stream,
+                       void** plan_out);
+int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid,
+                      int32_t* status); /* status 1 converged, 2 max_iter, 3 breakdown (NaN) */
+int mgp_cg_plan_destroy(void* plan);
+int mgp_cg_solve(const mgp_operator_t* op, const float* B, int C, float* X, const float* minv,
+                 const mgp_cg_params_t* params, int32_t* iters, float* resid, void* work,
+                 size_t work_bytes, void* stream);
+/* cheap Jacobi preconditioner: minv_i = 1 / A_ii with the polynomial's off-diagonal
+ * contributions to the diagonal ignored for nu > 2 (exact for nu <= 2) */
+int mgp_operator_jacobi(const mgp_operator_t* op, float* minv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Eigensolve: the m smallest eigenpairs of L_sym by a Chebyshev-filtered block Krylov iteration
+ * with Rayleigh-Ritz on L_sym itself (csrc/eigen.hip explains why not single-vector Lanczos; the
+ * plain Lanczos tridiagonalisation is mgp_lanczos_tridiag below).
+ * Replaces torch.linalg.eigh on the densified N x N matrix at
+ * manifold_gp/kernels/riemann_kernel.py:121-125 and
+ * GraphLaplacianOperator.diagonalization (graph_laplacian_operator.py:132-144).
+ *   evals [m] ascending (host), evecs [n,m] row-major (device, orthonormal), resid [m] (host)
+ *   = ||L v - lambda v||_2.  Synchronises `stream`. */
+typedef struct {
+  int32_t max_basis;   /* block size b (0 = default m + max(m/4, 16)), <= 256 */
+  int32_t degree;      /* Chebyshev filter degree (0 = adaptive 8..80) */
+  int32_t max_restarts;/* outer filter + Rayleigh-Ritz rounds (0 = 40) */
+  float tol;           /* residual tolerance relative to lambda_max */
+  uint64_t seed;
+} mgp_lanczos_params_t;
+
+size_t mgp_lanczos_workspace_bytes(int64_t n, int m, const mgp_lanczos_params_t* p);
+int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals,
+                         float* evecs, float* resid, int32_t* info, void* work, size_t work_bytes,
+                         void* stream);
+
+/* k-step Lanczos tridiagonalisation of a precision-family operator with full re-orthogonalisation
+ * (classical Gram-Schmidt against all previous vectors, twice).  Replaces
+ * linear_operator.utils.lanczos.lanczos_tridiag as reached from
+ * GraphLaplacianOperator.diagonalization (graph_laplacian_operator.py:132-135, Lanczos branch)
+ * and from the stochastic-Lanczos-quadrature log-determinant of inv_quad_logdet
+ * (train_model.py:68).  q0 [n] device start vector; alpha[steps], beta[steps] host;
+ * Q_out (nullable) device [steps, n], row j = q_j.  Synchronises `stream`. */
+size_t mgp_lanczos_tridiag_workspace_bytes(const mgp_operator_t* op, int steps);
+int mgp_lanczos_tridiag(const mgp_operator_t* op, const float* q0, int steps, float* alpha,
+                        float* beta, float* Q_out, void* work, size_t work_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Spectral features and the kernel block.
+ * mgp_features_insample: Z = sqrt(N s / sum s) * Phi, s = (2 nu/kappa^2 + lambda)^-nu
+ *   (riemann_kernel.py:134-136, riemann_matern_kernel.py:21-22); also the eval()-time
+ *   post-processing Phi = normalise_cols(D^-1/2 U), lambda_0 = 0 (riemann_kernel.py:126-128)
+ *   via mgp_eigvec_postprocess.
+ * mgp_features_oos: fused Nystrom extension (graph_laplacian_operator.py:146-157) + bump
+ *   modulation (riemann_kernel.py:138-147, torch_utils.py:38-41) without the [T,k,m] temporary.
+ * mgp_kernel_block: K = Z1 Z2^T on the fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *   (MatmulLinearOperator / LowRankRootLinearOperator evaluation, riemann_kernel.py:92-100). */
+size_t mgp_eigvec_postprocess_work_floats(int m);   /* size of colnorm_work in floats */
+int mgp_eigvec_postprocess(float* evecs, int64_t n, int m, const float* degree, float* colnorm_work,
+                           void* stream);
+int mgp_features_insample(const float* evals_dev, const float* evecs, int64_t n, int m, int nu,
+                          float kappa, float* Z, void* stream);
+int mgp_features_oos(const float* evals_dev, const float* evecs, int64_t n, int m, int nu,
+                     float kappa, float eps, int normalization, const float* degree_unnorm,
+                     const float* degree, const float* knn_d2, const int32_t* knn_idx, int64_t T,
+                     int k, float bump_scale, float bump_decay, float* Z, void* stream);
+int mgp_kernel_block(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale,
+                     float* K, void* stream);
+int mgp_kernel_diag(const float* Z1, const float* Z2, int64_t n, int m, float scale, float* out,
+                    void* stream);
+/* y = alpha * Z (Z^T x) + beta * x : the low-rank covariance K + sigma^2 I applied matrix-free */
+size_t mgp_lowrank_workspace_bytes(int m, int C);
+int mgp_lowrank_apply(const float* Z, int64_t n, int m, const float* X, int C, float alpha,
+                      float beta, float* Y, void* work, size_t work_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGP_HIP_H */

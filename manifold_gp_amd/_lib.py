@@ -1,0 +1,170 @@
+"""ctypes binding of libmgp_hip.so (the C-ABI declared in include/mgp_hip.h).
+
+The HIP library IS the product path: there is no CPU or torch fallback.  `lib()` raises when
+the shared object is missing, and every wrapper raises when handed a tensor that does not live
+on a HIP device.
+"""
+import ctypes
+import os
+import threading
+from ctypes import (POINTER, Structure, byref, c_float, c_int, c_int32, c_int64, c_size_t,
+                    c_uint64, c_void_p)
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgp_hip.so")
+_LIB = None
+_LOCK = threading.Lock()
+
+MGP_ERRORS = {
+    -1: "MGP_ERR_ARG (null pointer / bad size / bad enum)",
+    -2: "MGP_ERR_WORKSPACE (work buffer too small)",
+    -3: "MGP_ERR_UNSUPPORTED",
+    -4: "MGP_ERR_NOT_CONVERGED",
+    -5: "MGP_ERR_KNN_AMBIGUOUS",
+}
+
+
+class MgpError(RuntimeError):
+    def __init__(self, fn, code):
+        self.code = code
+        what = MGP_ERRORS.get(code, "hipError_t %d" % code if code > 0 else "error %d" % code)
+        super().__init__("%s failed: %s" % (fn, what))
+
+
+class CsrT(Structure):
+    _fields_ = [("n", c_int64), ("rowptr", c_void_p), ("col", c_void_p), ("vals", c_void_p),
+                ("diag", c_void_p)]
+
+
+class OperatorT(Structure):
+    _fields_ = [("L", CsrT), ("pre", c_void_p), ("post", c_void_p), ("nu", c_int32),
+                ("kappa", c_float), ("scale", c_float), ("form", c_int32), ("noise", c_float)]
+
+
+class CgParamsT(Structure):
+    _fields_ = [("tol", c_float), ("max_iter", c_int32), ("min_iter", c_int32),
+                ("stop_mode", c_int32), ("check_every", c_int32), ("use_graph", c_int32)]
+
+
+class LanczosParamsT(Structure):
+    _fields_ = [("max_basis", c_int32), ("degree", c_int32), ("max_restarts", c_int32),
+                ("tol", c_float), ("seed", c_uint64)]
+
+
+_P = c_void_p
+# name -> (restype, argtypes); mirrors include/mgp_hip.h one to one
+SIGNATURES = {
+    "mgp_version": (c_int, []),
+    "mgp_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
+    "mgp_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "mgp_knn_search": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, _P, _P, c_size_t,
+                               POINTER(c_int64), _P]),
+    "mgp_graph_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "mgp_graph_build": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, POINTER(c_int64), _P, _P, _P, _P,
+                                POINTER(c_int64), _P, c_size_t, _P]),
+    "mgp_graph_coo_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "mgp_graph_from_coo": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, POINTER(c_int64), _P,
+                                   c_size_t, _P]),
+    "mgp_laplacian_build": (c_int, [c_int64, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "mgp_edge_values": (c_int, [_P, _P, _P, c_int64, _P, _P, c_float, c_int, _P, _P]),
+    "mgp_spmm_dot_blocks": (c_int, [c_int64, c_int]),
+    "mgp_spmm_set_group_hint": (c_int, [c_int]),
+    "mgp_spmm_fused": (c_int, [POINTER(CsrT), _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
+                               c_float, _P, _P, _P]),
+    "mgp_laplacian_matmul": (c_int, [POINTER(CsrT), _P, _P, c_int, _P, c_int, _P, _P, _P]),
+    "mgp_operator_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int]),
+    "mgp_operator_apply": (c_int, [POINTER(OperatorT), _P, c_int, _P, _P, c_size_t, _P]),
+    "mgp_operator_apply_dot": (c_int, [POINTER(OperatorT), _P, c_int, _P, _P, _P, _P, c_size_t, _P]),
+    "mgp_operator_jacobi": (c_int, [POINTER(OperatorT), _P, _P]),
+    "mgp_cg_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int]),
+    "mgp_cg_solve": (c_int, [POINTER(OperatorT), _P, c_int, _P, _P, POINTER(CgParamsT), POINTER(c_int32),
+                             POINTER(c_float), _P, c_size_t, _P]),
+    "mgp_cg_plan_create": (c_int, [POINTER(OperatorT), c_int, _P, POINTER(CgParamsT), _P, c_size_t, _P,
+                                   POINTER(c_void_p)]),
+    "mgp_cg_plan_solve": (c_int, [_P, _P, _P, POINTER(c_int32), POINTER(c_float), POINTER(c_int32)]),
+    "mgp_cg_plan_destroy": (c_int, [_P]),
+    "mgp_lanczos_workspace_bytes": (c_size_t, [c_int64, c_int, POINTER(LanczosParamsT)]),
+    "mgp_lanczos_smallest": (c_int, [POINTER(CsrT), c_int, POINTER(LanczosParamsT), POINTER(c_float), _P,
+                                     POINTER(c_float), POINTER(c_int32), _P, c_size_t, _P]),
+    "mgp_lanczos_tridiag_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int]),
+    "mgp_lanczos_tridiag": (c_int, [POINTER(OperatorT), _P, c_int, POINTER(c_float), POINTER(c_float), _P, _P,
+                                    c_size_t, _P]),
+    "mgp_eigvec_postprocess_work_floats": (c_size_t, [c_int]),
+    "mgp_eigvec_postprocess": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
+    "mgp_features_insample": (c_int, [_P, _P, c_int64, c_int, c_int, c_float, _P, _P]),
+    "mgp_features_oos": (c_int, [_P, _P, c_int64, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P,
+                                 c_int64, c_int, c_float, c_float, _P, _P]),
+    "mgp_kernel_block": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, _P, _P]),
+    "mgp_kernel_diag": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _P]),
+    "mgp_lowrank_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "mgp_lowrank_apply": (c_int, [_P, c_int64, c_int, _P, c_int, c_float, c_float, _P, _P, c_size_t, _P]),
+}
+
+
+def lib():
+    """Load libmgp_hip.so once.  Raises (no fallback) when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        with _LOCK:
+            if _LIB is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "manifold_gp_amd: %s is missing -- the HIP extension is the product path and "
+                        "there is no fallback.  Build it with `python -c \"import __graft_entry__ as g; "
+                        "g.build()\"` or manifold_gp_amd/csrc/build.sh" % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(handle, name)   # AttributeError = header/library mismatch
+                    fn.restype = res
+                    fn.argtypes = args
+                _LIB = handle
+    return _LIB
+
+
+def check(code, fn):
+    if code != 0:
+        raise MgpError(fn, code)
+
+
+def require_device(*tensors):
+    """The product path runs on the MI355X only: refuse host tensors instead of computing on CPU."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not torch.is_tensor(t) or t.device.type != "cuda":
+            raise RuntimeError("manifold_gp_amd: expected a tensor on a HIP device (cuda:N), got %s -- "
+                               "there is no CPU path" % (t.device if torch.is_tensor(t) else type(t)))
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def f32c(t):
+    """float32 + contiguous (the reference calls rhs.contiguous() at every _matmul)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+_WORK = {}
+
+
+def workspace(nbytes, tag, device):
+    """Per-(tag, device) scratch tensor, grown geometrically; owned by the torch caching allocator."""
+    key = (tag, str(device))
+    buf = _WORK.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8, device=device)
+        _WORK[key] = buf
+    return buf
+
+
+def csr_struct(n, rowptr, col, vals, diag):
+    return CsrT(int(n), rowptr.data_ptr(), col.data_ptr(), vals.data_ptr(), diag.data_ptr())

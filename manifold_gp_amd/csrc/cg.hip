@@ -1,0 +1,366 @@
+// (Preconditioned) conjugate gradients for the precision-side operators, multi right-hand side.
+//
+// Replaces linear_operator.utils.linear_cg as reached from the reference at
+// precision_matern_operator.py:53, schur_complement_operator.py:28 and train_model.py:68
+// (per iteration there: one operator apply = s x (2 spmm + elementwise) launches, then ~15 tiny
+// reduction / elementwise launches, host-side convergence test every iteration).
+//
+// MI355X design
+//   * single-reduction (Chronopoulos-Gear) recurrence: per iteration ONE fused vector kernel
+//     (p,s,x,r,u updates + the two dot products of the new residual) and the s SpMM launches of
+//     the operator chain, whose last launch carries the third dot product (u . A u);
+//   * dot products are per-workgroup partials reduced again, in a fixed order, by every
+//     workgroup of the consuming kernel: no atomics, no separate reduction launch, bitwise
+//     reproducible, and a kernel boundary (~1.5 us) is the only synchronisation;
+//   * the iteration index and the convergence flag live in device memory, so `check_every`
+//     iterations are captured once into a hipGraph and replayed; after convergence the remaining
+//     launches of a replay return at their first instruction;
+//   * column freezing / stopping follow linear_cg (stop_mode 0) or a per-column relative
+//     residual (stop_mode 1).
+#include <math.h>
+#include <new>
+#include <string.h>
+#include "mgp_common.h"
+#include "mgp_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxC = 256;
+constexpr int kMaxGridVec = 512;
+
+struct CgArgs {
+  int64_t n;
+  int C, TC, TS;
+  float *x, *r, *u, *w, *p, *s;
+  const float* minv;
+  float* pd_gamma;  // [2][nbv][C]
+  float* pd_rr;     // [2][nbv][C]
+  int nbv;
+  const float* pd_delta;  // [nbs][C]
+  int nbs;
+  float* gamma_old;  // [2][C]
+  float* alpha_old;  // [2][C]
+  float* bb;         // [C]  ||b||^2
+  float* resid;      // [C]  relative residual norm
+  int* state;        // [0] iteration (1-based), [1] done, [2] status
+  float tol;
+  int max_iter, min_iter, stop_mode;
+  int64_t rows_per_block;
+};
+
+__global__ __launch_bounds__(kBlock) void cg_init_kernel(CgArgs a, const float* __restrict__ B) {
+  __shared__ float sh[2][kBlock];
+  const int tid = threadIdx.x, cc = tid % a.TC, sl = tid / a.TC;
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.n) r1 = a.n;
+  if (blockIdx.x == 0 && tid == 0) { a.state[0] = 1; a.state[1] = 0; a.state[2] = 0; }
+  float g = 0.f, rr = 0.f;
+  if (cc < a.C) {
+    for (int64_t r = r0 + sl; r < r1; r += a.TS) {
+      const int64_t i = r * a.C + cc;
+      const float b = B[i];
+      const float u = a.minv ? a.minv[r] * b : b;
+      a.x[i] = 0.f; a.p[i] = 0.f; a.s[i] = 0.f;
+      a.r[i] = b;
+      if (a.minv) a.u[i] = u;
+      g = fmaf(b, u, g);
+      rr = fmaf(b, b, rr);
+    }
+  }
+  sh[0][tid] = g; sh[1][tid] = rr;
+  __syncthreads();
+  if (tid < a.TC && tid < a.C) {
+    float sg = 0.f, sr = 0.f;
+    for (int s = 0; s < a.TS; ++s) { sg += sh[0][s * a.TC + tid]; sr += sh[1][s * a.TC + tid]; }
+    a.pd_gamma[(int64_t)blockIdx.x * a.C + tid] = sg;   // parity slot 0 = "previous" of iteration 1
+    a.pd_rr[(int64_t)blockIdx.x * a.C + tid] = sr;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
+  __shared__ float sh[3][kBlock];
+  __shared__ float sh_alpha[kMaxC], sh_beta[kMaxC], sh_rel[kMaxC];
+  __shared__ int sh_done;
+  // workgroup 0 may raise the flag while this launch runs: read it once per workgroup so that
+  // all waves of a workgroup take the same branch (every workgroup reaches the same decision)
+  if (threadIdx.x == 0) sh_done = a.state[1];
+  __syncthreads();
+  if (sh_done) return;
+  const int it = a.state[0];
+  const int par = it & 1, prev = par ^ 1;
+  const int tid = threadIdx.x, cc = tid % a.TC, sl = tid / a.TC;
+  const int C = a.C;
+
+  // ---- every workgroup reduces the partials in the same fixed order
+  float g = 0.f, rr = 0.f, d = 0.f;
+  if (cc < C) {
+    const float* pg = a.pd_gamma + (int64_t)prev * a.nbv * C;
+    const float* pr = a.pd_rr + (int64_t)prev * a.nbv * C;
+    for (int b = sl; b < a.nbv; b += a.TS) { g += pg[(int64_t)b * C + cc]; rr += pr[(int64_t)b * C + cc]; }
+    for (int b = sl; b < a.nbs; b += a.TS) d += a.pd_delta[(int64_t)b * C + cc];
+  }
+  sh[0][tid] = g; sh[1][tid] = rr; sh[2][tid] = d;
+  __syncthreads();
+  if (tid < C) {
+    float gamma = 0.f, rr2 = 0.f, delta = 0.f;
+    for (int s = 0; s < a.TS; ++s) {
+      gamma += sh[0][s * a.TC + tid];
+      rr2 += sh[1][s * a.TC + tid];
+      delta += sh[2][s * a.TC + tid];
+    }
+    const float bb = (it == 1) ? rr2 : a.bb[tid];
+    const float rel = (bb > 0.f) ? sqrtf(rr2 / bb) : 0.f;
+    sh_rel[tid] = rel;
+    const bool frozen = (a.stop_mode == 0) ? (rel < 1e-10f) : (rel <= a.tol);
+    float alpha = 0.f, beta = 0.f;
+    if (!frozen) {
+      if (it == 1) {
+        alpha = (delta != 0.f) ? gamma / delta : 0.f;
+      } else {
+        const float go = a.gamma_old[prev * C + tid], ao = a.alpha_old[prev * C + tid];
+        beta = (go != 0.f) ? gamma / go : 0.f;
+        const float den = delta - ((ao != 0.f) ? beta * gamma / ao : 0.f);
+        alpha = (den != 0.f) ? gamma / den : 0.f;
+      }
+      if (!isfinite(alpha) || !isfinite(beta)) { alpha = 0.f; beta = 0.f; }
+    }
+    sh_alpha[tid] = alpha;
+    sh_beta[tid] = beta;
+    if (blockIdx.x == 0) {
+      a.gamma_old[par * C + tid] = gamma;
+      a.alpha_old[par * C + tid] = alpha;
+      if (it == 1) a.bb[tid] = bb;
+      a.resid[tid] = rel;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int done = 0, status = 0;
+    if (a.stop_mode == 0) {
+      float m = 0.f;
+      for (int c = 0; c < C; ++c) m += sh_rel[c];
+      m /= (float)C;
+      if (it > a.min_iter && m < a.tol) { done = 1; status = 1; }   // >= min_iter iterations done
+    } else {
+      int all = 1;
+      for (int c = 0; c < C; ++c) all &= (sh_rel[c] <= a.tol) ? 1 : 0;
+      if (all) { done = 1; status = 1; }
+    }
+    for (int c = 0; c < C; ++c) if (!isfinite(sh_rel[c])) { done = 1; status = 3; }
+    if (!done && it > a.max_iter) { done = 1; status = 2; }
+    sh_done = done;
+    if (done && blockIdx.x == 0) { a.state[2] = status; a.state[1] = 1; }
+  }
+  __syncthreads();
+  if (sh_done) return;
+
+  // ---- fused vector update over this workgroup's contiguous rows
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.n) r1 = a.n;
+  float ng = 0.f, nrr = 0.f;
+  if (cc < C) {
+    const float alpha = sh_alpha[cc], beta = sh_beta[cc];
+    for (int64_t r = r0 + sl; r < r1; r += a.TS) {
+      const int64_t i = r * C + cc;
+      const float un = a.u[i];
+      const float p = fmaf(beta, a.p[i], un);
+      const float s = fmaf(beta, a.s[i], a.w[i]);
+      a.p[i] = p;
+      a.s[i] = s;
+      a.x[i] = fmaf(alpha, p, a.x[i]);
+      const float rn = fmaf(-alpha, s, a.r[i]);
+      a.r[i] = rn;
+      float u2 = rn;
+      if (a.minv) { u2 = a.minv[r] * rn; a.u[i] = u2; }
+      ng = fmaf(rn, u2, ng);
+      nrr = fmaf(rn, rn, nrr);
+    }
+  }
+  __syncthreads();
+  sh[0][tid] = ng; sh[1][tid] = nrr;
+  __syncthreads();
+  if (tid < a.TC && tid < C) {
+    float sg = 0.f, sr = 0.f;
+    for (int s = 0; s < a.TS; ++s) { sg += sh[0][s * a.TC + tid]; sr += sh[1][s * a.TC + tid]; }
+    a.pd_gamma[((int64_t)par * a.nbv + blockIdx.x) * C + tid] = sg;
+    a.pd_rr[((int64_t)par * a.nbv + blockIdx.x) * C + tid] = sr;
+  }
+}
+
+struct CgPlan {
+  mgp_operator_t op;
+  int C;
+  mgp_cg_params_t prm;
+  CgArgs args;
+  void* op_work;
+  size_t op_work_bytes;
+  float* pd_delta;
+  hipStream_t stream;       // caller's stream: all work is enqueued here
+  hipStream_t cap_stream;   // private stream used only to capture the iteration graph
+  hipGraphExec_t exec;
+  bool has_graph;
+  int chunk;
+  int32_t* host_state;      // pinned
+  float* host_resid;        // pinned
+};
+
+int tile_cols(int C) {
+  int t = 1;
+  while (t < C) t <<= 1;
+  return t;
+}
+
+size_t cg_bytes(const mgp_operator_t* op, int C) {
+  const size_t nc = mgp_align((size_t)op->L.n * C * sizeof(float));
+  const int nbs = mgp_spmm_dot_blocks(op->L.n, C);
+  size_t b = 6 * nc;                                   // x r u w p s
+  b += mgp_operator_workspace_bytes(op, C);
+  b += 4 * mgp_align((size_t)kMaxGridVec * C * sizeof(float));   // pd_gamma[2], pd_rr[2]
+  b += mgp_align((size_t)nbs * C * sizeof(float));              // pd_delta
+  b += 6 * mgp_align((size_t)C * sizeof(float));                // gamma_old[2] alpha_old[2] bb resid
+  b += mgp_align(16 * sizeof(int));
+  return b + 1024;
+}
+
+int enqueue_iteration(CgPlan* pl, hipStream_t st) {
+  hipLaunchKernelGGL(cg_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+  MGP_LAUNCH_CHECK();
+  // w = A u ; partials of u . w ; skipped once converged ; ticks the iteration counter
+  return mgp_operator_apply_ex(&pl->op, pl->args.u, pl->C, pl->args.w, pl->args.u, pl->pd_delta,
+                               pl->args.state + 1, pl->args.state, pl->op_work, pl->op_work_bytes, st);
+}
+
+}  // namespace
+
+extern "C" size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C) {
+  if (!op || C <= 0 || C > kMaxC || op->L.n <= 0) return 0;
+  return cg_bytes(op, C);
+}
+
+extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
+                                  const mgp_cg_params_t* params, void* work, size_t work_bytes,
+                                  void* stream, void** plan_out) {
+  if (!op || !params || !work || !plan_out) return MGP_ERR_ARG;
+  if (C <= 0 || C > kMaxC) return C > kMaxC ? MGP_ERR_UNSUPPORTED : MGP_ERR_ARG;
+  if (work_bytes < mgp_cg_workspace_bytes(op, C)) return MGP_ERR_WORKSPACE;
+  CgPlan* pl = new (std::nothrow) CgPlan();
+  if (!pl) return MGP_ERR_ARG;
+  memset(pl, 0, sizeof(*pl));
+  pl->op = *op;
+  pl->C = C;
+  pl->prm = *params;
+  if (pl->prm.max_iter <= 0) pl->prm.max_iter = 1000;
+  if (pl->prm.min_iter < 0) pl->prm.min_iter = 0;
+  pl->chunk = pl->prm.check_every > 0 ? pl->prm.check_every : 10;
+  pl->stream = mgp_stream(stream);
+  const int64_t n = op->L.n;
+  const size_t nc = (size_t)n * C;
+  MgpArena ar(work, work_bytes);
+  CgArgs& a = pl->args;
+  a.n = n; a.C = C; a.TC = tile_cols(C); a.TS = kBlock / a.TC;
+  a.x = ar.take<float>(nc); a.r = ar.take<float>(nc);
+  float* ubuf = ar.take<float>(nc);
+  a.w = ar.take<float>(nc); a.p = ar.take<float>(nc); a.s = ar.take<float>(nc);
+  a.minv = minv;
+  a.u = minv ? ubuf : a.r;
+  pl->op_work_bytes = mgp_operator_workspace_bytes(op, C);
+  pl->op_work = ar.take<char>(pl->op_work_bytes);
+  // contiguous row ranges per workgroup, at most kMaxGridVec workgroups
+  int64_t rpb = a.TS * 4;
+  int64_t nbv = mgp_cdiv(n, rpb);
+  if (nbv > kMaxGridVec) { rpb = mgp_cdiv(mgp_cdiv(n, kMaxGridVec), a.TS) * a.TS; nbv = mgp_cdiv(n, rpb); }
+  a.rows_per_block = rpb; a.nbv = (int)nbv;
+  a.pd_gamma = ar.take<float>(2 * (size_t)kMaxGridVec * C);
+  a.pd_rr = ar.take<float>(2 * (size_t)kMaxGridVec * C);
+  a.nbs = mgp_spmm_dot_blocks(n, C);
+  pl->pd_delta = ar.take<float>((size_t)a.nbs * C);
+  a.pd_delta = pl->pd_delta;
+  a.gamma_old = ar.take<float>(2 * (size_t)C);
+  a.alpha_old = ar.take<float>(2 * (size_t)C);
+  a.bb = ar.take<float>(C);
+  a.resid = ar.take<float>(C);
+  a.state = ar.take<int>(16);
+  a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter;
+  a.stop_mode = pl->prm.stop_mode;
+  if (!ar.ok()) { delete pl; return MGP_ERR_WORKSPACE; }
+  hipError_t e = hipHostMalloc((void**)&pl->host_state, 16 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_resid, (size_t)C * sizeof(float));
+  if (e != hipSuccess) { delete pl; return (int)e; }
+
+  if (pl->prm.use_graph) {
+    e = hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal);
+    int rc = MGP_OK;
+    if (e == hipSuccess) {
+      for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) rc = enqueue_iteration(pl, pl->cap_stream);
+      hipGraph_t graph = nullptr;
+      hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
+      if (rc == MGP_OK && e2 == hipSuccess && graph) {
+        e2 = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0);
+        pl->has_graph = (e2 == hipSuccess);
+      }
+      if (graph) (void)hipGraphDestroy(graph);
+    }
+    (void)hipGetLastError();   // a failed capture falls back to eager launches
+  }
+  *plan_out = pl;
+  return MGP_OK;
+}
+
+extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid,
+                                 int32_t* status) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  if (!pl || !B || !X) return MGP_ERR_ARG;
+  hipStream_t st = pl->stream;
+  const size_t nc = (size_t)pl->args.n * pl->C;
+  hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, B);
+  MGP_LAUNCH_CHECK();
+  MGP_TRY(mgp_operator_apply_ex(&pl->op, pl->args.u, pl->C, pl->args.w, pl->args.u, pl->pd_delta, nullptr,
+                                nullptr, pl->op_work, pl->op_work_bytes, st));
+  int guard = 0;
+  for (;;) {
+    if (pl->has_graph) {
+      MGP_HIP_TRY(hipGraphLaunch(pl->exec, st));
+    } else {
+      for (int i = 0; i < pl->chunk; ++i) MGP_TRY(enqueue_iteration(pl, st));
+    }
+    MGP_HIP_TRY(hipMemcpyAsync(pl->host_state, pl->args.state, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    if (pl->host_state[1]) break;
+    if (++guard > pl->prm.max_iter / pl->chunk + 4) break;
+  }
+  MGP_HIP_TRY(hipMemcpyAsync(X, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipMemcpyAsync(pl->host_resid, pl->args.resid, (size_t)pl->C * sizeof(float),
+                             hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  if (iters) *iters = pl->host_state[0] - 1;
+  if (status) *status = pl->host_state[2];
+  if (resid) memcpy(resid, pl->host_resid, (size_t)pl->C * sizeof(float));
+  return MGP_OK;
+}
+
+extern "C" int mgp_cg_plan_destroy(void* plan) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  if (!pl) return MGP_ERR_ARG;
+  if (pl->has_graph) (void)hipGraphExecDestroy(pl->exec);
+  if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
+  if (pl->host_state) (void)hipHostFree(pl->host_state);
+  if (pl->host_resid) (void)hipHostFree(pl->host_resid);
+  delete pl;
+  return MGP_OK;
+}
+
+extern "C" int mgp_cg_solve(const mgp_operator_t* op, const float* B, int C, float* X, const float* minv,
+                            const mgp_cg_params_t* params, int32_t* iters, float* resid, void* work,
+                            size_t work_bytes, void* stream) {
+  void* plan = nullptr;
+  MGP_TRY(mgp_cg_plan_create(op, C, minv, params, work, work_bytes, stream, &plan));
+  int32_t status = 0;
+  int rc = mgp_cg_plan_solve(plan, B, X, iters, resid, &status);
+  (void)mgp_cg_plan_destroy(plan);
+  if (rc != MGP_OK) return rc;
+  return status == 1 ? MGP_OK : MGP_ERR_NOT_CONVERGED;
+}

@@ -1,0 +1,598 @@
+// Eigensolve for the m smallest eigenpairs of the symmetric graph Laplacian, and the k-step
+// Lanczos tridiagonalisation of a precision-family operator.
+//
+// Replaces torch.linalg.eigh on the densified N x N matrix (manifold_gp/kernels/riemann_kernel.py:
+// 121-125, O(N^3) and 14 GB at N = 60k) and GraphLaplacianOperator.diagonalization
+// (manifold_gp/operators/graph_laplacian_operator.py:132-144; its Lanczos branch is
+// linear_operator's lanczos_tridiag with full re-orthogonalisation).
+//
+// mgp_lanczos_smallest: Chebyshev-filtered block Krylov iteration with Rayleigh-Ritz
+//   The low end of a graph-Laplacian spectrum is clustered and, for a k-NN graph with several
+//   connected components, degenerate; single-vector Lanczos needs thousands of steps there and
+//   misses multiplicities (the reference itself abandoned its Lanczos call for dense eigh,
+//   riemann_kernel.py:120).  So: (1) Gershgorin gives a safe upper bound ub of the spectrum,
+//   (2) a block of b = m + pad vectors is filtered by a scaled Chebyshev polynomial of L that
+//   damps [a, ub] (a = largest Ritz value of the previous round) -- d fused SpMM launches, the
+//   matrix is streamed once per launch for all b columns, (3) Rayleigh-Ritz in the filtered
+//   block: Gram matrices V^T V, V^T L V accumulated in fp64 on device, b x b generalized
+//   eigenproblem in fp64 on the host (Jacobi), rotation V <- V W on the fp32 MFMA kernel,
+//   (4) residuals ||L v - theta v|| decide convergence.
+//
+// mgp_lanczos_tridiag: q_{j+1} beta_j = A q_j - alpha_j q_j - beta_{j-1} q_{j-1} with classical
+//   Gram-Schmidt against ALL previous vectors, twice; alpha/beta stay on device until the end.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "mgp_common.h"
+#include "mgp_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------- small kernels
+__global__ void gershgorin_kernel(int64_t n, const int32_t* __restrict__ rowptr, const float* __restrict__ vals,
+                                  const float* __restrict__ diag, float* __restrict__ block_max) {
+  __shared__ float sh[kBlock];
+  float mx = 0.f;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+    float s = fabsf(diag[r]);
+    for (int i = rowptr[r]; i < rowptr[r + 1]; ++i) s += fabsf(vals[i]);
+    mx = fmaxf(mx, s);
+  }
+  sh[threadIdx.x] = mx;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_max[blockIdx.x] = sh[0];
+}
+
+__device__ __forceinline__ uint32_t hash32(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (uint32_t)x;
+}
+
+// V[r, c0:c1) = uniform(-1, 1), counter-based (reproducible for a seed)
+__global__ void random_cols_kernel(float* __restrict__ V, int64_t n, int ld, int c0, int c1, uint64_t seed) {
+  const int w = c1 - c0;
+  const int64_t total = n * w;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / w;
+    const int c = c0 + (int)(i % w);
+    const uint32_t h = hash32(seed * 0x9E3779B97F4A7C15ULL + (uint64_t)r * 1315423911ULL + (uint64_t)c * 2654435761ULL + 12345);
+    V[r * ld + c] = (float)h * (2.0f / 4294967296.0f) - 1.0f;
+  }
+}
+
+// partial[chunk][i][j] = sum_{r in chunk} A[r,i] * B[r,j], fp64 accumulation, 64 x 64 tile per block
+__global__ __launch_bounds__(kBlock) void gram_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                      int64_t n, int b, int64_t rows_per_chunk,
+                                                      double* __restrict__ partial) {
+  __shared__ float As[16][64 + 1];
+  __shared__ float Bs[16][64 + 1];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.z * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > n) r1 = n;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;   // outputs i = ti*64 + ty*4 + a, j = tj*64 + tx*4 + c
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[a][c] = 0.0;
+  for (int64_t rr = r0; rr < r1; rr += 16) {
+    for (int e = threadIdx.x; e < 16 * 64; e += kBlock) {
+      const int lr = e >> 6, lc = e & 63;
+      const int64_t r = rr + lr;
+      const int ci = ti * 64 + lc, cj = tj * 64 + lc;
+      As[lr][lc] = (r < r1 && ci < b) ? A[r * b + ci] : 0.f;
+      Bs[lr][lc] = (r < r1 && cj < b) ? B[r * b + cj] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int lr = 0; lr < 16; ++lr) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) av[a] = (double)As[lr][ty * 4 + a];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[c] = (double)Bs[lr][tx * 4 + c];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = fma(av[a], bv[c], acc[a][c]);
+    }
+    __syncthreads();
+  }
+  double* out = partial + (int64_t)blockIdx.z * b * b;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = ti * 64 + ty * 4 + a, j = tj * 64 + tx * 4 + c;
+      if (i < b && j < b) out[(int64_t)i * b + j] = acc[a][c];
+    }
+}
+
+__global__ void gram_reduce_kernel(const double* __restrict__ partial, int chunks, int bb, double* __restrict__ G) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bb; i += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int c = 0; c < chunks; ++c) s += partial[(int64_t)c * bb + i];
+    G[i] = s;
+  }
+}
+
+// column partial sums of (LV[r,c] - theta[c] * V[r,c])^2 in fp64
+__global__ __launch_bounds__(kBlock) void residual_kernel(const float* __restrict__ LV, const float* __restrict__ V,
+                                                          const float* __restrict__ theta, int64_t n, int b,
+                                                          int64_t rows_per_chunk, double* __restrict__ partial) {
+  __shared__ double sh[kBlock];
+  int TC = 1;
+  while (TC < b && TC < kBlock) TC <<= 1;
+  const int TS = kBlock / TC;
+  const int cc = threadIdx.x % TC, sl = threadIdx.x / TC;
+  const int64_t r0 = blockIdx.x * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > n) r1 = n;
+  double acc = 0.0;
+  if (cc < b) {
+    const float th = theta[cc];
+    for (int64_t r = r0 + sl; r < r1; r += TS) {
+      const float d = LV[r * b + cc] - th * V[r * b + cc];
+      acc += (double)d * (double)d;
+    }
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0 && cc < b) {
+    double t = 0.0;
+    for (int s = 0; s < TS; ++s) t += sh[s * TC + cc];
+    partial[(int64_t)blockIdx.x * b + cc] = t;
+  }
+}
+
+__global__ void copy_cols_kernel(const float* __restrict__ V, int64_t n, int ld, int m, float* __restrict__ out) {
+  const int64_t total = n * m;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = V[(i / m) * ld + (i % m)];
+}
+
+// ---------------------------------------------------------------- host: symmetric eigensolver (cyclic Jacobi, fp64)
+// A [n x n] row-major symmetric (destroyed); evals ascending; evecs columns (row-major [n x n]).
+void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& evals, std::vector<double>& V) {
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, dsum = 0.0;
+    for (int i = 0; i < n; ++i) {
+      dsum += A[(size_t)i * n + i] * A[(size_t)i * n + i];
+      for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+    }
+    if (off <= 1e-26 * (dsum + 1e-300)) break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        if (fabs(apq) < 1e-18 * sqrt(fabs(app * aqq)) && sweep > 2) continue;
+        const double theta = (aqq - app) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {   // columns p, q of A
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - s * akq;
+          A[(size_t)k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {   // rows p, q of A
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - s * aqk;
+          A[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - s * vkq;
+          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return A[(size_t)a * n + a] < A[(size_t)b * n + b]; });
+  evals.resize(n);
+  std::vector<double> Vs((size_t)n * n);
+  for (int j = 0; j < n; ++j) {
+    evals[j] = A[(size_t)order[j] * n + order[j]];
+    for (int k = 0; k < n; ++k) Vs[(size_t)k * n + j] = V[(size_t)k * n + order[j]];
+  }
+  V.swap(Vs);
+}
+
+// symmetric tridiagonal (alpha[k], beta[k-1]) eigenvalues + first components of eigenvectors
+void tridiag_eigh(int k, const std::vector<double>& alpha, const std::vector<double>& beta, std::vector<double>& evals,
+                  std::vector<double>& evecs) {
+  std::vector<double> T((size_t)k * k, 0.0);
+  for (int i = 0; i < k; ++i) {
+    T[(size_t)i * k + i] = alpha[i];
+    if (i + 1 < k) { T[(size_t)i * k + i + 1] = beta[i]; T[(size_t)(i + 1) * k + i] = beta[i]; }
+  }
+  jacobi_eigh(k, T, evals, evecs);
+}
+
+struct EigWork {
+  float* buf[5];
+  double* gpart;
+  double* G;
+  double* H;
+  double* rpart;
+  float* wt;        // W^T upload [b x b]
+  float* theta;     // [b]
+  float* bmax;      // gershgorin partials
+  void* opwork;
+  size_t opwork_bytes;
+  int chunks;
+  int64_t rows_per_chunk;
+  int rchunks;
+  int64_t rrows;
+};
+
+int block_size_for(int m, const mgp_lanczos_params_t* p) {
+  int b = (p && p->max_basis > 0) ? p->max_basis : m + std::max(m / 4, 16);
+  if (b < m + 2) b = m + 2;
+  return b;
+}
+
+void chunking(int64_t n, int* chunks, int64_t* rpc, int max_chunks, int64_t min_rows) {
+  int64_t r = std::max<int64_t>(min_rows, mgp_cdiv(mgp_cdiv(n, max_chunks), 16) * 16);
+  *rpc = r;
+  *chunks = (int)mgp_cdiv(n, r);
+}
+
+size_t eig_bytes(int64_t n, int m, const mgp_lanczos_params_t* p) {
+  const int b = block_size_for(m, p);
+  int chunks, rch; int64_t rpc, rr;
+  chunking(n, &chunks, &rpc, 96, 512);
+  chunking(n, &rch, &rr, 256, 256);
+  size_t s = 5 * mgp_align((size_t)n * b * sizeof(float));
+  s += mgp_align((size_t)chunks * b * b * sizeof(double));
+  s += 2 * mgp_align((size_t)b * b * sizeof(double));
+  s += mgp_align((size_t)rch * b * sizeof(double));
+  s += mgp_align((size_t)b * b * sizeof(float)) + mgp_align(b * sizeof(float)) + mgp_align(1024 * sizeof(float));
+  return s + 4096;
+}
+
+int launch_gram(const float* A, const float* B, int64_t n, int b, EigWork& w, double* out, hipStream_t st) {
+  dim3 grid((unsigned)mgp_cdiv(b, 64), (unsigned)mgp_cdiv(b, 64), (unsigned)w.chunks);
+  hipLaunchKernelGGL(gram_kernel, grid, dim3(kBlock), 0, st, A, B, n, b, w.rows_per_chunk, w.gpart);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)mgp_cdiv((int64_t)b * b, kBlock)), dim3(kBlock), 0, st, w.gpart,
+                     w.chunks, b * b, out);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+}  // namespace
+
+int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale, float* K,
+                        int64_t ldk, void* stream);
+
+extern "C" size_t mgp_lanczos_workspace_bytes(int64_t n, int m, const mgp_lanczos_params_t* p) {
+  if (n <= 0 || m <= 0) return 0;
+  return eig_bytes(n, m, p);
+}
+
+extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals,
+                                    float* evecs, float* resid, int32_t* info, void* work, size_t work_bytes,
+                                    void* stream) {
+  if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !evals || !evecs || !work) return MGP_ERR_ARG;
+  const int64_t n = L->n;
+  if (n <= 0 || m <= 0 || m > n) return MGP_ERR_ARG;
+  int b = block_size_for(m, p);
+  if (b > n) b = (int)n;
+  if (b > 256) return MGP_ERR_UNSUPPORTED;   // one SpMM launch handles <= 256 columns
+  if (work_bytes < eig_bytes(n, m, p)) return MGP_ERR_WORKSPACE;
+  hipStream_t st = mgp_stream(stream);
+  const float tol = (p && p->tol > 0.f) ? p->tol : 1e-5f;
+  const int max_outer = (p && p->max_restarts > 0) ? p->max_restarts : 40;
+  const uint64_t seed = p ? p->seed : 1337;
+
+  EigWork w;
+  MgpArena ar(work, work_bytes);
+  for (int i = 0; i < 5; ++i) w.buf[i] = ar.take<float>((size_t)n * b);
+  chunking(n, &w.chunks, &w.rows_per_chunk, 96, 512);
+  chunking(n, &w.rchunks, &w.rrows, 256, 256);
+  w.gpart = ar.take<double>((size_t)w.chunks * b * b);
+  w.G = ar.take<double>((size_t)b * b);
+  w.H = ar.take<double>((size_t)b * b);
+  w.rpart = ar.take<double>((size_t)w.rchunks * b);
+  w.wt = ar.take<float>((size_t)b * b);
+  w.theta = ar.take<float>(b);
+  w.bmax = ar.take<float>(1024);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+
+  // ---- spectrum upper bound (Gershgorin: always >= lambda_max)
+  const int gb = (int)std::min<int64_t>(1024, mgp_cdiv(n, kBlock));
+  hipLaunchKernelGGL(gershgorin_kernel, dim3(gb), dim3(kBlock), 0, st, n, L->rowptr, L->vals, L->diag, w.bmax);
+  MGP_LAUNCH_CHECK();
+  std::vector<float> hb(gb);
+  MGP_HIP_TRY(hipMemcpyAsync(hb.data(), w.bmax, gb * sizeof(float), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  double ub = 0.0;
+  for (float v : hb) ub = std::max(ub, (double)v);
+  ub *= 1.0 + 1e-6;
+  if (!(ub > 0.0)) return MGP_ERR_ARG;
+
+  const int rgrid = (int)std::min<int64_t>(4096, mgp_cdiv(n * b, kBlock));
+  hipLaunchKernelGGL(random_cols_kernel, dim3(rgrid), dim3(kBlock), 0, st, w.buf[0], n, b, 0, b, seed);
+  MGP_LAUNCH_CHECK();
+
+  int iV = 0;                      // buffer holding the current block
+  double a = ub / 4.0, a0 = 0.0;
+  int deg = (p && p->degree > 0) ? p->degree : 10;
+  std::vector<double> G((size_t)b * b), H((size_t)b * b), th, S, lam, U;
+  std::vector<float> wt((size_t)b * b), thf(b);
+  std::vector<double> rp((size_t)w.rchunks * b), res(b, 1e300);
+  int outer = 0, nspmm = 0, nconv = 0, kept = b;
+  for (outer = 0; outer < max_outer; ++outer) {
+    // ---- scaled Chebyshev filter of degree `deg` damping [a, ub], normalised at a0
+    const double e = (ub - a) / 2.0, c = (ub + a) / 2.0;
+    double sig = e / (a0 - c);
+    const double tau = 2.0 / sig;
+    int iX = iV, iY = (iV + 1) % 5, iN = (iV + 2) % 5;
+    // Y = (sig/e) (L X - c X)
+    MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iX], b, w.buf[iY], (float)(-c * sig / e), (float)(sig / e), nullptr, nullptr,
+                              nullptr, 0.f, 1.f, nullptr, nullptr, nullptr, nullptr, stream));
+    ++nspmm;
+    for (int i = 2; i <= deg; ++i) {
+      const double sn = 1.0 / (tau - sig);
+      // Ynew = (2 sn / e) (L Y - c Y) - (sig sn) X
+      MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iY], b, w.buf[iN], (float)(-c * 2.0 * sn / e), (float)(2.0 * sn / e),
+                                nullptr, nullptr, w.buf[iX], (float)(-sig * sn), 1.f, nullptr, nullptr, nullptr,
+                                nullptr, stream));
+      ++nspmm;
+      const int t = iX; iX = iY; iY = iN; iN = t;
+      sig = sn;
+    }
+    const int iF = iY;                                   // filtered block
+    int free_[4], nf = 0;
+    for (int i = 0; i < 5; ++i) if (i != iF) free_[nf++] = i;
+    const int iLV = free_[0], iVn = free_[1], iLVn = free_[2];
+    MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iF], b, w.buf[iLV], 0.f, 1.f, nullptr, nullptr, nullptr, 0.f, 1.f, nullptr,
+                              nullptr, nullptr, nullptr, stream));
+    ++nspmm;
+    // ---- Rayleigh-Ritz: G = V^T V, H = V^T L V (fp64), generalized eigenproblem on the host
+    MGP_TRY(launch_gram(w.buf[iF], w.buf[iF], n, b, w, w.G, st));
+    MGP_TRY(launch_gram(w.buf[iF], w.buf[iLV], n, b, w, w.H, st));
+    MGP_HIP_TRY(hipMemcpyAsync(G.data(), w.G, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipMemcpyAsync(H.data(), w.H, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    std::vector<double> dg(b);
+    for (int i = 0; i < b; ++i) {
+      const double g = G[(size_t)i * b + i];
+      if (!(g > 0.0) || !std::isfinite(g)) return MGP_ERR_NOT_CONVERGED;
+      dg[i] = 1.0 / sqrt(g);
+    }
+    std::vector<double> Gn((size_t)b * b);
+    for (int i = 0; i < b; ++i)
+      for (int j = 0; j < b; ++j) Gn[(size_t)i * b + j] = 0.5 * (G[(size_t)i * b + j] + G[(size_t)j * b + i]) * dg[i] * dg[j];
+    jacobi_eigh(b, Gn, lam, U);
+    const double lmax = lam[b - 1];
+    int k0 = 0;
+    while (k0 < b && lam[k0] <= 1e-10 * lmax) ++k0;
+    kept = b - k0;
+    // T = D U[:, k0:] Lambda^-1/2   (b x kept)
+    std::vector<double> T((size_t)b * kept);
+    for (int i = 0; i < b; ++i)
+      for (int j = 0; j < kept; ++j) T[(size_t)i * kept + j] = dg[i] * U[(size_t)i * b + k0 + j] / sqrt(lam[k0 + j]);
+    // Hp = T^T Hs T
+    std::vector<double> HT((size_t)b * kept, 0.0), Hp((size_t)kept * kept, 0.0);
+    for (int i = 0; i < b; ++i)
+      for (int l = 0; l < b; ++l) {
+        const double h = 0.5 * (H[(size_t)i * b + l] + H[(size_t)l * b + i]);
+        if (h == 0.0) continue;
+        for (int j = 0; j < kept; ++j) HT[(size_t)i * kept + j] += h * T[(size_t)l * kept + j];
+      }
+    for (int i = 0; i < b; ++i)
+      for (int j = 0; j < kept; ++j) {
+        const double t = T[(size_t)i * kept + j];
+        for (int l = 0; l < kept; ++l) Hp[(size_t)j * kept + l] += t * HT[(size_t)i * kept + l];
+      }
+    jacobi_eigh(kept, Hp, th, S);
+    // W = T S (b x kept); upload W^T rows = Ritz directions, zero-padded to b
+    std::fill(wt.begin(), wt.end(), 0.f);
+    for (int i = 0; i < b; ++i)
+      for (int j = 0; j < kept; ++j) {
+        double s = 0.0;
+        for (int l = 0; l < kept; ++l) s += T[(size_t)i * kept + l] * S[(size_t)l * kept + j];
+        wt[(size_t)j * b + i] = (float)s;
+      }
+    for (int j = 0; j < b; ++j) thf[j] = j < kept ? (float)th[j] : 0.f;
+    MGP_HIP_TRY(hipMemcpyAsync(w.wt, wt.data(), (size_t)b * b * sizeof(float), hipMemcpyHostToDevice, st));
+    MGP_HIP_TRY(hipMemcpyAsync(w.theta, thf.data(), b * sizeof(float), hipMemcpyHostToDevice, st));
+    // ---- rotate on the MFMA: Vn = V W, LVn = LV W   (K = Z1 Z2^T with Z2 = W^T)
+    MGP_TRY(mgp_kernel_block_ld(w.buf[iF], n, w.wt, b, b, 1.f, w.buf[iVn], b, stream));
+    MGP_TRY(mgp_kernel_block_ld(w.buf[iLV], n, w.wt, b, b, 1.f, w.buf[iLVn], b, stream));
+    hipLaunchKernelGGL(residual_kernel, dim3(w.rchunks), dim3(kBlock), 0, st, w.buf[iLVn], w.buf[iVn], w.theta, n, b,
+                       w.rrows, w.rpart);
+    MGP_LAUNCH_CHECK();
+    MGP_HIP_TRY(hipMemcpyAsync(rp.data(), w.rpart, (size_t)w.rchunks * b * sizeof(double), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    for (int j = 0; j < b; ++j) {
+      double s = 0.0;
+      for (int cch = 0; cch < w.rchunks; ++cch) s += rp[(size_t)cch * b + j];
+      res[j] = sqrt(s);
+    }
+    if (kept < b) {   // refill dropped directions with fresh random vectors
+      hipLaunchKernelGGL(random_cols_kernel, dim3(rgrid), dim3(kBlock), 0, st, w.buf[iVn], n, b, kept, b,
+                         seed + 7919ULL * (outer + 1));
+      MGP_LAUNCH_CHECK();
+    }
+    iV = iVn;
+    nconv = 0;
+    if (kept >= m) {
+      for (int j = 0; j < m; ++j) nconv += (res[j] <= tol * ub) ? 1 : 0;
+      if (nconv == m) { ++outer; break; }
+      a = th[kept - 1];
+      a0 = std::min(th[0], 0.0);
+      const double gap = std::max(a - th[m - 1], 1e-12 * ub);
+      int dnew = (int)ceil(3.0 / (2.0 * sqrt(gap / (ub - a))));
+      deg = std::min(std::max(dnew, 8), 80);
+      if (p && p->degree > 0) deg = p->degree;
+    }
+  }
+  const int cgrid = (int)std::min<int64_t>(4096, mgp_cdiv(n * m, kBlock));
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(cgrid), dim3(kBlock), 0, st, w.buf[iV], n, b, m, evecs);
+  MGP_LAUNCH_CHECK();
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  for (int j = 0; j < m; ++j) {
+    evals[j] = (kept >= m) ? (float)th[j] : 0.f;
+    if (resid) resid[j] = (float)res[j];
+  }
+  if (info) { info[0] = outer; info[1] = nspmm; info[2] = nconv; info[3] = b; }
+  return nconv == m ? MGP_OK : MGP_ERR_NOT_CONVERGED;
+}
+
+// ================================================================= Lanczos tridiagonalisation
+namespace {
+
+// partial[blk][j] = sum_{r in chunk} w[r] * Q[j][r],  j = 0..nq-1   (Q column vectors contiguous)
+__global__ __launch_bounds__(kBlock) void lz_dots_kernel(const float* __restrict__ w, const float* __restrict__ Q,
+                                                         int64_t n, int nq, int64_t rows_per_block,
+                                                         float* __restrict__ partial) {
+  __shared__ float sh[kBlock / 64];
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  for (int j = 0; j < nq; ++j) {
+    const float* q = Q + (int64_t)j * n;
+    float acc = 0.f;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += kBlock) acc = fmaf(w[r], q[r], acc);
+    acc = mgp_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * nq + j] = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+  }
+}
+
+// h[j] = sum_blk partial[blk][j]; w -= sum_j h[j] Q[j]; alpha_acc += h[nq-1] (block 0); norm partials of new w
+__global__ __launch_bounds__(kBlock) void lz_update_kernel(float* __restrict__ w, const float* __restrict__ Q, int64_t n,
+                                                           int nq, int64_t rows_per_block, const float* __restrict__ partial,
+                                                           int nblk, float* __restrict__ alpha_slot, int accumulate,
+                                                           float* __restrict__ norm_partial) {
+  extern __shared__ float hs[];   // [nq] + reduction scratch [4]
+  float* red = hs + nq;
+  for (int j = threadIdx.x; j < nq; j += kBlock) {
+    float s = 0.f;
+    for (int bI = 0; bI < nblk; ++bI) s += partial[(int64_t)bI * nq + j];
+    hs[j] = s;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (accumulate) *alpha_slot += hs[nq - 1]; else *alpha_slot = hs[nq - 1];
+  }
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  float nn = 0.f;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += kBlock) {
+    float v = w[r];
+    for (int j = 0; j < nq; ++j) v = fmaf(-hs[j], Q[(int64_t)j * n + r], v);
+    w[r] = v;
+    nn = fmaf(v, v, nn);
+  }
+  nn = mgp_wave_sum(nn);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nn;
+  __syncthreads();
+  if (threadIdx.x == 0) norm_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// beta = sqrt(sum norm_partial); qnext = w / beta
+__global__ __launch_bounds__(kBlock) void lz_normalize_kernel(const float* __restrict__ w, float* __restrict__ qnext,
+                                                              int64_t n, const float* __restrict__ norm_partial, int nblk,
+                                                              float* __restrict__ beta_slot) {
+  __shared__ float sh_beta;
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int bI = 0; bI < nblk; ++bI) s += norm_partial[bI];
+    sh_beta = sqrtf(s);
+    if (blockIdx.x == 0) *beta_slot = sh_beta;
+  }
+  __syncthreads();
+  const float inv = sh_beta > 0.f ? 1.0f / sh_beta : 0.f;
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
+    qnext[r] = w[r] * inv;
+}
+
+}  // namespace
+
+extern "C" size_t mgp_lanczos_tridiag_workspace_bytes(const mgp_operator_t* op, int steps) {
+  if (!op || steps <= 0 || op->L.n <= 0) return 0;
+  const int64_t n = op->L.n;
+  size_t s = mgp_align((size_t)(steps + 1) * n * sizeof(float));   // Q
+  s += mgp_align((size_t)n * sizeof(float));                      // w
+  s += mgp_operator_workspace_bytes(op, 1);
+  s += mgp_align((size_t)512 * (steps + 1) * sizeof(float));       // dot partials
+  s += mgp_align(512 * sizeof(float));                            // norm partials
+  s += 2 * mgp_align((size_t)(steps + 1) * sizeof(float));         // alpha, beta
+  return s + 4096;
+}
+
+// q0 [n] start vector (need not be normalised).  alpha[steps], beta[steps] on the host;
+// Q_out (nullable, device [steps, n]) receives the orthonormal Lanczos vectors (row j = q_j).
+extern "C" int mgp_lanczos_tridiag(const mgp_operator_t* op, const float* q0, int steps, float* alpha, float* beta,
+                                   float* Q_out, void* work, size_t work_bytes, void* stream) {
+  if (!op || !q0 || !alpha || !beta || !work || steps <= 0) return MGP_ERR_ARG;
+  if (work_bytes < mgp_lanczos_tridiag_workspace_bytes(op, steps)) return MGP_ERR_WORKSPACE;
+  const int64_t n = op->L.n;
+  hipStream_t st = mgp_stream(stream);
+  MgpArena ar(work, work_bytes);
+  float* Q = ar.take<float>((size_t)(steps + 1) * n);
+  float* w = ar.take<float>(n);
+  const size_t owb = mgp_operator_workspace_bytes(op, 1);
+  void* ow = ar.take<char>(owb);
+  float* dpart = ar.take<float>((size_t)512 * (steps + 1));
+  float* npart = ar.take<float>(512);
+  float* d_alpha = ar.take<float>(steps + 1);
+  float* d_beta = ar.take<float>(steps + 1);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  int64_t nblk = std::min<int64_t>(512, mgp_cdiv(n, 1024));
+  if (nblk < 1) nblk = 1;
+  const int64_t rpb = mgp_cdiv(n, nblk);
+  nblk = mgp_cdiv(n, rpb);
+  const int egrid = (int)std::min<int64_t>(2048, mgp_cdiv(n, kBlock));
+
+  // q_0 = q0 / ||q0||: reuse the update kernel with nq = 0 to get the norm partials
+  MGP_HIP_TRY(hipMemcpyAsync(w, q0, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipMemsetAsync(d_alpha, 0, (steps + 1) * sizeof(float), st));
+  {
+    // norm of w without subtraction: nq = 1 with a zero coefficient is simpler than a new kernel
+    MGP_HIP_TRY(hipMemsetAsync(dpart, 0, (size_t)512 * sizeof(float), st));
+    MGP_HIP_TRY(hipMemcpyAsync(Q, w, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(lz_update_kernel, dim3((int)nblk), dim3(kBlock), (1 + 4) * sizeof(float), st, w, Q, n, 1, rpb,
+                       dpart, (int)nblk, d_alpha + steps, 0, npart);
+    MGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(lz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, w, Q, n, npart, (int)nblk, d_beta + steps);
+    MGP_LAUNCH_CHECK();
+  }
+  for (int j = 0; j < steps; ++j) {
+    float* qj = Q + (int64_t)j * n;
+    MGP_TRY(mgp_operator_apply_ex(op, qj, 1, w, nullptr, nullptr, nullptr, nullptr, ow, owb, stream));
+    for (int pass = 0; pass < 2; ++pass) {   // classical Gram-Schmidt against q_0..q_j, twice
+      hipLaunchKernelGGL(lz_dots_kernel, dim3((int)nblk), dim3(kBlock), 0, st, w, Q, n, j + 1, rpb, dpart);
+      MGP_LAUNCH_CHECK();
+      hipLaunchKernelGGL(lz_update_kernel, dim3((int)nblk), dim3(kBlock), (j + 1 + 4) * sizeof(float), st, w, Q, n,
+                         j + 1, rpb, dpart, (int)nblk, d_alpha + j, pass, npart);
+      MGP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(lz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, w, Q + (int64_t)(j + 1) * n, n, npart,
+                       (int)nblk, d_beta + j);
+    MGP_LAUNCH_CHECK();
+  }
+  MGP_HIP_TRY(hipMemcpyAsync(alpha, d_alpha, steps * sizeof(float), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipMemcpyAsync(beta, d_beta, steps * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (Q_out) MGP_HIP_TRY(hipMemcpyAsync(Q_out, Q, (size_t)steps * n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  return MGP_OK;
+}

@@ -1,0 +1,404 @@
+// Exact brute-force k-NN (squared L2, ascending (d2, index)), bit-exact against oracle/knn_oracle.c.
+//
+// Replaces faiss IndexFlatL2 / IndexIVFFlat(nlist=1) (+ Gpu variants) `search` as called from
+// manifold_gp/utils/nearest_neighbors.py:35-37.
+//
+// Pipeline per chunk of query rows (sized so the fp32 distance slab stays ~1 GB of HBM):
+//   1. dist_tile_kernel   fp32 direct-difference distances, 128x128 tile per workgroup,
+//                         8x8 register micro-tile per lane, operands staged k-major in LDS so
+//                         a lane reads its 8 queries / 8 points with two ds_read_b128 each
+//                         (VALU FMA, not MFMA: MFMA is reserved for the eigenfeature contraction)
+//   2. select_kernel      one workgroup per query row: 3-pass radix select (11/11/10 bits) of
+//                         the K' smallest fp32 keys, K' = pow2 >= k + pad; fp64 re-evaluation of
+//                         those K' candidates in the oracle's exact operation order; bitonic
+//                         sort by (d64, index); sufficiency check
+//                            d64[k-1] < T32 / (1 + gamma)      (T32 = K'-th smallest fp32 key,
+//                                                               gamma = fp32 relative error bound)
+//                         which proves no unselected point can enter the top k.
+//   3. rows that fail the check are redone with K' x 4 (up to 2048), then by exact_row_kernel:
+//      fp64 distances to every point + k rounds of (d, index) arg-min.
+#include <math.h>
+#include <limits.h>
+#include "mgp_common.h"
+
+namespace {
+
+constexpr int kTile = 128;   // queries x points per workgroup
+constexpr int kDK = 16;      // feature chunk staged in LDS
+constexpr int kBlock = 256;
+constexpr int kMaxKp = 2048;
+constexpr int kMaxDimLds = 4096;
+
+// ------------------------------------------------------------------ 1. distance tiles
+__global__ __launch_bounds__(kBlock) void dist_tile_kernel(const float* __restrict__ db, int64_t N, int d,
+                                                           const float* __restrict__ q, int64_t nq,
+                                                           float* __restrict__ out, int64_t ld) {
+  __shared__ float Qs[kDK][kTile + 4];
+  __shared__ float Ps[kDK][kTile + 4];
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int64_t p0 = (int64_t)blockIdx.x * kTile, q0 = (int64_t)blockIdx.y * kTile;
+  float acc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = 0; k0 < d; k0 += kDK) {
+    // stage: element e -> (row = e / 16, kk = e % 16): 64 contiguous bytes per row
+#pragma unroll
+    for (int e = tid; e < kTile * kDK; e += kBlock) {
+      const int row = e >> 4, kk = e & 15;
+      const int kg = k0 + kk;
+      float qv = 0.f, pv = 0.f;
+      if (kg < d) {
+        if (q0 + row < nq) qv = q[(q0 + row) * d + kg];
+        if (p0 + row < N) pv = db[(p0 + row) * d + kg];
+      }
+      Qs[kk][row] = qv;
+      Ps[kk][row] = pv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < kDK; ++kk) {
+      float qa[8], pa[8];
+      const float4 q_lo = *reinterpret_cast<const float4*>(&Qs[kk][ty * 8]);
+      const float4 q_hi = *reinterpret_cast<const float4*>(&Qs[kk][ty * 8 + 4]);
+      const float4 p_lo = *reinterpret_cast<const float4*>(&Ps[kk][tx * 8]);
+      const float4 p_hi = *reinterpret_cast<const float4*>(&Ps[kk][tx * 8 + 4]);
+      qa[0] = q_lo.x; qa[1] = q_lo.y; qa[2] = q_lo.z; qa[3] = q_lo.w;
+      qa[4] = q_hi.x; qa[5] = q_hi.y; qa[6] = q_hi.z; qa[7] = q_hi.w;
+      pa[0] = p_lo.x; pa[1] = p_lo.y; pa[2] = p_lo.z; pa[3] = p_lo.w;
+      pa[4] = p_hi.x; pa[5] = p_hi.y; pa[6] = p_hi.z; pa[7] = p_hi.w;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float df = qa[i] - pa[j];
+          acc[i][j] = fmaf(df, df, acc[i][j]);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int64_t qr = q0 + ty * 8 + i;
+    if (qr >= nq) continue;
+    const int64_t pc = p0 + tx * 8;
+    float* o = out + qr * ld + pc;
+    if (pc + 8 <= N) {
+      *reinterpret_cast<float4*>(o) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (pc + j < N) o[j] = acc[i][j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ helpers
+// exact oracle distance: fp64, ascending feature order, no contraction (oracle/knn_oracle.c)
+__device__ __forceinline__ double oracle_d2(const float* __restrict__ qrow, const float* __restrict__ xrow, int d) {
+  double acc = 0.0;
+  for (int j = 0; j < d; ++j) {
+    const double df = __dsub_rn((double)qrow[j], (double)xrow[j]);
+    acc = __dadd_rn(acc, __dmul_rn(df, df));
+  }
+  return acc;
+}
+
+__device__ __forceinline__ bool cand_less(double d1, int i1, double d2, int i2) {
+  return (d1 < d2) || (d1 == d2 && i1 < i2);
+}
+
+// block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, total in *total
+__device__ int block_excl_scan(int v, int* sh_wave /*[4]*/, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) sh_wave[w] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += sh_wave[i];
+  *total = sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+struct SelectArgs {
+  const float* dist;     // [rows_in_chunk, ld] fp32 distances
+  int64_t ld;
+  int64_t N;
+  const float* db;
+  const float* q;        // queries of this chunk [rows_in_chunk, d]
+  int d;
+  int k;
+  int Kp;                // candidate count (pow2, <= kMaxKp)
+  const int* rows;       // nullable: row list (local row ids)
+  float* D;              // [rows_in_chunk, k] (chunk-local base)
+  int32_t* I;
+  int* fail_list;
+  int* fail_count;
+  double gamma;
+};
+
+// ------------------------------------------------------------------ 2. select + re-rank
+__global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
+  __shared__ int hist[2048];
+  __shared__ int sh_wave[4];
+  __shared__ int sh_bin, sh_rank, sh_cnt_lt, sh_cnt_eq;
+  __shared__ int cand_idx[kMaxKp];
+  __shared__ double cand_d[kMaxKp];
+  __shared__ float qrow_s[kMaxDimLds];
+
+  const int tid = threadIdx.x;
+  const int row = a.rows ? a.rows[blockIdx.x] : (int)blockIdx.x;
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.dist + (int64_t)row * a.ld);
+  const int64_t N = a.N;
+  const int Kp = a.Kp;
+  const int want = (int64_t)Kp < N ? Kp : (int)N;   // number of real candidates
+
+  uint32_t prefix = 0, pmask = 0;
+  int rank = want;   // 1-based rank of the threshold key among keys matching the prefix
+  uint32_t T = 0xffffffffu;
+  if (want < N) {
+    const int shifts[3] = {21, 10, 0};
+    const int nbits[3] = {11, 11, 10};
+    for (int ps = 0; ps < 3; ++ps) {
+      const int nb = 1 << nbits[ps];
+      for (int i = tid; i < nb; i += kBlock) hist[i] = 0;
+      __syncthreads();
+      for (int64_t i = tid; i < N; i += kBlock) {
+        const uint32_t key = keys[i];
+        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[ps]) & (nb - 1)], 1);
+      }
+      __syncthreads();
+      // 256 threads x (nb/256) bins: find the bin holding the rank-th key
+      const int per = nb / kBlock;
+      int local = 0;
+      for (int j = 0; j < per; ++j) local += hist[tid * per + j];
+      int total;
+      int excl = block_excl_scan(local, sh_wave, &total);
+      if (rank > excl && rank <= excl + local) {
+        int run = excl;
+        for (int j = 0; j < per; ++j) {
+          const int h = hist[tid * per + j];
+          if (rank <= run + h) { sh_bin = tid * per + j; sh_rank = rank - run; break; }
+          run += h;
+        }
+      }
+      __syncthreads();
+      prefix |= ((uint32_t)sh_bin) << shifts[ps];
+      pmask |= ((uint32_t)(nb - 1)) << shifts[ps];
+      rank = sh_rank;
+      __syncthreads();
+    }
+    T = prefix;   // exact K'-th smallest key; `rank` of the keys equal to T are still wanted
+  }
+
+  // ---- collect candidates: all keys < T, plus `rank` keys == T (any of them; see header)
+  if (tid == 0) { sh_cnt_lt = 0; sh_cnt_eq = 0; }
+  for (int i = tid; i < Kp; i += kBlock) { cand_idx[i] = INT_MAX; cand_d[i] = INFINITY; }
+  __syncthreads();
+  if (want < N) {
+    for (int64_t i = tid; i < N; i += kBlock) {
+      const uint32_t key = keys[i];
+      if (key < T) {
+        const int slot = atomicAdd(&sh_cnt_lt, 1);
+        cand_idx[slot] = (int)i;
+      } else if (key == T) {
+        const int e = atomicAdd(&sh_cnt_eq, 1);
+        if (e < rank) cand_idx[want - 1 - e] = (int)i;
+      }
+    }
+  } else {
+    for (int i = tid; i < want; i += kBlock) cand_idx[i] = i;
+  }
+  // query row to LDS (falls back to global reads for very wide features)
+  const float* qrow = a.q + (int64_t)row * a.d;
+  const bool q_lds = a.d <= kMaxDimLds;
+  if (q_lds) for (int j = tid; j < a.d; j += kBlock) qrow_s[j] = qrow[j];
+  __syncthreads();
+
+  // ---- fp64 re-evaluation in the oracle's operation order
+  for (int c = tid; c < want; c += kBlock) {
+    const int idx = cand_idx[c];
+    cand_d[c] = oracle_d2(q_lds ? qrow_s : qrow, a.db + (int64_t)idx * a.d, a.d);
+  }
+  __syncthreads();
+
+  // ---- bitonic sort of Kp (pow2) entries by (d64, index)
+  for (int size = 2; size <= Kp; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < Kp / 2; t += kBlock) {
+        const int lo = (t / stride) * stride * 2 + (t % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const double dl = cand_d[lo], dh = cand_d[hi];
+        const int il = cand_idx[lo], ih = cand_idx[hi];
+        const bool swap = up ? cand_less(dh, ih, dl, il) : cand_less(dl, il, dh, ih);
+        if (swap) { cand_d[lo] = dh; cand_d[hi] = dl; cand_idx[lo] = ih; cand_idx[hi] = il; }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- sufficiency check, then write or flag
+  bool ok = true;
+  if (want < N) {
+    const double t32 = (double)__uint_as_float(T);
+    ok = cand_d[a.k - 1] < t32 / (1.0 + a.gamma) * (1.0 - 1e-12);
+  }
+  if (ok) {
+    for (int t = tid; t < a.k; t += kBlock) {
+      a.D[(int64_t)row * a.k + t] = (float)cand_d[t];
+      a.I[(int64_t)row * a.k + t] = cand_idx[t];
+    }
+  } else if (tid == 0) {
+    const int slot = atomicAdd(a.fail_count, 1);
+    a.fail_list[slot] = row;
+  }
+}
+
+// ------------------------------------------------------------------ 3. exact fallback
+__global__ __launch_bounds__(kBlock) void exact_row_kernel(const float* __restrict__ db, int64_t N, int d,
+                                                           const float* __restrict__ q, const int* __restrict__ rows,
+                                                           int k, double* __restrict__ scratch, float* __restrict__ D,
+                                                           int32_t* __restrict__ I) {
+  __shared__ double sh_d[kBlock];
+  __shared__ int sh_i[kBlock];
+  __shared__ double last_d;
+  __shared__ int last_i;
+  const int tid = threadIdx.x;
+  const int row = rows[blockIdx.x];
+  double* dist = scratch + (int64_t)blockIdx.x * N;
+  const float* qrow = q + (int64_t)row * d;
+  for (int64_t i = tid; i < N; i += kBlock) dist[i] = oracle_d2(qrow, db + i * d, d);
+  if (tid == 0) { last_d = -1.0; last_i = -1; }
+  __syncthreads();
+  for (int t = 0; t < k; ++t) {
+    double bd = INFINITY;
+    int bi = INT_MAX;
+    const double ld_ = last_d;
+    const int li = last_i;
+    for (int64_t i = tid; i < N; i += kBlock) {
+      const double v = dist[i];
+      if (cand_less(ld_, li, v, (int)i) && cand_less(v, (int)i, bd, bi)) { bd = v; bi = (int)i; }
+    }
+    sh_d[tid] = bd; sh_i[tid] = bi;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+      if (tid < s && cand_less(sh_d[tid + s], sh_i[tid + s], sh_d[tid], sh_i[tid])) {
+        sh_d[tid] = sh_d[tid + s]; sh_i[tid] = sh_i[tid + s];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      last_d = sh_d[0]; last_i = sh_i[0];
+      D[(int64_t)row * k + t] = (float)sh_d[0];
+      I[(int64_t)row * k + t] = sh_i[0];
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kExactBatch = 16;
+
+int64_t chunk_rows(int64_t N, int64_t n) {
+  const int64_t ld = mgp_cdiv(N, 4) * 4;
+  int64_t qc = ((int64_t)1 << 28) / ld;           // ~1 GiB of fp32 distances
+  qc = qc / kTile * kTile;
+  if (qc < kTile) qc = kTile;
+  const int64_t ncap = mgp_cdiv(n, kTile) * kTile;
+  return qc < ncap ? qc : ncap;
+}
+
+int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+extern "C" size_t mgp_knn_workspace_bytes(int64_t N, int64_t n, int d, int k) {
+  if (N <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
+  const int64_t ld = mgp_cdiv(N, 4) * 4;
+  const int64_t qc = chunk_rows(N, n);
+  size_t b = mgp_align((size_t)qc * ld * sizeof(float));
+  b += 2 * mgp_align((size_t)qc * sizeof(int));
+  b += mgp_align(64);
+  b += mgp_align((size_t)kExactBatch * N * sizeof(double));
+  return b + 1024;
+}
+
+extern "C" int mgp_knn_search(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
+                              int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream) {
+  if (!db || !q || !D || !I || !work) return MGP_ERR_ARG;
+  if (N <= 0 || n <= 0 || d <= 0 || k <= 0 || k > N || k > 1024 || N > INT_MAX) return MGP_ERR_ARG;
+  if (work_bytes < mgp_knn_workspace_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
+  hipStream_t st = mgp_stream(stream);
+  const int64_t ld = mgp_cdiv(N, 4) * 4;
+  const int64_t qc = chunk_rows(N, n);
+  MgpArena ar(work, work_bytes);
+  float* slab = ar.take<float>((size_t)qc * ld);
+  int* list_a = ar.take<int>(qc);
+  int* list_b = ar.take<int>(qc);
+  int* counter = ar.take<int>(16);
+  double* scratch = ar.take<double>((size_t)kExactBatch * N);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+
+  int Kp0 = next_pow2(k + (k / 4 > 16 ? k / 4 : 16));
+  if (Kp0 < 64) Kp0 = 64;
+  if (Kp0 > kMaxKp) Kp0 = kMaxKp;
+  // fp32 direct-difference distance: one rounding per subtraction, one per fused accumulate
+  const double gamma = (double)(d + 4) * 1.1920928955078125e-07;   // (d+4) * 2^-23
+  int64_t n_wide = 0, n_exact = 0, n_chunks = 0;
+
+  for (int64_t q0 = 0; q0 < n; q0 += qc) {
+    const int64_t rows = (n - q0) < qc ? (n - q0) : qc;
+    ++n_chunks;
+    dim3 grid((unsigned)mgp_cdiv(N, kTile), (unsigned)mgp_cdiv(rows, kTile));
+    hipLaunchKernelGGL(dist_tile_kernel, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
+    MGP_LAUNCH_CHECK();
+    SelectArgs a{slab, ld, N, db, q + q0 * d, d, k, Kp0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, gamma};
+    MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, a);
+    MGP_LAUNCH_CHECK();
+    int fails = 0;
+    MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    int Kp = Kp0;
+    int* cur = list_a;
+    int* nxt = list_b;
+    while (fails > 0 && Kp < kMaxKp && Kp < N) {
+      Kp = Kp * 4 > kMaxKp ? kMaxKp : Kp * 4;
+      n_wide += fails;
+      SelectArgs b = a;
+      b.Kp = Kp; b.rows = cur; b.fail_list = nxt;
+      MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
+      hipLaunchKernelGGL(select_kernel, dim3((unsigned)fails), dim3(kBlock), 0, st, b);
+      MGP_LAUNCH_CHECK();
+      MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
+      MGP_HIP_TRY(hipStreamSynchronize(st));
+      int* t = cur; cur = nxt; nxt = t;
+    }
+    if (fails > 0) {
+      n_exact += fails;
+      for (int f0 = 0; f0 < fails; f0 += kExactBatch) {
+        const int nb = (fails - f0) < kExactBatch ? (fails - f0) : kExactBatch;
+        hipLaunchKernelGGL(exact_row_kernel, dim3(nb), dim3(kBlock), 0, st, db, N, d, q + q0 * d, cur + f0, k,
+                           scratch, D + q0 * k, I + q0 * k);
+        MGP_LAUNCH_CHECK();
+      }
+    }
+  }
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  if (stats) { stats[0] = n_wide; stats[1] = n_exact; stats[2] = n_chunks; stats[3] = Kp0; }
+  return MGP_OK;
+}

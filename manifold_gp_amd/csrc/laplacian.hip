@@ -1,0 +1,137 @@
+// Diffusion-maps Laplacian build over the padded symmetric CSR: three gather-only row passes.
+//
+// Replaces the cached-property chain of manifold_gp/operators/graph_laplacian_operator.py:52-106
+// (exp, 4 atomic scatter_add_ passes over int64 COO indices, 4 gathers, sqrt/div/pow passes):
+//   pass 1  W_ij = exp(-d2_ij / (4 eps^2));  D~_i = [self_loops] + sum_j W_ij            (:54-69)
+//   pass 2  A_ij = W_ij / (D~_i D~_j);       D_i  = [self_loops] D~_i^-2 + sum_j A_ij    (:73-88)
+//   pass 3  S_ij = A_ij / (sqrt(D_i) sqrt(D_j)) / eps^2;  diag_i = (1 - D~_i^-2 / D_i) / eps^2
+//           (or 1/eps^2 without self loops)                                              (:92-106)
+// W is recomputed from d2 in every pass instead of being stored (exp is cheaper than 4 B/entry
+// of HBM traffic); row sums are sequential per 16-lane group + shuffle tree, so the result is
+// deterministic (the reference's atomic scatter order is not).
+// Padding entries carry d2 = +inf -> W = 0 -> contribute nothing.
+#include <math.h>
+#include "mgp_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int G = 16;  // lanes per row
+
+__device__ __forceinline__ float wexp(float d2, float neg_4eps2) {
+  // x.div(-4 eps^2).exp() exactly as graph_laplacian_operator.py:56 (true division, accurate expf)
+  return expf(d2 / neg_4eps2);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void lap_pass(int64_t n, const int32_t* __restrict__ rowptr,
+                                                   const int32_t* __restrict__ col,
+                                                   const float* __restrict__ d2, float eps, int self_loops,
+                                                   float* __restrict__ dtil, float* __restrict__ deg,
+                                                   float* __restrict__ diag, float* __restrict__ dsqrt,
+                                                   float* __restrict__ dinvsqrt, float* __restrict__ vals) {
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t g = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int64_t ng = ((int64_t)gridDim.x * blockDim.x) / G;
+  const float eps2 = eps * eps;
+  const float nq = -4.0f * eps2;
+  for (int64_t r = g; r < n; r += ng) {
+    const int s = rowptr[r], e = rowptr[r + 1];
+    float acc = 0.f;
+    float dt_r = 0.f, sq_r = 0.f;
+    if (PASS >= 2) dt_r = dtil[r];
+    if (PASS == 3) sq_r = dsqrt[r];
+    for (int i = s + 4 * lane; i < e; i += 4 * G) {
+      const float4 dd = *reinterpret_cast<const float4*>(d2 + i);
+      float w[4] = {wexp(dd.x, nq), wexp(dd.y, nq), wexp(dd.z, nq), wexp(dd.w, nq)};
+      if (PASS == 1) {
+        acc += (w[0] + w[1]) + (w[2] + w[3]);
+      } else {
+        const int4 c = *reinterpret_cast<const int4*>(col + i);
+        const int cc[4] = {c.x, c.y, c.z, c.w};
+        float a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = w[t] / (dt_r * dtil[cc[t]]);
+        if (PASS == 2) {
+          acc += (a[0] + a[1]) + (a[2] + a[3]);
+        } else {
+          float4 sv;
+          sv.x = a[0] / (sq_r * dsqrt[cc[0]]) / eps2;
+          sv.y = a[1] / (sq_r * dsqrt[cc[1]]) / eps2;
+          sv.z = a[2] / (sq_r * dsqrt[cc[2]]) / eps2;
+          sv.w = a[3] / (sq_r * dsqrt[cc[3]]) / eps2;
+          *reinterpret_cast<float4*>(vals + i) = sv;
+        }
+      }
+    }
+    if (PASS != 3) {
+      acc = mgp_group_sum<G>(acc);
+      if (lane == 0) {
+        if (PASS == 1) {
+          dtil[r] = (self_loops ? 1.0f : 0.0f) + acc;
+        } else {
+          const float base = self_loops ? 1.0f / (dt_r * dt_r) : 0.0f;
+          const float d = base + acc;
+          deg[r] = d;
+          const float sq = sqrtf(d);
+          dsqrt[r] = sq;
+          dinvsqrt[r] = 1.0f / sq;
+          diag[r] = self_loops ? (1.0f - (1.0f / (dt_r * dt_r)) * (1.0f / d)) / eps2 : 1.0f / eps2;
+        }
+      }
+    }
+  }
+}
+
+__global__ void edge_values_kernel(const int32_t* __restrict__ tr, const int32_t* __restrict__ tc,
+                                   const float* __restrict__ tv, int64_t M, const float* __restrict__ dtil,
+                                   const float* __restrict__ deg, float eps, int which, float* __restrict__ out) {
+  const float eps2 = eps * eps;
+  const float nq = -4.0f * eps2;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < M;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    float v = wexp(tv[e], nq);
+    if (which >= 1) v = v / (dtil[tr[e]] * dtil[tc[e]]);
+    if (which >= 2) v = v / (sqrtf(deg[tr[e]]) * sqrtf(deg[tc[e]])) / eps2;
+    out[e] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int mgp_laplacian_build(int64_t n, const int32_t* rowptr, const int32_t* col, const float* d2,
+                                   float eps, int self_loops, float* degree_unnorm, float* degree,
+                                   float* diag, float* dsqrt, float* dinvsqrt, float* vals, void* stream) {
+  if (!rowptr || !col || !d2 || !degree_unnorm || !degree || !diag || !dsqrt || !dinvsqrt || !vals)
+    return MGP_ERR_ARG;
+  if (n <= 0 || !(eps > 0.f)) return MGP_ERR_ARG;
+  hipStream_t st = mgp_stream(stream);
+  int64_t groups_per_block = kBlock / G;
+  int64_t grid = mgp_cdiv(n, groups_per_block);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL((lap_pass<1>), dim3((int)grid), dim3(kBlock), 0, st, n, rowptr, col, d2, eps, self_loops,
+                     degree_unnorm, degree, diag, dsqrt, dinvsqrt, vals);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL((lap_pass<2>), dim3((int)grid), dim3(kBlock), 0, st, n, rowptr, col, d2, eps, self_loops,
+                     degree_unnorm, degree, diag, dsqrt, dinvsqrt, vals);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL((lap_pass<3>), dim3((int)grid), dim3(kBlock), 0, st, n, rowptr, col, d2, eps, self_loops,
+                     degree_unnorm, degree, diag, dsqrt, dinvsqrt, vals);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+extern "C" int mgp_edge_values(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val, int64_t M,
+                               const float* degree_unnorm, const float* degree, float eps, int which,
+                               float* out, void* stream) {
+  if (!tri_row || !tri_col || !tri_val || !out || which < 0 || which > 2) return MGP_ERR_ARG;
+  if (which >= 1 && !degree_unnorm) return MGP_ERR_ARG;
+  if (which >= 2 && !degree) return MGP_ERR_ARG;
+  if (M <= 0) return M == 0 ? MGP_OK : MGP_ERR_ARG;
+  int64_t grid = mgp_cdiv(M, kBlock);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(edge_values_kernel, dim3((int)grid), dim3(kBlock), 0, mgp_stream(stream), tri_row, tri_col,
+                     tri_val, M, degree_unnorm, degree, eps, which, out);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}

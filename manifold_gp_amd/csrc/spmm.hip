@@ -1,0 +1,317 @@
+// Fused CSR SpMV / SpMM with the symmetric graph Laplacian (the hot kernel of the path).
+//
+//   xs_j = pre ? pre[j] * X[j,:] : X[j,:]
+//   lx_i = diag[i] * xs_i - sum_j vals[ij] * xs_j
+//   t_i  = (post ? post[i] : 1) * (a * xs_i + b * lx_i)
+//   Y[i,:] = (base ? cb * base[i,:] : 0) + co * t_i ;  partial sums of dotw[i,:] * Y[i,:]
+//
+// Replaces GraphLaplacianOperator._matmul (manifold_gp/operators/graph_laplacian_operator.py:
+// 108-124), i.e. 2 x torch_sparse.spmm (index_select + mul + atomic scatter_add) + ~5
+// elementwise launches, by ONE launch without atomics over a full symmetric CSR.
+//
+// gfx950 mapping
+//   * rows are padded to 4 entries and 16-byte aligned, so every lane issues
+//     global_load_dwordx4 for 4 column ids and 4 values (coalesced 1 KiB per wave-instruction);
+//   * C == 1: a row is owned by a G-lane sub-wave group (G in 4..64 chosen from the mean row
+//     length), partial products are reduced with wave shuffles inside the group;
+//   * C  > 1: a row is owned by G = pow2(min(C,64)) lanes laid over the right-hand-side
+//     columns; the group loads G (col,val) pairs coalesced and broadcasts them one by one
+//     (readlane -> scalar base address when G = 64), so every X row is read as one contiguous
+//     burst; dot partials go through LDS across the groups of a workgroup;
+//   * the grid is capped (<= 1024 workgroups, contiguous row ranges per workgroup) and remapped
+//     so that each XCD streams one contiguous slice of rows and keeps its slice of x in its L2.
+#include "mgp_common.h"
+#include "mgp_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxGrid = 1024;
+
+struct SpmmArgs {
+  int64_t n;
+  const int32_t* rowptr;
+  const int32_t* col;
+  const float* vals;
+  const float* diag;
+  const float* X;
+  float* Y;
+  int C;
+  float a, b;
+  const float* pre;
+  const float* post;
+  const float* base;
+  float cb, co;
+  const float* dotw;
+  float* dot_partials;
+  int64_t rows_per_block;
+  const int* skip;   // nullable: workgroups return at once when *skip != 0 (CG converged)
+  int* tick;         // nullable: workgroup 0 adds 1 when the launch is not skipped
+};
+
+__device__ __forceinline__ float epilogue(const SpmmArgs& p, int64_t r, int c, float xs, float acc) {
+  float lx = p.diag[r] * xs - acc;
+  float t = p.a * xs + p.b * lx;
+  if (p.post) t *= p.post[r];
+  float y = p.co * t;
+  if (p.base) y += p.cb * p.base[r * p.C + c];
+  return y;
+}
+
+// ---------------------------------------------------------------- C == 1
+template <int G, bool PRE>
+__global__ __launch_bounds__(kBlock) void spmv_kernel(SpmmArgs p) {
+  if (p.skip && *p.skip) return;
+  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & (G - 1);
+  const int grp = threadIdx.x / G;
+  constexpr int kGroups = kBlock / G;
+  const int64_t r0 = (int64_t)lb * p.rows_per_block;
+  int64_t r1 = r0 + p.rows_per_block;
+  if (r1 > p.n) r1 = p.n;
+  const float* __restrict__ x = p.X;
+  float dsum = 0.f;
+  for (int64_t r = r0 + grp; r < r1; r += kGroups) {
+    const int s = p.rowptr[r], e = p.rowptr[r + 1];
+    float acc = 0.f;
+    for (int i = s + 4 * lane; i < e; i += 4 * G) {
+      const int4 c = *reinterpret_cast<const int4*>(p.col + i);
+      const float4 v = *reinterpret_cast<const float4*>(p.vals + i);
+      float x0 = x[c.x], x1 = x[c.y], x2 = x[c.z], x3 = x[c.w];
+      if (PRE) { x0 *= p.pre[c.x]; x1 *= p.pre[c.y]; x2 *= p.pre[c.z]; x3 *= p.pre[c.w]; }
+      acc = fmaf(v.x, x0, acc);
+      acc = fmaf(v.y, x1, acc);
+      acc = fmaf(v.z, x2, acc);
+      acc = fmaf(v.w, x3, acc);
+    }
+    acc = mgp_group_sum<G>(acc);
+    if (lane == 0) {
+      float xs = x[r];
+      if (PRE) xs *= p.pre[r];
+      float y = epilogue(p, r, 0, xs, acc);
+      p.Y[r] = y;
+      if (p.dotw) dsum = fmaf(p.dotw[r], y, dsum);
+    }
+  }
+  if (p.dot_partials) {
+    __shared__ float red[kBlock / MGP_WAVE];
+    dsum = mgp_wave_sum(dsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kBlock / MGP_WAVE; ++w) t += red[w];
+      p.dot_partials[lb] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- C > 1
+// G lanes per row laid over columns; NACC column accumulators per lane (columns lane + a*G).
+template <int G, int NACC, bool PRE>
+__global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs p) {
+  if (p.skip && *p.skip) return;
+  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & (G - 1);
+  const int grp = threadIdx.x / G;
+  constexpr int kGroups = kBlock / G;
+  const int C = p.C;
+  const int64_t r0 = (int64_t)lb * p.rows_per_block;
+  int64_t r1 = r0 + p.rows_per_block;
+  if (r1 > p.n) r1 = p.n;
+  float dsum[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) dsum[a] = 0.f;
+
+  for (int64_t r = r0 + grp; r < r1; r += kGroups) {
+    const int s = p.rowptr[r], e = p.rowptr[r + 1];
+    float acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) acc[a] = 0.f;
+    for (int i0 = s; i0 < e; i0 += G) {
+      const int i = i0 + lane;
+      int cj = (int)r;
+      float vj = 0.f;
+      if (i < e) { cj = p.col[i]; vj = p.vals[i]; }
+      if (PRE) vj *= p.pre[cj];
+      const int cnt = (e - i0) < G ? (e - i0) : G;
+      for (int t = 0; t < cnt; ++t) {
+        int ct;
+        float vt;
+        if (G == 64) {
+          ct = __builtin_amdgcn_readlane(cj, t);
+          vt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vj), t));
+        } else {
+          ct = __shfl(cj, t, G);
+          vt = __shfl(vj, t, G);
+        }
+        const float* xr = p.X + (int64_t)ct * C;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          const int c = lane + a * G;
+          if (c < C) acc[a] = fmaf(vt, xr[c], acc[a]);
+        }
+      }
+    }
+    const float prer = PRE ? p.pre[r] : 1.f;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) {
+      const int c = lane + a * G;
+      if (c < C) {
+        const float xs = p.X[r * C + c] * prer;
+        const float y = epilogue(p, r, c, xs, acc[a]);
+        p.Y[r * C + c] = y;
+        if (p.dotw) dsum[a] = fmaf(p.dotw[r * C + c], y, dsum[a]);
+      }
+    }
+  }
+  if (p.dot_partials) {
+    // cross-group reduction through LDS: red[group][G*NACC]
+    __shared__ float red[kBlock * NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) red[(grp * NACC + a) * G + lane] = dsum[a];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < G * NACC; idx += kBlock) {
+      const int a = idx / G, l = idx % G;
+      const int c = l + a * G;
+      if (c < C) {
+        float t = 0.f;
+        for (int g = 0; g < kGroups; ++g) t += red[(g * NACC + a) * G + l];
+        p.dot_partials[(int64_t)lb * C + c] = t;
+      }
+    }
+  }
+}
+
+struct Plan {
+  int grid;
+  int64_t rows_per_block;
+};
+
+Plan make_plan(int64_t n, int groups_per_block) {
+  // contiguous row range per workgroup, at least one pass of the groups, grid <= kMaxGrid
+  int64_t rpb = groups_per_block * 4;
+  int64_t grid = mgp_cdiv(n, rpb);
+  if (grid > kMaxGrid) {
+    rpb = mgp_cdiv(mgp_cdiv(n, kMaxGrid), groups_per_block) * groups_per_block;
+    grid = mgp_cdiv(n, rpb);
+  }
+  if (grid < 1) grid = 1;
+  return Plan{(int)grid, rpb};
+}
+
+// lanes per row for C == 1 (4 entries per lane per pass).  The host wrapper sets it from the
+// mean padded row length of the graph it built (mgp_spmm_set_group_hint); 16 suits k ~ 50.
+int g_row_group_hint = 16;
+
+}  // namespace
+
+extern "C" int mgp_spmm_set_group_hint(int lanes) {
+  if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return MGP_ERR_ARG;
+  g_row_group_hint = lanes;
+  return MGP_OK;
+}
+
+static int spmm_cols_group(int C) {
+  int g = 4;
+  while (g < C && g < 64) g <<= 1;
+  return g;
+}
+
+extern "C" int mgp_spmm_dot_blocks(int64_t n, int C) {
+  if (n <= 0 || C <= 0) return MGP_ERR_ARG;
+  int groups = (C == 1) ? kBlock / g_row_group_hint : kBlock / spmm_cols_group(C);
+  return make_plan(n, groups).grid;
+}
+
+template <int G, bool PRE>
+static void launch_spmv(const SpmmArgs& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((spmv_kernel<G, PRE>), dim3(grid), dim3(kBlock), 0, st, a);
+}
+
+template <int G, int NACC, bool PRE>
+static void launch_spmm(const SpmmArgs& a, int grid, hipStream_t st) {
+  hipLaunchKernelGGL((spmm_kernel<G, NACC, PRE>), dim3(grid), dim3(kBlock), 0, st, a);
+}
+
+extern "C" int mgp_spmm_fused(const mgp_csr_t* L, const float* X, int C, float* Y, float a, float b,
+                              const float* pre, const float* post, const float* base, float cb,
+                              float co, const float* dotw, float* dot_partials, void* stream) {
+  return mgp_spmm_fused_ex(L, X, C, Y, a, b, pre, post, base, cb, co, dotw, dot_partials, nullptr, nullptr,
+                           stream);
+}
+
+int mgp_spmm_fused_ex(const mgp_csr_t* L, const float* X, int C, float* Y, float a, float b,
+                      const float* pre, const float* post, const float* base, float cb, float co,
+                      const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream) {
+  if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !X || !Y) return MGP_ERR_ARG;
+  if (L->n <= 0 || C <= 0 || C > 256) return C > 256 ? MGP_ERR_UNSUPPORTED : MGP_ERR_ARG;
+  if (X == Y) return MGP_ERR_ARG;  // rows gather other rows of X: never in place
+  hipStream_t st = mgp_stream(stream);
+  SpmmArgs p{L->n, L->rowptr, L->col, L->vals, L->diag, X, Y, C, a, b, pre, post, base, cb, co,
+             dotw, dotw ? dot_partials : nullptr, 0, skip, tick};
+  if (C == 1) {
+    const int G = g_row_group_hint;
+    Plan pl = make_plan(L->n, kBlock / G);
+    p.rows_per_block = pl.rows_per_block;
+#define MGP_SPMV_CASE(GG)                                          \
+  case GG:                                                         \
+    if (pre) launch_spmv<GG, true>(p, pl.grid, st);                \
+    else launch_spmv<GG, false>(p, pl.grid, st);                   \
+    break;
+    switch (G) {
+      MGP_SPMV_CASE(4)
+      MGP_SPMV_CASE(8)
+      MGP_SPMV_CASE(16)
+      MGP_SPMV_CASE(32)
+      MGP_SPMV_CASE(64)
+      default: return MGP_ERR_ARG;
+    }
+#undef MGP_SPMV_CASE
+  } else {
+    const int G = spmm_cols_group(C);
+    const int nacc = (int)mgp_cdiv(C, G);
+    Plan pl = make_plan(L->n, kBlock / G);
+    p.rows_per_block = pl.rows_per_block;
+#define MGP_SPMM_LAUNCH(GG, NA)                                    \
+  do {                                                             \
+    if (pre) launch_spmm<GG, NA, true>(p, pl.grid, st);            \
+    else launch_spmm<GG, NA, false>(p, pl.grid, st);               \
+  } while (0)
+    if (G == 4) MGP_SPMM_LAUNCH(4, 1);
+    else if (G == 8) MGP_SPMM_LAUNCH(8, 1);
+    else if (G == 16) MGP_SPMM_LAUNCH(16, 1);
+    else if (G == 32) MGP_SPMM_LAUNCH(32, 1);
+    else if (nacc == 1) MGP_SPMM_LAUNCH(64, 1);
+    else if (nacc == 2) MGP_SPMM_LAUNCH(64, 2);
+    else MGP_SPMM_LAUNCH(64, 4);
+#undef MGP_SPMM_LAUNCH
+  }
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+// elementwise y = s[i] * x[i,:]
+__global__ void scale_rows_kernel(const float* __restrict__ s, const float* __restrict__ x,
+                                  float* __restrict__ y, int64_t n, int C) {
+  int64_t total = n * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = s[i / C] * x[i];
+}
+
+extern "C" int mgp_laplacian_matmul(const mgp_csr_t* L, const float* dsqrt, const float* dinvsqrt,
+                                    int mode, const float* X, int C, float* Y, float* work_nc,
+                                    void* stream) {
+  (void)work_nc;
+  if (mode < 0 || mode > 2) return MGP_ERR_ARG;
+  if (mode != 0 && (!dsqrt || !dinvsqrt)) return MGP_ERR_ARG;
+  // graph_laplacian_operator.py:111-122: vec = rhs * D^{1/2} (rw) or rhs / D^{1/2} (rw^T);
+  // out = L_sym vec; out *= D^{-1/2} (rw) or D^{1/2} (rw^T)
+  const float* pre = mode == 0 ? nullptr : (mode == 1 ? dsqrt : dinvsqrt);
+  const float* post = mode == 0 ? nullptr : (mode == 1 ? dinvsqrt : dsqrt);
+  return mgp_spmm_fused(L, X, C, Y, 0.f, 1.f, pre, post, nullptr, 0.f, 1.f, nullptr, nullptr, stream);
+}

@@ -1,0 +1,153 @@
+"""Device-resident graph containers and their HIP builders (thin host glue over the C-ABI).
+
+KnnGraph       symmetrised k-NN graph: the reference's COO view (idx[2,M], val[M]) plus the padded
+               full-symmetric CSR the kernels sweep (manifold_gp/utils/nearest_neighbors.py:39-55).
+LaplacianData  everything graph_laplacian_operator.py:52-106 caches, computed by three fused
+               row passes for one (eps, self_loops).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream
+
+
+class KnnGraph:
+    def __init__(self, n, tri_row, tri_col, tri_val, rowptr, col, d2, eid):
+        self.n = int(n)
+        self.tri_row, self.tri_col, self.tri_val = tri_row, tri_col, tri_val
+        self.rowptr, self.col, self.d2, self.eid = rowptr, col, d2, eid
+        self.M = int(tri_val.shape[0])
+        self.nnz = int(col.shape[0])
+        self._edge_index = None
+        # sub-wave group width for the C == 1 SpMV: 4 entries per lane per pass
+        mean_row = self.nnz / max(self.n, 1)
+        lanes = 4
+        while lanes < 64 and lanes * 5 < mean_row:
+            lanes *= 2
+        self.spmv_lanes = lanes
+
+    @property
+    def device(self):
+        return self.tri_val.device
+
+    @property
+    def edge_index(self):
+        """idx[2, M] int64, row<col, sorted -- what NearestNeighbors.graph returns."""
+        if self._edge_index is None:
+            self._edge_index = torch.stack([self.tri_row, self.tri_col]).long()
+        return self._edge_index
+
+    @property
+    def edge_value(self):
+        return self.tri_val
+
+    # ------------------------------------------------------------------ builders
+    @classmethod
+    def from_knn(cls, D, I):
+        """(D[n,k] f32, I[n,k] i32) on device -> KnnGraph via mgp_graph_build."""
+        _lib.require_device(D, I)
+        n, k = I.shape
+        dev = D.device
+        D = _lib.f32c(D)
+        I = I.to(torch.int32).contiguous()
+        cap_e = n * (k - 1)
+        cap_z = 2 * cap_e + 4 * n
+        tri_row = torch.empty(cap_e, dtype=torch.int32, device=dev)
+        tri_col = torch.empty(cap_e, dtype=torch.int32, device=dev)
+        tri_val = torch.empty(cap_e, dtype=torch.float32, device=dev)
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(cap_z, dtype=torch.int32, device=dev)
+        d2 = torch.empty(cap_z, dtype=torch.float32, device=dev)
+        eid = torch.empty(cap_z, dtype=torch.int32, device=dev)
+        wb = lib().mgp_graph_workspace_bytes(n, k)
+        work = _lib.workspace(wb, "graph", dev)
+        M, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib().mgp_graph_build(ptr(D), ptr(I), n, k, ptr(tri_row), ptr(tri_col), ptr(tri_val),
+                                    ctypes.byref(M), ptr(rowptr), ptr(col), ptr(d2), ptr(eid),
+                                    ctypes.byref(nnz), ptr(work), work.numel(), stream()), "mgp_graph_build")
+        M, nnz = M.value, nnz.value
+        return cls(n, tri_row[:M].clone(), tri_col[:M].clone(), tri_val[:M].clone(), rowptr,
+                   col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone())
+
+    @classmethod
+    def from_coo(cls, idx, val, n):
+        """Reference-style edge list (idx[2,M] any int dtype, val[M]) -> KnnGraph."""
+        _lib.require_device(idx, val)
+        dev = val.device
+        M = int(val.shape[0])
+        tri_row = idx[0].to(torch.int32).contiguous()
+        tri_col = idx[1].to(torch.int32).contiguous()
+        tri_val = _lib.f32c(val.reshape(-1))
+        cap_z = 2 * M + 4 * n
+        rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(cap_z, dtype=torch.int32, device=dev)
+        d2 = torch.empty(cap_z, dtype=torch.float32, device=dev)
+        eid = torch.empty(cap_z, dtype=torch.int32, device=dev)
+        wb = lib().mgp_graph_coo_workspace_bytes(n, M)
+        work = _lib.workspace(wb, "graph", dev)
+        nnz = ctypes.c_int64(0)
+        check(lib().mgp_graph_from_coo(ptr(tri_row), ptr(tri_col), ptr(tri_val), M, n, ptr(rowptr), ptr(col),
+                                       ptr(d2), ptr(eid), ctypes.byref(nnz), ptr(work), work.numel(), stream()),
+              "mgp_graph_from_coo")
+        nnz = nnz.value
+        g = cls(n, tri_row, tri_col, tri_val, rowptr, col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone())
+        if idx.dtype == torch.int64:
+            g._edge_index = idx
+        return g
+
+
+_COO_CACHE = {}
+
+
+def graph_for_coo(idx, val, n):
+    """Operators built straight from (val, idx) as in the reference ctor share one CSR per edge list."""
+    key = (idx.data_ptr(), val.data_ptr(), int(val.shape[0]), int(n), str(val.device))
+    g = _COO_CACHE.get(key)
+    if g is None:
+        if len(_COO_CACHE) > 16:
+            _COO_CACHE.clear()
+        g = KnnGraph.from_coo(idx, val, n)
+        g._keepalive = (idx, val)   # the cache key is a pointer: keep the tensors alive with it
+        _COO_CACHE[key] = g
+    return g
+
+
+class LaplacianData:
+    """degree_unnorm D~, degree D, diag, sqrt(D), 1/sqrt(D), CSR values S for one (eps, self_loops)."""
+
+    def __init__(self, graph, eps, self_loops):
+        dev = graph.device
+        n = graph.n
+        self.graph = graph
+        self.eps = float(eps)
+        self.self_loops = bool(self_loops)
+        f = dict(dtype=torch.float32, device=dev)
+        self.degree_unnorm = torch.empty(n, **f)
+        self.degree = torch.empty(n, **f)
+        self.diag = torch.empty(n, **f)
+        self.dsqrt = torch.empty(n, **f)
+        self.dinvsqrt = torch.empty(n, **f)
+        self.vals = torch.empty(graph.nnz, **f)
+        check(lib().mgp_laplacian_build(n, ptr(graph.rowptr), ptr(graph.col), ptr(graph.d2), self.eps,
+                                        int(self.self_loops), ptr(self.degree_unnorm), ptr(self.degree),
+                                        ptr(self.diag), ptr(self.dsqrt), ptr(self.dinvsqrt), ptr(self.vals),
+                                        stream()), "mgp_laplacian_build")
+        self._edge = {}
+
+    def csr(self):
+        g = self.graph
+        return _lib.csr_struct(g.n, g.rowptr, g.col, self.vals, self.diag)
+
+    def edge_values(self, which):
+        """0: W (adjacency_unnorm_mat), 1: A (adjacency_mat), 2: S (laplacian_triu) in COO order."""
+        out = self._edge.get(which)
+        if out is None:
+            g = self.graph
+            out = torch.empty(g.M, dtype=torch.float32, device=g.device)
+            check(lib().mgp_edge_values(ptr(g.tri_row), ptr(g.tri_col), ptr(g.tri_val), g.M,
+                                        ptr(self.degree_unnorm), ptr(self.degree), self.eps, which, ptr(out),
+                                        stream()), "mgp_edge_values")
+            self._edge[which] = out
+        return out

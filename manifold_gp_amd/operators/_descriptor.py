@@ -1,0 +1,79 @@
+"""Host-side description of a precision-family operator as ONE chain of fused SpMMs
+(mgp_operator_t in include/mgp_hip.h):  A = form(scale * diag(post) (tau I + L_sym)^nu diag(pre))."""
+import ctypes
+from dataclasses import dataclass, replace
+from typing import Optional
+
+import torch
+
+from .. import _lib
+from .._lib import OperatorT, check, lib, ptr, stream
+
+
+@dataclass
+class Descriptor:
+    data: object                       # graph.LaplacianData (CSR of L_sym + node vectors)
+    nu: int
+    kappa: float
+    pre: Optional[torch.Tensor] = None
+    post: Optional[torch.Tensor] = None
+    scale: float = 1.0
+    form: int = 0                      # 0: Q2, 1: Q2 - s Q2^2 + s^2 Q2^3, 2: I + s Q2
+    noise: float = 0.0
+
+    @property
+    def n(self):
+        return self.data.graph.n
+
+    def with_(self, **kw):
+        return replace(self, **kw)
+
+    def masked(self, row_mask=None, col_mask=None):
+        """diag(row_mask) A diag(col_mask) for form 0 (MaskedLinearOperator blocks)."""
+        assert self.form == 0
+        pre, post = self.pre, self.post
+        if col_mask is not None:
+            pre = col_mask if pre is None else pre * col_mask
+        if row_mask is not None:
+            post = row_mask if post is None else post * row_mask
+        return replace(self, pre=pre, post=post)
+
+    def struct(self):
+        d = self.data
+        g = d.graph
+        check(lib().mgp_spmm_set_group_hint(g.spmv_lanes), "mgp_spmm_set_group_hint")
+        op = OperatorT()
+        op.L = d.csr()
+        op.pre = self.pre.data_ptr() if self.pre is not None else None
+        op.post = self.post.data_ptr() if self.post is not None else None
+        op.nu = int(self.nu)
+        op.kappa = float(self.kappa)
+        op.scale = float(self.scale)
+        op.form = int(self.form)
+        op.noise = float(self.noise)
+        return op
+
+    def apply(self, X):
+        """Y = A X for X [n, C] fp32 on device (C chunks of 256)."""
+        _lib.require_device(X)
+        squeeze = X.dim() == 1
+        X = _lib.f32c(X.unsqueeze(-1) if squeeze else X)
+        op = self.struct()
+        out = torch.empty_like(X)
+        C = X.shape[1]
+        for c0 in range(0, C, 256):
+            Xc = X if C <= 256 else X[:, c0:c0 + 256].contiguous()
+            Yc = out if C <= 256 else torch.empty_like(Xc)
+            wb = lib().mgp_operator_workspace_bytes(ctypes.byref(op), Xc.shape[1])
+            work = _lib.workspace(wb, "operator", X.device)
+            check(lib().mgp_operator_apply(ctypes.byref(op), ptr(Xc), Xc.shape[1], ptr(Yc), ptr(work), work.numel(),
+                                           stream()), "mgp_operator_apply")
+            if Yc is not out:
+                out[:, c0:c0 + 256] = Yc
+        return out.squeeze(-1) if squeeze else out
+
+    def jacobi(self):
+        op = self.struct()
+        minv = torch.empty(self.n, dtype=torch.float32, device=self.data.graph.device)
+        check(lib().mgp_operator_jacobi(ctypes.byref(op), ptr(minv), stream()), "mgp_operator_jacobi")
+        return minv

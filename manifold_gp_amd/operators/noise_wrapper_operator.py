@@ -1,0 +1,45 @@
+"""NoiseWrapperOperator (manifold_gp/operators/noise_wrapper_operator.py:8-28):
+Q (v - s Q (v - s Q v)) = (Q - s Q^2 + s^2 Q^3) v, the 2nd-order Neumann form of (Q^-1 + s I)^-1."""
+import torch
+
+from .._compat import LinearOperator
+
+
+def _scalar(t):
+    return float(t.reshape(-1)[0].item()) if torch.is_tensor(t) else float(t)
+
+
+class NoiseWrapperOperator(LinearOperator):
+    def __init__(self, operator, noise):
+        super().__init__(operator, noise=noise)
+        self.operator = operator
+        self.noise = noise
+
+    def _descriptor(self):
+        inner = getattr(self.operator, "_descriptor", lambda: None)()
+        if inner is None or inner.form != 0:
+            return None
+        return inner.with_(form=1, noise=_scalar(self.noise))
+
+    def _matmul(self, rhs):
+        d = self._descriptor()
+        if d is not None:
+            return d.apply(rhs)
+        s = _scalar(self.noise)
+        Q = self.operator._matmul
+        rhs = rhs.contiguous()
+        return Q(rhs - s * Q(rhs - s * Q(rhs)))
+
+    def _size(self):
+        return self.operator._size()
+
+    def _transpose_nonbatch(self):
+        return NoiseWrapperOperator(self.operator._transpose_nonbatch(), self.noise)
+
+    def _solve(self, rhs, preconditioner=None, num_tridiag=0):
+        d = self._descriptor()
+        if d is not None:
+            from ..solvers import cg_solve
+            return cg_solve(d, rhs)[0]
+        from ..solvers import generic_cg
+        return generic_cg(self, rhs)

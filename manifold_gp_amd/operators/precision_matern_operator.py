@@ -1,0 +1,49 @@
+"""PrecisionMaternOperator: Q = (2 nu / kappa^2 I + L)^nu (x D for random walk), reference
+manifold_gp/operators/precision_matern_operator.py:10-53, applied as nu fused SpMM launches."""
+import torch
+
+from .._compat import LinearOperator
+from ._descriptor import Descriptor
+
+
+def _scalar(t):
+    return float(t.reshape(-1)[0].item()) if torch.is_tensor(t) else float(t)
+
+
+class PrecisionMaternOperator(LinearOperator):
+    def __init__(self, laplacian, nu, lengthscale):
+        super().__init__(laplacian, nu=nu, lengthscale=lengthscale)
+        self.laplacian = laplacian
+        self.nu = nu
+        self.lengthscale = lengthscale
+
+    def _descriptor(self):
+        d = self.laplacian.data
+        sq = d.dsqrt if self.laplacian.normalization == "randomwalk" else None
+        # D (tau I + L_rw)^nu = D^1/2 (tau I + L_sym)^nu D^1/2   (precision_matern_operator.py:30-37)
+        return Descriptor(d, int(self.nu), _scalar(self.lengthscale), pre=sq, post=sq)
+
+    def _matmul(self, rhs):
+        return self._descriptor().apply(rhs)
+
+    def _size(self):
+        return self.laplacian._size()
+
+    def _transpose_nonbatch(self):
+        return self
+
+    def _solve(self, rhs, preconditioner=None, num_tridiag=0):
+        from ..solvers import cg_solve
+        return cg_solve(self._descriptor(), rhs)[0]
+
+    def _average_variance(self, num_rand_vec=100):
+        """precision_matern_operator.py:45-53: mean_i (Q^-1)_ii over random one-hot columns
+        (indices drawn from [0, d-2] with replacement, as the reference does)."""
+        d = self.shape[0]
+        dev = self.laplacian.x.device
+        if num_rand_vec >= d:
+            rand_vec = torch.eye(d, device=dev)
+        else:
+            rand_idx = torch.randint(0, d - 1, (1, num_rand_vec), device=dev)
+            rand_vec = torch.zeros(d, num_rand_vec, device=dev).scatter_(0, rand_idx, 1.0)
+        return self.inv_quad_logdet(inv_quad_rhs=rand_vec, logdet=False)[0] / rand_vec.shape[1]

@@ -1,0 +1,50 @@
+"""SchurComplementOperator (manifold_gp/operators/schur_complement_operator.py:12-36):
+Q_ll - Q_lu Q_uu^-1 Q_ul on the labelled nodes.
+
+The reference builds three MaskedLinearOperators per matvec and runs linear_cg on Q_uu.  Here the
+four blocks are the SAME polynomial chain with a 0/1 mask folded into its input / output row
+scalings, acting on full-length zero-padded vectors, and the inner solve is the HIP CG."""
+import torch
+
+from .. import _lib
+from .._compat import LinearOperator
+
+
+class SchurComplementOperator(LinearOperator):
+    def __init__(self, base, mask):
+        super().__init__(base, mask)
+        self.base = base
+        self.mask = mask
+        self._fmask = None
+        self._lidx = None
+
+    def _masks(self):
+        if self._fmask is None:
+            dev = self.base.laplacian.x.device if hasattr(self.base, "laplacian") else self.mask.device
+            m = self.mask.to(dev)
+            self._fmask = (m.float().contiguous(), (~m).float().contiguous())
+            self._lidx = torch.nonzero(m, as_tuple=False).squeeze(-1)
+        return self._fmask
+
+    def _matmul(self, rhs):
+        from ..solvers import cg_solve
+        _lib.require_device(rhs)
+        squeeze = rhs.dim() == 1
+        v = _lib.f32c(rhs.unsqueeze(-1) if squeeze else rhs)
+        ml, mu = self._masks()
+        desc = self.base._descriptor()
+        n = desc.n
+        full = torch.zeros(n, v.shape[1], device=v.device, dtype=torch.float32)
+        full[self._lidx] = v
+        tmp = desc.masked(col_mask=ml).apply(full)                 # Q[:, l] v           (:27)
+        sol = cg_solve(desc.masked(row_mask=mu, col_mask=mu), tmp * mu.view(-1, 1))[0]   # Q_uu^-1 (:28)
+        out = desc.masked(row_mask=ml, col_mask=mu).apply(sol)     # Q_lu (.)            (:29)
+        res = (tmp - out)[self._lidx]                              # (:30)
+        return res.squeeze(-1) if squeeze else res
+
+    def _size(self):
+        k = int(self.mask.sum())
+        return torch.Size([k, k])
+
+    def _transpose_nonbatch(self):
+        return SchurComplementOperator(self.base._transpose_nonbatch(), self.mask)

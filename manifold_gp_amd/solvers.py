@@ -1,0 +1,236 @@
+"""Host drivers for the iterative pieces of the path: CG solves, inv_quad_logdet, eigensolves and
+the GP posterior.  All arithmetic is in libmgp_hip; this file only sizes workspaces, reads the
+gpytorch-style settings and mirrors the call conventions of linear_operator that the reference
+relies on."""
+import ctypes
+import math
+import warnings
+
+import torch
+
+from . import _lib
+from ._compat import settings
+from ._lib import CgParamsT, LanczosParamsT, check, lib, ptr, stream
+
+
+# ------------------------------------------------------------------------------ CG
+class CgPlan:
+    """A reusable HIP CG solver for one operator descriptor and column count: owns the workspace
+    and the captured iteration graph (mgp_cg_plan_* in include/mgp_hip.h)."""
+
+    def __init__(self, desc, C, tol=None, max_iter=None, min_iter=None, stop_mode=None, jacobi=None,
+                 check_every=0, use_graph=True):
+        self.desc = desc
+        self.C = int(C)
+        dev = desc.data.graph.device
+        self.op = desc.struct()
+        stop_mode = settings.cg_stop_mode.value() if stop_mode is None else stop_mode
+        self.params = CgParamsT(
+            float(settings.cg_tolerance.value() if tol is None else tol),
+            int(settings.max_cg_iterations.value() if max_iter is None else max_iter),
+            int((10 if stop_mode == 0 else 0) if min_iter is None else min_iter),
+            int(stop_mode), int(check_every), int(bool(use_graph)))
+        jacobi = settings.cg_jacobi_preconditioner.value() if jacobi is None else jacobi
+        self.minv = desc.jacobi() if jacobi else None
+        wb = lib().mgp_cg_workspace_bytes(ctypes.byref(self.op), self.C)
+        if wb == 0:
+            raise RuntimeError("mgp_cg_workspace_bytes: unsupported operator / column count %d" % C)
+        self.work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        self.handle = ctypes.c_void_p(0)
+        check(lib().mgp_cg_plan_create(ctypes.byref(self.op), self.C, ptr(self.minv), ctypes.byref(self.params),
+                                       ptr(self.work), self.work.numel(), stream(), ctypes.byref(self.handle)),
+              "mgp_cg_plan_create")
+        self.iters = 0
+        self.status = 0
+        self.resid = None
+
+    def solve(self, B, out=None):
+        _lib.require_device(B)
+        B = _lib.f32c(B)
+        assert B.shape == (self.desc.n, self.C)
+        X = torch.empty_like(B) if out is None else out
+        iters, status = ctypes.c_int32(0), ctypes.c_int32(0)
+        resid = (ctypes.c_float * self.C)()
+        check(lib().mgp_cg_plan_solve(self.handle, ptr(B), ptr(X), ctypes.byref(iters), resid,
+                                      ctypes.byref(status)), "mgp_cg_plan_solve")
+        self.iters, self.status = iters.value, status.value
+        self.resid = list(resid)
+        return X
+
+    def close(self):
+        if self.handle:
+            lib().mgp_cg_plan_destroy(self.handle)
+            self.handle = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cg_solve(desc, rhs, **kw):
+    """Solve A X = rhs with the HIP CG.  Returns (X, iterations, relative residuals)."""
+    squeeze = rhs.dim() == 1
+    B = _lib.f32c(rhs.unsqueeze(-1) if squeeze else rhs)
+    outs, its, res = [], 0, []
+    for c0 in range(0, B.shape[1], 256):
+        Bc = B if B.shape[1] <= 256 else B[:, c0:c0 + 256].contiguous()
+        plan = CgPlan(desc, Bc.shape[1], **kw)
+        outs.append(plan.solve(Bc))
+        its = max(its, plan.iters)
+        res += plan.resid
+        if plan.status == 2:
+            warnings.warn("CG did not converge in %d iterations (residuals up to %.3g)"
+                          % (plan.iters, max(plan.resid)))
+        elif plan.status == 3:
+            raise RuntimeError("NaNs encountered in CG")          # linear_cg raises on NaN too
+        plan.close()
+    X = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
+    return (X.squeeze(-1) if squeeze else X), its, res
+
+
+def generic_cg(operator, rhs, tol=None, max_iter=None):
+    """linear_cg's recurrence in torch ops for operators that are not one polynomial chain (e.g.
+    wrappers around a Schur complement).  Every `_matmul` underneath is still a HIP launch."""
+    _lib.require_device(rhs)
+    tol = settings.cg_tolerance.value() if tol is None else tol
+    max_iter = settings.max_cg_iterations.value() if max_iter is None else max_iter
+    squeeze = rhs.dim() == 1
+    B = _lib.f32c(rhs.unsqueeze(-1) if squeeze else rhs)
+    bn = B.norm(dim=0, keepdim=True).clamp_min(1e-10)
+    Bn = B / bn
+    x = torch.zeros_like(Bn)
+    r = Bn.clone()
+    p = r.clone()
+    rz = (r * r).sum(0, keepdim=True)
+    for it in range(1, max_iter + 1):
+        q = operator._matmul(p)
+        pq = (p * q).sum(0, keepdim=True)
+        alpha = rz / pq.where(pq.abs() > 1e-30, torch.full_like(pq, 1e-30))
+        x = x + alpha * p
+        r = r - alpha * q
+        rz_new = (r * r).sum(0, keepdim=True)
+        if it >= 10 and rz_new.sqrt().mean().item() < tol:
+            break
+        p = r + (rz_new / rz.clamp_min(1e-30)) * p
+        rz = rz_new
+    x = x * bn
+    return x.squeeze(-1) if squeeze else x
+
+
+# ------------------------------------------------------------------------------ inv_quad / logdet
+def inv_quad_logdet(operator, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
+    """linear_operator's inv_quad_logdet as the reference uses it (precision_matern_operator.py:53,
+    train_model.py:68, test_model.py:23): dense Cholesky of to_dense() when N <= max_cholesky_size,
+    iterative otherwise (CG for the quadratic form; stochastic Lanczos quadrature for logdet)."""
+    n = operator.shape[-1]
+    inv_quad = None
+    logdet_term = None
+    dense_ok = n <= settings.max_cholesky_size.value()
+    chol = None
+    if dense_ok:
+        A = operator.to_dense()
+        A = 0.5 * (A + A.t())
+        chol = torch.linalg.cholesky(A.double())
+    if inv_quad_rhs is not None:
+        rhs = inv_quad_rhs if inv_quad_rhs.dim() == 2 else inv_quad_rhs.unsqueeze(-1)
+        if chol is not None:
+            sol = torch.cholesky_solve(rhs.double(), chol).float()
+        else:
+            sol = operator.solve(rhs)
+        iq = (rhs * sol).sum(0)
+        inv_quad = iq.sum() if reduce_inv_quad else iq
+    if logdet:
+        if chol is not None:
+            logdet_term = (2.0 * chol.diagonal().log().sum()).float()
+        else:
+            from .slq import slq_logdet
+            logdet_term = slq_logdet(operator)
+    return inv_quad, logdet_term
+
+
+def dense_symeig(operator):
+    """`symeig` branch of LinearOperator.diagonalization: eigh of to_dense() (small N only)."""
+    A = operator.to_dense()
+    evals, evecs = torch.linalg.eigh(0.5 * (A + A.t()))
+    return evals, evecs
+
+
+# ------------------------------------------------------------------------------ Lanczos
+def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=8, seed=1337):
+    """m smallest eigenpairs of L_sym (CSR in `lap_data`) by the HIP filtered Lanczos.
+    Returns (evals[m] device, evecs[n,m] device, resid[m] host list)."""
+    g = lap_data.graph
+    dev = g.device
+    check(lib().mgp_spmm_set_group_hint(g.spmv_lanes), "mgp_spmm_set_group_hint")
+    csr = lap_data.csr()
+    prm = LanczosParamsT(int(max_basis), int(degree), int(max_restarts), float(tol), int(seed))
+    wb = lib().mgp_lanczos_workspace_bytes(g.n, int(m), ctypes.byref(prm))
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    evals = (ctypes.c_float * m)()
+    resid = (ctypes.c_float * m)()
+    info = (ctypes.c_int32 * 4)()
+    evecs = torch.empty(g.n, m, dtype=torch.float32, device=dev)
+    check(lib().mgp_lanczos_smallest(ctypes.byref(csr), int(m), ctypes.byref(prm), evals, ptr(evecs), resid, info,
+                                     ptr(work), work.numel(), stream()), "mgp_lanczos_smallest")
+    ev = torch.tensor(list(evals), dtype=torch.float32, device=dev)
+    lanczos_smallest.last_info = list(info)
+    return ev, evecs, list(resid)
+
+
+# ------------------------------------------------------------------------------ posterior
+def lowrank_apply(Z, X, alpha, beta):
+    """alpha * Z (Z^T X) + beta * X on device (K + sigma^2 I with K = outputscale Z Z^T)."""
+    _lib.require_device(Z, X)
+    squeeze = X.dim() == 1
+    Xc = _lib.f32c(X.unsqueeze(-1) if squeeze else X)
+    Z = _lib.f32c(Z)
+    n, m = Z.shape
+    Y = torch.empty_like(Xc)
+    wb = lib().mgp_lowrank_workspace_bytes(m, Xc.shape[1])
+    work = _lib.workspace(wb, "lowrank", Z.device)
+    check(lib().mgp_lowrank_apply(ptr(Z), n, m, ptr(Xc), Xc.shape[1], float(alpha), float(beta), ptr(Y), ptr(work),
+                                  work.numel(), stream()), "mgp_lowrank_apply")
+    return Y.squeeze(-1) if squeeze else Y
+
+
+def lowrank_cg(Z, y, outputscale, noise, tol=1e-6, max_iter=500):
+    """(outputscale Z Z^T + noise I)^-1 y by CG on device -- the '(K + sigma^2 I) x = y' solve of
+    the spectral kernel (reference: gpytorch's Woodbury path)."""
+    x = torch.zeros_like(y)
+    r = y.clone()
+    p = r.clone()
+    rz = torch.dot(r, r)
+    bn = rz.sqrt()
+    it = 0
+    for it in range(1, max_iter + 1):
+        q = lowrank_apply(Z, p, outputscale, noise)
+        alpha = rz / torch.dot(p, q)
+        x += alpha * p
+        r -= alpha * q
+        rz_new = torch.dot(r, r)
+        if rz_new.sqrt() <= tol * bn:
+            break
+        p = r + (rz_new / rz) * p
+        rz = rz_new
+    return x, it
+
+
+def kernel_block(Z1, Z2, scale=1.0):
+    """K = scale * Z1 Z2^T on the fp32 MFMA."""
+    _lib.require_device(Z1, Z2)
+    Z1, Z2 = _lib.f32c(Z1), _lib.f32c(Z2)
+    K = torch.empty(Z1.shape[0], Z2.shape[0], dtype=torch.float32, device=Z1.device)
+    check(lib().mgp_kernel_block(ptr(Z1), Z1.shape[0], ptr(Z2), Z2.shape[0], Z1.shape[1], float(scale), ptr(K),
+                                 stream()), "mgp_kernel_block")
+    return K
+
+
+def kernel_diag(Z1, Z2, scale=1.0):
+    _lib.require_device(Z1, Z2)
+    Z1, Z2 = _lib.f32c(Z1), _lib.f32c(Z2)
+    out = torch.empty(Z1.shape[0], dtype=torch.float32, device=Z1.device)
+    check(lib().mgp_kernel_diag(ptr(Z1), ptr(Z2), Z1.shape[0], Z1.shape[1], float(scale), ptr(out), stream()),
+          "mgp_kernel_diag")
+    return out

@@ -1,0 +1,83 @@
+"""NearestNeighbors on MI355X: the interface of manifold_gp/utils/nearest_neighbors.py:10-63
+(train / search / graph, `min_ivf`, `nlist`, `nprobe`) over the exact HIP k-NN kernels.
+
+faiss' Flat and IVFFlat(nlist=1) indices are both exhaustive searches, so `train` only records the
+points; `search` returns (D f32 squared-L2 ascending, I int64); `graph` returns the reference's
+(idx[2,M] int64 with row<col sorted, val[M] mean squared distance) and keeps the padded CSR of the
+same graph in `self.knn_graph` for the operators."""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .._lib import check, lib, ptr, stream
+from ..graph import KnnGraph
+
+
+class NearestNeighbors():
+    def __init__(self, x=None, nlist=1) -> None:
+        self.min_ivf = 5000
+        self.knn_graph = None
+        self.last_stats = None
+        if x is not None:
+            self.train(x, nlist)
+
+    def train(self, x, nlist=1):
+        _lib.require_device(x)
+        if x.dim() != 2:
+            raise ValueError("x must be [n, d]")
+        self.x = x
+        self._xc = _lib.f32c(x)
+        self.nlist = nlist
+        self.is_trained = True
+        return self
+
+    def search(self, x, k, nprobe=1):
+        _lib.require_device(x)
+        assert self.is_trained
+        q = _lib.f32c(x)
+        N, d = self._xc.shape
+        n = q.shape[0]
+        if q.shape[1] != d:
+            raise ValueError("query dimension %d != index dimension %d" % (q.shape[1], d))
+        if not (0 < k <= min(N, 1024)):
+            raise ValueError("k must be in [1, min(N, 1024)]")
+        D = torch.empty(n, k, dtype=torch.float32, device=q.device)
+        I = torch.empty(n, k, dtype=torch.int32, device=q.device)
+        wb = lib().mgp_knn_workspace_bytes(N, n, d, k)
+        work = _lib.workspace(wb, "knn", q.device)
+        stats = (ctypes.c_int64 * 4)()
+        check(lib().mgp_knn_search(ptr(self._xc), N, d, ptr(q), n, k, ptr(D), ptr(I), ptr(work), work.numel(),
+                                   stats, stream()), "mgp_knn_search")
+        self.last_stats = dict(rows_redone_wide=stats[0], rows_redone_exact=stats[1], chunks=stats[2],
+                               candidates=stats[3])
+        return D, I.long()
+
+    def graph(self, k, symmetric=True, self_loop=False, nprobe=1):
+        val, idx = self.search(self.x, k, nprobe)
+        n = self.x.shape[0]
+        if symmetric and not self_loop:
+            self.knn_graph = KnnGraph.from_knn(val, idx.to(torch.int32))
+            return self.knn_graph.edge_index, self.knn_graph.edge_value
+        # non-default variants: plain torch index bookkeeping (no arithmetic), as
+        # nearest_neighbors.py:42-53
+        if not self_loop:
+            val, idx = val[:, 1:], idx[:, 1:]
+        rows = torch.arange(n, device=self.x.device).repeat_interleave(idx.shape[1])
+        cols = idx.reshape(-1)
+        val = val.reshape(-1)
+        if symmetric:
+            lo, hi = torch.minimum(rows, cols), torch.maximum(rows, cols)
+            key = lo * n + hi
+            uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
+            s = torch.zeros(uniq.shape[0], device=val.device).index_add_(0, inv, val)
+            return torch.stack([uniq // n, uniq % n]), s / cnt
+        return torch.stack([rows, cols]), val
+
+    @property
+    def min_ivf(self):
+        return self._min_ivf
+
+    @min_ivf.setter
+    def min_ivf(self, value):
+        self._min_ivf = value

@@ -1,0 +1,449 @@
+"""GPU parity tests: the HIP path (through the package classes -> ctypes -> C-ABI of
+include/mgp_hip.h) against the committed golden vectors and the CPU oracle on the same inputs.
+
+Tolerances (written next to each assert):
+  * k-NN indices, graph structure, edge values: bit-exact;
+  * fp32 Laplacian / precision products: a few fp32 ulps of |L| * |v| (the round-off of the
+    reference's own dense product, see tests/test_oracle_golden.py);
+  * CG solutions / posterior: 1e-4 relative to the fp64 oracle (north-star tolerance);
+  * eigenvalues: 1e-5 * lambda_max absolute.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["dumbbell_k50_noloop", "dumbbell_k10_loop"]
+NORMS = ["symmetric", "randomwalk"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def mgp():
+    import manifold_gp_amd
+    from manifold_gp_amd import _lib
+    _lib.lib()   # fails loudly if the HIP extension is missing
+    return manifold_gp_amd
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _operator(mgp, g, dev, norm, transposed=False):
+    idx = T(g["edge_index"].astype(np.int64), dev)
+    val = T(g["edge_value"], dev)
+    eps = torch.tensor([[float(g["eps"])]], device=dev)
+    return mgp.operators.GraphLaplacianOperator(val, idx, g["train_x"].shape[0], eps, norm,
+                                                bool(g["self_loops"]), transposed)
+
+
+# ----------------------------------------------------------------------------- k-NN + graph
+@pytest.mark.parametrize("case", CASES)
+def test_knn_bit_exact_vs_golden(mgp, golden, dev, case):
+    g = golden(case)
+    k = int(g["k"])
+    knn = mgp.utils.NearestNeighbors(T(g["train_x"], dev))
+    D, I = knn.search(T(g["train_x"], dev), k)
+    assert I.dtype == torch.int64
+    assert np.array_equal(I.cpu().numpy(), g["knn_I"].astype(np.int64))          # bit-exact indices
+    assert np.array_equal(D.cpu().numpy(), g["knn_D"])                           # (float) of the fp64 distance
+    Dt, It = knn.search(T(g["test_x"], dev), k)
+    assert np.array_equal(It.cpu().numpy(), g["knn_test_I"].astype(np.int64))
+    assert np.array_equal(Dt.cpu().numpy(), g["knn_test_D"])
+    idx, val = knn.graph(k)
+    assert idx.dtype == torch.int64 and idx.shape[0] == 2
+    assert np.array_equal(idx.cpu().numpy(), g["edge_index"].astype(np.int64))   # sorted unique row<col
+    assert np.array_equal(val.cpu().numpy(), g["edge_value"])
+    # padded CSR invariants
+    kg = knn.knn_graph
+    rp = kg.rowptr.cpu().numpy()
+    assert (rp % 4 == 0).all() and rp[0] == 0 and rp[-1] == kg.nnz
+    col, eid, d2 = kg.col.cpu().numpy(), kg.eid.cpu().numpy(), kg.d2.cpu().numpy()
+    assert (eid >= 0).sum() == 2 * kg.M
+    assert np.isinf(d2[eid < 0]).all()
+    for r in (0, 17, kg.n - 1):
+        seg = col[rp[r]:rp[r + 1]][eid[rp[r]:rp[r + 1]] >= 0]
+        assert (np.diff(seg) > 0).all()
+
+
+def test_knn_highdim_random_vs_oracle(mgp, dev):
+    from oracle import knn as oknn
+    rng = np.random.default_rng(3)
+    base = rng.normal(size=(40, 784)).astype(np.float32)
+    x = (base[rng.integers(0, 40, 2500)] + 0.05 * rng.normal(size=(2500, 784))).astype(np.float32)
+    q = x[:300]
+    Dr, Ir = oknn.knn_search(x, q, 33)
+    knn = mgp.utils.NearestNeighbors(T(x, dev))
+    D, I = knn.search(T(q, dev), 33)
+    assert np.array_equal(I.cpu().numpy(), Ir)
+    assert np.array_equal(D.cpu().numpy(), Dr)
+
+
+def test_knn_ties_duplicates_and_small_sets(mgp, dev):
+    from oracle import knn as oknn
+    # lattice: masses of exact ties; duplicates; k close to N (candidate set = everything)
+    gx, gy = np.meshgrid(np.arange(12), np.arange(12))
+    x = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    x = np.concatenate([x, x[:7]])           # duplicate points
+    for k in (1, 5, 64, 100, x.shape[0]):
+        Dr, Ir = oknn.knn_search(x, x, k)
+        D, I = mgp.utils.NearestNeighbors(T(x, dev)).search(T(x, dev), k)
+        assert np.array_equal(I.cpu().numpy(), Ir), k
+        assert np.array_equal(D.cpu().numpy(), Dr), k
+    stats = mgp.utils.NearestNeighbors(T(x, dev))
+    stats.search(T(x, dev), 20)
+    assert stats.last_stats["chunks"] == 1
+
+
+def test_knn_near_ties_force_fallbacks(mgp, dev):
+    """Near-ties at fp32 resolution around the k-th neighbour (the dumbbell's uniform spacing
+    problem) must be resolved exactly by the fp64 re-rank / fallbacks."""
+    from oracle import knn as oknn
+    rng = np.random.default_rng(5)
+    t = np.arange(3000, dtype=np.float64) * 1e-3
+    x = np.stack([t, np.zeros_like(t)], 1)
+    x += rng.normal(scale=1e-9, size=x.shape)
+    x = x.astype(np.float32)
+    Dr, Ir = oknn.knn_search(x, x, 51)
+    nn = mgp.utils.NearestNeighbors(T(x, dev))
+    D, I = nn.search(T(x, dev), 51)
+    assert np.array_equal(I.cpu().numpy(), Ir)
+    assert np.array_equal(D.cpu().numpy(), Dr)
+
+
+# ----------------------------------------------------------------------------- Laplacian
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("norm", NORMS)
+def test_laplacian_pieces_and_matmul(mgp, golden, dev, case, norm):
+    g = golden(case)
+    p = norm + "_"
+    op = _operator(mgp, g, dev, norm)
+    np.testing.assert_allclose(op.degree_unnorm_mat.cpu().numpy(), g[p + "degree_unnorm"], rtol=2e-6)
+    np.testing.assert_allclose(op.degree_mat.cpu().numpy(), g[p + "degree"], rtol=5e-6)
+    np.testing.assert_allclose(op.laplacian_diag.cpu().numpy(), g[p + "diag"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(op.diagonal().cpu().numpy(), g[p + "diag"], rtol=1e-5, atol=2e-5)
+    if norm == "symmetric":
+        np.testing.assert_allclose(-op.laplacian_triu[:64].cpu().numpy(), g[p + "offdiag64"], rtol=2e-5)
+    y, P = T(g["train_y"], dev), T(g["probes"], dev)
+    dmax = float(np.abs(g[p + "diag"]).max())
+    tol_y = 2e-6 * dmax * float(np.abs(g["train_y"]).max())      # ~16 ulp of |L||v|
+    tol_p = 2e-6 * dmax * float(np.abs(g["probes"]).max())
+    np.testing.assert_allclose(op.matmul(y).cpu().numpy(), g[p + "mv"], rtol=0, atol=tol_y)
+    np.testing.assert_allclose(op.T.matmul(y).cpu().numpy(), g[p + "mvT"], rtol=0, atol=tol_y)
+    np.testing.assert_allclose(op.matmul(P).cpu().numpy(), g[p + "mm"], rtol=0, atol=tol_p)
+    np.testing.assert_allclose(op.T.matmul(P).cpu().numpy(), g[p + "mmT"], rtol=0, atol=tol_p)
+    assert tuple(op.shape) == (g["train_x"].shape[0],) * 2
+
+
+@pytest.mark.parametrize("norm", NORMS)
+def test_reference_pass_criterion(mgp, golden, dev, norm):
+    """test/_test_functions.py:11-44: first 10 entries equal after rounding (4 decimals: fp32)."""
+    from conftest import ref_round_equal
+    g = golden("dumbbell_k50_noloop")
+    p = norm + "_"
+    op = _operator(mgp, g, dev, norm)
+    y = T(g["train_y"], dev)
+    assert ref_round_equal(op.matmul(y.view(-1, 1)).squeeze().cpu().numpy(), g[p + "mv"], decimals=4)
+    assert ref_round_equal(op.T.matmul(y.view(-1, 1)).squeeze().cpu().numpy(), g[p + "mvT"], decimals=4)
+    assert ref_round_equal(op.diagonal().cpu().numpy(), g[p + "diag"])
+
+
+@pytest.mark.parametrize("C", [1, 2, 3, 7, 16, 33, 64, 100, 130, 256, 300])
+def test_spmm_column_counts_vs_oracle(mgp, golden, dev, C):
+    from oracle.laplacian import LaplacianOracle
+    g = golden("dumbbell_k10_loop")
+    n = g["train_x"].shape[0]
+    rng = np.random.default_rng(C)
+    X = rng.normal(size=(n, C)).astype(np.float32)
+    for norm in NORMS:
+        ref = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), norm, True,
+                              dtype=np.float64).matmul(X.astype(np.float64))
+        out = _operator(mgp, g, dev, norm).matmul(T(X, dev)).cpu().numpy()
+        np.testing.assert_allclose(out, ref, rtol=0, atol=3e-6 * np.abs(g[norm + "_diag"]).max() * np.abs(X).max())
+
+
+def test_to_dense_symmetry_and_diag(mgp, golden, dev):
+    g = golden("dumbbell_k50_noloop")
+    op = _operator(mgp, g, dev, "symmetric")
+    A = op.to_dense()
+    assert torch.allclose(A, A.t(), atol=1e-6)
+    assert torch.allclose(A.diagonal(), op.diagonal(), atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- precision family
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("norm", NORMS)
+def test_precision_and_wrappers(mgp, golden, dev, case, norm):
+    g = golden(case)
+    p = norm + "_"
+    O = mgp.operators
+    lap = _operator(mgp, g, dev, norm)
+    kappa = torch.tensor([[float(g["kappa"])]], device=dev)
+    y, P = T(g["train_y"], dev), T(g["probes"], dev)
+    nus = sorted(int(k[len(p) + 1:-3]) for k in g if k.startswith(p + "Q") and k.endswith("_mv") and k[len(p) + 1:-3].isdigit())
+    for nu in nus:
+        Q = O.PrecisionMaternOperator(lap, nu, kappa)
+        ref = g[p + f"Q{nu}_mv"]
+        np.testing.assert_allclose(Q.matmul(y).cpu().numpy(), ref, rtol=0, atol=3e-4 * np.abs(ref).max())
+        refm = g[p + f"Q{nu}_mm"]
+        np.testing.assert_allclose(Q.matmul(P).cpu().numpy(), refm, rtol=0, atol=3e-4 * np.abs(refm).max())
+    Q = O.PrecisionMaternOperator(lap, nus[0], kappa)
+    ref = g[p + "Qscaled_mv"]
+    out = O.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev), inverse_scale=True).matmul(y)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=3e-4 * np.abs(ref).max())
+    ref = g[p + "Qnoisy_mv"]
+    out = O.NoiseWrapperOperator(Q, torch.tensor(1e-2, device=dev)).matmul(y)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-3 * np.abs(ref).max())
+    # Schur complement on a 10 % labelled subset (inner solve = HIP CG, tight tolerance)
+    mask = g[p + "schur_mask"]
+    ref = g[p + "schur_mv"]
+    with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(4000):
+        out = O.SchurComplementOperator(Q, T(mask, dev)).matmul(T(g["train_y"][mask], dev))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("norm", NORMS)
+def test_cg_solve_vs_dense_fp64(mgp, golden, dev, norm):
+    """solve(Q, y) against torch.linalg.solve of the reference's dense Q in fp64
+    (test/_test_functions.py:47-56 `test_solve`)."""
+    g = golden("dumbbell_k50_noloop")
+    p = norm + "_"
+    lap = _operator(mgp, g, dev, norm)
+    Q = mgp.operators.PrecisionMaternOperator(lap, 1, torch.tensor([[float(g["kappa"])]], device=dev))
+    y = T(g["train_y"], dev)
+    ref = g[p + "solve"]
+    for jac in (False, True):
+        with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.cg_jacobi_preconditioner(jac):
+            x = Q.solve(y)
+        err = np.abs(x.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err < 1e-4, (jac, err)          # north-star tolerance
+    # multi right-hand side incl. a zero column and wide blocks
+    B = torch.cat([T(g["probes"], dev), torch.zeros(lap.shape[0], 1, device=dev), y.view(-1, 1)], dim=1)
+    with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1):
+        X = Q.solve(B)
+    R = Q.matmul(X) - B
+    assert float(R.norm(dim=0).max() / B.norm(dim=0).max()) < 5e-6
+    assert float(X[:, 4].abs().max()) == 0.0
+
+
+def test_cg_linear_cg_stopping_rule(mgp, golden, dev):
+    """stop_mode 0 restates linear_cg: >= 10 iterations, mean relative residual < tol."""
+    from oracle.laplacian import LaplacianOracle
+    from oracle.precision import PrecisionMaternOracle
+    from oracle.solvers import linear_cg
+    from manifold_gp_amd.solvers import cg_solve
+    g = golden("dumbbell_k50_noloop")
+    n = g["train_x"].shape[0]
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 1, torch.tensor([[float(g["kappa"])]], device=dev))
+    B = T(g["probes"], dev)
+    X, its, res = cg_solve(Q._descriptor(), B, tol=1e-2, stop_mode=0)
+    Qo = PrecisionMaternOracle(LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "symmetric",
+                                               False, dtype=np.float64), 1, float(g["kappa"]))
+    Xo, its_o, rn = linear_cg(Qo.matmul, g["probes"].astype(np.float64), tolerance=1e-2)
+    assert its >= 10
+    assert abs(its - its_o) <= 2, (its, its_o)
+    assert np.mean(res) < 1e-2
+    np.testing.assert_allclose(X.cpu().numpy(), Xo, rtol=0, atol=5e-2 * np.abs(Xo).max())
+
+
+def test_posterior_mean_precision_form(mgp, golden, dev):
+    """(K + s I)^-1-type solve in precision form: (I + s Q2)^-1 y within 1e-4 of the fp64 oracle."""
+    from oracle.laplacian import LaplacianOracle
+    from oracle.precision import PrecisionMaternOracle
+    from oracle.solvers import precision_posterior_mean
+    from manifold_gp_amd.solvers import cg_solve
+    g = golden("dumbbell_k10_loop")
+    n = g["train_x"].shape[0]
+    nu, kappa, outputscale, noise = 2, float(g["kappa"]), 0.7, 1e-2
+    for norm in NORMS:
+        lap = _operator(mgp, g, dev, norm)
+        Q = mgp.operators.PrecisionMaternOperator(lap, nu, torch.tensor([[kappa]], device=dev))
+        desc = Q._descriptor().with_(scale=outputscale, form=2, noise=noise)
+        x, its, res = cg_solve(desc, T(g["train_y"], dev), tol=1e-7, stop_mode=1, max_iter=5000)
+        Qo = PrecisionMaternOracle(LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), norm, True,
+                                                   dtype=np.float64), nu, kappa)
+        ref, _, _ = precision_posterior_mean(lambda v: outputscale * Qo.matmul(v), g["train_y"], noise)
+        err = np.abs(x.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert err < 1e-4, (norm, err, its)
+
+
+# ----------------------------------------------------------------------------- spectrum / features
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("norm", NORMS)
+def test_kernel_eval_features_oos(mgp, golden, dev, case, norm):
+    g = golden(case)
+    if not bool(g["self_loops"]):
+        pytest.skip("RiemannKernel.laplacian() always uses self loops (riemann_kernel.py:115)")
+    p = norm + "_"
+    m = int(g["modes"])
+    kern = mgp.kernels.RiemannMaternKernel(nu=1, x=T(g["train_x"], dev), nearest_neighbors=int(g["k"]),
+                                           laplacian_normalization=norm, num_modes=m,
+                                           bump_scale=float(g["bump"][0]), bump_decay=float(g["bump"][1])).to(dev)
+    kern.initialize(graphbandwidth=float(g["eps"]), lengthscale=float(g["kappa"]))
+    kern.eval()
+    lam_max = float(np.abs(g[p + "diag"]).max()) * 2
+    np.testing.assert_allclose(kern.eigval.cpu().numpy()[1:], g[p + "evals"][1:], rtol=0, atol=1e-5 * lam_max)
+    assert float(kern.eigval[0]) == 0.0
+    assert max(kern.eigen_residuals) <= 2e-5 * lam_max
+    x = T(g["train_x"], dev)
+    Z = kern.features(x)
+    gram = (Z[:64] @ Z[:64].t()).cpu().numpy()
+    ref = g[p + "features_gram_64"]
+    np.testing.assert_allclose(gram, ref, rtol=0, atol=2e-3 * np.abs(ref).max())
+    np.testing.assert_allclose(kern(x, x, diag=True).cpu().numpy(), g[p + "features_diag"], rtol=5e-3)
+    # out of sample (the golden block is the un-bumped dense extension: divide the bump out)
+    xt = T(g["test_x"], dev)
+    Zt = kern.features(xt).cpu().numpy()
+    b = g[p + "oos_bump"]
+    sel = b > 0
+    assert sel.any()
+    ext = (Zt / np.where(sel, b, 1)[:, None]) @ Z[:64].cpu().numpy().T
+    refo = g[p + "oos_gram"]
+    np.testing.assert_allclose(ext[sel], refo[sel], rtol=0, atol=3e-3 * np.abs(refo).max())
+    assert np.abs(Zt[~sel]).max(initial=0.0) == 0.0
+    # lazy kernel block == dense MFMA block
+    K = kern(xt, x).to_dense().cpu().numpy()
+    np.testing.assert_allclose(K, Zt @ Z.cpu().numpy().T, rtol=0, atol=1e-4 * np.abs(K).max() + 1e-6)
+
+
+def test_eigensolver_vs_dense_eigh_k50(mgp, golden, dev):
+    """test/_test_functions.py:107-131 `test_eigen` for the symmetric operator: eigenvalues[1:10]."""
+    g = golden("dumbbell_k50_noloop")
+    op = _operator(mgp, g, dev, "symmetric")
+    from manifold_gp_amd.solvers import lanczos_smallest
+    evals, evecs, resid = lanczos_smallest(op.data, 20, tol=1e-6)
+    ref = g["symmetric_evals_raw"]
+    np.testing.assert_allclose(evals.cpu().numpy()[1:], ref[1:20], rtol=0, atol=2e-5)
+    orth = (evecs.t() @ evecs - torch.eye(20, device=dev)).abs().max()
+    assert float(orth) < 5e-5
+    # dense symeig branch of diagonalization() (N <= max_cholesky_size) agrees
+    with mgp.settings.max_cholesky_size(2000):
+        ev2, _ = op.diagonalization()
+    np.testing.assert_allclose(ev2.cpu().numpy()[1:20], ref[1:20], rtol=0, atol=2e-5)
+
+
+def test_eigensolver_disconnected_components(mgp, dev):
+    """k-NN graphs can be disconnected: lambda = 0 with multiplicity = #components."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(c * 10, 1, (300, 6)) for c in range(7)]).astype(np.float32)
+    knn = mgp.utils.NearestNeighbors(T(x, dev))
+    idx, val = knn.graph(12)
+    op = mgp.operators.GraphLaplacianOperator(val, idx, x.shape[0], torch.tensor([[2.0]], device=dev), "symmetric",
+                                              graph=knn.knn_graph)
+    from manifold_gp_amd.solvers import lanczos_smallest
+    evals, evecs, resid = lanczos_smallest(op.data, 20, tol=1e-6)
+    A = op.to_dense().double().cpu().numpy()
+    w = np.linalg.eigvalsh(0.5 * (A + A.T))[:20]
+    assert (np.abs(w[:7]) < 1e-6).all()
+    np.testing.assert_allclose(evals.cpu().numpy(), w, rtol=0, atol=2e-6 * np.abs(np.diag(A)).max())
+
+
+def test_lanczos_tridiag_matches_operator(mgp, golden, dev):
+    """Full-reorth Lanczos: Q^T A Q = T and Q^T Q = I."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Qop = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[0.5]], device=dev))
+    desc = Qop._descriptor()
+    op = desc.struct()
+    n, steps = desc.n, 30
+    q0 = torch.randn(n, device=dev)
+    wb = _lib.lib().mgp_lanczos_tridiag_workspace_bytes(ctypes.byref(op), steps)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    alpha = (ctypes.c_float * steps)()
+    beta = (ctypes.c_float * steps)()
+    Qm = torch.empty(steps, n, device=dev)
+    _lib.check(_lib.lib().mgp_lanczos_tridiag(ctypes.byref(op), _lib.ptr(q0), steps, alpha, beta, _lib.ptr(Qm),
+                                              _lib.ptr(work), work.numel(), _lib.stream()), "mgp_lanczos_tridiag")
+    QtQ = Qm @ Qm.t()
+    assert float((QtQ - torch.eye(steps, device=dev)).abs().max()) < 1e-4
+    Tm = Qm @ Qop.matmul(Qm.t().contiguous())
+    Tref = torch.diag(torch.tensor(list(alpha))) + torch.diag(torch.tensor(list(beta)[:-1]), 1) + \
+        torch.diag(torch.tensor(list(beta)[:-1]), -1)
+    scale = float(Tref.abs().max())
+    assert float((Tm.cpu() - Tref).abs().max()) < 2e-4 * scale
+
+
+def test_kernel_block_mfma_layout(mgp, dev):
+    """A = I check with an ASYMMETRIC B (catches a transposed C/D map), odd sizes, edge tiles."""
+    from manifold_gp_amd.solvers import kernel_block, kernel_diag, lowrank_apply
+    m = 37
+    Z1 = torch.zeros(200, m, device=dev)
+    Z1[torch.arange(m), torch.arange(m)] = 1.0
+    Z2 = (torch.arange(333 * m, device=dev, dtype=torch.float32).reshape(333, m) % 17) - 5.0
+    K = kernel_block(Z1, Z2, 2.0)
+    assert torch.equal(K[:m], 2.0 * Z2.t())
+    assert float(K[m:].abs().max()) == 0.0
+    A, B = torch.randn(517, 100, device=dev), torch.randn(389, 100, device=dev)
+    ref = (A.double() @ B.double().t())
+    assert float((kernel_block(A, B).double() - ref).abs().max()) < 2e-5 * float(ref.abs().max()) + 1e-5
+    assert torch.allclose(kernel_diag(A[:389], B), (A[:389] * B).sum(-1), atol=1e-4)
+    X = torch.randn(517, 3, device=dev)
+    ref = 0.3 * (A.double() @ (A.double().t() @ X.double())) + 0.2 * X.double()
+    assert float((lowrank_apply(A, X, 0.3, 0.2).double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+
+
+def test_spectral_posterior_vs_woodbury_fp64(mgp, golden, dev):
+    """Posterior mean / variance with K = s Z Z^T + noise I: CG on device vs the fp64 Woodbury
+    closed form (what gpytorch evaluates for the reference), 1e-4 relative."""
+    from oracle.solvers import gp_posterior_lowrank
+    from manifold_gp_amd.solvers import kernel_block, lowrank_cg
+    g = golden("dumbbell_k10_loop")
+    kern = mgp.kernels.RiemannMaternKernel(nu=2, x=T(g["train_x"], dev), nearest_neighbors=10,
+                                           laplacian_normalization="randomwalk", num_modes=50).to(dev)
+    kern.initialize(graphbandwidth=float(g["eps"]), lengthscale=0.5)
+    kern.eval()
+    x, xt, y = T(g["train_x"], dev), T(g["test_x"], dev), T(g["train_y"], dev)
+    Z, Zt = kern.features(x), kern.features(xt)
+    s, noise = 0.8, 1e-2
+    alpha, its = lowrank_cg(Z, y, s, noise, tol=1e-7)
+    mean = kernel_block(Zt, Z, s) @ alpha
+    ref_mean, ref_cov, ref_alpha = gp_posterior_lowrank(Z.cpu().numpy(), g["train_y"], Zt.cpu().numpy(), s, noise)
+    assert np.abs(mean.cpu().numpy() - ref_mean).max() < 1e-4 * max(np.abs(ref_mean).max(), 1e-3)
+    assert np.abs(alpha.cpu().numpy() - ref_alpha).max() < 1e-4 * np.abs(ref_alpha).max()
+
+
+# ----------------------------------------------------------------------------- full-size properties
+def test_full_size_properties_60k(mgp, dev):
+    """BASELINE size (N = 60k, ~50 neighbours): size-independent properties of the HIP path --
+    symmetry <x, A y> = <A x, y>, linearity, constants in the null space of L_rw, CG residual."""
+    from manifold_gp_amd.solvers import cg_solve
+    n, k = 60000, 50
+    gen = torch.Generator(device="cpu").manual_seed(1)
+    # synthetic symmetric k-NN-like graph: ring lattice neighbours + random long edges
+    base = torch.arange(n).view(-1, 1)
+    offs = torch.cat([torch.arange(1, 21), torch.randint(21, n // 2, (k - 21,), generator=gen)])
+    I = torch.cat([base, (base + offs.view(1, -1)) % n], dim=1).to(torch.int32)
+    D = torch.cat([torch.zeros(n, 1), torch.rand(n, k - 1, generator=gen) * 2.0], dim=1)
+    from manifold_gp_amd.graph import KnnGraph
+    graph = KnnGraph.from_knn(D.to(dev), I.to(dev))
+    assert graph.M > n * 20 and graph.nnz % 4 == 0
+    eps = torch.tensor([[0.9]], device=dev)
+    O = mgp.operators
+    lap_s = O.GraphLaplacianOperator(graph.edge_value, graph.edge_index, n, eps, "symmetric", graph=graph)
+    lap_r = O.GraphLaplacianOperator(graph.edge_value, graph.edge_index, n, eps, "randomwalk", graph=graph)
+    x, y = torch.randn(n, device=dev), torch.randn(n, device=dev)
+    Q = O.PrecisionMaternOperator(lap_r, 2, torch.tensor([[1.9]], device=dev))
+    for A in (lap_s, Q):
+        lhs, rhs = torch.dot(x, A.matmul(y)), torch.dot(A.matmul(x), y)
+        assert abs(float(lhs - rhs)) < 1e-4 * float(A.matmul(x).norm() * y.norm())
+        lin = A.matmul(2.0 * x - 3.0 * y) - (2.0 * A.matmul(x) - 3.0 * A.matmul(y))
+        assert float(lin.norm()) < 1e-5 * float(A.matmul(x).norm() + A.matmul(y).norm())
+    ones = torch.ones(n, device=dev)
+    assert float(lap_r.matmul(ones).abs().max()) < 5e-5 * float(lap_r.diagonal().abs().max())
+    desc = Q._descriptor().with_(scale=0.2433, form=2, noise=0.0026)
+    sol, its, res = cg_solve(desc, y, tol=1e-6, stop_mode=1)
+    r = desc.apply(sol) - y
+    assert float(r.norm() / y.norm()) < 5e-6 and its < 200
+    # graph replay and eager launches give the same bits
+    sol2, _, _ = cg_solve(desc, y, tol=1e-6, stop_mode=1, use_graph=False)
+    assert torch.equal(sol, sol2)
