@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the hot path on MI355X.
+
+Metric (BASELINE.json): "CG-solve wall-time + SpMV HBM GB/s, N=60k RMNIST graph, 1/2/4/8 GPUs".
+Workload at N=1 (config C3 of SURVEY.md section 8): synthetic RMNIST-like 60 000 x 784 points
+(tools/synth.py), exact k-NN graph k=50 built by the HIP kernels, random-walk Laplacian, Matern
+nu=2 precision with the reference's trained hyper-parameters (models/srmnist_manifold_
+semisupervised.pth -> tests/golden/hyperparameters.json, bandwidth raised to the notebooks' eps_min
+rule when weights would underflow), posterior-mean system (K + s I) in precision form
+A = I + s Q2, right-hand side = standardised rotation angle.
+
+One "step" = one complete CG solve of A x = y to a relative residual of 1e-6 on device-resident
+inputs.  `value` = algorithmic SpMV bytes streamed by the solves / wall time (whole job, GB/s);
+`ms_per_step` = CG-solve wall time.  `roofline` times the dominant kernel (the fused C=1 SpMV)
+back to back with HIP events on the launch stream; `cpu_baseline` times the reference-style torch
+CPU operator (oracle/ref_torch.py, kind "port") on the host cores in the same run.
+
+N>1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- N x 60 000 points, rows of
+the graph partitioned across ranks, one RCCL all-gather (carrying the dot-product partials) per
+SpMV (manifold_gp_amd/parallel.py).
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def spmm_bytes(n, M, C=1):
+    """full symmetric CSR, fp32 values, int32 col, int32 rowptr, fp32 diag,
+    x read once, y written once."""
+    return 8 * (2 * M) + 4 * (n + 1) + 4 * n + 8 * n * C
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_workload(args, dev, rank, world):
+    import manifold_gp_amd as mgp
+    from tools import synth
+    t0 = time.time()
+    if args.workload == "c3":
+        bases = args.nodes // 100 if args.nodes else 600
+        x_np, y_np = synth.rmnist_like(bases * world, 100, seed=1337)
+        k, nu, norm = 50, 2, "randomwalk"
+        with open(os.path.join(ROOT, "tests", "golden", "hyperparameters.json")) as fh:
+            hp = json.load(fh)["srmnist_manifold_semisupervised"]
+        name = "C3 RMNIST-like N=%d d=784 k=50 nu=2 randomwalk" % x_np.shape[0]
+    elif args.workload == "s5":
+        n = args.nodes or 1000000
+        x_np, y_np = synth.swiss_roll(n * world)
+        k, nu, norm = 64, 2, "symmetric"
+        hp = dict(graphbandwidth=0.0, lengthscale=1.0, outputscale=1.0, noise=0.01)
+        name = "S5 swiss-roll N=%d d=3 k=64 nu=2 symmetric" % x_np.shape[0]
+    else:
+        raise SystemExit("unknown workload " + args.workload)
+    t_data = time.time() - t0
+    x = torch.from_numpy(x_np).to(dev)
+    y = torch.from_numpy(y_np).to(dev)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    knn = mgp.utils.NearestNeighbors(x)
+    idx, val = knn.graph(k)
+    torch.cuda.synchronize()
+    t_graph = time.time() - t0
+    graph = knn.knn_graph
+    d1 = None
+    # eps: trained value, floored by the notebooks' eps_min rule on the 1-NN distances
+    D1, _ = knn.search(x[: min(20000, x.shape[0])], 2)
+    eps, eps_min = synth.bandwidth_rule(D1[:, 1].cpu().numpy(), hp["graphbandwidth"])
+    log("[bench] data %.1fs, k-NN+graph %.2fs (knn stats %s), N=%d M=%d nnz_padded=%d eps=%.4f (eps_min %.4f)"
+        % (t_data, t_graph, knn.last_stats, graph.n, graph.M, graph.nnz, eps, eps_min))
+    lap = mgp.operators.GraphLaplacianOperator(val, idx, graph.n, torch.tensor([[eps]], device=dev), norm, graph=graph)
+    Q = mgp.operators.PrecisionMaternOperator(lap, nu, torch.tensor([[hp["lengthscale"]]], device=dev))
+    desc = Q._descriptor().with_(scale=hp["outputscale"], form=2, noise=hp["noise"])
+    return dict(mgp=mgp, graph=graph, lap=lap, desc=desc, y=y, nu=nu, name=name, hp=hp, eps=eps, norm=norm,
+                t_graph=t_graph)
+
+
+def time_spmv_kernel(wl, reps=200):
+    """Average duration of the dominant kernel (fused C=1 SpMV, L_sym) launched back to back from C
+    (mgp_spmm_repeat), HIP events on the launch stream (= torch's current stream)."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    lap = wl["lap"]
+    g = wl["graph"]
+    v = torch.rand(lap.shape[0], 1, device=wl["y"].device)
+    out = torch.empty_like(v)
+    lib = _lib.lib()
+    lib.mgp_spmm_set_group_hint(g.spmv_lanes)
+    csr = lap.data.csr()
+    st = _lib.stream()
+    _lib.check(lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 20, st), "mgp_spmm_repeat")
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    _lib.check(lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), reps, st), "mgp_spmm_repeat")
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps * 1e-3   # seconds per launch
+
+
+def cpu_baseline(wl, gpu_iters):
+    """Reference-style CPU path (oracle/ref_torch.py) on the host cores: SpMV rate and the same CG
+    solve.  Bounded: 20 SpMVs + one CG solve (a few seconds at N=60k)."""
+    from oracle.ref_torch import TorchCooLaplacian, TorchPrecision, torch_cg
+    g, lap = wl["graph"], wl["lap"]
+    # the GPU box exposes every host core (256) but one GPU's share is 16; over-subscribing the torch
+    # CPU ops (index_add_) with 256 threads is ~100x slower than 16
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    idx = g.edge_index.cpu()
+    triu = lap.laplacian_triu.cpu()
+    diag = lap.laplacian_diag.cpu()
+    deg = lap.degree_mat.cpu()
+    ref = TorchCooLaplacian(idx, triu, diag, deg, wl["norm"])
+    torch.manual_seed(1337)
+    v = torch.rand(g.n)                               # bench_sparse_laplacian.py:63-64
+    t0 = time.perf_counter()
+    ref.matmul(v)
+    first = time.perf_counter() - t0                  # the reference's single-shot time.time() style
+    for _ in range(3):
+        ref.matmul(v)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        ref.matmul(v)
+        ts.append(time.perf_counter() - t0)
+    t_mv = statistics.median(ts)
+    prec = TorchPrecision(ref, wl["nu"], wl["hp"]["lengthscale"], wl["hp"]["outputscale"], wl["hp"]["noise"])
+    y = wl["y"].cpu()
+    t0 = time.perf_counter()
+    xs, its = torch_cg(prec.posterior_system, y, 1e-6, 1000)
+    t_cg = time.perf_counter() - t0
+    B = spmm_bytes(g.n, g.M)
+    spmvs = (its + 1) * wl["nu"]
+    return dict(value=round(B * spmvs / t_cg / 1e9, 3), unit="GB/s", cores=cores, kind="port",
+                sample="full C3 workload: 1 CG solve (%d iterations, %d SpMV) + 20 SpMV repeats on %d threads"
+                       % (its, spmvs, torch.get_num_threads()),
+                spmv_ms=round(t_mv * 1e3, 3), spmv_first_call_ms=round(first * 1e3, 3),
+                spmv_gbs=round(B / t_mv / 1e9, 3), cg_solve_ms=round(t_cg * 1e3, 2), cg_iters=its), xs
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "s5"])
+    ap.add_argument("--nodes", type=int, default=0, help="override nodes per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tol", type=float, default=1e-6)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    if world > 1:
+        from manifold_gp_amd import parallel
+        return parallel.bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, HBM_PEAK_GBS)
+
+    wl = build_workload(args, dev, rank, world)
+    from manifold_gp_amd.solvers import CgPlan
+    g = wl["graph"]
+    plan = CgPlan(wl["desc"], 1, tol=args.tol, max_iter=2000, stop_mode=1, check_every=8)
+    y = wl["y"].view(-1, 1).contiguous()
+    out = torch.empty_like(y)
+    for _ in range(args.warmup):
+        plan.solve(y, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        plan.solve(y, out=out)
+        iters += plan.iters
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    its = iters / args.steps
+    B = spmm_bytes(g.n, g.M)
+    spmvs_per_solve = (its + 1) * wl["nu"]
+    value = B * spmvs_per_solve * args.steps / dt / 1e9
+    resid = max(plan.resid)
+    # residual re-check with one explicit operator apply
+    r = wl["desc"].apply(out) - y
+    true_res = float(r.norm() / y.norm())
+
+    t_k = time_spmv_kernel(wl)
+    roof = dict(bound="hbm", achieved=round(B / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=round(B / t_k / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
+                kernel="spmv_kernel<%d,2,false> (fused CSR SpMV, C=1, %d lanes x 2 rows in flight)" % (g.spmv_lanes, g.spmv_lanes),
+                bytes_per_launch=B, avg_launch_us=round(t_k * 1e6, 2),
+                note="N=60k working set (%.0f MB) is Infinity-Cache resident; see DESIGN.md" % (B / 1e6))
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            roof["traffic"] = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
+        except Exception:
+            pass
+    line = dict(metric="CG-solve wall-time + SpMV HBM GB/s, N=60k RMNIST graph", value=round(value, 2),
+                unit="GB/s (algorithmic SpMV bytes inside the CG solve)", n_gpus=1, steps=args.steps,
+                warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
+                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload=wl["name"], nodes=g.n, edges=g.M, nnz_padded=g.nnz, rhs_columns=1,
+                            system="A = I + noise*outputscale*Q, Q=(2nu/kappa^2 I + L)^nu x D",
+                            cg_tol=args.tol, cg_iters=its, cg_rel_residual=resid, cg_true_residual=true_res,
+                            spmv_per_solve=spmvs_per_solve, eps=wl["eps"], knn_graph_build_s=round(wl["t_graph"], 3)),
+                cg_solve_ms=round(dt / args.steps * 1e3, 4), roofline=roof)
+    if not args.no_cpu_baseline:
+        cb, xs = cpu_baseline(wl, its)
+        line["cpu_baseline"] = cb
+        err = float((out.view(-1).cpu() - xs).abs().max() / xs.abs().max())
+        line["config"]["max_rel_diff_vs_cpu_solution"] = err
+    plan.close()
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -115,9 +115,14 @@ typedef struct {
 
 int mgp_spmm_dot_blocks(int64_t n, int C);   /* workgroups that write dot partials */
 int mgp_spmm_set_group_hint(int lanes);      /* C == 1: lanes per row, one of 4,8,16,32,64 */
+int mgp_spmm_set_rows_in_flight(int rows);   /* C == 1: rows a lane group loads at once: 1,2,4,8 */
+int mgp_spmm_set_entry_layout(int layout);   /* C == 1: 0 = 16-B per lane, 1 = lane-strided (default) */
 int mgp_spmm_fused(const mgp_csr_t* L, const float* X, int C, float* Y, float a, float b,
                    const float* pre, const float* post, const float* base, float cb, float co,
                    const float* dotw, float* dot_partials, void* stream);
+
+/* measurement helper: `reps` back-to-back launches of Y = L X enqueued from C */
+int mgp_spmm_repeat(const mgp_csr_t* L, const float* X, int C, float* Y, int reps, void* stream);
 
 /* L @ X in the three flavours of graph_laplacian_operator.py:108-124:
  * mode 0 symmetric, 1 randomwalk (D^-1/2 L_sym D^1/2), 2 randomwalk transposed */

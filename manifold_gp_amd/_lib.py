@@ -71,8 +71,11 @@ SIGNATURES = {
     "mgp_edge_values": (c_int, [_P, _P, _P, c_int64, _P, _P, c_float, c_int, _P, _P]),
     "mgp_spmm_dot_blocks": (c_int, [c_int64, c_int]),
     "mgp_spmm_set_group_hint": (c_int, [c_int]),
+    "mgp_spmm_set_rows_in_flight": (c_int, [c_int]),
+    "mgp_spmm_set_entry_layout": (c_int, [c_int]),
     "mgp_spmm_fused": (c_int, [POINTER(CsrT), _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
                                c_float, _P, _P, _P]),
+    "mgp_spmm_repeat": (c_int, [POINTER(CsrT), _P, c_int, _P, c_int, _P]),
     "mgp_laplacian_matmul": (c_int, [POINTER(CsrT), _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "mgp_operator_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int]),
     "mgp_operator_apply": (c_int, [POINTER(OperatorT), _P, c_int, _P, _P, c_size_t, _P]),

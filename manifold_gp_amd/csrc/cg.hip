@@ -93,6 +93,20 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   const int tid = threadIdx.x, cc = tid % a.TC, sl = tid / a.TC;
   const int C = a.C;
 
+  // operands of this thread's first element: issued before the reduction so that their latency
+  // overlaps it (the kernel is a chain of dependent L2 round trips otherwise)
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.n) r1 = a.n;
+  const int64_t rf = r0 + sl;
+  const bool have = cc < C && rf < r1;
+  float f_u = 0.f, f_p = 0.f, f_s = 0.f, f_w = 0.f, f_x = 0.f, f_r = 0.f, f_m = 1.f;
+  if (have) {
+    const int64_t i = rf * C + cc;
+    f_u = a.u[i]; f_p = a.p[i]; f_s = a.s[i]; f_w = a.w[i]; f_x = a.x[i]; f_r = a.r[i];
+    if (a.minv) f_m = a.minv[rf];
+  }
+
   // ---- every workgroup reduces the partials in the same fixed order
   float g = 0.f, rr = 0.f, d = 0.f;
   if (cc < C) {
@@ -157,24 +171,26 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   if (sh_done) return;
 
   // ---- fused vector update over this workgroup's contiguous rows
-  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
-  int64_t r1 = r0 + a.rows_per_block;
-  if (r1 > a.n) r1 = a.n;
   float ng = 0.f, nrr = 0.f;
   if (cc < C) {
     const float alpha = sh_alpha[cc], beta = sh_beta[cc];
-    for (int64_t r = r0 + sl; r < r1; r += a.TS) {
+    for (int64_t r = rf; r < r1; r += a.TS) {
       const int64_t i = r * C + cc;
-      const float un = a.u[i];
-      const float p = fmaf(beta, a.p[i], un);
-      const float s = fmaf(beta, a.s[i], a.w[i]);
+      float un, po, so, wo, xo, ro, mo = 1.f;
+      if (r == rf) { un = f_u; po = f_p; so = f_s; wo = f_w; xo = f_x; ro = f_r; mo = f_m; }
+      else {
+        un = a.u[i]; po = a.p[i]; so = a.s[i]; wo = a.w[i]; xo = a.x[i]; ro = a.r[i];
+        if (a.minv) mo = a.minv[r];
+      }
+      const float p = fmaf(beta, po, un);
+      const float s = fmaf(beta, so, wo);
       a.p[i] = p;
       a.s[i] = s;
-      a.x[i] = fmaf(alpha, p, a.x[i]);
-      const float rn = fmaf(-alpha, s, a.r[i]);
+      a.x[i] = fmaf(alpha, p, xo);
+      const float rn = fmaf(-alpha, s, ro);
       a.r[i] = rn;
       float u2 = rn;
-      if (a.minv) { u2 = a.minv[r] * rn; a.u[i] = u2; }
+      if (a.minv) { u2 = mo * rn; a.u[i] = u2; }
       ng = fmaf(rn, u2, ng);
       nrr = fmaf(rn, rn, nrr);
     }
@@ -200,9 +216,10 @@ struct CgPlan {
   float* pd_delta;
   hipStream_t stream;       // caller's stream: all work is enqueued here
   hipStream_t cap_stream;   // private stream used only to capture the iteration graph
-  hipGraphExec_t exec;
+  hipGraphExec_t exec;        // `chunk` iterations
+  hipGraphExec_t exec_small;  // `chunk_small` iterations (first replay: short solves finish here)
   bool has_graph;
-  int chunk;
+  int chunk, chunk_small;
   int32_t* host_state;      // pinned
   float* host_resid;        // pinned
 };
@@ -255,6 +272,7 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
   if (pl->prm.max_iter <= 0) pl->prm.max_iter = 1000;
   if (pl->prm.min_iter < 0) pl->prm.min_iter = 0;
   pl->chunk = pl->prm.check_every > 0 ? pl->prm.check_every : 10;
+  pl->chunk_small = pl->chunk < 4 ? pl->chunk : 4;
   pl->stream = mgp_stream(stream);
   const int64_t n = op->L.n;
   const size_t nc = (size_t)n * C;
@@ -269,7 +287,7 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
   pl->op_work_bytes = mgp_operator_workspace_bytes(op, C);
   pl->op_work = ar.take<char>(pl->op_work_bytes);
   // contiguous row ranges per workgroup, at most kMaxGridVec workgroups
-  int64_t rpb = a.TS * 4;
+  int64_t rpb = a.TS;
   int64_t nbv = mgp_cdiv(n, rpb);
   if (nbv > kMaxGridVec) { rpb = mgp_cdiv(mgp_cdiv(n, kMaxGridVec), a.TS) * a.TS; nbv = mgp_cdiv(n, rpb); }
   a.rows_per_block = rpb; a.nbv = (int)nbv;
@@ -292,18 +310,20 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
 
   if (pl->prm.use_graph) {
     e = hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal);
-    int rc = MGP_OK;
-    if (e == hipSuccess) {
-      for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) rc = enqueue_iteration(pl, pl->cap_stream);
+    bool ok = (e == hipSuccess);
+    for (int which = 0; which < 2 && ok; ++which) {
+      const int len = which == 0 ? pl->chunk_small : pl->chunk;
+      ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+      if (!ok) break;
+      int rc = MGP_OK;
+      for (int i = 0; i < len && rc == MGP_OK; ++i) rc = enqueue_iteration(pl, pl->cap_stream);
       hipGraph_t graph = nullptr;
       hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
-      if (rc == MGP_OK && e2 == hipSuccess && graph) {
-        e2 = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0);
-        pl->has_graph = (e2 == hipSuccess);
-      }
+      ok = (rc == MGP_OK && e2 == hipSuccess && graph != nullptr);
+      if (ok) ok = hipGraphInstantiate(which == 0 ? &pl->exec_small : &pl->exec, graph, nullptr, nullptr, 0) == hipSuccess;
       if (graph) (void)hipGraphDestroy(graph);
     }
+    pl->has_graph = ok;
     (void)hipGetLastError();   // a failed capture falls back to eager launches
   }
   *plan_out = pl;
@@ -321,21 +341,24 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
   MGP_TRY(mgp_operator_apply_ex(&pl->op, pl->args.u, pl->C, pl->args.w, pl->args.u, pl->pd_delta, nullptr,
                                 nullptr, pl->op_work, pl->op_work_bytes, st));
   int guard = 0;
+  bool first = true;
   for (;;) {
+    const int len = first ? pl->chunk_small : pl->chunk;
     if (pl->has_graph) {
-      MGP_HIP_TRY(hipGraphLaunch(pl->exec, st));
+      MGP_HIP_TRY(hipGraphLaunch(first ? pl->exec_small : pl->exec, st));
     } else {
-      for (int i = 0; i < pl->chunk; ++i) MGP_TRY(enqueue_iteration(pl, st));
+      for (int i = 0; i < len; ++i) MGP_TRY(enqueue_iteration(pl, st));
     }
+    first = false;
+    // results ride behind every chunk so that one synchronisation ends the solve
+    MGP_HIP_TRY(hipMemcpyAsync(X, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
+    MGP_HIP_TRY(hipMemcpyAsync(pl->host_resid, pl->args.resid, (size_t)pl->C * sizeof(float),
+                               hipMemcpyDeviceToHost, st));
     MGP_HIP_TRY(hipMemcpyAsync(pl->host_state, pl->args.state, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     MGP_HIP_TRY(hipStreamSynchronize(st));
     if (pl->host_state[1]) break;
-    if (++guard > pl->prm.max_iter / pl->chunk + 4) break;
+    if (++guard > pl->prm.max_iter / pl->chunk_small + 4) break;
   }
-  MGP_HIP_TRY(hipMemcpyAsync(X, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
-  MGP_HIP_TRY(hipMemcpyAsync(pl->host_resid, pl->args.resid, (size_t)pl->C * sizeof(float),
-                             hipMemcpyDeviceToHost, st));
-  MGP_HIP_TRY(hipStreamSynchronize(st));
   if (iters) *iters = pl->host_state[0] - 1;
   if (status) *status = pl->host_state[2];
   if (resid) memcpy(resid, pl->host_resid, (size_t)pl->C * sizeof(float));
@@ -345,7 +368,8 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
 extern "C" int mgp_cg_plan_destroy(void* plan) {
   CgPlan* pl = static_cast<CgPlan*>(plan);
   if (!pl) return MGP_ERR_ARG;
-  if (pl->has_graph) (void)hipGraphExecDestroy(pl->exec);
+  if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
+  if (pl->exec_small) (void)hipGraphExecDestroy(pl->exec_small);
   if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
   if (pl->host_state) (void)hipHostFree(pl->host_state);
   if (pl->host_resid) (void)hipHostFree(pl->host_resid);

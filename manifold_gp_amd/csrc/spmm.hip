@@ -26,7 +26,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kMaxGrid = 1024;
+constexpr int kMaxGrid = 4096;
 
 struct SpmmArgs {
   int64_t n;
@@ -59,7 +59,12 @@ __device__ __forceinline__ float epilogue(const SpmmArgs& p, int64_t r, int c, f
 }
 
 // ---------------------------------------------------------------- C == 1
-template <int G, bool PRE>
+// A G-lane group owns R consecutive rows and issues ALL their loads before the first use:
+// R+1 row pointers, then R x (16 B of column ids + 16 B of values) per lane, then 4R gathers of x,
+// then R shuffle reductions.  Three dependent memory phases per group instead of 3R: at N = 60k
+// the kernel is latency-bound (the matrix is cache resident), so bytes in flight per lane is
+// what sets the rate.  Rows longer than 4G entries take the (rare) remainder loop.
+template <int G, int R, bool PRE>
 __global__ __launch_bounds__(kBlock) void spmv_kernel(SpmmArgs p) {
   if (p.skip && *p.skip) return;
   if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
@@ -72,26 +77,177 @@ __global__ __launch_bounds__(kBlock) void spmv_kernel(SpmmArgs p) {
   if (r1 > p.n) r1 = p.n;
   const float* __restrict__ x = p.X;
   float dsum = 0.f;
-  for (int64_t r = r0 + grp; r < r1; r += kGroups) {
-    const int s = p.rowptr[r], e = p.rowptr[r + 1];
-    float acc = 0.f;
-    for (int i = s + 4 * lane; i < e; i += 4 * G) {
-      const int4 c = *reinterpret_cast<const int4*>(p.col + i);
-      const float4 v = *reinterpret_cast<const float4*>(p.vals + i);
-      float x0 = x[c.x], x1 = x[c.y], x2 = x[c.z], x3 = x[c.w];
-      if (PRE) { x0 *= p.pre[c.x]; x1 *= p.pre[c.y]; x2 *= p.pre[c.z]; x3 *= p.pre[c.w]; }
-      acc = fmaf(v.x, x0, acc);
-      acc = fmaf(v.y, x1, acc);
-      acc = fmaf(v.z, x2, acc);
-      acc = fmaf(v.w, x3, acc);
+  for (int64_t rb = r0 + (int64_t)grp * R; rb < r1; rb += (int64_t)kGroups * R) {
+    int s[R + 1];
+#pragma unroll
+    for (int t = 0; t <= R; ++t) {
+      const int64_t rr = rb + t;
+      s[t] = p.rowptr[rr < r1 ? rr : r1];
     }
-    acc = mgp_group_sum<G>(acc);
-    if (lane == 0) {
-      float xs = x[r];
-      if (PRE) xs *= p.pre[r];
-      float y = epilogue(p, r, 0, xs, acc);
-      p.Y[r] = y;
-      if (p.dotw) dsum = fmaf(p.dotw[r], y, dsum);
+    // epilogue operands of "my" row (lane t finishes row rb + t): in flight with everything else
+    // every load below is UNCONDITIONAL on a clamped (always valid) address and masked by a
+    // select afterwards: a load under `if` makes hipcc wait vmcnt(0) at each join, which
+    // serialises the R rows (seen in the .s: one s_waitcnt vmcnt(0) per 16-B load)
+    const int64_t myr = rb + lane;
+    const bool mine = lane < R && myr < r1;
+    const int64_t er = mine ? myr : r0;
+    float e_x = x[er];
+    if (PRE) e_x *= p.pre[er];
+    const float e_diag = p.diag[er];
+    const float e_post = p.post ? p.post[er] : 1.f;
+    const float e_base = p.base ? p.base[er] : 0.f;
+    const float e_dotw = p.dotw ? p.dotw[er] : 0.f;
+    int4 c[R];
+    float4 v[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const int i = s[t] + 4 * lane;
+      const bool on = i < s[t + 1];
+      const int ii = on ? i : 0;
+      c[t] = *reinterpret_cast<const int4*>(p.col + ii);
+      const float4 vv = *reinterpret_cast<const float4*>(p.vals + ii);
+      v[t] = make_float4(on ? vv.x : 0.f, on ? vv.y : 0.f, on ? vv.z : 0.f, on ? vv.w : 0.f);
+    }
+    // keep the phases apart: all 2R stream loads are in flight before the first gather issues
+    __builtin_amdgcn_sched_barrier(0);
+    float xg[R][4];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      xg[t][0] = x[c[t].x]; xg[t][1] = x[c[t].y]; xg[t][2] = x[c[t].z]; xg[t][3] = x[c[t].w];
+      if (PRE) {
+        xg[t][0] *= p.pre[c[t].x]; xg[t][1] *= p.pre[c[t].y]; xg[t][2] *= p.pre[c[t].z]; xg[t][3] *= p.pre[c[t].w];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float acc[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      float a = v[t].x * xg[t][0];
+      a = fmaf(v[t].y, xg[t][1], a);
+      a = fmaf(v[t].z, xg[t][2], a);
+      a = fmaf(v[t].w, xg[t][3], a);
+      acc[t] = a;
+    }
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      for (int i = s[t] + 4 * lane + 4 * G; i < s[t + 1]; i += 4 * G) {
+        const int4 cc = *reinterpret_cast<const int4*>(p.col + i);
+        const float4 vv = *reinterpret_cast<const float4*>(p.vals + i);
+        float x0 = x[cc.x], x1 = x[cc.y], x2 = x[cc.z], x3 = x[cc.w];
+        if (PRE) { x0 *= p.pre[cc.x]; x1 *= p.pre[cc.y]; x2 *= p.pre[cc.z]; x3 *= p.pre[cc.w]; }
+        acc[t] = fmaf(vv.x, x0, acc[t]);
+        acc[t] = fmaf(vv.y, x1, acc[t]);
+        acc[t] = fmaf(vv.z, x2, acc[t]);
+        acc[t] = fmaf(vv.w, x3, acc[t]);
+      }
+    }
+    float my_acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const float tot = mgp_group_sum<G>(acc[t]);
+      if (lane == t) my_acc = tot;
+    }
+    if (mine) {
+      const float lx = e_diag * e_x - my_acc;
+      const float tt = (p.a * e_x + p.b * lx) * e_post;
+      const float y = p.co * tt + p.cb * e_base;
+      p.Y[myr] = y;
+      dsum = fmaf(e_dotw, y, dsum);
+    }
+  }
+  if (p.dot_partials) {
+    __shared__ float red[kBlock / MGP_WAVE];
+    dsum = mgp_wave_sum(dsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < kBlock / MGP_WAVE; ++w) t += red[w];
+      p.dot_partials[lb] = t;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- C == 1, lane-strided entries
+// Same ownership (G lanes x R rows) but lane l reads entries l, l+G, l+2G, ... of a row with 4-byte
+// loads: one gather instruction then covers G CONSECUTIVE sorted column ids of a row, which mostly
+// fall into a few cache lines of x, so the texture unit merges them into few L2 requests.  With
+// 16-byte-per-lane loads every lane of a gather instruction sits 4 entries apart and nearly every
+// lane pulls its own 64-B line: measured on the 60k graph the L2 -> L1 gather traffic (not HBM, not
+// latency) is what bounds the kernel.
+template <int G, int R, bool PRE>
+__global__ __launch_bounds__(kBlock) void spmv_strided_kernel(SpmmArgs p) {
+  if (p.skip && *p.skip) return;
+  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & (G - 1);
+  const int grp = threadIdx.x / G;
+  constexpr int kGroups = kBlock / G;
+  const int64_t r0 = (int64_t)lb * p.rows_per_block;
+  int64_t r1 = r0 + p.rows_per_block;
+  if (r1 > p.n) r1 = p.n;
+  const float* __restrict__ x = p.X;
+  float dsum = 0.f;
+  for (int64_t rb = r0 + (int64_t)grp * R; rb < r1; rb += (int64_t)kGroups * R) {
+    int s[R + 1];
+#pragma unroll
+    for (int t = 0; t <= R; ++t) {
+      const int64_t rr = rb + t;
+      s[t] = p.rowptr[rr < r1 ? rr : r1];
+    }
+    const int64_t myr = rb + lane;
+    const bool mine = lane < R && myr < r1;
+    const int64_t er = mine ? myr : r0;
+    float e_x = x[er];
+    if (PRE) e_x *= p.pre[er];
+    const float e_diag = p.diag[er];
+    const float e_post = p.post ? p.post[er] : 1.f;
+    const float e_base = p.base ? p.base[er] : 0.f;
+    const float e_dotw = p.dotw ? p.dotw[er] : 0.f;
+    int c[R];
+    float v[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const int i = s[t] + lane;
+      const bool on = i < s[t + 1];
+      const int ii = on ? i : 0;
+      c[t] = p.col[ii];
+      const float vv = p.vals[ii];
+      v[t] = on ? vv : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float xg[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      xg[t] = x[c[t]];
+      if (PRE) xg[t] *= p.pre[c[t]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float acc[R];
+#pragma unroll
+    for (int t = 0; t < R; ++t) acc[t] = v[t] * xg[t];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      for (int i = s[t] + lane + G; i < s[t + 1]; i += G) {
+        const int cc = p.col[i];
+        float xv = x[cc];
+        if (PRE) xv *= p.pre[cc];
+        acc[t] = fmaf(p.vals[i], xv, acc[t]);
+      }
+    }
+    float my_acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const float tot = mgp_group_sum<G>(acc[t]);
+      if (lane == t) my_acc = tot;
+    }
+    if (mine) {
+      const float lx = e_diag * e_x - my_acc;
+      const float tt = (p.a * e_x + p.b * lx) * e_post;
+      const float y = p.co * tt + p.cb * e_base;
+      p.Y[myr] = y;
+      dsum = fmaf(e_dotw, y, dsum);
     }
   }
   if (p.dot_partials) {
@@ -191,21 +347,24 @@ struct Plan {
   int64_t rows_per_block;
 };
 
-Plan make_plan(int64_t n, int groups_per_block) {
-  // contiguous row range per workgroup, at least one pass of the groups, grid <= kMaxGrid
-  int64_t rpb = groups_per_block * 4;
+Plan make_plan(int64_t n, int rows_per_pass) {
+  // contiguous row range per workgroup (a multiple of one pass of its lane groups), grid <= kMaxGrid
+  int64_t rpb = rows_per_pass;
   int64_t grid = mgp_cdiv(n, rpb);
   if (grid > kMaxGrid) {
-    rpb = mgp_cdiv(mgp_cdiv(n, kMaxGrid), groups_per_block) * groups_per_block;
+    rpb = mgp_cdiv(mgp_cdiv(n, kMaxGrid), rows_per_pass) * rows_per_pass;
     grid = mgp_cdiv(n, rpb);
   }
   if (grid < 1) grid = 1;
   return Plan{(int)grid, rpb};
 }
 
-// lanes per row for C == 1 (4 entries per lane per pass).  The host wrapper sets it from the
-// mean padded row length of the graph it built (mgp_spmm_set_group_hint); 16 suits k ~ 50.
+// C == 1 shape: lanes per row (4 entries per lane per pass) and rows in flight per lane group.
+// The host wrapper sets the lanes from the mean padded row length of the graph it built
+// (mgp_spmm_set_group_hint); 16 lanes x 4 rows suits k ~ 50.
 int g_row_group_hint = 16;
+int g_rows_in_flight = 2;
+int g_entry_layout = 0;   // 0: 4 consecutive entries per lane (16-B loads), 1: lane-strided entries
 
 }  // namespace
 
@@ -213,6 +372,24 @@ extern "C" int mgp_spmm_set_group_hint(int lanes) {
   if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return MGP_ERR_ARG;
   g_row_group_hint = lanes;
   return MGP_OK;
+}
+
+extern "C" int mgp_spmm_set_rows_in_flight(int rows) {
+  if (rows != 1 && rows != 2 && rows != 4 && rows != 8) return MGP_ERR_ARG;
+  g_rows_in_flight = rows;
+  return MGP_OK;
+}
+
+extern "C" int mgp_spmm_set_entry_layout(int layout) {
+  if (layout != 0 && layout != 1) return MGP_ERR_ARG;
+  g_entry_layout = layout;
+  return MGP_OK;
+}
+
+static int spmv_rows_in_flight() {
+  int r = g_rows_in_flight;
+  if (r > g_row_group_hint) r = g_row_group_hint;   // lane t finishes row t: needs R <= G
+  return r;
 }
 
 static int spmm_cols_group(int C) {
@@ -223,13 +400,27 @@ static int spmm_cols_group(int C) {
 
 extern "C" int mgp_spmm_dot_blocks(int64_t n, int C) {
   if (n <= 0 || C <= 0) return MGP_ERR_ARG;
-  int groups = (C == 1) ? kBlock / g_row_group_hint : kBlock / spmm_cols_group(C);
+  int groups = (C == 1) ? (kBlock / g_row_group_hint) * spmv_rows_in_flight() : kBlock / spmm_cols_group(C) * 4;
   return make_plan(n, groups).grid;
 }
 
-template <int G, bool PRE>
+template <int G, int R, bool PRE>
 static void launch_spmv(const SpmmArgs& a, int grid, hipStream_t st) {
-  hipLaunchKernelGGL((spmv_kernel<G, PRE>), dim3(grid), dim3(kBlock), 0, st, a);
+  if (g_entry_layout == 1)
+    hipLaunchKernelGGL((spmv_strided_kernel<G, R, PRE>), dim3(grid), dim3(kBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL((spmv_kernel<G, R, PRE>), dim3(grid), dim3(kBlock), 0, st, a);
+}
+
+template <int G, bool PRE>
+static int launch_spmv_r(const SpmmArgs& a, int R, int grid, hipStream_t st) {
+  switch (R) {
+    case 1: launch_spmv<G, 1, PRE>(a, grid, st); return MGP_OK;
+    case 2: launch_spmv<G, 2, PRE>(a, grid, st); return MGP_OK;
+    case 4: launch_spmv<G, 4, PRE>(a, grid, st); return MGP_OK;
+    case 8: if (G >= 8) { launch_spmv<G, (G >= 8 ? 8 : 4), PRE>(a, grid, st); return MGP_OK; }
+  }
+  return MGP_ERR_ARG;
 }
 
 template <int G, int NACC, bool PRE>
@@ -255,12 +446,13 @@ int mgp_spmm_fused_ex(const mgp_csr_t* L, const float* X, int C, float* Y, float
              dotw, dotw ? dot_partials : nullptr, 0, skip, tick};
   if (C == 1) {
     const int G = g_row_group_hint;
-    Plan pl = make_plan(L->n, kBlock / G);
+    const int R = spmv_rows_in_flight();
+    Plan pl = make_plan(L->n, (kBlock / G) * R);
     p.rows_per_block = pl.rows_per_block;
-#define MGP_SPMV_CASE(GG)                                          \
-  case GG:                                                         \
-    if (pre) launch_spmv<GG, true>(p, pl.grid, st);                \
-    else launch_spmv<GG, false>(p, pl.grid, st);                   \
+    int rc = MGP_OK;
+#define MGP_SPMV_CASE(GG)                                                                     \
+  case GG:                                                                                    \
+    rc = pre ? launch_spmv_r<GG, true>(p, R, pl.grid, st) : launch_spmv_r<GG, false>(p, R, pl.grid, st); \
     break;
     switch (G) {
       MGP_SPMV_CASE(4)
@@ -271,10 +463,11 @@ int mgp_spmm_fused_ex(const mgp_csr_t* L, const float* X, int C, float* Y, float
       default: return MGP_ERR_ARG;
     }
 #undef MGP_SPMV_CASE
+    MGP_TRY(rc);
   } else {
     const int G = spmm_cols_group(C);
     const int nacc = (int)mgp_cdiv(C, G);
-    Plan pl = make_plan(L->n, kBlock / G);
+    Plan pl = make_plan(L->n, (kBlock / G) * 4);
     p.rows_per_block = pl.rows_per_block;
 #define MGP_SPMM_LAUNCH(GG, NA)                                    \
   do {                                                             \
@@ -314,4 +507,13 @@ extern "C" int mgp_laplacian_matmul(const mgp_csr_t* L, const float* dsqrt, cons
   const float* pre = mode == 0 ? nullptr : (mode == 1 ? dsqrt : dinvsqrt);
   const float* post = mode == 0 ? nullptr : (mode == 1 ? dinvsqrt : dsqrt);
   return mgp_spmm_fused(L, X, C, Y, 0.f, 1.f, pre, post, nullptr, 0.f, 1.f, nullptr, nullptr, stream);
+}
+
+// Measurement helper (bench.py / tools): `reps` back-to-back launches of Y = L X enqueued from C,
+// so that host-side launch cost per call (Python, ctypes) does not pace the kernels.
+extern "C" int mgp_spmm_repeat(const mgp_csr_t* L, const float* X, int C, float* Y, int reps, void* stream) {
+  for (int i = 0; i < reps; ++i)
+    MGP_TRY(mgp_spmm_fused_ex(L, X, C, Y, 0.f, 1.f, nullptr, nullptr, nullptr, 0.f, 1.f, nullptr, nullptr, nullptr,
+                              nullptr, stream));
+  return MGP_OK;
 }

@@ -22,9 +22,11 @@ class KnnGraph:
         self.nnz = int(col.shape[0])
         self._edge_index = None
         # sub-wave group width for the C == 1 SpMV: 4 entries per lane per pass
+        # measured on the 60k bench graph (tools/tune_spmv.py): 8 lanes x 2 rows in flight is the
+        # fastest shape for mean rows of ~60 entries; wider groups only pay for much longer rows
         mean_row = self.nnz / max(self.n, 1)
-        lanes = 4
-        while lanes < 64 and lanes * 5 < mean_row:
+        lanes = 8
+        while lanes < 64 and lanes * 16 < mean_row:
             lanes *= 2
         self.spmv_lanes = lanes
 

@@ -1,0 +1,77 @@
+"""Synthetic workloads of SURVEY.md section 8(d) (bench / test infrastructure, CPU numpy).
+
+S3 "RMNIST-like": `bases` smooth random 28x28 blob images (uint8 range) x (1 original + 99 rotations
+drawn from U(-45, 45) degrees, bilinear rotation about the centre) flattened to 784 features and
+scaled (x - 127.5) / 255, i.e. the recipe of manifold_gp/utils/rotate_mnist.py:11-31 and
+load_dataset.py:75-77 with synthetic digits (MNIST itself needs a network download).  Target = the
+rotation angle, standardised.  S5: points on a swiss-roll surface in R^3 with N(0, 1e-3) jitter.
+"""
+import numpy as np
+
+
+def blob_images(count, rng, size=28):
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    imgs = np.zeros((count, size, size), np.float32)
+    for i in range(count):
+        k = rng.integers(3, 7)
+        cx, cy = rng.uniform(6, size - 6, k), rng.uniform(6, size - 6, k)
+        sx, sy = rng.uniform(1.5, 4.0, k), rng.uniform(1.5, 4.0, k)
+        amp = rng.uniform(0.5, 1.0, k)
+        img = sum(a * np.exp(-((xx - x0) ** 2) / (2 * s0 ** 2) - ((yy - y0) ** 2) / (2 * s1 ** 2))
+                  for a, x0, y0, s0, s1 in zip(amp, cx, cy, sx, sy))
+        imgs[i] = img / img.max() * 255.0
+    return np.round(imgs).astype(np.uint8)
+
+
+def _rotate_batch(img, angles_deg):
+    """Bilinear rotation of one image about its centre by each angle (zero fill), vectorised."""
+    size = img.shape[0]
+    c = (size - 1) / 2.0
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    a = np.deg2rad(angles_deg).astype(np.float32)[:, None, None]
+    ys = np.cos(a) * (yy - c) + np.sin(a) * (xx - c) + c
+    xs = -np.sin(a) * (yy - c) + np.cos(a) * (xx - c) + c
+    y0, x0 = np.floor(ys).astype(np.int32), np.floor(xs).astype(np.int32)
+    fy, fx = ys - y0, xs - x0
+    pad = np.zeros((size + 2, size + 2), np.float32)
+    pad[1:-1, 1:-1] = img
+
+    def at(yi, xi):
+        ok = (yi >= -1) & (yi <= size) & (xi >= -1) & (xi <= size)
+        return np.where(ok, pad[np.clip(yi + 1, 0, size + 1), np.clip(xi + 1, 0, size + 1)], 0.0)
+
+    out = (at(y0, x0) * (1 - fy) * (1 - fx) + at(y0, x0 + 1) * (1 - fy) * fx +
+           at(y0 + 1, x0) * fy * (1 - fx) + at(y0 + 1, x0 + 1) * fy * fx)
+    return out
+
+
+def rmnist_like(bases=600, per_base=100, seed=1337, max_angle=45.0):
+    """Returns x [bases*per_base, 784] f32 in [-0.5, 0.5], y [N] f32 (standardised angle)."""
+    rng = np.random.default_rng(seed)
+    imgs = blob_images(bases, rng).astype(np.float32)
+    n = bases * per_base
+    x = np.empty((n, 28 * 28), np.float32)
+    ang = np.empty(n, np.float32)
+    for b in range(bases):
+        angles = np.concatenate([[0.0], rng.uniform(-max_angle, max_angle, per_base - 1)]).astype(np.float32)
+        x[b * per_base:(b + 1) * per_base] = _rotate_batch(imgs[b], angles).reshape(per_base, -1)
+        ang[b * per_base:(b + 1) * per_base] = angles
+    x = (np.round(x) - 127.5) / 255.0          # uint8 range like the reference's arrays
+    y = (ang - ang.mean()) / ang.std()
+    return x.astype(np.float32), y.astype(np.float32)
+
+
+def swiss_roll(n, seed=1337):
+    rng = np.random.default_rng(seed)
+    t = 1.5 * np.pi * (1 + 2 * rng.random(n))
+    h = 21 * rng.random(n)
+    x = np.stack([t * np.cos(t), h, t * np.sin(t)], 1) + rng.normal(scale=1e-3, size=(n, 3))
+    y = np.sin(t) + 0.05 * h + rng.normal(scale=0.1, size=n)
+    return x.astype(np.float32), y.astype(np.float32)
+
+
+def bandwidth_rule(knn_d2_first, floor):
+    """Notebook rule (examples/RMNIST_supervised_learning.ipynb:123-125): the smallest eps for which
+    every node keeps a nearest-neighbour weight >= 1e-4: eps_min = sqrt(max_i d2_i,1nn / (-4 ln 1e-4))."""
+    eps_min = float(np.sqrt(np.max(knn_d2_first) / (-4.0 * np.log(1e-4))))
+    return max(float(floor), eps_min), eps_min
