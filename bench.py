@@ -45,7 +45,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(args, dev, rank, world):
+def build_workload(args, dev, rank, world, shard_knn=False):
     import manifold_gp_amd as mgp
     from tools import synth
     t0 = time.time()
@@ -70,11 +70,30 @@ def build_workload(args, dev, rank, world):
     torch.cuda.synchronize()
     t0 = time.time()
     knn = mgp.utils.NearestNeighbors(x)
-    idx, val = knn.graph(k)
+    if shard_knn and world > 1:
+        # k-NN queries sharded by rows (X replicated, no collective in the search); the lists are
+        # all-gathered once and every rank symmetrises the full graph (setup, untimed)
+        import torch.distributed as dist
+        from manifold_gp_amd.graph import KnnGraph
+        n = x.shape[0]
+        per = -(-n // world)
+        r0, r1 = rank * per, min(n, (rank + 1) * per)
+        Dl, Il = knn.search(x[r0:r1], k)
+        Dp = torch.zeros(per, k, device=dev)
+        Ip = torch.zeros(per, k, dtype=torch.int32, device=dev)
+        Dp[: r1 - r0] = Dl
+        Ip[: r1 - r0] = Il.to(torch.int32)
+        Dg = torch.empty(world * per, k, device=dev)
+        Ig = torch.empty(world * per, k, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(Dg, Dp)
+        dist.all_gather_into_tensor(Ig, Ip)
+        knn.knn_graph = KnnGraph.from_knn(Dg[:n].contiguous(), Ig[:n].contiguous())
+        idx, val = knn.knn_graph.edge_index, knn.knn_graph.edge_value
+    else:
+        idx, val = knn.graph(k)
     torch.cuda.synchronize()
     t_graph = time.time() - t0
     graph = knn.knn_graph
-    d1 = None
     # eps: trained value, floored by the notebooks' eps_min rule on the 1-NN distances
     D1, _ = knn.search(x[: min(20000, x.shape[0])], 2)
     eps, eps_min = synth.bandwidth_rule(D1[:, 1].cpu().numpy(), hp["graphbandwidth"])
@@ -175,7 +194,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    if world > 1:
+    if world > 1 or os.environ.get("MGP_FORCE_DIST") == "1":
         from manifold_gp_amd import parallel
         return parallel.bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, HBM_PEAK_GBS)
 
@@ -184,14 +203,13 @@ def main():
     g = wl["graph"]
     plan = CgPlan(wl["desc"], 1, tol=args.tol, max_iter=2000, stop_mode=1, check_every=8)
     y = wl["y"].view(-1, 1).contiguous()
-    out = torch.empty_like(y)
     for _ in range(args.warmup):
-        plan.solve(y, out=out)
+        out = plan.solve(y, copy=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     iters = 0
     for _ in range(args.steps):
-        plan.solve(y, out=out)
+        out = plan.solve(y, copy=False)      # solution stays in the plan's device buffer
         iters += plan.iters
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0

@@ -121,6 +121,12 @@ int mgp_spmm_fused(const mgp_csr_t* L, const float* X, int C, float* Y, float a,
                    const float* pre, const float* post, const float* base, float cb, float co,
                    const float* dotw, float* dot_partials, void* stream);
 
+/* row-partitioned form: L_local = rows [row_offset, row_offset + L_local->n) of the operator (column
+ * ids global), vectors of global length; writes only the local rows of Y (and local dot partials) */
+int mgp_spmm_fused_rows(const mgp_csr_t* L_local, int64_t row_offset, const float* X, int C, float* Y,
+                        float a, float b, const float* pre, const float* post, const float* base,
+                        float cb, float co, const float* dotw, float* dot_partials, void* stream);
+
 /* measurement helper: `reps` back-to-back launches of Y = L X enqueued from C */
 int mgp_spmm_repeat(const mgp_csr_t* L, const float* X, int C, float* Y, int reps, void* stream);
 
@@ -193,6 +199,8 @@ int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
                        void** plan_out);
 int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid,
                       int32_t* status); /* status 1 converged, 2 max_iter, 3 breakdown (NaN) */
+float* mgp_cg_plan_x(void* plan);    /* device pointer of the plan's own solution buffer [n,C]; pass
+                                         X = NULL to mgp_cg_plan_solve to skip the copy into X */
 int mgp_cg_plan_destroy(void* plan);
 int mgp_cg_solve(const mgp_operator_t* op, const float* B, int C, float* X, const float* minv,
                  const mgp_cg_params_t* params, int32_t* iters, float* resid, void* work,
@@ -261,6 +269,33 @@ int mgp_kernel_diag(const float* Z1, const float* Z2, int64_t n, int m, float sc
 size_t mgp_lowrank_workspace_bytes(int m, int C);
 int mgp_lowrank_apply(const float* Z, int64_t n, int m, const float* X, int C, float alpha,
                       float beta, float* Y, void* work, size_t work_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-GPU (one process per GPU, RCCL over xGMI): row-partitioned operator apply and CG.
+ * The reference has no distributed code; this is the north-star's
+ * "CG SpMV row-partitions across the 8 GPUs of one node with one RCCL collective per iteration".
+ *   - rank p owns global rows [p*n_loc, (p+1)*n_loc) of L (op_local->L: local CSR slice whose
+ *     column ids are global; op_local->pre/post and every vector have GLOBAL length world*n_loc and
+ *     are replicated on every rank);
+ *   - per SpMM launch each rank computes its row slice, then ONE grouped ncclAllGather assembles
+ *     the output on every rank; on the last launch of a chain the dot-product partials ride in the
+ *     same group, so CG needs no separate scalar reduction (the vector updates are replicated and
+ *     every rank takes bit-identical decisions);
+ *   - the communicator comes from ncclCommInitRank over a unique id the host distributes. */
+int mgp_dist_unique_id_bytes(void);
+int mgp_dist_unique_id(void* id_out);                          /* rank 0 */
+int mgp_dist_init(int rank, int world, const void* id_bytes, void** comm_out);
+int mgp_dist_destroy(void* comm);
+int mgp_dist_allgather(void* comm, int rank, int world, float* buf, int64_t count_per_rank,
+                       void* stream);                          /* in place, slice p at p*count */
+int mgp_operator_apply_part(const mgp_operator_t* op_local, void* comm, int rank, int world,
+                            const float* X, int C, float* Y, void* work, size_t work_bytes,
+                            void* stream);                     /* work: 4 global-length buffers */
+size_t mgp_cg_dist_workspace_bytes(const mgp_operator_t* op_local, int C, int world);
+int mgp_cg_plan_create_dist(const mgp_operator_t* op_local, int C, const float* minv,
+                            const mgp_cg_params_t* params, void* comm, int rank, int world,
+                            void* work, size_t work_bytes, void* stream, void** plan_out);
+/* solve / x / destroy: mgp_cg_plan_solve, mgp_cg_plan_x, mgp_cg_plan_destroy (B, X global length) */
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,8 @@ SIGNATURES = {
     "mgp_spmm_set_entry_layout": (c_int, [c_int]),
     "mgp_spmm_fused": (c_int, [POINTER(CsrT), _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
                                c_float, _P, _P, _P]),
+    "mgp_spmm_fused_rows": (c_int, [POINTER(CsrT), c_int64, _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
+                                    c_float, _P, _P, _P]),
     "mgp_spmm_repeat": (c_int, [POINTER(CsrT), _P, c_int, _P, c_int, _P]),
     "mgp_laplacian_matmul": (c_int, [POINTER(CsrT), _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "mgp_operator_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int]),
@@ -87,7 +89,17 @@ SIGNATURES = {
     "mgp_cg_plan_create": (c_int, [POINTER(OperatorT), c_int, _P, POINTER(CgParamsT), _P, c_size_t, _P,
                                    POINTER(c_void_p)]),
     "mgp_cg_plan_solve": (c_int, [_P, _P, _P, POINTER(c_int32), POINTER(c_float), POINTER(c_int32)]),
+    "mgp_cg_plan_x": (c_void_p, [_P]),
     "mgp_cg_plan_destroy": (c_int, [_P]),
+    "mgp_dist_unique_id_bytes": (c_int, []),
+    "mgp_dist_unique_id": (c_int, [_P]),
+    "mgp_dist_init": (c_int, [c_int, c_int, _P, POINTER(c_void_p)]),
+    "mgp_dist_destroy": (c_int, [_P]),
+    "mgp_dist_allgather": (c_int, [_P, c_int, c_int, _P, c_int64, _P]),
+    "mgp_operator_apply_part": (c_int, [POINTER(OperatorT), _P, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
+    "mgp_cg_dist_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int, c_int]),
+    "mgp_cg_plan_create_dist": (c_int, [POINTER(OperatorT), c_int, _P, POINTER(CgParamsT), _P, c_int, c_int, _P,
+                                        c_size_t, _P, POINTER(c_void_p)]),
     "mgp_lanczos_workspace_bytes": (c_size_t, [c_int64, c_int, POINTER(LanczosParamsT)]),
     "mgp_lanczos_smallest": (c_int, [POINTER(CsrT), c_int, POINTER(LanczosParamsT), POINTER(c_float), _P,
                                      POINTER(c_float), POINTER(c_int32), _P, c_size_t, _P]),

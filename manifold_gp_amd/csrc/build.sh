@@ -17,5 +17,5 @@ for src in "$here"/*.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$out/libmgp_hip.so" "$obj"/*.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$out/libmgp_hip.so" "$obj"/*.o -L/opt/rocm/lib -lrccl
 echo "built $out/libmgp_hip.so"

@@ -33,6 +33,8 @@ struct CgArgs {
   int64_t n;
   int C, TC, TS;
   float *x, *r, *u, *w, *p, *s;
+  float* us;          // nullable: pre (.) u, the pre-scaled SpMM input (op->pre != NULL)
+  const float* pre;   // op->pre
   const float* minv;
   float* pd_gamma;  // [2][nbv][C]
   float* pd_rr;     // [2][nbv][C]
@@ -44,6 +46,8 @@ struct CgArgs {
   float* bb;         // [C]  ||b||^2
   float* resid;      // [C]  relative residual norm
   int* state;        // [0] iteration (1-based), [1] done, [2] status
+  int* host_state;   // host-mapped mirror of state[0..3], written when the solve ends
+  float* host_resid; // host-mapped [C]
   float tol;
   int max_iter, min_iter, stop_mode;
   int64_t rows_per_block;
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(kBlock) void cg_init_kernel(CgArgs a, const float* 
       a.x[i] = 0.f; a.p[i] = 0.f; a.s[i] = 0.f;
       a.r[i] = b;
       if (a.minv) a.u[i] = u;
+      if (a.us) a.us[i] = a.pre[r] * u;
       g = fmaf(b, u, g);
       rr = fmaf(b, b, rr);
     }
@@ -100,20 +105,45 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   if (r1 > a.n) r1 = a.n;
   const int64_t rf = r0 + sl;
   const bool have = cc < C && rf < r1;
-  float f_u = 0.f, f_p = 0.f, f_s = 0.f, f_w = 0.f, f_x = 0.f, f_r = 0.f, f_m = 1.f;
-  if (have) {
-    const int64_t i = rf * C + cc;
+  float f_u = 0.f, f_p = 0.f, f_s = 0.f, f_w = 0.f, f_x = 0.f, f_r = 0.f, f_m = 1.f, f_pre = 1.f;
+  {
+    const int64_t rs = have ? rf : 0;          // clamped: unconditional loads, no exec-masked waits
+    const int64_t i = rs * C + (cc < C ? cc : 0);
     f_u = a.u[i]; f_p = a.p[i]; f_s = a.s[i]; f_w = a.w[i]; f_x = a.x[i]; f_r = a.r[i];
-    if (a.minv) f_m = a.minv[rf];
+    if (a.minv) f_m = a.minv[rs];
+    if (a.us) f_pre = a.pre[rs];
   }
 
-  // ---- every workgroup reduces the partials in the same fixed order
+  // ---- every workgroup reduces the partials in the same fixed order: thread (sl, cc) sums
+  // partials sl, sl+TS, ... of column cc with independent loads, LDS combines the TS slices
   float g = 0.f, rr = 0.f, d = 0.f;
   if (cc < C) {
     const float* pg = a.pd_gamma + (int64_t)prev * a.nbv * C;
     const float* pr = a.pd_rr + (int64_t)prev * a.nbv * C;
-    for (int b = sl; b < a.nbv; b += a.TS) { g += pg[(int64_t)b * C + cc]; rr += pr[(int64_t)b * C + cc]; }
-    for (int b = sl; b < a.nbs; b += a.TS) d += a.pd_delta[(int64_t)b * C + cc];
+    {
+      float g4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+      int b = sl;
+      for (; b + 3 * a.TS < a.nbv; b += 4 * a.TS) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          g4[q] += pg[(int64_t)(b + q * a.TS) * C + cc];
+          r4[q] += pr[(int64_t)(b + q * a.TS) * C + cc];
+        }
+      }
+      for (; b < a.nbv; b += a.TS) { g4[0] += pg[(int64_t)b * C + cc]; r4[0] += pr[(int64_t)b * C + cc]; }
+      g = (g4[0] + g4[1]) + (g4[2] + g4[3]);
+      rr = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+    }
+    {
+      float d8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int b = sl;
+      for (; b + 7 * a.TS < a.nbs; b += 8 * a.TS) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d8[q] += a.pd_delta[(int64_t)(b + q * a.TS) * C + cc];
+      }
+      for (; b < a.nbs; b += a.TS) d8[0] += a.pd_delta[(int64_t)b * C + cc];
+      d = ((d8[0] + d8[1]) + (d8[2] + d8[3])) + ((d8[4] + d8[5]) + (d8[6] + d8[7]));
+    }
   }
   sh[0][tid] = g; sh[1][tid] = rr; sh[2][tid] = d;
   __syncthreads();
@@ -165,7 +195,14 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
     for (int c = 0; c < C; ++c) if (!isfinite(sh_rel[c])) { done = 1; status = 3; }
     if (!done && it > a.max_iter) { done = 1; status = 2; }
     sh_done = done;
-    if (done && blockIdx.x == 0) { a.state[2] = status; a.state[1] = 1; }
+    if (done && blockIdx.x == 0) {
+      a.state[2] = status; a.state[1] = 1;
+      // zero-copy results for the host: no blit kernels behind the solve
+      for (int c = 0; c < C; ++c) a.host_resid[c] = sh_rel[c];
+      a.host_state[0] = it; a.host_state[2] = status;
+      __threadfence_system();
+      a.host_state[1] = 1;
+    }
   }
   __syncthreads();
   if (sh_done) return;
@@ -191,6 +228,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
       a.r[i] = rn;
       float u2 = rn;
       if (a.minv) { u2 = mo * rn; a.u[i] = u2; }
+      if (a.us) a.us[i] = (r == rf ? f_pre : a.pre[r]) * u2;
       ng = fmaf(rn, u2, ng);
       nrr = fmaf(rn, rn, nrr);
     }
@@ -208,6 +246,9 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
 
 struct CgPlan {
   mgp_operator_t op;
+  MgpDist dist;             // row partition (is_dist): op.L holds the local rows only
+  bool is_dist;
+  int nb_loc;               // SpMM workgroups per rank that write dot partials
   int C;
   mgp_cg_params_t prm;
   CgArgs args;
@@ -230,11 +271,11 @@ int tile_cols(int C) {
   return t;
 }
 
-size_t cg_bytes(const mgp_operator_t* op, int C) {
-  const size_t nc = mgp_align((size_t)op->L.n * C * sizeof(float));
-  const int nbs = mgp_spmm_dot_blocks(op->L.n, C);
-  size_t b = 6 * nc;                                   // x r u w p s
-  b += mgp_operator_workspace_bytes(op, C);
+size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
+  const size_t nc = mgp_align((size_t)op->L.n * world * C * sizeof(float));
+  const int nbs = mgp_spmm_dot_blocks(op->L.n, C) * world;
+  size_t b = 7 * nc;                                   // x r u w p s us
+  b += 4 * nc + 256;                                   // operator chain scratch (global length)
   b += 4 * mgp_align((size_t)kMaxGridVec * C * sizeof(float));   // pd_gamma[2], pd_rr[2]
   b += mgp_align((size_t)nbs * C * sizeof(float));              // pd_delta
   b += 6 * mgp_align((size_t)C * sizeof(float));                // gamma_old[2] alpha_old[2] bb resid
@@ -246,8 +287,9 @@ int enqueue_iteration(CgPlan* pl, hipStream_t st) {
   hipLaunchKernelGGL(cg_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
   MGP_LAUNCH_CHECK();
   // w = A u ; partials of u . w ; skipped once converged ; ticks the iteration counter
-  return mgp_operator_apply_ex(&pl->op, pl->args.u, pl->C, pl->args.w, pl->args.u, pl->pd_delta,
-                               pl->args.state + 1, pl->args.state, pl->op_work, pl->op_work_bytes, st);
+  return mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
+                                 pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, pl->args.state + 1,
+                                 pl->args.state, pl->op_work, pl->op_work_bytes, st);
 }
 
 }  // namespace
@@ -257,16 +299,20 @@ extern "C" size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C) {
   return cg_bytes(op, C);
 }
 
-extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
-                                  const mgp_cg_params_t* params, void* work, size_t work_bytes,
-                                  void* stream, void** plan_out) {
+static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, const mgp_cg_params_t* params,
+                            const MgpDist* dist, void* work, size_t work_bytes, void* stream, void** plan_out) {
   if (!op || !params || !work || !plan_out) return MGP_ERR_ARG;
   if (C <= 0 || C > kMaxC) return C > kMaxC ? MGP_ERR_UNSUPPORTED : MGP_ERR_ARG;
-  if (work_bytes < mgp_cg_workspace_bytes(op, C)) return MGP_ERR_WORKSPACE;
+  const int world = dist ? dist->world : 1;
+  if (dist && (dist->n_loc != op->L.n || dist->world < 1 || dist->rank < 0 || dist->rank >= dist->world))
+    return MGP_ERR_ARG;
+  if (work_bytes < cg_bytes(op, C, world)) return MGP_ERR_WORKSPACE;
   CgPlan* pl = new (std::nothrow) CgPlan();
   if (!pl) return MGP_ERR_ARG;
   memset(pl, 0, sizeof(*pl));
   pl->op = *op;
+  pl->is_dist = dist != nullptr;
+  if (dist) pl->dist = *dist;
   pl->C = C;
   pl->prm = *params;
   if (pl->prm.max_iter <= 0) pl->prm.max_iter = 1000;
@@ -274,7 +320,7 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
   pl->chunk = pl->prm.check_every > 0 ? pl->prm.check_every : 10;
   pl->chunk_small = pl->chunk < 4 ? pl->chunk : 4;
   pl->stream = mgp_stream(stream);
-  const int64_t n = op->L.n;
+  const int64_t n = op->L.n * world;        // global vector length
   const size_t nc = (size_t)n * C;
   MgpArena ar(work, work_bytes);
   CgArgs& a = pl->args;
@@ -282,9 +328,12 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
   a.x = ar.take<float>(nc); a.r = ar.take<float>(nc);
   float* ubuf = ar.take<float>(nc);
   a.w = ar.take<float>(nc); a.p = ar.take<float>(nc); a.s = ar.take<float>(nc);
+  float* usbuf = ar.take<float>(nc);
   a.minv = minv;
   a.u = minv ? ubuf : a.r;
-  pl->op_work_bytes = mgp_operator_workspace_bytes(op, C);
+  a.pre = op->pre;
+  a.us = op->pre ? usbuf : nullptr;
+  pl->op_work_bytes = 4 * mgp_align(nc * sizeof(float)) + 256;
   pl->op_work = ar.take<char>(pl->op_work_bytes);
   // contiguous row ranges per workgroup, at most kMaxGridVec workgroups
   int64_t rpb = a.TS;
@@ -293,7 +342,8 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
   a.rows_per_block = rpb; a.nbv = (int)nbv;
   a.pd_gamma = ar.take<float>(2 * (size_t)kMaxGridVec * C);
   a.pd_rr = ar.take<float>(2 * (size_t)kMaxGridVec * C);
-  a.nbs = mgp_spmm_dot_blocks(n, C);
+  pl->nb_loc = mgp_spmm_dot_blocks(op->L.n, C);
+  a.nbs = pl->nb_loc * world;
   pl->pd_delta = ar.take<float>((size_t)a.nbs * C);
   a.pd_delta = pl->pd_delta;
   a.gamma_old = ar.take<float>(2 * (size_t)C);
@@ -304,11 +354,13 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
   a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter;
   a.stop_mode = pl->prm.stop_mode;
   if (!ar.ok()) { delete pl; return MGP_ERR_WORKSPACE; }
-  hipError_t e = hipHostMalloc((void**)&pl->host_state, 16 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_resid, (size_t)C * sizeof(float));
+  hipError_t e = hipHostMalloc((void**)&pl->host_state, 16 * sizeof(int32_t), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_resid, (size_t)C * sizeof(float), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&a.host_state, pl->host_state, 0);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&a.host_resid, pl->host_resid, 0);
   if (e != hipSuccess) { delete pl; return (int)e; }
 
-  if (pl->prm.use_graph) {
+  if (pl->prm.use_graph && !pl->is_dist) {   // collectives are enqueued eagerly (no capture)
     e = hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking);
     bool ok = (e == hipSuccess);
     for (int which = 0; which < 2 && ok; ++which) {
@@ -330,16 +382,37 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
   return MGP_OK;
 }
 
+extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
+                                  const mgp_cg_params_t* params, void* work, size_t work_bytes,
+                                  void* stream, void** plan_out) {
+  return plan_create_impl(op, C, minv, params, nullptr, work, work_bytes, stream, plan_out);
+}
+
+extern "C" size_t mgp_cg_dist_workspace_bytes(const mgp_operator_t* op_local, int C, int world) {
+  if (!op_local || C <= 0 || C > kMaxC || op_local->L.n <= 0 || world < 1) return 0;
+  return cg_bytes(op_local, C, world);
+}
+
+extern "C" int mgp_cg_plan_create_dist(const mgp_operator_t* op_local, int C, const float* minv,
+                                       const mgp_cg_params_t* params, void* comm, int rank, int world,
+                                       void* work, size_t work_bytes, void* stream, void** plan_out) {
+  if (!op_local || !comm) return MGP_ERR_ARG;
+  MgpDist d{comm, rank, world, op_local->L.n, (int64_t)rank * op_local->L.n};
+  return plan_create_impl(op_local, C, minv, params, &d, work, work_bytes, stream, plan_out);
+}
+
 extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid,
                                  int32_t* status) {
   CgPlan* pl = static_cast<CgPlan*>(plan);
-  if (!pl || !B || !X) return MGP_ERR_ARG;
+  if (!pl || !B) return MGP_ERR_ARG;   // X == NULL: leave the solution in the plan (mgp_cg_plan_x)
   hipStream_t st = pl->stream;
   const size_t nc = (size_t)pl->args.n * pl->C;
   hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, B);
   MGP_LAUNCH_CHECK();
-  MGP_TRY(mgp_operator_apply_ex(&pl->op, pl->args.u, pl->C, pl->args.w, pl->args.u, pl->pd_delta, nullptr,
-                                nullptr, pl->op_work, pl->op_work_bytes, st));
+  MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
+                                  pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, nullptr, nullptr, pl->op_work,
+                                  pl->op_work_bytes, st));
+  pl->host_state[1] = 0;
   int guard = 0;
   bool first = true;
   for (;;) {
@@ -350,11 +423,9 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
       for (int i = 0; i < len; ++i) MGP_TRY(enqueue_iteration(pl, st));
     }
     first = false;
-    // results ride behind every chunk so that one synchronisation ends the solve
-    MGP_HIP_TRY(hipMemcpyAsync(X, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
-    MGP_HIP_TRY(hipMemcpyAsync(pl->host_resid, pl->args.resid, (size_t)pl->C * sizeof(float),
-                               hipMemcpyDeviceToHost, st));
-    MGP_HIP_TRY(hipMemcpyAsync(pl->host_state, pl->args.state, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // the solution rides behind every chunk so that one synchronisation ends the solve; the
+    // convergence flag / residuals arrive through host-mapped memory written by the update kernel
+    if (X) MGP_HIP_TRY(hipMemcpyAsync(X, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
     MGP_HIP_TRY(hipStreamSynchronize(st));
     if (pl->host_state[1]) break;
     if (++guard > pl->prm.max_iter / pl->chunk_small + 4) break;
@@ -363,6 +434,12 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
   if (status) *status = pl->host_state[2];
   if (resid) memcpy(resid, pl->host_resid, (size_t)pl->C * sizeof(float));
   return MGP_OK;
+}
+
+// device pointer of the plan's solution buffer [n, C] (valid until the plan is destroyed)
+extern "C" float* mgp_cg_plan_x(void* plan) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  return pl ? pl->args.x : nullptr;
 }
 
 extern "C" int mgp_cg_plan_destroy(void* plan) {

@@ -8,7 +8,33 @@ int mgp_spmm_fused_ex(const mgp_csr_t* L, const float* X, int C, float* Y, float
                       const float* pre, const float* post, const float* base, float cb, float co,
                       const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream);
 
+// row-partitioned form: L holds the LOCAL rows [0, L->n) of a larger operator whose vectors are
+// global; local row r is global row r + row_offset (columns in L->col are global already)
+int mgp_spmm_fused_part(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
+                        const float* pre, const float* post, const float* base, float cb, float co,
+                        const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream);
+
 // operator chain with the same hooks on its LAST SpMM
 int mgp_operator_apply_ex(const mgp_operator_t* op, const float* X, int C, float* Y, const float* dotw,
                           float* dot_partials, const int* skip, int* tick, void* work, size_t work_bytes,
                           void* stream);
+
+// as above with Xs = diag(op->pre) X precomputed by the caller (nullable)
+int mgp_operator_apply_ex2(const mgp_operator_t* op, const float* X, const float* Xs, int C, float* Y,
+                           const float* dotw, float* dot_partials, const int* skip, int* tick, void* work,
+                           size_t work_bytes, void* stream);
+
+// Row partition over the ranks of one node: rank p owns global rows [p * n_loc, (p+1) * n_loc);
+// vectors are replicated (global length world * n_loc); after every local SpMM the output slices
+// (and, on the last launch of a chain, the dot-product partials) are all-gathered over RCCL.
+struct MgpDist {
+  void* comm;          // ncclComm_t
+  int rank, world;
+  int64_t n_loc;
+  int64_t row_offset;  // rank * n_loc
+};
+
+int mgp_operator_apply_dist(const mgp_operator_t* op, const MgpDist* d, const float* X, const float* Xs, int C,
+                            float* Y, const float* dotw, float* dot_partials, int nb_loc, const int* skip, int* tick,
+                            void* work, size_t work_bytes, void* stream);
+int mgp_dist_allgather_f32(const MgpDist* d, float* buf, int64_t count_per_rank, void* stream);

@@ -10,6 +10,7 @@
 // fresh [N,C] tensor for each; here one Q application is nu launches that ping-pong between two
 // workspace buffers, the axpy of the wrappers rides in the epilogue of the last launch
 // (base / cb / co), and the dot product CG needs rides along as per-workgroup partials.
+#include <rccl/rccl.h>
 #include "mgp_common.h"
 #include "mgp_internal.h"
 
@@ -22,20 +23,45 @@ struct Hooks {
   int* tick;
 };
 
+}  // namespace
+
+// in-place all-gather of `count_per_rank` floats per rank (slice p at buf + p * count_per_rank)
+int mgp_dist_allgather_f32(const MgpDist* d, float* buf, int64_t count_per_rank, void* stream) {
+  ncclResult_t r = ncclAllGather(buf + (int64_t)d->rank * count_per_rank, buf, (size_t)count_per_rank, ncclFloat,
+                                 static_cast<ncclComm_t>(d->comm), mgp_stream(stream));
+  return r == ncclSuccess ? MGP_OK : 1000 + (int)r;
+}
+
+namespace {
+
 // Y = cb * base + co * Q2 X   (base nullable).  t0/t1: [n*C] scratch, distinct from X and Y.
-int q2_chain(const mgp_operator_t* op, const float* X, int C, float* Y, const float* base, float cb,
-             float co, float* t0, float* t1, const Hooks* hk, void* stream) {
+// Xs (nullable): diag(pre) X already formed by the producer of X (saves the second gather per entry)
+// d (nullable): row partition -- each launch computes the local rows, then the slices are gathered
+int q2_chain(const mgp_operator_t* op, const MgpDist* d, int nb_loc, const float* X, const float* Xs, int C,
+             float* Y, const float* base, float cb, float co, float* t0, float* t1, const Hooks* hk, void* stream) {
   const float tau = 2.0f * (float)op->nu / (op->kappa * op->kappa);
-  const float* in = X;
+  const float* in = Xs ? Xs : X;
   for (int s = 0; s < op->nu; ++s) {
     const bool first = (s == 0), last = (s == op->nu - 1);
     float* out = last ? Y : ((s & 1) ? t1 : t0);
     // (x + delta L x) / delta == tau x + L x  with delta = 1/tau (precision_matern_operator.py:31-33)
-    MGP_TRY(mgp_spmm_fused_ex(&op->L, in, C, out, tau, 1.0f, first ? op->pre : nullptr,
-                              last ? op->post : nullptr, last ? base : nullptr, cb,
-                              last ? co * op->scale : 1.0f, (last && hk) ? hk->dotw : nullptr,
-                              (last && hk) ? hk->dot_partials : nullptr, hk ? hk->skip : nullptr,
-                              (last && hk) ? hk->tick : nullptr, stream));
+    float* dp = (last && hk) ? hk->dot_partials : nullptr;
+    if (dp && d) dp += (int64_t)d->rank * nb_loc * C;      // this rank's segment of the gathered partials
+    MGP_TRY(mgp_spmm_fused_part(&op->L, d ? d->row_offset : 0, in, C, out, tau, 1.0f,
+                                (first && !Xs) ? op->pre : nullptr, last ? op->post : nullptr,
+                                last ? base : nullptr, cb, last ? co * op->scale : 1.0f,
+                                (last && hk) ? hk->dotw : nullptr, dp, hk ? hk->skip : nullptr,
+                                (last && hk) ? hk->tick : nullptr, stream));
+    if (d) {
+      // the collectives run unconditionally (also after convergence) so that every rank issues
+      // the same sequence; a skipped launch leaves stale but finite data behind them
+      if (dp) ncclGroupStart();
+      MGP_TRY(mgp_dist_allgather_f32(d, out, d->n_loc * C, stream));
+      if (dp) {
+        MGP_TRY(mgp_dist_allgather_f32(d, hk->dot_partials, (int64_t)nb_loc * C, stream));
+        ncclGroupEnd();
+      }
+    }
     in = out;
   }
   return MGP_OK;
@@ -58,11 +84,26 @@ extern "C" size_t mgp_operator_workspace_bytes(const mgp_operator_t* op, int C) 
 int mgp_operator_apply_ex(const mgp_operator_t* op, const float* X, int C, float* Y, const float* dotw,
                           float* dot_partials, const int* skip, int* tick, void* work, size_t work_bytes,
                           void* stream) {
+  return mgp_operator_apply_ex2(op, X, nullptr, C, Y, dotw, dot_partials, skip, tick, work, work_bytes, stream);
+}
+
+int mgp_operator_apply_ex2(const mgp_operator_t* op, const float* X, const float* Xs, int C, float* Y,
+                           const float* dotw, float* dot_partials, const int* skip, int* tick, void* work,
+                           size_t work_bytes, void* stream) {
+  return mgp_operator_apply_dist(op, nullptr, X, Xs, C, Y, dotw, dot_partials, 0, skip, tick, work, work_bytes,
+                                 stream);
+}
+
+// work must hold 4 buffers of the GLOBAL vector length (world * n_loc * C floats) when d != NULL
+int mgp_operator_apply_dist(const mgp_operator_t* op, const MgpDist* d, const float* X, const float* Xs, int C,
+                            float* Y, const float* dotw, float* dot_partials, int nb_loc, const int* skip, int* tick,
+                            void* work, size_t work_bytes, void* stream) {
   MGP_TRY(check_op(op));
   if (!X || !Y || X == Y || C <= 0) return MGP_ERR_ARG;
-  if (!work || work_bytes < mgp_operator_workspace_bytes(op, C)) return MGP_ERR_WORKSPACE;
+  const int64_t nrows = d ? d->n_loc * d->world : op->L.n;
+  if (!work || work_bytes < 4 * mgp_align((size_t)nrows * C * sizeof(float))) return MGP_ERR_WORKSPACE;
   MgpArena ar(work, work_bytes);
-  const size_t nc = (size_t)op->L.n * C;
+  const size_t nc = (size_t)nrows * C;
   float* t0 = ar.take<float>(nc);
   float* t1 = ar.take<float>(nc);
   float* ua = ar.take<float>(nc);
@@ -72,14 +113,14 @@ int mgp_operator_apply_ex(const mgp_operator_t* op, const float* X, int C, float
   Hooks hk_mid{nullptr, nullptr, skip, nullptr};
   switch (op->form) {
     case 0:
-      return q2_chain(op, X, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
+      return q2_chain(op, d, nb_loc, X, Xs, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
     case 2:
-      return q2_chain(op, X, C, Y, X, 1.f, op->noise, t0, t1, &hk, stream);
+      return q2_chain(op, d, nb_loc, X, Xs, C, Y, X, 1.f, op->noise, t0, t1, &hk, stream);
     case 1:
       // Q(v - s Q(v - s Q v))
-      MGP_TRY(q2_chain(op, X, C, ua, X, 1.f, -op->noise, t0, t1, &hk_mid, stream));
-      MGP_TRY(q2_chain(op, ua, C, ub, X, 1.f, -op->noise, t0, t1, &hk_mid, stream));
-      return q2_chain(op, ub, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
+      MGP_TRY(q2_chain(op, d, nb_loc, X, Xs, C, ua, X, 1.f, -op->noise, t0, t1, &hk_mid, stream));
+      MGP_TRY(q2_chain(op, d, nb_loc, ua, nullptr, C, ub, X, 1.f, -op->noise, t0, t1, &hk_mid, stream));
+      return q2_chain(op, d, nb_loc, ub, nullptr, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
   }
   return MGP_ERR_ARG;
 }

@@ -47,14 +47,17 @@ struct SpmmArgs {
   int64_t rows_per_block;
   const int* skip;   // nullable: workgroups return at once when *skip != 0 (CG converged)
   int* tick;         // nullable: workgroup 0 adds 1 when the launch is not skipped
+  int64_t goff;      // row partition: CSR rows are local [0, n), vectors are global -> row r is
+                     // element r + goff of X / Y / pre / post / base / dotw (0 on one GPU)
 };
 
 __device__ __forceinline__ float epilogue(const SpmmArgs& p, int64_t r, int c, float xs, float acc) {
+  const int64_t gr = r + p.goff;
   float lx = p.diag[r] * xs - acc;
   float t = p.a * xs + p.b * lx;
-  if (p.post) t *= p.post[r];
+  if (p.post) t *= p.post[gr];
   float y = p.co * t;
-  if (p.base) y += p.cb * p.base[r * p.C + c];
+  if (p.base) y += p.cb * p.base[gr * p.C + c];
   return y;
 }
 
@@ -91,12 +94,13 @@ __global__ __launch_bounds__(kBlock) void spmv_kernel(SpmmArgs p) {
     const int64_t myr = rb + lane;
     const bool mine = lane < R && myr < r1;
     const int64_t er = mine ? myr : r0;
-    float e_x = x[er];
-    if (PRE) e_x *= p.pre[er];
+    const int64_t ger = er + p.goff;
+    float e_x = x[ger];
+    if (PRE) e_x *= p.pre[ger];
     const float e_diag = p.diag[er];
-    const float e_post = p.post ? p.post[er] : 1.f;
-    const float e_base = p.base ? p.base[er] : 0.f;
-    const float e_dotw = p.dotw ? p.dotw[er] : 0.f;
+    const float e_post = p.post ? p.post[ger] : 1.f;
+    const float e_base = p.base ? p.base[ger] : 0.f;
+    const float e_dotw = p.dotw ? p.dotw[ger] : 0.f;
     int4 c[R];
     float4 v[R];
 #pragma unroll
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void spmv_kernel(SpmmArgs p) {
       const float lx = e_diag * e_x - my_acc;
       const float tt = (p.a * e_x + p.b * lx) * e_post;
       const float y = p.co * tt + p.cb * e_base;
-      p.Y[myr] = y;
+      p.Y[myr + p.goff] = y;
       dsum = fmaf(e_dotw, y, dsum);
     }
   }
@@ -199,12 +203,13 @@ __global__ __launch_bounds__(kBlock) void spmv_strided_kernel(SpmmArgs p) {
     const int64_t myr = rb + lane;
     const bool mine = lane < R && myr < r1;
     const int64_t er = mine ? myr : r0;
-    float e_x = x[er];
-    if (PRE) e_x *= p.pre[er];
+    const int64_t ger = er + p.goff;
+    float e_x = x[ger];
+    if (PRE) e_x *= p.pre[ger];
     const float e_diag = p.diag[er];
-    const float e_post = p.post ? p.post[er] : 1.f;
-    const float e_base = p.base ? p.base[er] : 0.f;
-    const float e_dotw = p.dotw ? p.dotw[er] : 0.f;
+    const float e_post = p.post ? p.post[ger] : 1.f;
+    const float e_base = p.base ? p.base[ger] : 0.f;
+    const float e_dotw = p.dotw ? p.dotw[ger] : 0.f;
     int c[R];
     float v[R];
 #pragma unroll
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(kBlock) void spmv_strided_kernel(SpmmArgs p) {
       const float lx = e_diag * e_x - my_acc;
       const float tt = (p.a * e_x + p.b * lx) * e_post;
       const float y = p.co * tt + p.cb * e_base;
-      p.Y[myr] = y;
+      p.Y[myr + p.goff] = y;
       dsum = fmaf(e_dotw, y, dsum);
     }
   }
@@ -289,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs p) {
     for (int a = 0; a < NACC; ++a) acc[a] = 0.f;
     for (int i0 = s; i0 < e; i0 += G) {
       const int i = i0 + lane;
-      int cj = (int)r;
+      int cj = (int)(r + p.goff);
       float vj = 0.f;
       if (i < e) { cj = p.col[i]; vj = p.vals[i]; }
       if (PRE) vj *= p.pre[cj];
@@ -312,15 +317,16 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs p) {
         }
       }
     }
-    const float prer = PRE ? p.pre[r] : 1.f;
+    const int64_t gr = r + p.goff;
+    const float prer = PRE ? p.pre[gr] : 1.f;
 #pragma unroll
     for (int a = 0; a < NACC; ++a) {
       const int c = lane + a * G;
       if (c < C) {
-        const float xs = p.X[r * C + c] * prer;
+        const float xs = p.X[gr * C + c] * prer;
         const float y = epilogue(p, r, c, xs, acc[a]);
-        p.Y[r * C + c] = y;
-        if (p.dotw) dsum[a] = fmaf(p.dotw[r * C + c], y, dsum[a]);
+        p.Y[gr * C + c] = y;
+        if (p.dotw) dsum[a] = fmaf(p.dotw[gr * C + c], y, dsum[a]);
       }
     }
   }
@@ -438,12 +444,18 @@ extern "C" int mgp_spmm_fused(const mgp_csr_t* L, const float* X, int C, float* 
 int mgp_spmm_fused_ex(const mgp_csr_t* L, const float* X, int C, float* Y, float a, float b,
                       const float* pre, const float* post, const float* base, float cb, float co,
                       const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream) {
+  return mgp_spmm_fused_part(L, 0, X, C, Y, a, b, pre, post, base, cb, co, dotw, dot_partials, skip, tick, stream);
+}
+
+int mgp_spmm_fused_part(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
+                        const float* pre, const float* post, const float* base, float cb, float co,
+                        const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream) {
   if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !X || !Y) return MGP_ERR_ARG;
   if (L->n <= 0 || C <= 0 || C > 256) return C > 256 ? MGP_ERR_UNSUPPORTED : MGP_ERR_ARG;
   if (X == Y) return MGP_ERR_ARG;  // rows gather other rows of X: never in place
   hipStream_t st = mgp_stream(stream);
   SpmmArgs p{L->n, L->rowptr, L->col, L->vals, L->diag, X, Y, C, a, b, pre, post, base, cb, co,
-             dotw, dotw ? dot_partials : nullptr, 0, skip, tick};
+             dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset};
   if (C == 1) {
     const int G = g_row_group_hint;
     const int R = spmv_rows_in_flight();
@@ -507,6 +519,18 @@ extern "C" int mgp_laplacian_matmul(const mgp_csr_t* L, const float* dsqrt, cons
   const float* pre = mode == 0 ? nullptr : (mode == 1 ? dsqrt : dinvsqrt);
   const float* post = mode == 0 ? nullptr : (mode == 1 ? dinvsqrt : dsqrt);
   return mgp_spmm_fused(L, X, C, Y, 0.f, 1.f, pre, post, nullptr, 0.f, 1.f, nullptr, nullptr, stream);
+}
+
+// Row-partitioned form of mgp_spmm_fused: L_local holds rows [row_offset, row_offset + L_local->n) of
+// the operator (column ids global), every vector has the global length; only the local rows of Y are
+// written.  The multi-GPU path gathers the slices with RCCL (operator.hip); callers with their own
+// exchange layer can use this entry directly.
+extern "C" int mgp_spmm_fused_rows(const mgp_csr_t* L_local, int64_t row_offset, const float* X, int C, float* Y,
+                                   float a, float b, const float* pre, const float* post, const float* base,
+                                   float cb, float co, const float* dotw, float* dot_partials, void* stream) {
+  if (row_offset < 0) return MGP_ERR_ARG;
+  return mgp_spmm_fused_part(L_local, row_offset, X, C, Y, a, b, pre, post, base, cb, co, dotw, dot_partials, nullptr,
+                             nullptr, stream);
 }
 
 // Measurement helper (bench.py / tools): `reps` back-to-back launches of Y = L X enqueued from C,

@@ -44,15 +44,26 @@ class CgPlan:
         self.status = 0
         self.resid = None
 
-    def solve(self, B, out=None):
+    def solution_view(self):
+        """The plan's own solution buffer as a tensor view (no copy; overwritten by the next solve)."""
+        off = int(lib().mgp_cg_plan_x(self.handle)) - self.work.data_ptr()
+        nb = self.desc.n * self.C * 4
+        return self.work[off:off + nb].view(torch.float32).view(self.desc.n, self.C)
+
+    def solve(self, B, out=None, copy=True):
         _lib.require_device(B)
         B = _lib.f32c(B)
         assert B.shape == (self.desc.n, self.C)
-        X = torch.empty_like(B) if out is None else out
+        if copy:
+            X = torch.empty_like(B) if out is None else out
+        else:
+            X = None
         iters, status = ctypes.c_int32(0), ctypes.c_int32(0)
         resid = (ctypes.c_float * self.C)()
         check(lib().mgp_cg_plan_solve(self.handle, ptr(B), ptr(X), ctypes.byref(iters), resid,
                                       ctypes.byref(status)), "mgp_cg_plan_solve")
+        if X is None:
+            X = self.solution_view()
         self.iters, self.status = iters.value, status.value
         self.resid = list(resid)
         return X

@@ -447,3 +447,68 @@ def test_full_size_properties_60k(mgp, dev):
     # graph replay and eager launches give the same bits
     sol2, _, _ = cg_solve(desc, y, tol=1e-6, stop_mode=1, use_graph=False)
     assert torch.equal(sol, sol2)
+
+
+# ----------------------------------------------------------------------------- row partition (multi-GPU path)
+@pytest.mark.parametrize("P", [2, 3, 8])
+@pytest.mark.parametrize("C", [1, 5])
+def test_row_partitioned_spmm_tiles_the_full_product(mgp, golden, dev, P, C):
+    """Virtual ranks on one GPU: every rank's row slice (mgp_spmm_fused_rows) written into one global
+    Y must reproduce the single-GPU product bit for bit, including the dot partials' sum."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.graph import LaplacianData
+    from manifold_gp_amd.parallel import RowPartition, local_csr, pad_graph
+    g = golden("dumbbell_k10_loop")
+    op = _operator(mgp, g, dev, "symmetric")
+    n = op.shape[0]
+    part = RowPartition(n, P)
+    gp = pad_graph(op.graph, part.n_pad)
+    data = LaplacianData(gp, float(g["eps"]), True)
+    X = torch.randn(part.n_pad, C, device=dev)
+    X[n:] = 0
+    pre = torch.rand(part.n_pad, device=dev) + 0.5
+    full = torch.empty_like(X)
+    lib = _lib.lib()
+    lib.mgp_spmm_set_group_hint(gp.spmv_lanes)
+    csr = data.csr()
+    _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(full), 1.5, 1.0, _lib.ptr(pre), _lib.ptr(pre),
+                                  _lib.ptr(X), 0.5, 2.0, None, None, _lib.stream()), "mgp_spmm_fused")
+    tiled = torch.full_like(X, float("nan"))
+    for r in range(P):
+        loc = local_csr(data, part, r)
+        lc = _lib.csr_struct(loc["n_loc"], loc["rowptr"], loc["col"], loc["vals"], loc["diag"])
+        _lib.check(lib.mgp_spmm_fused_rows(ctypes.byref(lc), part.range(r)[0], _lib.ptr(X), C, _lib.ptr(tiled), 1.5, 1.0,
+                                           _lib.ptr(pre), _lib.ptr(pre), _lib.ptr(X), 0.5, 2.0, None, None,
+                                           _lib.stream()), "mgp_spmm_fused_rows")
+    assert torch.equal(tiled, full)
+    # padding rows behave as isolated nodes: L row = 0 -> y = post * a * pre * x (x = 0 there)
+    assert float(tiled[n:].abs().max()) == 0.0
+
+
+def test_distributed_plan_world1_matches_single_gpu(mgp, golden, dev):
+    """The RCCL path with a communicator of size 1: same iterates as the single-GPU plan."""
+    from manifold_gp_amd.graph import LaplacianData
+    from manifold_gp_amd.parallel import DistCgPlan, RowPartition, apply_partitioned, init_comm, pad_graph
+    from manifold_gp_amd.solvers import cg_solve
+    g = golden("dumbbell_k10_loop")
+    lap = _operator(mgp, g, dev, "randomwalk")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[float(g["kappa"])]], device=dev))
+    desc = Q._descriptor().with_(scale=0.7, form=2, noise=1e-2)
+    n = desc.n
+    part = RowPartition(n, 1)
+    comm = init_comm(0, 1)
+    gp = pad_graph(lap.graph, part.n_pad)
+    data = LaplacianData(gp, float(g["eps"]), True)
+    dd = desc.with_(data=data, pre=data.dsqrt, post=data.dsqrt)
+    y = part.pad(T(g["train_y"], dev).view(-1, 1)).contiguous()
+    plan = DistCgPlan(dd, part, 0, comm, C=1, tol=1e-7, stop_mode=1, max_iter=3000)
+    xd = plan.solve(y).clone()
+    xs, its, _ = cg_solve(desc, T(g["train_y"], dev), tol=1e-7, stop_mode=1, max_iter=3000)
+    assert plan.status == 1 and abs(plan.iters - its) <= 1
+    assert float((xd[:n, 0] - xs).abs().max()) <= 2e-6 * float(xs.abs().max())
+    # true residual: fp32 attainable accuracy ~ eps32 * cond-ish (|A| ~ 1e3 here), same as one GPU
+    r = apply_partitioned(dd, part, 0, comm, xd) - y
+    r1 = desc.apply(xs) - T(g["train_y"], dev)
+    assert float(r.norm() / y.norm()) < max(1e-4, 3 * float(r1.norm() / y.norm()))
+    plan.close()

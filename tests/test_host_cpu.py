@@ -1,0 +1,175 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/mgp_hip.h
+declares, the ctypes table mirrors the header, the plugin-surface compatibility layer behaves like
+the reference's base classes, and the product path refuses to run without a device."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    hdr = open(os.path.join(ROOT, "include", "mgp_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(mgp_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_header_symbol():
+    from manifold_gp_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    names = _header_symbols()
+    assert len(names) >= 35
+    for name in names:
+        assert hasattr(handle, name), "libmgp_hip.so does not export %s" % name
+    # the ctypes signature table and the header name the same entry points
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib().mgp_version() >= 100
+
+
+def test_struct_layouts_match_c_abi():
+    """mgp_csr_t / mgp_operator_t / params structs: sizes as the C compiler lays them out."""
+    from manifold_gp_amd import _lib
+    assert ctypes.sizeof(_lib.CsrT) == 40
+    assert ctypes.sizeof(_lib.OperatorT) == 40 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
+    assert ctypes.sizeof(_lib.CgParamsT) == 24
+    assert ctypes.sizeof(_lib.LanczosParamsT) == 24
+    assert _lib.OperatorT.pre.offset == 40 and _lib.OperatorT.nu.offset == 56
+
+
+def test_argument_errors_without_gpu():
+    """Entry points validate arguments before touching the device."""
+    from manifold_gp_amd import _lib
+    lib = _lib.lib()
+    assert lib.mgp_knn_workspace_bytes(0, 0, 0, 0) == 0
+    assert lib.mgp_graph_workspace_bytes(-1, 5) == 0
+    assert lib.mgp_spmm_dot_blocks(0, 1) == -1
+    assert lib.mgp_spmm_set_group_hint(3) == -1 and lib.mgp_spmm_set_group_hint(8) == 0
+    assert lib.mgp_spmm_set_rows_in_flight(3) == -1 and lib.mgp_spmm_set_rows_in_flight(2) == 0
+    assert lib.mgp_spmm_fused(None, None, 1, None, 0.0, 1.0, None, None, None, 0.0, 1.0, None, None, None) == -1
+    assert lib.mgp_laplacian_build(10, None, None, None, 1.0, 1, None, None, None, None, None, None, None) == -1
+    assert lib.mgp_cg_plan_destroy(None) == -1
+    with pytest.raises(_lib.MgpError):
+        _lib.check(-2, "x")
+
+
+def test_product_path_refuses_cpu_tensors():
+    import manifold_gp_amd as mgp
+    x = torch.randn(50, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mgp.utils.NearestNeighbors(x)
+    idx = torch.tensor([[0, 1], [1, 2]])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        mgp.operators.GraphLaplacianOperator(torch.rand(2), idx, 3, torch.tensor([[0.5]]))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from manifold_gp_amd import _lib
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libmgp_hip.so"))
+    with pytest.raises(RuntimeError, match="no fallback"):
+        _lib.lib()
+
+
+def test_settings_context_managers():
+    from manifold_gp_amd import settings
+    assert settings.cg_tolerance.value() == 1.0 and settings.max_cholesky_size.value() == 800
+    with settings.cg_tolerance(1e-2), settings.max_cg_iterations(77):
+        assert settings.cg_tolerance.value() == 1e-2
+        assert settings.max_cg_iterations.value() == 77
+        with settings.cg_tolerance(1e-3):
+            assert settings.cg_tolerance.value() == 1e-3
+        assert settings.cg_tolerance.value() == 1e-2
+    assert settings.cg_tolerance.value() == 1.0 and settings.max_cg_iterations.value() == 1000
+
+
+def test_protocol_linear_operator_surface():
+    """The stand-in base offers the entry points the reference's tests call
+    (test/_test_functions.py: matmul, .T, diagonal, solve, inv_quad_logdet, diagonalization)."""
+    from manifold_gp_amd._compat import LinearOperator
+
+    class Dense(LinearOperator):
+        def __init__(self, A):
+            super().__init__(A)
+            self.A = A
+
+        def _matmul(self, rhs):
+            return self.A @ rhs
+
+        def _size(self):
+            return self.A.shape
+
+        def _transpose_nonbatch(self):
+            return Dense(self.A.t())
+
+        def _diagonal(self):
+            return self.A.diagonal()
+
+    A = torch.tensor([[2.0, 1.0], [0.5, 3.0]])
+    op = Dense(A)
+    v = torch.tensor([1.0, -1.0])
+    assert torch.allclose(op.matmul(v), A @ v)
+    assert torch.allclose(op.matmul(v.view(-1, 1)), (A @ v).view(-1, 1))
+    assert torch.allclose(op.T.matmul(v), A.t() @ v)
+    assert torch.allclose(op.diagonal(), A.diagonal())
+    assert tuple(op.shape) == (2, 2)
+    for name in ("solve", "inv_quad_logdet", "diagonalization", "to_dense", "logdet", "inv_quad"):
+        assert hasattr(op, name)
+
+
+def test_kernel_parameter_surface_without_device():
+    """RiemannMaternKernel's constructor signature (riemann_kernel.py:28-37,
+    riemann_matern_kernel.py:13-19) and the Positive (softplus) constraint round trip."""
+    import inspect
+    import manifold_gp_amd as mgp
+    from manifold_gp_amd._compat import Positive
+    sig = inspect.signature(mgp.kernels.RiemannMaternKernel.__init__)
+    assert list(sig.parameters)[:2] == ["self", "nu"]
+    base = inspect.signature(mgp.kernels.riemann_kernel.RiemannKernel.__init__)
+    assert list(base.parameters)[1:9] == ["x", "nearest_neighbors", "laplacian_normalization", "num_modes",
+                                          "bump_scale", "bump_decay", "graphbandwidth_prior",
+                                          "graphbandwidth_constraint"]
+    assert base.parameters["nearest_neighbors"].default == 10
+    assert base.parameters["laplacian_normalization"].default == "symmetric"
+    assert base.parameters["num_modes"].default == 100
+    p = Positive()
+    v = torch.tensor([0.05, 0.5, 3.0])
+    assert torch.allclose(p.transform(p.inverse_transform(v)), v, atol=1e-6)
+    assert abs(float(p.transform(torch.zeros(1))) - 0.6931) < 1e-3       # default bandwidth softplus(0)
+
+
+def test_operator_exports_match_reference_names():
+    import manifold_gp_amd as mgp
+    assert mgp.operators.__all__ == ["GraphLaplacianOperator", "PrecisionMaternOperator", "ScaleWrapperOperator",
+                                     "NoiseWrapperOperator", "SchurComplementOperator"]
+    assert mgp.kernels.__all__ == ["RiemannMaternKernel"]
+    base = mgp.install_as_manifold_gp(force=True)
+    import importlib
+    assert importlib.import_module("manifold_gp.kernels").RiemannMaternKernel is mgp.kernels.RiemannMaternKernel
+    assert importlib.import_module("manifold_gp.operators").GraphLaplacianOperator is mgp.operators.GraphLaplacianOperator
+    import sys
+    for k in [k for k in sys.modules if k == "manifold_gp" or k.startswith("manifold_gp.")]:
+        del sys.modules[k]
+
+
+def test_bump_function_matches_golden(golden):
+    from manifold_gp_amd.utils import bump_function
+    g = golden("bump")
+    for a in (0.5, 1.0):
+        for b in (0.01, 1.0):
+            out = bump_function(torch.from_numpy(g["x"]), a, b).numpy()
+            np.testing.assert_allclose(out, g[f"a{a}_b{b}"], rtol=2e-5, atol=1e-7)
+
+
+def test_synthetic_workloads_are_deterministic():
+    from tools import synth
+    x1, y1 = synth.rmnist_like(3, 10, seed=7)
+    x2, y2 = synth.rmnist_like(3, 10, seed=7)
+    assert x1.shape == (30, 784) and np.array_equal(x1, x2) and np.array_equal(y1, y2)
+    assert x1.min() >= -0.5 and x1.max() <= 0.5
+    eps, eps_min = synth.bandwidth_rule(np.array([0.1, 0.4]), 0.05)
+    assert abs(eps_min - np.sqrt(0.4 / (-4 * np.log(1e-4)))) < 1e-9 and eps == eps_min

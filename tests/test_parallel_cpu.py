@@ -1,0 +1,157 @@
+"""CPU tests of the multi-GPU host logic: the row partition, graph padding / slicing, and the
+distributed CG algorithm run under torch.distributed `gloo` with world_size 2 (the oracle is the
+local operator), compared with the single-process fp64 solve."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_row_partition_arithmetic():
+    from manifold_gp_amd.parallel import RowPartition
+    p = RowPartition(1546, 2)
+    assert p.n_loc % 64 == 0 and p.n_pad == 2 * p.n_loc and p.n_pad >= 1546
+    assert p.range(0) == (0, p.n_loc) and p.range(1) == (p.n_loc, 2 * p.n_loc)
+    assert p.owned(1) == (p.n_loc, 1546)
+    v = torch.arange(1546.0)
+    vp = p.pad(v)
+    assert vp.shape[0] == p.n_pad and torch.equal(p.unpad(vp), v) and float(vp[1546:].abs().sum()) == 0
+    q = RowPartition(60000 * 8, 8)
+    assert q.n_loc == 60032 - 32 or q.n_loc % 64 == 0
+    assert sum(q.owned(r)[1] - q.owned(r)[0] for r in range(8)) == 480000
+    # more ranks than 64-row blocks: trailing ranks own only padding
+    t = RowPartition(100, 4)
+    assert t.n_loc == 64 and t.owned(2) == (128, 128) and t.owned(3) == (192, 192)
+    with pytest.raises(ValueError):
+        RowPartition(0, 2)
+
+
+def test_pad_and_slice_graph_on_cpu_tensors(golden):
+    """pad_graph / local_csr are pure index bookkeeping: run them on CPU tensors and check that the
+    row slices tile the padded CSR exactly."""
+    from manifold_gp_amd.graph import KnnGraph
+    from manifold_gp_amd.parallel import RowPartition, local_csr, pad_graph
+    from oracle import knn as oknn
+    g = golden("dumbbell_k10_loop")
+    n = g["train_x"].shape[0]
+    idx, val = g["edge_index"].astype(np.int64), g["edge_value"]
+    # padded symmetric CSR built on the host (same layout as mgp_graph_from_coo)
+    rows = np.r_[idx[0], idx[1]]
+    cols = np.r_[idx[1], idx[0]]
+    order = np.lexsort((cols, rows))
+    rows, cols = rows[order], cols[order]
+    cnt = np.bincount(rows, minlength=n)
+    pc = (cnt + 3) // 4 * 4
+    rowptr = np.r_[0, np.cumsum(pc)].astype(np.int32)
+    col = np.repeat(np.arange(n), pc).astype(np.int32)
+    start = np.r_[0, np.cumsum(cnt)]
+    for r in range(n):
+        col[rowptr[r]:rowptr[r] + cnt[r]] = cols[start[r]:start[r + 1]]
+    graph = KnnGraph(n, torch.from_numpy(idx[0].astype(np.int32)), torch.from_numpy(idx[1].astype(np.int32)),
+                     torch.from_numpy(val), torch.from_numpy(rowptr), torch.from_numpy(col),
+                     torch.zeros(len(col)), torch.zeros(len(col), dtype=torch.int32))
+    part = RowPartition(n, 3)
+    gp = pad_graph(graph, part.n_pad)
+    assert gp.n == part.n_pad and gp.rowptr.shape[0] == part.n_pad + 1
+    assert int(gp.rowptr[-1]) == int(graph.rowptr[-1]) and torch.equal(gp.rowptr[: n + 1], graph.rowptr)
+
+    class FakeData:
+        pass
+    d = FakeData()
+    d.graph = gp
+    d.vals = torch.arange(len(col), dtype=torch.float32)
+    d.diag = torch.arange(part.n_pad, dtype=torch.float32)
+    total = 0
+    for r in range(3):
+        loc = local_csr(d, part, r)
+        r0, r1 = part.range(r)
+        assert loc["rowptr"][0] == 0 and loc["rowptr"].shape[0] == part.n_loc + 1
+        nn = int(loc["rowptr"][-1])
+        total += nn
+        if nn:
+            assert torch.equal(loc["vals"][:nn], d.vals[loc["e0"]:loc["e1"]])
+            assert loc["e0"] % 4 == 0                     # 16-byte aligned slice start
+        assert torch.equal(loc["diag"], d.diag[r0:r1])
+    assert total == int(graph.rowptr[-1])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from manifold_gp_amd.parallel import RowPartition, distributed_cg_reference
+        from oracle.laplacian import LaplacianOracle
+        from oracle.precision import PrecisionMaternOracle
+        g = dict(np.load(os.path.join(ROOT, "tests", "golden", "dumbbell_k10_loop.npz")))
+        n = g["train_x"].shape[0]
+        lap = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "randomwalk", True, dtype=np.float64)
+        Q = PrecisionMaternOracle(lap, 2, float(g["kappa"]))
+        s_out, noise = 0.7, 1e-2
+        part = RowPartition(n, world)
+        r0, r1 = part.range(rank)
+
+        def full_apply(u):           # A = I + noise * s * Q on the padded space (padding rows: identity)
+            un = u[:n].numpy()
+            out = u.clone()
+            out[:n] += torch.from_numpy(noise * s_out * Q.matmul(un))
+            return out
+
+        def local_matvec(u):         # this rank's rows only -- what the HIP SpMM slice computes
+            return full_apply(u)[r0:r1]
+
+        B = torch.zeros(part.n_pad, 2, dtype=torch.float64)
+        B[:n, 0] = torch.from_numpy(g["train_y"].astype(np.float64))
+        B[:n, 1] = torch.from_numpy(g["probes"][:, 0].astype(np.float64))
+        x, its = distributed_cg_reference(local_matvec, B, part, rank, tol=1e-11, max_iter=2000)
+        # every rank holds the same replicated solution
+        xs = [torch.empty_like(x) for _ in range(world)]
+        dist.all_gather(xs, x)
+        same = all(torch.equal(xs[0], t) for t in xs)
+        res = float((full_apply(x) - B).norm() / B.norm())
+        if rank == 0:
+            q.put(dict(ok=True, same=same, res=res, its=its, x=x[:n].numpy(), pad=float(x[n:].abs().max()) if part.n_pad > n else 0.0))
+    except Exception as e:  # pragma: no cover
+        if rank == 0:
+            q.put(dict(ok=False, err=repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_distributed_cg_world2_gloo_matches_single_process(golden):
+    from oracle.laplacian import LaplacianOracle
+    from oracle.precision import PrecisionMaternOracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert out["ok"], out.get("err")
+    assert out["same"] and out["res"] < 1e-10 and out["pad"] == 0.0
+    g = golden("dumbbell_k10_loop")
+    n = g["train_x"].shape[0]
+    lap = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "randomwalk", True, dtype=np.float64)
+    A = np.eye(n) + 1e-2 * 0.7 * PrecisionMaternOracle(lap, 2, float(g["kappa"])).dense()
+    ref = np.linalg.solve(A, np.stack([g["train_y"], g["probes"][:, 0]], 1).astype(np.float64))
+    assert np.abs(out["x"] - ref).max() < 1e-9 * np.abs(ref).max()
