@@ -170,7 +170,35 @@ def cpu_baseline(wl, gpu_iters):
                 spmv_gbs=round(B / t_mv / 1e9, 3), cg_solve_ms=round(t_cg * 1e3, 2), cg_iters=its), xs
 
 
+class _QuietStdout:
+    """Exactly ONE JSON line may reach stdout: libraries (RCCL prints a version banner at communicator
+    creation) write to fd 1, so fd 1 is pointed at stderr until the result is ready."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def emit(self, text):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        print(text, flush=True)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def main():
+    with _QuietStdout() as quiet:
+        _main(quiet)
+
+
+def _main(quiet):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -196,7 +224,7 @@ def main():
 
     if world > 1 or os.environ.get("MGP_FORCE_DIST") == "1":
         from manifold_gp_amd import parallel
-        return parallel.bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, HBM_PEAK_GBS)
+        return parallel.bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, HBM_PEAK_GBS, quiet.emit)
 
     wl = build_workload(args, dev, rank, world)
     from manifold_gp_amd.solvers import CgPlan
@@ -249,7 +277,7 @@ def main():
         err = float((out.view(-1).cpu() - xs).abs().max() / xs.abs().max())
         line["config"]["max_rel_diff_vs_cpu_solution"] = err
     plan.close()
-    print(json.dumps(line), flush=True)
+    quiet.emit(json.dumps(line))
 
 
 if __name__ == "__main__":

@@ -211,7 +211,7 @@ def distributed_cg_reference(local_matvec, b_pad, part, rank, tol=1e-10, max_ite
 
 
 # ------------------------------------------------------------------------------ bench (N > 1)
-def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_peak):
+def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_peak, emit=print):
     """bench.py body for world > 1 (also reachable at world == 1 with MGP_FORCE_DIST=1): weak scaling,
     `world` x 60 000 points; k-NN queries sharded by rows, lists all-gathered, graph + Laplacian
     built redundantly per rank (setup, untimed), rows of the operator partitioned for the CG."""
@@ -276,7 +276,7 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
                                   frac=round(value / world / hbm_peak, 4), traffic=None,
                                   note="per-GPU share of the whole-job rate (includes collectives and vector "
                                        "kernels); the kernel-only figure is the N=1 line"))
-        print(json.dumps(line), flush=True)
+        emit(json.dumps(line))
     plan.close()
     if world > 1:
         dist.barrier()

@@ -4,7 +4,17 @@
 #include <vector>
 #include <random>
 
-template <int NG>
+template <int MODE>
+__device__ __forceinline__ float gload(const float* p) {
+  float v;
+  if (MODE == 0) return *p;
+  if (MODE == 1) return __builtin_nontemporal_load(p);
+  if (MODE == 2) { asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+  if (MODE == 3) { asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory"); return v; }
+  return 0.f;
+}
+
+template <int NG, int MODE = 0>
 __global__ __launch_bounds__(256) void gather_kernel(const int* __restrict__ idx, const float* __restrict__ x, float* __restrict__ out, long n) {
   long i = (long)blockIdx.x * 256 * NG + threadIdx.x;
   float acc = 0.f;
@@ -12,7 +22,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const int* __restrict__ idx
 #pragma unroll
   for (int g = 0; g < NG; ++g) c[g] = idx[i + g * 256];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) acc += x[c[g]];
+  for (int g = 0; g < NG; ++g) acc += gload<MODE>(x + c[g]);
   out[(long)blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
@@ -63,7 +73,8 @@ int main() {
     float t1 = time_it([&] { hipLaunchKernelGGL((gather_kernel<1>), dim3(NE / 256), dim3(256), 0, st, idx, x, out, NE); }, 50, st);
     float t4 = time_it([&] { hipLaunchKernelGGL((gather_kernel<4>), dim3(NE / 1024), dim3(256), 0, st, idx, x, out, NE); }, 50, st);
     float t16 = time_it([&] { hipLaunchKernelGGL((gather_kernel<16>), dim3(NE / 4096), dim3(256), 0, st, idx, x, out, NE); }, 50, st);
-    printf("%-62s NG=1 %.2f us | NG=4 %.2f us | NG=16 %.2f us\n", names[pat], t1, t4, t16);
+    float tnt = time_it([&] { hipLaunchKernelGGL((gather_kernel<4, 1>), dim3(NE / 1024), dim3(256), 0, st, idx, x, out, NE); }, 50, st);
+    printf("%-62s NG=1 %.2f us | NG=4 %.2f us | NG=16 %.2f us | NG=4 nontemporal %.2f us\n", names[pat], t1, t4, t16, tnt);
   }
   return 0;
 }
