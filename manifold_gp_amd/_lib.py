@@ -35,7 +35,8 @@ class MgpError(RuntimeError):
 
 class CsrT(Structure):
     _fields_ = [("n", c_int64), ("rowptr", c_void_p), ("col", c_void_p), ("vals", c_void_p),
-                ("diag", c_void_p)]
+                ("diag", c_void_p), ("segptr", c_void_p), ("panels", c_int32), ("panel_width", c_int32),
+                ("ncols", c_int64)]
 
 
 class OperatorT(Structure):
@@ -61,11 +62,11 @@ SIGNATURES = {
     "mgp_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
     "mgp_knn_search": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, _P, _P, c_size_t,
                                POINTER(c_int64), _P]),
-    "mgp_graph_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "mgp_graph_build": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, POINTER(c_int64), _P, _P, _P, _P,
+    "mgp_graph_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "mgp_graph_build": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, POINTER(c_int64), _P, _P, _P, _P, _P,
                                 POINTER(c_int64), _P, c_size_t, _P]),
-    "mgp_graph_coo_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "mgp_graph_from_coo": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, POINTER(c_int64), _P,
+    "mgp_graph_coo_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "mgp_graph_from_coo": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, POINTER(c_int64), _P,
                                    c_size_t, _P]),
     "mgp_laplacian_build": (c_int, [c_int64, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mgp_edge_values": (c_int, [_P, _P, _P, c_int64, _P, _P, c_float, c_int, _P, _P]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "mgp_spmm_set_group_hint": (c_int, [c_int]),
     "mgp_spmm_set_rows_in_flight": (c_int, [c_int]),
     "mgp_spmm_set_entry_layout": (c_int, [c_int]),
+    "mgp_spmm_set_panel_mode": (c_int, [c_int]),
+    "mgp_spmm_set_stream_nt": (c_int, [c_int]),
     "mgp_spmm_fused": (c_int, [POINTER(CsrT), _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
                                c_float, _P, _P, _P]),
     "mgp_spmm_fused_rows": (c_int, [POINTER(CsrT), c_int64, _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
@@ -181,5 +184,6 @@ def workspace(nbytes, tag, device):
     return buf
 
 
-def csr_struct(n, rowptr, col, vals, diag):
-    return CsrT(int(n), rowptr.data_ptr(), col.data_ptr(), vals.data_ptr(), diag.data_ptr())
+def csr_struct(n, rowptr, col, vals, diag, segptr=None, panels=0, panel_width=0, ncols=0):
+    return CsrT(int(n), rowptr.data_ptr(), col.data_ptr(), vals.data_ptr(), diag.data_ptr(),
+                segptr.data_ptr() if segptr is not None else None, int(panels), int(panel_width), int(ncols))

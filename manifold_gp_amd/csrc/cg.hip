@@ -279,7 +279,7 @@ int tile_cols(int C) {
 
 size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   const size_t nc = mgp_align((size_t)op->L.n * world * C * sizeof(float));
-  const int nbs = mgp_spmm_dot_blocks(op->L.n, C) * world;
+  const int nbs = mgp_spmm_dot_blocks_for(&op->L, C) * world;
   size_t b = 7 * nc;                                   // x r u w p s us
   b += 4 * nc + 256;                                   // operator chain scratch (global length)
   b += 4 * mgp_align((size_t)kMaxGridVec * C * sizeof(float));   // pd_gamma[2], pd_rr[2]
@@ -348,7 +348,7 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   a.rows_per_block = rpb; a.nbv = (int)nbv;
   a.pd_gamma = ar.take<float>(2 * (size_t)kMaxGridVec * C);
   a.pd_rr = ar.take<float>(2 * (size_t)kMaxGridVec * C);
-  pl->nb_loc = mgp_spmm_dot_blocks(op->L.n, C);
+  pl->nb_loc = mgp_spmm_dot_blocks_for(&op->L, C);
   a.nbs = pl->nb_loc * world;
   pl->pd_delta = ar.take<float>((size_t)a.nbs * C);
   a.pd_delta = pl->pd_delta;

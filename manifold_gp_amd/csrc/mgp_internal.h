@@ -14,6 +14,9 @@ int mgp_spmm_fused_part(const mgp_csr_t* L, int64_t row_offset, const float* X, 
                         const float* pre, const float* post, const float* base, float cb, float co,
                         const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream);
 
+// workgroups that write dot partials for this CSR (depends on whether the panel kernel is used)
+int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C);
+
 // operator chain with the same hooks on its LAST SpMM
 int mgp_operator_apply_ex(const mgp_operator_t* op, const float* X, int C, float* Y, const float* dotw,
                           float* dot_partials, const int* skip, int* tick, void* work, size_t work_bytes,

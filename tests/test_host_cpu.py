@@ -34,11 +34,11 @@ def test_library_exports_every_header_symbol():
 def test_struct_layouts_match_c_abi():
     """mgp_csr_t / mgp_operator_t / params structs: sizes as the C compiler lays them out."""
     from manifold_gp_amd import _lib
-    assert ctypes.sizeof(_lib.CsrT) == 40
-    assert ctypes.sizeof(_lib.OperatorT) == 40 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
+    assert ctypes.sizeof(_lib.CsrT) == 64
+    assert ctypes.sizeof(_lib.OperatorT) == 64 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
     assert ctypes.sizeof(_lib.CgParamsT) == 24
     assert ctypes.sizeof(_lib.LanczosParamsT) == 24
-    assert _lib.OperatorT.pre.offset == 40 and _lib.OperatorT.nu.offset == 56
+    assert _lib.OperatorT.pre.offset == 64 and _lib.OperatorT.nu.offset == 80
 
 
 def test_argument_errors_without_gpu():
@@ -46,7 +46,7 @@ def test_argument_errors_without_gpu():
     from manifold_gp_amd import _lib
     lib = _lib.lib()
     assert lib.mgp_knn_workspace_bytes(0, 0, 0, 0) == 0
-    assert lib.mgp_graph_workspace_bytes(-1, 5) == 0
+    assert lib.mgp_graph_workspace_bytes(-1, 5, 0) == 0
     assert lib.mgp_spmm_dot_blocks(0, 1) == -1
     assert lib.mgp_spmm_set_group_hint(3) == -1 and lib.mgp_spmm_set_group_hint(8) == 0
     assert lib.mgp_spmm_set_rows_in_flight(3) == -1 and lib.mgp_spmm_set_rows_in_flight(2) == 0

@@ -14,6 +14,31 @@ __device__ __forceinline__ float gload(const float* p) {
   return 0.f;
 }
 
+typedef int v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4i make_rsrc(const void* p, unsigned bytes) {
+  unsigned long long a = (unsigned long long)p;
+  v4i r;
+  r.x = (int)(a & 0xffffffffu);
+  r.y = (int)((a >> 32) & 0xffffu);
+  r.z = (int)bytes;
+  r.w = 0x00020000;      // DATA_FORMAT = 32 (raw buffer)
+  return r;
+}
+
+// gathers through the buffer path with a cache-policy immediate (aux): 0 plain, 1 sc0, 2 nt, 16 sc1, 17 sc0+sc1
+template <int NG, int AUX>
+__global__ __launch_bounds__(256) void gather_buf_kernel(const int* __restrict__ idx, const float* __restrict__ x, float* __restrict__ out, long n, int nx) {
+  long i = (long)blockIdx.x * 256 * NG + threadIdx.x;
+  __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)x, (short)0, nx * 4, 0x00020000);
+  float acc = 0.f;
+  int c[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) c[g] = idx[i + g * 256];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) acc += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, c[g] * 4, 0, AUX));
+  out[(long)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 template <int NG, int MODE = 0>
 __global__ __launch_bounds__(256) void gather_kernel(const int* __restrict__ idx, const float* __restrict__ x, float* __restrict__ out, long n) {
   long i = (long)blockIdx.x * 256 * NG + threadIdx.x;
@@ -74,7 +99,12 @@ int main() {
     float t4 = time_it([&] { hipLaunchKernelGGL((gather_kernel<4>), dim3(NE / 1024), dim3(256), 0, st, idx, x, out, NE); }, 50, st);
     float t16 = time_it([&] { hipLaunchKernelGGL((gather_kernel<16>), dim3(NE / 4096), dim3(256), 0, st, idx, x, out, NE); }, 50, st);
     float tnt = time_it([&] { hipLaunchKernelGGL((gather_kernel<4, 1>), dim3(NE / 1024), dim3(256), 0, st, idx, x, out, NE); }, 50, st);
-    printf("%-62s NG=1 %.2f us | NG=4 %.2f us | NG=16 %.2f us | NG=4 nontemporal %.2f us\n", names[pat], t1, t4, t16, tnt);
+    float b0 = time_it([&] { hipLaunchKernelGGL((gather_buf_kernel<4, 0>), dim3(NE / 1024), dim3(256), 0, st, idx, x, out, NE, NX); }, 50, st);
+    float b1 = time_it([&] { hipLaunchKernelGGL((gather_buf_kernel<4, 1>), dim3(NE / 1024), dim3(256), 0, st, idx, x, out, NE, NX); }, 50, st);
+    float b16 = time_it([&] { hipLaunchKernelGGL((gather_buf_kernel<4, 16>), dim3(NE / 1024), dim3(256), 0, st, idx, x, out, NE, NX); }, 50, st);
+    float b17 = time_it([&] { hipLaunchKernelGGL((gather_buf_kernel<4, 17>), dim3(NE / 1024), dim3(256), 0, st, idx, x, out, NE, NX); }, 50, st);
+    printf("%-62s NG=4 %.2f | nt %.2f | buffer plain %.2f sc0 %.2f sc1 %.2f sc0sc1 %.2f us\n", names[pat], t4, tnt, b0, b1, b16, b17);
+    (void)t1; (void)t16;
   }
   return 0;
 }
