@@ -58,10 +58,10 @@ def build_workload(args, dev, rank, world, shard_knn=False):
         name = "C3 RMNIST-like N=%d d=784 k=50 nu=2 randomwalk" % x_np.shape[0]
     elif args.workload == "s5":
         n = args.nodes or 1000000
-        x_np, y_np = synth.swiss_roll(n * world)
+        x_np, y_np = synth.swiss_roll(n * world, order=args.s5_order)
         k, nu, norm = 64, 2, "symmetric"
-        hp = dict(graphbandwidth=0.0, lengthscale=1.0, outputscale=1.0, noise=0.01)
-        name = "S5 swiss-roll N=%d d=3 k=64 nu=2 symmetric" % x_np.shape[0]
+        hp = dict(graphbandwidth=0.0, lengthscale=1.0, outputscale=1.0, noise=0.01, eps_scale=3.0)
+        name = "S5 swiss-roll N=%d d=3 k=64 nu=2 symmetric (%s order)" % (x_np.shape[0], args.s5_order)
     else:
         raise SystemExit("unknown workload " + args.workload)
     t_data = time.time() - t0
@@ -97,6 +97,7 @@ def build_workload(args, dev, rank, world, shard_knn=False):
     # eps: trained value, floored by the notebooks' eps_min rule on the 1-NN distances
     D1, _ = knn.search(x[: min(20000, x.shape[0])], 2)
     eps, eps_min = synth.bandwidth_rule(D1[:, 1].cpu().numpy(), hp["graphbandwidth"])
+    eps = max(eps, hp.get("eps_scale", 1.0) * eps_min)
     log("[bench] data %.1fs, k-NN+graph %.2fs (knn stats %s), N=%d M=%d nnz_padded=%d eps=%.4f (eps_min %.4f)"
         % (t_data, t_graph, knn.last_stats, graph.n, graph.M, graph.nnz, eps, eps_min))
     lap = mgp.operators.GraphLaplacianOperator(val, idx, graph.n, torch.tensor([[eps]], device=dev), norm, graph=graph)
@@ -207,6 +208,7 @@ def _main(quiet):
     ap.add_argument("--nodes", type=int, default=0, help="override nodes per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tol", type=float, default=1e-6)
+    ap.add_argument("--s5-order", default="morton", choices=["random", "morton"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -255,7 +257,8 @@ def _main(quiet):
                 frac=round(B / t_k / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
                 kernel="spmv_kernel<%d,2,false> (fused CSR SpMV, C=1, %d lanes x 2 rows in flight)" % (g.spmv_lanes, g.spmv_lanes),
                 bytes_per_launch=B, avg_launch_us=round(t_k * 1e6, 2),
-                note="N=60k working set (%.0f MB) is Infinity-Cache resident; see DESIGN.md" % (B / 1e6))
+                note=("working set %.0f MB is Infinity-Cache resident; the kernel is gather-bound, see DESIGN.md"
+                      if B < 2.5e8 else "working set %.0f MB streams from HBM") % (B / 1e6))
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc):
         try:

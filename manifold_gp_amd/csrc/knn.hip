@@ -3,7 +3,7 @@
 // Replaces faiss IndexFlatL2 / IndexIVFFlat(nlist=1) (+ Gpu variants) `search` as called from
 // manifold_gp/utils/nearest_neighbors.py:35-37.
 //
-// Pipeline per chunk of query rows (sized so the fp32 distance slab stays ~1 GB of HBM):
+// Pipeline per chunk of query rows (fp32 distance slab of 1-8 GiB of HBM, see chunk_rows):
 //   1. dist_tile_kernel   fp32 direct-difference distances, 128x128 tile per workgroup,
 //                         8x8 register micro-tile per lane, operands staged k-major in LDS so
 //                         a lane reads its 8 queries / 8 points with two ds_read_b128 each
@@ -311,7 +311,12 @@ constexpr int kExactBatch = 16;
 
 int64_t chunk_rows(int64_t N, int64_t n) {
   const int64_t ld = mgp_cdiv(N, 4) * 4;
-  int64_t qc = ((int64_t)1 << 28) / ld;           // ~1 GiB of fp32 distances
+  // fp32 distance slab: 1 GiB for small N (cache friendly), up to 8 GiB for large N so that a chunk
+  // still holds >= 2048 query rows and the per-chunk launch + host poll is amortised (288 GB of HBM)
+  int64_t slab_floats = (int64_t)1 << 28;
+  if (ld * 2048 > slab_floats) slab_floats = ld * 2048;
+  if (slab_floats > ((int64_t)1 << 31)) slab_floats = (int64_t)1 << 31;
+  int64_t qc = slab_floats / ld;
   qc = qc / kTile * kTile;
   if (qc < kTile) qc = kTile;
   const int64_t ncap = mgp_cdiv(n, kTile) * kTile;

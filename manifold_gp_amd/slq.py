@@ -1,0 +1,64 @@
+"""Stochastic Lanczos quadrature log-determinant.
+
+What `inv_quad_logdet(logdet=True)` does in linear_operator for N > max_cholesky_size
+(manifold_gp/utils/train_model.py:68): with Rademacher probes z_p (||z||^2 = N) and the k-step Lanczos
+tridiagonal T_p = Q_p^T A Q_p started at z_p / ||z_p||,
+
+    logdet(A) ~= (N / P) * sum_p  e_1^T log(T_p) e_1 = (N / P) * sum_p sum_i tau_{p,i}^2 log(theta_{p,i}).
+
+The Lanczos runs on device (mgp_lanczos_tridiag: operator chain = fused SpMM launches, full
+re-orthogonalisation); the k x k tridiagonal eigenproblems are solved on the host in fp64.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._compat import settings
+from ._lib import check, lib, ptr, stream
+
+
+def lanczos_tridiag(desc, q0, steps):
+    """(alpha[steps], beta[steps]) of the Lanczos tridiagonal of the operator `desc` started at q0."""
+    _lib.require_device(q0)
+    op = desc.struct()
+    wb = lib().mgp_lanczos_tridiag_workspace_bytes(ctypes.byref(op), int(steps))
+    work = _lib.workspace(wb, "lanczos_tridiag", q0.device)
+    alpha = (ctypes.c_float * steps)()
+    beta = (ctypes.c_float * steps)()
+    check(lib().mgp_lanczos_tridiag(ctypes.byref(op), ptr(_lib.f32c(q0)), int(steps), alpha, beta, None, ptr(work),
+                                    work.numel(), stream()), "mgp_lanczos_tridiag")
+    return np.array(alpha, dtype=np.float64), np.array(beta, dtype=np.float64)
+
+
+def _quadrature_log(alpha, beta):
+    k = len(alpha)
+    # an (almost) zero beta means the Krylov space is exhausted: truncate there
+    cut = k
+    for j in range(k - 1):
+        if not np.isfinite(beta[j]) or abs(beta[j]) < 1e-6 * max(abs(alpha[j]), 1e-30):
+            cut = j + 1
+            break
+    T = np.diag(alpha[:cut]) + np.diag(beta[:cut - 1], 1) + np.diag(beta[:cut - 1], -1)
+    theta, S = np.linalg.eigh(T)
+    theta = np.maximum(theta, 1e-30)
+    return float(np.sum(S[0, :] ** 2 * np.log(theta)))
+
+
+def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
+    desc = getattr(operator, "_descriptor", lambda: None)()
+    if desc is None:
+        raise NotImplementedError("SLQ log-determinant needs an operator that is one polynomial chain "
+                                  "(PrecisionMatern / Scale / Noise wrappers)")
+    n = desc.n
+    num_probes = settings.num_trace_samples.value() if num_probes is None else num_probes
+    steps = min(n, 20 if steps is None else steps)
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    dev = desc.data.graph.device
+    total = 0.0
+    for _ in range(num_probes):
+        z = (torch.randint(0, 2, (n,), generator=gen).float() * 2 - 1).to(dev)
+        a, b = lanczos_tridiag(desc, z, steps)
+        total += _quadrature_log(a, b)
+    return torch.tensor(n * total / num_probes, dtype=torch.float32, device=dev)

@@ -558,3 +558,27 @@ def test_panel_spmv_matches_gather_kernel(mgp, golden, dev, pw):
     for mode in (0, 1):
         np.testing.assert_allclose(outs[mode][0].cpu().numpy(), ref, rtol=0, atol=tol)
         assert abs(outs[mode][1] - float((x.cpu().double() * torch.from_numpy(ref)).sum())) < 1e-3 * np.abs(ref).max() * n ** 0.5
+
+
+def test_slq_logdet_vs_dense(mgp, golden, dev):
+    """train_model.py:68 `inv_quad_logdet(logdet=True)`: dense-Cholesky branch (N <= max_cholesky_size)
+    is exact; the stochastic-Lanczos branch agrees with it within its Monte-Carlo error."""
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 1, torch.tensor([[float(g["kappa"])]], device=dev))
+    Qn = mgp.operators.NoiseWrapperOperator(mgp.operators.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev)),
+                                            torch.tensor(1e-2, device=dev))
+    A = Qn.to_dense().double()
+    ref = float(torch.linalg.slogdet(0.5 * (A + A.t()))[1])
+    with mgp.settings.max_cholesky_size(2000):
+        _, ld_dense = Qn.inv_quad_logdet(logdet=True)
+    assert abs(float(ld_dense) - ref) < 1e-3 * abs(ref)
+    from manifold_gp_amd.slq import slq_logdet
+    ld = float(slq_logdet(Qn, num_probes=60, steps=40))
+    assert abs(ld - ref) < 0.02 * abs(ref), (ld, ref)
+    with mgp.settings.max_cholesky_size(100), mgp.settings.num_trace_samples(30):
+        iq, ld2 = Qn.inv_quad_logdet(inv_quad_rhs=T(g["train_y"], dev).view(-1, 1), logdet=True)
+    assert abs(float(ld2) - ref) < 0.05 * abs(ref)
+    y = g["train_y"].astype(np.float64)
+    iq_ref = float(y @ np.linalg.solve(A.cpu().numpy(), y))
+    assert abs(float(iq) - iq_ref) < 0.05 * abs(iq_ref)       # cg_tolerance default (1.0 -> >= 10 iterations)

@@ -61,13 +61,32 @@ def rmnist_like(bases=600, per_base=100, seed=1337, max_angle=45.0):
     return x.astype(np.float32), y.astype(np.float32)
 
 
-def swiss_roll(n, seed=1337):
+def morton_order(x, bits=10):
+    """Permutation that sorts points by the Morton (Z-order) code of their quantised coordinates
+    (first three features): consecutive indices are spatial neighbours."""
+    q = x[:, :3].astype(np.float64)
+    q = (q - q.min(0)) / np.maximum(q.max(0) - q.min(0), 1e-30)
+    q = np.minimum((q * (1 << bits)).astype(np.uint64), (1 << bits) - 1)
+    code = np.zeros(len(x), np.uint64)
+    for b in range(bits):
+        for a in range(q.shape[1]):
+            code |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    return np.argsort(code, kind="stable")
+
+
+def swiss_roll(n, seed=1337, order="random"):
+    """order: "random" (i.i.d. samples in generation order) or "morton" (the same points stored in
+    Z-order, i.e. what a locality-aware loader would hand over)."""
     rng = np.random.default_rng(seed)
     t = 1.5 * np.pi * (1 + 2 * rng.random(n))
     h = 21 * rng.random(n)
     x = np.stack([t * np.cos(t), h, t * np.sin(t)], 1) + rng.normal(scale=1e-3, size=(n, 3))
     y = np.sin(t) + 0.05 * h + rng.normal(scale=0.1, size=n)
-    return x.astype(np.float32), y.astype(np.float32)
+    x, y = x.astype(np.float32), y.astype(np.float32)
+    if order == "morton":
+        p = morton_order(x)
+        x, y = np.ascontiguousarray(x[p]), np.ascontiguousarray(y[p])
+    return x, y
 
 
 def bandwidth_rule(knn_d2_first, floor):

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--reps", type=int, default=100)
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--s5-order", default="morton")
     a = ap.parse_args()
     a.gpus = 1
     dev = torch.device("cuda:0")
@@ -31,7 +32,7 @@ def main():
     B = bench.spmm_bytes(g.n, g.M)
     shapes = [(L, G, R) for L in (0, 1) for G in (8, 16, 32, 64) for R in (1, 2, 4, 8) if R <= G]
     if a.quick:
-        shapes = [(0, 8, 2), (0, 16, 4), (0, 32, 8), (1, 16, 4)]
+        shapes = [(0, 8, 1), (0, 8, 2), (0, 8, 4), (0, 16, 2), (0, 16, 4), (0, 16, 8), (0, 32, 4), (0, 32, 8)]
     times = {s: [] for s in shapes}
     lib = _lib.lib()
     for rnd in range(a.rounds):
