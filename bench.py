@@ -209,6 +209,7 @@ def _main(quiet):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--s5-order", default="morton", choices=["random", "morton"])
+    ap.add_argument("--refine", type=int, default=-1, help="CG refinement rounds (-1: 0 for c3, 3 for s5)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -231,7 +232,8 @@ def _main(quiet):
     wl = build_workload(args, dev, rank, world)
     from manifold_gp_amd.solvers import CgPlan
     g = wl["graph"]
-    plan = CgPlan(wl["desc"], 1, tol=args.tol, max_iter=2000, stop_mode=1, check_every=8)
+    refine = args.refine if args.refine >= 0 else (0 if args.workload == "c3" else 3)
+    plan = CgPlan(wl["desc"], 1, tol=args.tol, max_iter=5000, stop_mode=1, check_every=8, refine=refine)
     y = wl["y"].view(-1, 1).contiguous()
     for _ in range(args.warmup):
         out = plan.solve(y, copy=False)

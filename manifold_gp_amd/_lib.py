@@ -46,7 +46,8 @@ class OperatorT(Structure):
 
 class CgParamsT(Structure):
     _fields_ = [("tol", c_float), ("max_iter", c_int32), ("min_iter", c_int32),
-                ("stop_mode", c_int32), ("check_every", c_int32), ("use_graph", c_int32)]
+                ("stop_mode", c_int32), ("check_every", c_int32), ("use_graph", c_int32),
+                ("max_refine", c_int32)]
 
 
 class LanczosParamsT(Structure):

@@ -250,6 +250,48 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   }
 }
 
+// ---- iterative refinement (stop_mode 1, max_refine > 0): the recurrence residual of a single-
+// reduction CG drifts from the true residual on ill-conditioned systems in fp32; the true residual
+// R = B - A x is formed explicitly and, if it misses the tolerance, A d = R is solved and x += d.
+__global__ __launch_bounds__(kBlock) void refine_residual_kernel(const float* __restrict__ B, const float* __restrict__ T,
+                                                                 float* __restrict__ R, int64_t n, int C,
+                                                                 float* __restrict__ partial /*[grid][C][2]*/) {
+  __shared__ float sh[2][kBlock];
+  int TC = 1;
+  while (TC < C) TC <<= 1;
+  const int TS = kBlock / TC;
+  const int tid = threadIdx.x, cc = tid % TC, sl = tid / TC;
+  float rr = 0.f, bb = 0.f;
+  if (cc < C) {
+    for (int64_t r = (int64_t)blockIdx.x * TS + sl; r < n; r += (int64_t)gridDim.x * TS) {
+      const int64_t i = r * C + cc;
+      const float b = B[i], d = b - T[i];
+      R[i] = d;
+      rr = fmaf(d, d, rr);
+      bb = fmaf(b, b, bb);
+    }
+  }
+  sh[0][tid] = rr; sh[1][tid] = bb;
+  reduce_slices<2>(sh, TC, TS, sl, cc);
+  if (tid < TC && tid < C) {
+    partial[((int64_t)blockIdx.x * C + tid) * 2 + 0] = sh[0][tid];
+    partial[((int64_t)blockIdx.x * C + tid) * 2 + 1] = sh[1][tid];
+  }
+}
+
+__global__ void refine_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ host_rel) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float rr = 0.f, bb = 0.f;
+    for (int b = 0; b < nblk; ++b) { rr += partial[((int64_t)b * C + c) * 2]; bb += partial[((int64_t)b * C + c) * 2 + 1]; }
+    host_rel[c] = bb > 0.f ? sqrtf(rr / bb) : 0.f;
+  }
+}
+
+__global__ void refine_accumulate_kernel(float* __restrict__ xacc, const float* __restrict__ x, int64_t total, int first) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    xacc[i] = first ? x[i] : xacc[i] + x[i];
+}
+
 struct CgPlan {
   mgp_operator_t op;
   MgpDist dist;             // row partition (is_dist): op.L holds the local rows only
@@ -269,6 +311,9 @@ struct CgPlan {
   int chunk, chunk_small;
   int32_t* host_state;      // pinned
   float* host_resid;        // pinned
+  float *xacc, *rbuf, *tbuf, *rpart;   // refinement: accumulated solution, residual rhs, A x, partials
+  float* host_true_rel;     // host-mapped [C]: true relative residuals
+  float* dev_true_rel;
 };
 
 int tile_cols(int C) {
@@ -280,12 +325,13 @@ int tile_cols(int C) {
 size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   const size_t nc = mgp_align((size_t)op->L.n * world * C * sizeof(float));
   const int nbs = mgp_spmm_dot_blocks_for(&op->L, C) * world;
-  size_t b = 7 * nc;                                   // x r u w p s us
+  size_t b = 10 * nc;                                  // x r u w p s us + refinement xacc rbuf tbuf
   b += 4 * nc + 256;                                   // operator chain scratch (global length)
   b += 4 * mgp_align((size_t)kMaxGridVec * C * sizeof(float));   // pd_gamma[2], pd_rr[2]
   b += mgp_align((size_t)nbs * C * sizeof(float));              // pd_delta
   b += 6 * mgp_align((size_t)C * sizeof(float));                // gamma_old[2] alpha_old[2] bb resid
   b += mgp_align(16 * sizeof(int));
+  b += mgp_align((size_t)256 * C * 2 * sizeof(float));          // refinement partials
   return b + 1024;
 }
 
@@ -357,6 +403,8 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   a.bb = ar.take<float>(C);
   a.resid = ar.take<float>(C);
   a.state = ar.take<int>(16);
+  pl->xacc = ar.take<float>(nc); pl->rbuf = ar.take<float>(nc); pl->tbuf = ar.take<float>(nc);
+  pl->rpart = ar.take<float>((size_t)256 * C * 2);
   a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter;
   a.stop_mode = pl->prm.stop_mode;
   if (!ar.ok()) { delete pl; return MGP_ERR_WORKSPACE; }
@@ -364,6 +412,8 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_resid, (size_t)C * sizeof(float), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&a.host_state, pl->host_state, 0);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&a.host_resid, pl->host_resid, 0);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_true_rel, (size_t)C * sizeof(float), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&pl->dev_true_rel, pl->host_true_rel, 0);
   if (e != hipSuccess) { delete pl; return (int)e; }
 
   if (pl->prm.use_graph && !pl->is_dist) {   // collectives are enqueued eagerly (no capture)
@@ -407,13 +457,11 @@ extern "C" int mgp_cg_plan_create_dist(const mgp_operator_t* op_local, int C, co
   return plan_create_impl(op_local, C, minv, params, &d, work, work_bytes, stream, plan_out);
 }
 
-extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid,
-                                 int32_t* status) {
-  CgPlan* pl = static_cast<CgPlan*>(plan);
-  if (!pl || !B) return MGP_ERR_ARG;   // X == NULL: leave the solution in the plan (mgp_cg_plan_x)
+// one CG run on `rhs` into the plan's x buffer; ends with the stream synchronised
+static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   hipStream_t st = pl->stream;
   const size_t nc = (size_t)pl->args.n * pl->C;
-  hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, B);
+  hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, rhs);
   MGP_LAUNCH_CHECK();
   MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
                                   pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, nullptr, nullptr, pl->op_work,
@@ -431,14 +479,60 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
     first = false;
     // the solution rides behind every chunk so that one synchronisation ends the solve; the
     // convergence flag / residuals arrive through host-mapped memory written by the update kernel
-    if (X) MGP_HIP_TRY(hipMemcpyAsync(X, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (Xcopy) MGP_HIP_TRY(hipMemcpyAsync(Xcopy, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
     MGP_HIP_TRY(hipStreamSynchronize(st));
     if (pl->host_state[1]) break;
     if (++guard > pl->prm.max_iter / pl->chunk_small + 4) break;
   }
-  if (iters) *iters = pl->host_state[0] - 1;
-  if (status) *status = pl->host_state[2];
-  if (resid) memcpy(resid, pl->host_resid, (size_t)pl->C * sizeof(float));
+  return MGP_OK;
+}
+
+extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid,
+                                 int32_t* status) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  if (!pl || !B) return MGP_ERR_ARG;   // X == NULL: leave the solution in the plan (mgp_cg_plan_x)
+  hipStream_t st = pl->stream;
+  const size_t nc = (size_t)pl->args.n * pl->C;
+  const int max_refine = (pl->prm.stop_mode == 1) ? pl->prm.max_refine : 0;
+  if (max_refine <= 0) {
+    MGP_TRY(run_cg(pl, B, X));
+    if (iters) *iters = pl->host_state[0] - 1;
+    if (status) *status = pl->host_state[2];
+    if (resid) memcpy(resid, pl->host_resid, (size_t)pl->C * sizeof(float));
+    return MGP_OK;
+  }
+  int total_iters = 0, last_status = 0;
+  const float* rhs = B;
+  const int egrid = (int)(mgp_cdiv((int64_t)nc, kBlock) > 2048 ? 2048 : mgp_cdiv((int64_t)nc, kBlock));
+  for (int ref = 0; ref <= max_refine; ++ref) {
+    MGP_TRY(run_cg(pl, rhs, nullptr));
+    total_iters += pl->host_state[0] - 1;
+    last_status = pl->host_state[2];
+    hipLaunchKernelGGL(refine_accumulate_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->xacc, pl->args.x, (int64_t)nc,
+                       ref == 0 ? 1 : 0);
+    MGP_LAUNCH_CHECK();
+    // true residual R = B - A xacc
+    MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->xacc, nullptr, pl->C, pl->tbuf,
+                                    nullptr, nullptr, 0, nullptr, nullptr, pl->op_work, pl->op_work_bytes, st));
+    const int rgrid = 256;
+    hipLaunchKernelGGL(refine_residual_kernel, dim3(rgrid), dim3(kBlock), 0, st, B, pl->tbuf, pl->rbuf, pl->args.n,
+                       pl->C, pl->rpart);
+    MGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(refine_finalize_kernel, dim3(1), dim3(kBlock), 0, st, pl->rpart, rgrid, pl->C, pl->dev_true_rel);
+    MGP_LAUNCH_CHECK();
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    bool ok = true;
+    for (int c = 0; c < pl->C; ++c) ok = ok && (pl->host_true_rel[c] <= 2.0f * pl->prm.tol);
+    if (ok || ref == max_refine || last_status == 3) break;
+    rhs = pl->rbuf;
+  }
+  // publish the accumulated solution in the plan buffer (mgp_cg_plan_x) and, if asked, in X
+  MGP_HIP_TRY(hipMemcpyAsync(pl->args.x, pl->xacc, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (X) MGP_HIP_TRY(hipMemcpyAsync(X, pl->xacc, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  if (iters) *iters = total_iters;
+  if (status) *status = last_status;
+  if (resid) memcpy(resid, pl->host_true_rel, (size_t)pl->C * sizeof(float));   // TRUE relative residuals
   return MGP_OK;
 }
 
@@ -456,6 +550,7 @@ extern "C" int mgp_cg_plan_destroy(void* plan) {
   if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
   if (pl->host_state) (void)hipHostFree(pl->host_state);
   if (pl->host_resid) (void)hipHostFree(pl->host_resid);
+  if (pl->host_true_rel) (void)hipHostFree(pl->host_true_rel);
   delete pl;
   return MGP_OK;
 }

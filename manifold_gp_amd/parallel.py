@@ -133,7 +133,7 @@ class DistCgPlan:
         dev = desc.data.graph.device
         self.op, self._loc = local_operator_struct(desc, part, rank)
         self.params = CgParamsT(float(tol), int(max_iter), 10 if stop_mode == 0 else 0, int(stop_mode),
-                                int(check_every), 0)
+                                int(check_every), 0, 0)
         wb = lib().mgp_cg_dist_workspace_bytes(ctypes.byref(self.op), self.C, part.world)
         self.work = torch.empty(wb, dtype=torch.uint8, device=dev)
         self.handle = ctypes.c_void_p(0)

@@ -19,7 +19,7 @@ class CgPlan:
     and the captured iteration graph (mgp_cg_plan_* in include/mgp_hip.h)."""
 
     def __init__(self, desc, C, tol=None, max_iter=None, min_iter=None, stop_mode=None, jacobi=None,
-                 check_every=0, use_graph=True):
+                 check_every=0, use_graph=True, refine=0):
         self.desc = desc
         self.C = int(C)
         dev = desc.data.graph.device
@@ -29,7 +29,7 @@ class CgPlan:
             float(settings.cg_tolerance.value() if tol is None else tol),
             int(settings.max_cg_iterations.value() if max_iter is None else max_iter),
             int((10 if stop_mode == 0 else 0) if min_iter is None else min_iter),
-            int(stop_mode), int(check_every), int(bool(use_graph)))
+            int(stop_mode), int(check_every), int(bool(use_graph)), int(refine))
         jacobi = settings.cg_jacobi_preconditioner.value() if jacobi is None else jacobi
         self.minv = desc.jacobi() if jacobi else None
         wb = lib().mgp_cg_workspace_bytes(ctypes.byref(self.op), self.C)

@@ -36,7 +36,7 @@ def test_struct_layouts_match_c_abi():
     from manifold_gp_amd import _lib
     assert ctypes.sizeof(_lib.CsrT) == 64
     assert ctypes.sizeof(_lib.OperatorT) == 64 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
-    assert ctypes.sizeof(_lib.CgParamsT) == 24
+    assert ctypes.sizeof(_lib.CgParamsT) == 28
     assert ctypes.sizeof(_lib.LanczosParamsT) == 24
     assert _lib.OperatorT.pre.offset == 64 and _lib.OperatorT.nu.offset == 80
 
