@@ -139,8 +139,10 @@ int mgp_spmm_fused_rows(const mgp_csr_t* L_local, int64_t row_offset, const floa
                         float a, float b, const float* pre, const float* post, const float* base,
                         float cb, float co, const float* dotw, float* dot_partials, void* stream);
 
-/* measurement helper: `reps` back-to-back launches of Y = L X enqueued from C */
-int mgp_spmm_repeat(const mgp_csr_t* L, const float* X, int C, float* Y, int reps, void* stream);
+/* measurement helper: `reps` back-to-back launches of Y = L X replayed as one hipGraph; elapsed_ms
+ * (nullable, host) = HIP-event time of the launches on `stream`.  Synchronises `stream`. */
+int mgp_spmm_repeat(const mgp_csr_t* L, const float* X, int C, float* Y, int reps, float* elapsed_ms,
+                    void* stream);
 
 /* L @ X in the three flavours of graph_laplacian_operator.py:108-124:
  * mode 0 symmetric, 1 randomwalk (D^-1/2 L_sym D^1/2), 2 randomwalk transposed */

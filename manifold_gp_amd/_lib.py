@@ -81,7 +81,7 @@ SIGNATURES = {
                                c_float, _P, _P, _P]),
     "mgp_spmm_fused_rows": (c_int, [POINTER(CsrT), c_int64, _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
                                     c_float, _P, _P, _P]),
-    "mgp_spmm_repeat": (c_int, [POINTER(CsrT), _P, c_int, _P, c_int, _P]),
+    "mgp_spmm_repeat": (c_int, [POINTER(CsrT), _P, c_int, _P, c_int, POINTER(c_float), _P]),
     "mgp_laplacian_matmul": (c_int, [POINTER(CsrT), _P, _P, c_int, _P, c_int, _P, _P, _P]),
     "mgp_operator_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int]),
     "mgp_operator_apply": (c_int, [POINTER(OperatorT), _P, c_int, _P, _P, c_size_t, _P]),

@@ -80,6 +80,31 @@ class CgPlan:
             pass
 
 
+_PLAN_CACHE = {}
+_PLAN_CACHE_MAX = 8
+
+
+def _cached_plan(desc, C, kw):
+    """Plans own a captured hipGraph (~ms to build): reuse them for repeated solves with the same
+    operator (the nested CG of a Schur-complement matvec, _average_variance in a training loop)."""
+    key = (id(desc.data), desc.nu, desc.kappa, desc.scale, desc.form, desc.noise,
+           desc.pre.data_ptr() if desc.pre is not None else 0, desc.post.data_ptr() if desc.post is not None else 0,
+           int(C), settings.cg_tolerance.value(), settings.max_cg_iterations.value(), settings.cg_stop_mode.value(),
+           settings.cg_jacobi_preconditioner.value(), tuple(sorted(kw.items())))
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE))).close()
+        plan = CgPlan(desc, C, **kw)
+        _PLAN_CACHE[key] = plan
+    return plan
+
+
+def clear_plan_cache():
+    while _PLAN_CACHE:
+        _PLAN_CACHE.popitem()[1].close()
+
+
 def cg_solve(desc, rhs, **kw):
     """Solve A X = rhs with the HIP CG.  Returns (X, iterations, relative residuals)."""
     squeeze = rhs.dim() == 1
@@ -87,7 +112,7 @@ def cg_solve(desc, rhs, **kw):
     outs, its, res = [], 0, []
     for c0 in range(0, B.shape[1], 256):
         Bc = B if B.shape[1] <= 256 else B[:, c0:c0 + 256].contiguous()
-        plan = CgPlan(desc, Bc.shape[1], **kw)
+        plan = _cached_plan(desc, Bc.shape[1], kw)
         outs.append(plan.solve(Bc))
         its = max(its, plan.iters)
         res += plan.resid
@@ -96,7 +121,6 @@ def cg_solve(desc, rhs, **kw):
                           % (plan.iters, max(plan.resid)))
         elif plan.status == 3:
             raise RuntimeError("NaNs encountered in CG")          # linear_cg raises on NaN too
-        plan.close()
     X = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
     return (X.squeeze(-1) if squeeze else X), its, res
 
@@ -169,7 +193,7 @@ def dense_symeig(operator):
 
 
 # ------------------------------------------------------------------------------ Lanczos
-def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=8, seed=1337):
+def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=60, seed=1337):
     """m smallest eigenpairs of L_sym (CSR in `lap_data`) by the HIP filtered Lanczos.
     Returns (evals[m] device, evecs[n,m] device, resid[m] host list)."""
     g = lap_data.graph
@@ -183,8 +207,13 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
     resid = (ctypes.c_float * m)()
     info = (ctypes.c_int32 * 4)()
     evecs = torch.empty(g.n, m, dtype=torch.float32, device=dev)
-    check(lib().mgp_lanczos_smallest(ctypes.byref(csr), int(m), ctypes.byref(prm), evals, ptr(evecs), resid, info,
-                                     ptr(work), work.numel(), stream()), "mgp_lanczos_smallest")
+    rc = lib().mgp_lanczos_smallest(ctypes.byref(csr), int(m), ctypes.byref(prm), evals, ptr(evecs), resid, info,
+                                    ptr(work), work.numel(), stream())
+    if rc == -4:      # MGP_ERR_NOT_CONVERGED: the best block is returned, residuals say how good it is
+        warnings.warn("eigensolver stopped after %d rounds with %d/%d pairs below tol (max residual %.3g)"
+                      % (info[0], info[2], m, max(resid)))
+    else:
+        check(rc, "mgp_lanczos_smallest")
     ev = torch.tensor(list(evals), dtype=torch.float32, device=dev)
     lanczos_smallest.last_info = list(info)
     return ev, evecs, list(resid)

@@ -42,11 +42,11 @@ def main():
             lib.mgp_spmm_set_rows_in_flight(2)
             csr = data.csr()
             st = _lib.stream()
-            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 10, st)
+            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 10, None, st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
-            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 100, st)
+            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 100, None, st)
             e1.record()
             torch.cuda.synchronize()
             res.append((pw, data.graph.panels, data.graph.nnz, round(e0.elapsed_time(e1) / 100 * 1e3, 2)))

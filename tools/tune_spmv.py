@@ -45,11 +45,11 @@ def main():
             csr = sym.data.csr()
             out = torch.empty_like(v)
             st = _lib.stream()
-            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 10, st)
+            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 10, None, st)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
-            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), a.reps, st)
+            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), a.reps, None, st)
             e1.record()
             torch.cuda.synchronize()
             times[(L, G, R)].append(e0.elapsed_time(e1) / a.reps * 1e3)
