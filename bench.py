@@ -51,22 +51,22 @@ def build_workload(args, dev, rank, world, shard_knn=False):
     t0 = time.time()
     if args.workload == "c3":
         bases = args.nodes // 100 if args.nodes else 600
-        x_np, y_np = synth.rmnist_like(bases * world, 100, seed=1337)
+        x_t, y_t = synth.rmnist_like(bases * world, 100, seed=1337, device=dev)
         k, nu, norm = 50, 2, "randomwalk"
         with open(os.path.join(ROOT, "tests", "golden", "hyperparameters.json")) as fh:
             hp = json.load(fh)["srmnist_manifold_semisupervised"]
-        name = "C3 RMNIST-like N=%d d=784 k=50 nu=2 randomwalk" % x_np.shape[0]
+        name = "C3 RMNIST-like N=%d d=784 k=50 nu=2 randomwalk" % x_t.shape[0]
     elif args.workload == "s5":
         n = args.nodes or 1000000
         x_np, y_np = synth.swiss_roll(n * world, order=args.s5_order)
+        x_t, y_t = torch.from_numpy(x_np).to(dev), torch.from_numpy(y_np).to(dev)
         k, nu, norm = 64, 2, "symmetric"
         hp = dict(graphbandwidth=0.0, lengthscale=1.0, outputscale=1.0, noise=0.01, eps_scale=3.0)
         name = "S5 swiss-roll N=%d d=3 k=64 nu=2 symmetric (%s order)" % (x_np.shape[0], args.s5_order)
     else:
         raise SystemExit("unknown workload " + args.workload)
     t_data = time.time() - t0
-    x = torch.from_numpy(x_np).to(dev)
-    y = torch.from_numpy(y_np).to(dev)
+    x, y = x_t, y_t
     torch.cuda.synchronize()
     t0 = time.time()
     knn = mgp.utils.NearestNeighbors(x)

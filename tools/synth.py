@@ -45,9 +45,44 @@ def _rotate_batch(img, angles_deg):
     return out
 
 
-def rmnist_like(bases=600, per_base=100, seed=1337, max_angle=45.0):
-    """Returns x [bases*per_base, 784] f32 in [-0.5, 0.5], y [N] f32 (standardised angle)."""
+def _rmnist_like_torch(imgs, angles, device):
+    """All rotations at once on `device` (bilinear grid_sample about the image centre)."""
+    import torch
+    import torch.nn.functional as F
+    bases, per_base = angles.shape
+    out = torch.empty(bases * per_base, 28 * 28, dtype=torch.float32, device=device)
+    img_t = torch.from_numpy(imgs).to(device)
+    ang_t = torch.from_numpy(np.deg2rad(angles)).to(device)
+    step = 256
+    for b0 in range(0, bases, step):
+        b1 = min(bases, b0 + step)
+        a = ang_t[b0:b1].reshape(-1)
+        cos, sin = torch.cos(a), torch.sin(a)
+        theta = torch.zeros(a.shape[0], 2, 3, device=device)
+        theta[:, 0, 0], theta[:, 0, 1], theta[:, 1, 0], theta[:, 1, 1] = cos, -sin, sin, cos
+        grid = F.affine_grid(theta, (a.shape[0], 1, 28, 28), align_corners=True)
+        src = img_t[b0:b1].repeat_interleave(per_base, dim=0).unsqueeze(1)
+        rot = F.grid_sample(src, grid, mode="bilinear", padding_mode="zeros", align_corners=True)
+        out[b0 * per_base:b1 * per_base] = rot.reshape(-1, 28 * 28)
+    return out
+
+
+def rmnist_like(bases=600, per_base=100, seed=1337, max_angle=45.0, device=None):
+    """Returns x [bases*per_base, 784] f32 in [-0.5, 0.5], y [N] f32 (standardised angle).
+    device=None: numpy on the host (returns numpy arrays); device=torch device: the rotations run
+    there (returns torch tensors on that device) -- same blobs and angles, bilinear interpolation."""
     rng = np.random.default_rng(seed)
+    if device is not None:
+        import torch
+        imgs = blob_images(bases, rng).astype(np.float32)
+        angles = np.empty((bases, per_base), np.float32)
+        for b in range(bases):
+            angles[b] = np.concatenate([[0.0], rng.uniform(-max_angle, max_angle, per_base - 1)])
+        x = _rmnist_like_torch(imgs, angles, device)
+        x = (torch.round(x) - 127.5) / 255.0
+        ang = torch.from_numpy(angles.reshape(-1)).to(device)
+        y = (ang - ang.mean()) / ang.std(unbiased=False)
+        return x.contiguous(), y.contiguous()
     imgs = blob_images(bases, rng).astype(np.float32)
     n = bases * per_base
     x = np.empty((n, 28 * 28), np.float32)
