@@ -95,6 +95,14 @@ int mgp_graph_from_coo(const int32_t* tri_row, const int32_t* tri_col, const flo
 int mgp_laplacian_build(int64_t n, const int32_t* rowptr, const int32_t* col, const float* d2,
                         float eps, int self_loops, float* degree_unnorm, float* degree,
                         float* diag, float* dsqrt, float* dinvsqrt, float* vals, void* stream);
+/* Forward-mode tangent of mgp_laplacian_build wrt the graph bandwidth: d/d eps of D~, D, diag, sqrt(D),
+ * 1/sqrt(D) and the CSR values (same three row passes).  With it d(u^T L v)/d eps = u^T L' v is one more
+ * fused SpMV on (d_vals, d_diag): the hyper-parameter gradient path the reference obtains by autograd
+ * through graph_laplacian_operator.py:52-124 (pinned by test/_test_functions.py:59-74). */
+int mgp_laplacian_tangent(int64_t n, const int32_t* rowptr, const int32_t* col, const float* d2,
+                          float eps, int self_loops, const float* degree_unnorm, const float* degree,
+                          const float* diag, float* d_degree_unnorm, float* d_degree, float* d_diag,
+                          float* d_dsqrt, float* d_dinvsqrt, float* d_vals, void* stream);
 /* per-edge values in the reference's COO order: which = 0 W (adjacency_unnorm_mat :54-56),
  * 1 A (adjacency_mat :73-75), 2 S (laplacian_triu :104-106) */
 int mgp_edge_values(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val,

@@ -70,6 +70,7 @@ SIGNATURES = {
     "mgp_graph_from_coo": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, POINTER(c_int64), _P,
                                    c_size_t, _P]),
     "mgp_laplacian_build": (c_int, [c_int64, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "mgp_laplacian_tangent": (c_int, [c_int64, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mgp_edge_values": (c_int, [_P, _P, _P, c_int64, _P, _P, c_float, c_int, _P, _P]),
     "mgp_spmm_dot_blocks": (c_int, [c_int64, c_int]),
     "mgp_spmm_set_group_hint": (c_int, [c_int]),

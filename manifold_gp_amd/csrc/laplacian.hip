@@ -97,7 +97,106 @@ __global__ void edge_values_kernel(const int32_t* __restrict__ tr, const int32_t
   }
 }
 
+// ---------------------------------------------------------------- forward-mode tangent wrt eps
+// d/d eps of every quantity mgp_laplacian_build produces, by the same three gather-only row passes:
+//   dW  = W d2 / (2 eps^3)
+//   dD~ = sum_j dW                                   (pass 1)
+//   dA  = dW / (D~_i D~_j) - A (dD~_i / D~_i + dD~_j / D~_j)
+//   dD  = [self_loops] (-2 D~^-3 dD~) + sum_j dA      (pass 2)
+//   dS  = (dA - A (dD_i / (2 D_i) + dD_j / (2 D_j))) / (sqrt(D_i) sqrt(D_j) eps^2) - 2 S / eps   (pass 3)
+//   ddiag = [self_loops] (2 D~^-3 dD~ / D + D~^-2 dD / D^2) / eps^2 - 2 diag / eps
+// The gradient of any scalar loss wrt the graph bandwidth is then <dl/dvals, dvals> + <dl/ddiag, ddiag>
+// + ... ; in particular d(u^T L v)/d eps = u^T L' v with L' the CSR (dvals, ddiag) -- one more SpMV
+// (manifold_gp/operators/graph_laplacian_operator.py relies on autograd through its torch ops for
+// this, pinned by test/_test_functions.py:59-74 `test_grad`).
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void lap_tangent_pass(int64_t n, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col, const float* __restrict__ d2,
+                                                           float eps, int self_loops, const float* __restrict__ dtil,
+                                                           const float* __restrict__ deg, const float* __restrict__ diag,
+                                                           float* __restrict__ ddtil, float* __restrict__ ddeg,
+                                                           float* __restrict__ ddiag, float* __restrict__ ddsqrt,
+                                                           float* __restrict__ ddinvsqrt, float* __restrict__ dvals) {
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t g = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
+  const int64_t ng = ((int64_t)gridDim.x * blockDim.x) / G;
+  const float eps2 = eps * eps;
+  const float nq = -4.0f * eps2;
+  const float dwf = 1.0f / (2.0f * eps2 * eps);
+  for (int64_t r = g; r < n; r += ng) {
+    const int s = rowptr[r], e = rowptr[r + 1];
+    float acc = 0.f;
+    const float dt_r = dtil[r];
+    float ddt_r = 0.f, d_r = 0.f, dd_r = 0.f;
+    if (PASS >= 2) ddt_r = ddtil[r];
+    if (PASS == 3) { d_r = deg[r]; dd_r = ddeg[r]; }
+    for (int i = s + lane; i < e; i += G) {
+      const float dd = d2[i];
+      const float w = wexp(dd, nq);
+      const float dw = isinf(dd) ? 0.f : w * dd * dwf;
+      if (PASS == 1) {
+        acc += dw;
+      } else {
+        const int c = col[i];
+        const float dt_c = dtil[c], ddt_c = ddtil[c];
+        const float a = w / (dt_r * dt_c);
+        const float da = dw / (dt_r * dt_c) - a * (ddt_r / dt_r + ddt_c / dt_c);
+        if (PASS == 2) {
+          acc += da;
+        } else {
+          const float d_c = deg[c], dd_c = ddeg[c];
+          const float sq = sqrtf(d_r) * sqrtf(d_c);
+          const float sv = a / sq / eps2;
+          dvals[i] = (da - a * (0.5f * dd_r / d_r + 0.5f * dd_c / d_c)) / sq / eps2 - 2.0f * sv / eps;
+        }
+      }
+    }
+    if (PASS != 3) {
+      acc = mgp_group_sum<G>(acc);
+      if (lane == 0) {
+        if (PASS == 1) {
+          ddtil[r] = acc;
+        } else {
+          const float i2 = 1.0f / (dt_r * dt_r);
+          const float dbase = self_loops ? -2.0f * i2 / dt_r * ddt_r : 0.0f;
+          const float d = deg[r];
+          const float ddv = dbase + acc;
+          ddeg[r] = ddv;
+          const float sq = sqrtf(d);
+          ddsqrt[r] = 0.5f * ddv / sq;
+          ddinvsqrt[r] = -0.5f * ddv / (d * sq);
+          ddiag[r] = self_loops ? (2.0f * i2 / dt_r * ddt_r / d + i2 * ddv / (d * d)) / eps2 - 2.0f * diag[r] / eps
+                                : -2.0f / (eps2 * eps);
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int mgp_laplacian_tangent(int64_t n, const int32_t* rowptr, const int32_t* col, const float* d2, float eps,
+                                     int self_loops, const float* degree_unnorm, const float* degree,
+                                     const float* diag, float* d_degree_unnorm, float* d_degree, float* d_diag,
+                                     float* d_dsqrt, float* d_dinvsqrt, float* d_vals, void* stream) {
+  if (!rowptr || !col || !d2 || !degree_unnorm || !degree || !diag || !d_degree_unnorm || !d_degree || !d_diag ||
+      !d_dsqrt || !d_dinvsqrt || !d_vals)
+    return MGP_ERR_ARG;
+  if (n <= 0 || !(eps > 0.f)) return MGP_ERR_ARG;
+  hipStream_t st = mgp_stream(stream);
+  int64_t grid = mgp_cdiv(n, kBlock / G);
+  if (grid > 4096) grid = 4096;
+#define MGP_TAN(PASS)                                                                                              \
+  hipLaunchKernelGGL((lap_tangent_pass<PASS>), dim3((int)grid), dim3(kBlock), 0, st, n, rowptr, col, d2, eps,      \
+                     self_loops, degree_unnorm, degree, diag, d_degree_unnorm, d_degree, d_diag, d_dsqrt,          \
+                     d_dinvsqrt, d_vals);                                                                          \
+  MGP_LAUNCH_CHECK();
+  MGP_TAN(1)
+  MGP_TAN(2)
+  MGP_TAN(3)
+#undef MGP_TAN
+  return MGP_OK;
+}
 
 extern "C" int mgp_laplacian_build(int64_t n, const int32_t* rowptr, const int32_t* col, const float* d2,
                                    float eps, int self_loops, float* degree_unnorm, float* degree,

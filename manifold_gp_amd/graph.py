@@ -158,6 +158,25 @@ class LaplacianData:
                                         stream()), "mgp_laplacian_build")
         self._edge = {}
 
+    def tangent(self):
+        """d/d eps of every array of this object (mgp_laplacian_tangent), cached."""
+        if getattr(self, "_tangent", None) is None:
+            g = self.graph
+            f = dict(dtype=torch.float32, device=g.device)
+
+            class Tangent:
+                pass
+            t = Tangent()
+            t.d_degree_unnorm, t.d_degree = torch.empty(g.n, **f), torch.empty(g.n, **f)
+            t.d_diag, t.d_dsqrt, t.d_dinvsqrt = torch.empty(g.n, **f), torch.empty(g.n, **f), torch.empty(g.n, **f)
+            t.d_vals = torch.empty(g.nnz, **f)
+            check(lib().mgp_laplacian_tangent(g.n, ptr(g.rowptr), ptr(g.col), ptr(g.d2), self.eps, int(self.self_loops),
+                                              ptr(self.degree_unnorm), ptr(self.degree), ptr(self.diag),
+                                              ptr(t.d_degree_unnorm), ptr(t.d_degree), ptr(t.d_diag), ptr(t.d_dsqrt),
+                                              ptr(t.d_dinvsqrt), ptr(t.d_vals), stream()), "mgp_laplacian_tangent")
+            self._tangent = t
+        return self._tangent
+
     def csr(self):
         g = self.graph
         return _lib.csr_struct(g.n, g.rowptr, g.col, self.vals, self.diag, g.segptr, g.panels, g.panel_width)

@@ -87,8 +87,24 @@ class GraphLaplacianOperator(LinearOperator):
             return 0
         return 2 if self.transposed else 1
 
+    def _hyper_tensors(self):
+        return [self.graphbandwidth]
+
+    def _matmul_grad(self, rhs):
+        """Differentiable path (autograd.py): gradients wrt rhs and the graph bandwidth."""
+        from ..autograd import fused_spmm, node_vector
+        d, eps = self.data, self.graphbandwidth
+        pre = post = None
+        if self.normalization == "randomwalk":
+            sq, isq = node_vector(eps, d, "dsqrt"), node_vector(eps, d, "dinvsqrt")
+            pre, post = (isq, sq) if self.transposed else (sq, isq)
+        return fused_spmm(d, rhs, eps, a=0.0, b=1.0, pre=pre, post=post)
+
     def _matmul(self, rhs):
         _lib.require_device(rhs)
+        from ..autograd import needs_grad
+        if needs_grad(rhs, self.graphbandwidth):
+            return self._matmul_grad(rhs)
         squeeze = rhs.dim() == 1
         X = _lib.f32c(rhs.unsqueeze(-1) if squeeze else rhs)
         d = self.data

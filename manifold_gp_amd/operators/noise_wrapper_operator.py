@@ -21,7 +21,15 @@ class NoiseWrapperOperator(LinearOperator):
             return None
         return inner.with_(form=1, noise=_scalar(self.noise))
 
+    def _hyper_tensors(self):
+        return getattr(self.operator, "_hyper_tensors", lambda: [])() + [self.noise]
+
     def _matmul(self, rhs):
+        from ..autograd import needs_grad
+        if needs_grad(rhs, *self._hyper_tensors()):
+            Q = self.operator._matmul                        # noise_wrapper_operator.py:22, differentiable
+            rhs = rhs.contiguous()
+            return Q(rhs - self.noise * Q(rhs - self.noise * Q(rhs)))
         d = self._descriptor()
         if d is not None:
             return d.apply(rhs)

@@ -23,7 +23,27 @@ class PrecisionMaternOperator(LinearOperator):
         # D (tau I + L_rw)^nu = D^1/2 (tau I + L_sym)^nu D^1/2   (precision_matern_operator.py:30-37)
         return Descriptor(d, int(self.nu), _scalar(self.lengthscale), pre=sq, post=sq)
 
+    def _hyper_tensors(self):
+        return self.laplacian._hyper_tensors() + [self.lengthscale]
+
+    def _matmul_grad(self, rhs):
+        """Differentiable chain: gradients wrt rhs, graph bandwidth and lengthscale."""
+        from ..autograd import fused_spmm, node_vector
+        lap = self.laplacian
+        d, eps = lap.data, lap.graphbandwidth
+        ls = self.lengthscale.reshape(()) if torch.is_tensor(self.lengthscale) else torch.tensor(float(self.lengthscale))
+        tau = 2.0 * self.nu / ls.to(d.graph.device).square()
+        sq = node_vector(eps, d, "dsqrt") if lap.normalization == "randomwalk" else None
+        out = rhs
+        for s in range(self.nu):
+            out = fused_spmm(d, out, eps, a=tau, b=1.0, pre=sq if s == 0 else None,
+                             post=sq if s == self.nu - 1 else None)
+        return out
+
     def _matmul(self, rhs):
+        from ..autograd import needs_grad
+        if needs_grad(rhs, *self._hyper_tensors()):
+            return self._matmul_grad(rhs)
         return self._descriptor().apply(rhs)
 
     def _size(self):

@@ -26,7 +26,14 @@ class ScaleWrapperOperator(LinearOperator):
             return None
         return inner.with_(scale=inner.scale * self._factor())
 
+    def _hyper_tensors(self):
+        return getattr(self.operator, "_hyper_tensors", lambda: [])() + [self.scale]
+
     def _matmul(self, rhs):
+        from ..autograd import needs_grad
+        if needs_grad(rhs, *self._hyper_tensors()):
+            out = self.operator._matmul(rhs.contiguous())
+            return out / self.scale if self.inverse_scale else out * self.scale
         d = self._descriptor()
         if d is not None:
             return d.apply(rhs)

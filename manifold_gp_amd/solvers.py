@@ -158,11 +158,19 @@ def generic_cg(operator, rhs, tol=None, max_iter=None):
 def inv_quad_logdet(operator, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
     """linear_operator's inv_quad_logdet as the reference uses it (precision_matern_operator.py:53,
     train_model.py:68, test_model.py:23): dense Cholesky of to_dense() when N <= max_cholesky_size,
-    iterative otherwise (CG for the quadratic form; stochastic Lanczos quadrature for logdet)."""
+    iterative otherwise (HIP CG for the quadratic form; stochastic Lanczos quadrature for logdet).
+
+    Gradients (training): the dense branch is differentiable end to end (to_dense()
+    runs the differentiable fused SpMM).  The iterative branch returns the iterative VALUE plus a
+    zero-valued surrogate that carries the gradient, the way linear_operator's InvQuadLogdet does:
+        d logdet A = E_z[(A^-1 z)^T dA z],      d (b^T A^-1 b) = -(A^-1 b)^T dA (A^-1 b)
+    with the solves detached and one differentiable operator application each."""
+    from .autograd import needs_grad
     n = operator.shape[-1]
     inv_quad = None
     logdet_term = None
     dense_ok = n <= settings.max_cholesky_size.value()
+    grad = needs_grad(*getattr(operator, "_hyper_tensors", lambda: [])())
     chol = None
     if dense_ok:
         A = operator.to_dense()
@@ -172,16 +180,30 @@ def inv_quad_logdet(operator, inv_quad_rhs=None, logdet=False, reduce_inv_quad=T
         rhs = inv_quad_rhs if inv_quad_rhs.dim() == 2 else inv_quad_rhs.unsqueeze(-1)
         if chol is not None:
             sol = torch.cholesky_solve(rhs.double(), chol).float()
+            iq = (rhs * sol).sum(0)
         else:
-            sol = operator.solve(rhs)
-        iq = (rhs * sol).sum(0)
+            with torch.no_grad():
+                sol = operator.solve(rhs)
+            iq = (rhs * sol).sum(0)
+            if grad:
+                sur = -(sol * operator.matmul(sol)).sum(0)
+                iq = iq + (sur - sur.detach())
         inv_quad = iq.sum() if reduce_inv_quad else iq
     if logdet:
         if chol is not None:
             logdet_term = (2.0 * chol.diagonal().log().sum()).float()
         else:
             from .slq import slq_logdet
-            logdet_term = slq_logdet(operator)
+            with torch.no_grad():
+                logdet_term = slq_logdet(operator)
+            if grad:
+                P = settings.num_trace_samples.value()
+                gen = torch.Generator(device="cpu").manual_seed(4321)
+                Z = (torch.randint(0, 2, (n, P), generator=gen).float() * 2 - 1).to(logdet_term.device)
+                with torch.no_grad():
+                    S = operator.solve(Z)
+                sur = (S * operator.matmul(Z)).sum() / P
+                logdet_term = logdet_term + (sur - sur.detach())
     return inv_quad, logdet_term
 
 

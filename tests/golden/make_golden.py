@@ -110,6 +110,36 @@ def main():
                     out[p + "schur_mask"] = mask.numpy()
                     out[p + "schur_mv"] = (S @ train_y[mask].double()).float().numpy()
                     out[p + "solve"] = torch.linalg.solve(Q.double(), train_y.double()).float().numpy()
+            # ---- gradients (test/_test_functions.py:59-104 `test_grad`, `test_ml`): torch autograd through
+            # the reference's dense operators, evaluated in float64
+            torch.set_default_dtype(torch.float64)
+            e_ = torch.tensor([[eps]], dtype=torch.float64, requires_grad=True)
+            Lg = dense.graph_laplacian(idx, val.double(), e_, n, normalization=norm, self_loops=self_loops)[0]
+            (torch.mm(Lg.T, train_y.double().view(-1, 1)).sum()).backward()                 # test_grad's loss
+            out[p + "grad_eps_sum_LTv"] = np.float64(e_.grad.item())
+            e_ = torch.tensor([[eps]], dtype=torch.float64, requires_grad=True)
+            Lg = dense.graph_laplacian(idx, val.double(), e_, n, normalization=norm, self_loops=self_loops)[0]
+            ((probes.double() * torch.mm(Lg, probes.double())).sum()).backward()
+            out[p + "grad_eps_quadform"] = np.float64(e_.grad.item())
+            # hyper-parameters chosen so that noise * |Q2| < 1 (the Neumann noise model of
+            # noise_wrapper_operator.py:22 is meant for that regime)
+            nu_ml = 2 if tag == "k50_noloop" else 1
+            e_ = torch.tensor([[eps]], dtype=torch.float64, requires_grad=True)
+            k_ = torch.tensor([[kappa]], dtype=torch.float64, requires_grad=True)
+            s_ = torch.tensor(0.7, dtype=torch.float64, requires_grad=True)
+            z_ = torch.tensor(1e-3, dtype=torch.float64, requires_grad=True)
+            Lg, _, _, _, deg_g = dense.graph_laplacian(idx, val.double(), e_, n, normalization=norm, self_loops=self_loops)
+            Qg = dense.matern_precision(Lg, nu_ml, k_, deg_g if norm == "randomwalk" else None)
+            Q3 = dense.matern_noisy_precision(Qg * s_, z_)          # riemann_gp.py:32-39: scale multiplies
+            yv = train_y.double()
+            loss = 0.5 * (torch.dot(yv, torch.mv(Q3, yv)) - torch.logdet(Q3) + n * np.log(2 * np.pi))   # test_ml
+            loss.backward()
+            out[p + "ml_nu"] = np.int32(nu_ml)
+            out[p + "ml_loss"] = np.float64(loss.item())
+            out[p + "ml_quad"] = np.float64(torch.dot(yv, torch.mv(Q3, yv)).item())
+            out[p + "ml_logdet"] = np.float64(torch.logdet(Q3).item())
+            out[p + "ml_grads"] = np.array([e_.grad.item(), k_.grad.item(), s_.grad.item(), z_.grad.item()])
+            torch.set_default_dtype(torch.float32)
             # ---- spectrum / features (riemann_kernel.py:121-136 on the reference's dense L_sym) ----
             if norm == "symmetric":
                 Lsym, deg_sym, deg_un_sym = L, deg, deg_un

@@ -605,3 +605,77 @@ def test_cg_iterative_refinement_reaches_true_residual(mgp, golden, dev):
     assert it1 >= it0
     xr = np.linalg.solve(desc.apply(torch.eye(desc.n, device=dev)).double().cpu().numpy(), g["train_y"].astype(np.float64))
     assert np.abs(x1.cpu().numpy() - xr).max() <= np.abs(x0.cpu().numpy() - xr).max() * 1.5 + 1e-6
+
+
+# ----------------------------------------------------------------------------- gradients (next row f-1)
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("norm", NORMS)
+def test_grad_and_marginal_likelihood_vs_reference_autograd(mgp, golden, dev, case, norm):
+    """test/_test_functions.py:59-104 (`test_grad`, `test_ml`): gradients wrt the hyper-parameters through
+    the HIP operators against torch autograd through the reference's dense operators (float64 golden)."""
+    g = golden(case)
+    p = norm + "_"
+    O = mgp.operators
+    n = g["train_x"].shape[0]
+    idx, val = T(g["edge_index"].astype(np.int64), dev), T(g["edge_value"], dev)
+    y, P = T(g["train_y"], dev), T(g["probes"], dev)
+
+    def lap_op(eps_t, transposed=False):
+        return O.GraphLaplacianOperator(val, idx, n, eps_t, norm, bool(g["self_loops"]), transposed)
+
+    # d/d eps of sum(L^T v)  (test_grad) and of sum(P . (L P))
+    eps_t = torch.tensor([[float(g["eps"])]], device=dev, requires_grad=True)
+    loss = lap_op(eps_t).T.matmul(y.view(-1, 1)).sum()
+    loss.backward()
+    ref = float(g[p + "grad_eps_sum_LTv"])
+    scale = float(np.abs(g[p + "mvT"]).sum()) / float(g["eps"])          # size of the terms that cancel
+    assert abs(eps_t.grad.item() - ref) < 2e-5 * scale + 1e-3 * abs(ref)
+    eps_t = torch.tensor([[float(g["eps"])]], device=dev, requires_grad=True)
+    loss = (P * lap_op(eps_t).matmul(P)).sum()
+    loss.backward()
+    ref = float(g[p + "grad_eps_quadform"])
+    assert abs(eps_t.grad.item() - ref) < 2e-3 * abs(ref)
+
+    # marginal likelihood in precision form (train_model.py:67-69) and its four gradients
+    nu = int(g[p + "ml_nu"])
+    eps_t = torch.tensor([[float(g["eps"])]], device=dev, requires_grad=True)
+    kap_t = torch.tensor([[float(g["kappa"])]], device=dev, requires_grad=True)
+    s_t = torch.tensor(0.7, device=dev, requires_grad=True)
+    z_t = torch.tensor(1e-3, device=dev, requires_grad=True)
+    Q3 = O.NoiseWrapperOperator(O.ScaleWrapperOperator(O.PrecisionMaternOperator(lap_op(eps_t), nu, kap_t), s_t), z_t)
+    with mgp.settings.max_cholesky_size(2000):
+        quad = torch.dot(y, Q3.matmul(y.view(-1, 1)).squeeze())
+        logdet = Q3.inv_quad_logdet(logdet=True)[1]
+        loss = 0.5 * (quad - logdet + n * np.log(2 * np.pi))
+    loss.backward()
+    assert abs(quad.item() - float(g[p + "ml_quad"])) < 2e-4 * abs(float(g[p + "ml_quad"]))
+    assert abs(logdet.item() - float(g[p + "ml_logdet"])) < 2e-4 * abs(float(g[p + "ml_logdet"]))
+    got = np.array([eps_t.grad.item(), kap_t.grad.item(), s_t.grad.item(), z_t.grad.item()])
+    ref = g[p + "ml_grads"]
+    assert (np.abs(got - ref) < 5e-3 * np.abs(ref) + 1e-4 * np.abs(ref).max()).all(), (got, ref)
+
+
+def test_stochastic_gradients_large_n_branch(mgp, golden, dev):
+    """N > max_cholesky_size branch of the marginal likelihood: SLQ value + surrogate gradients
+    (d logdet = E[(A^-1 z)^T dA z]) against the float64 dense autograd golden, Monte-Carlo tolerance."""
+    g = golden("dumbbell_k50_noloop")
+    p = "randomwalk_"
+    O = mgp.operators
+    n = g["train_x"].shape[0]
+    idx, val = T(g["edge_index"].astype(np.int64), dev), T(g["edge_value"], dev)
+    y = T(g["train_y"], dev)
+    eps_t = torch.tensor([[float(g["eps"])]], device=dev, requires_grad=True)
+    kap_t = torch.tensor([[float(g["kappa"])]], device=dev, requires_grad=True)
+    s_t = torch.tensor(0.7, device=dev, requires_grad=True)
+    z_t = torch.tensor(1e-3, device=dev, requires_grad=True)
+    lap = O.GraphLaplacianOperator(val, idx, n, eps_t, "randomwalk", False)
+    Q3 = O.NoiseWrapperOperator(O.ScaleWrapperOperator(O.PrecisionMaternOperator(lap, int(g[p + "ml_nu"]), kap_t), s_t), z_t)
+    with mgp.settings.max_cholesky_size(100), mgp.settings.num_trace_samples(200), mgp.settings.cg_tolerance(1e-4), \
+            mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(4000):
+        logdet = Q3.inv_quad_logdet(logdet=True)[1]
+        loss = 0.5 * (torch.dot(y, Q3.matmul(y.view(-1, 1)).squeeze()) - logdet + n * np.log(2 * np.pi))
+    loss.backward()
+    assert abs(logdet.item() - float(g[p + "ml_logdet"])) < 0.03 * abs(float(g[p + "ml_logdet"]))
+    got = np.array([eps_t.grad.item(), kap_t.grad.item(), s_t.grad.item(), z_t.grad.item()])
+    ref = g[p + "ml_grads"]
+    assert (np.abs(got - ref) < 0.08 * np.abs(ref) + 0.02 * np.abs(ref).max()).all(), (got, ref)
