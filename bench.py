@@ -261,8 +261,10 @@ def _main(quiet):
                 bytes_per_launch=B, avg_launch_us=round(t_k * 1e6, 2),
                 note=("working set %.0f MB is Infinity-Cache resident; the kernel is gather-bound, see DESIGN.md"
                       if B < 2.5e8 else "working set %.0f MB streams from HBM") % (B / 1e6))
+    # HBM bytes per launch from the PMC passes of the same command (tools/profile.sh ->
+    # tools/summarize_profile.py): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and args.workload == "c3" and not args.nodes:
         try:
             roof["traffic"] = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
         except Exception:

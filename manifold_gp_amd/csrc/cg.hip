@@ -53,11 +53,36 @@ struct CgArgs {
   int64_t rows_per_block;
 };
 
-// sh[k][sl * TC + cc] holds the partial of slice sl for column cc: fixed-order tree over the slices
-// (TS is a power of two), result in sh[k][cc].  A single thread summing TS = 256 LDS words serially
-// cost ~2.5 us per call (profiled): the tree is 8 barriers.
+// sh[k][sl * TC + cc] holds the partial of slice sl for column cc; result in sh[k][cc] for cc < TC.
+// TC <= 64: the slices of a column sit TC lanes apart inside a wave -> xor-shuffle tree in registers,
+// then one LDS hop across the four waves (1 barrier).  TC > 64: LDS tree over the remaining 1-2 slices.
+// Fixed order in both cases (bitwise reproducible).  A single thread summing 256 LDS words serially
+// cost ~2.5 us per call and an 8-barrier LDS tree ~1 us (profiled).
 template <int K>
 __device__ __forceinline__ void reduce_slices(float (*sh)[kBlock], int TC, int TS, int sl, int cc) {
+  const int tid = threadIdx.x;
+  if (TC <= 64) {
+    float v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = sh[k][tid];
+    for (int o = TC; o < 64; o <<= 1) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], o, 64);
+    }
+    __syncthreads();                       // everyone has read its own slot
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane < TC) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) sh[k][wave * 64 + lane] = v[k];
+    }
+    __syncthreads();
+    if (tid < TC) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) sh[k][tid] = (sh[k][tid] + sh[k][64 + tid]) + (sh[k][128 + tid] + sh[k][192 + tid]);
+    }
+    __syncthreads();
+    return;
+  }
   for (int stride = TS >> 1; stride > 0; stride >>= 1) {
     __syncthreads();
     if (sl < stride) {
@@ -133,29 +158,33 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   if (cc < C) {
     const float* pg = a.pd_gamma + (int64_t)prev * a.nbv * C;
     const float* pr = a.pd_rr + (int64_t)prev * a.nbv * C;
-    {
-      float g4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
-      int b = sl;
-      for (; b + 3 * a.TS < a.nbv; b += 4 * a.TS) {
+    // batches of 4 / 8 loads on clamped indices, masked afterwards: all in flight together
+    for (int b0 = sl; b0 < a.nbv; b0 += 4 * a.TS) {
+      float gv[4], rv[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          g4[q] += pg[(int64_t)(b + q * a.TS) * C + cc];
-          r4[q] += pr[(int64_t)(b + q * a.TS) * C + cc];
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int b = b0 + q * a.TS;
+        const int bc = b < a.nbv ? b : a.nbv - 1;
+        gv[q] = pg[(int64_t)bc * C + cc];
+        rv[q] = pr[(int64_t)bc * C + cc];
       }
-      for (; b < a.nbv; b += a.TS) { g4[0] += pg[(int64_t)b * C + cc]; r4[0] += pr[(int64_t)b * C + cc]; }
-      g = (g4[0] + g4[1]) + (g4[2] + g4[3]);
-      rr = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool on = b0 + q * a.TS < a.nbv;
+        g += on ? gv[q] : 0.f;
+        rr += on ? rv[q] : 0.f;
+      }
     }
-    {
-      float d8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      int b = sl;
-      for (; b + 7 * a.TS < a.nbs; b += 8 * a.TS) {
+    for (int b0 = sl; b0 < a.nbs; b0 += 8 * a.TS) {
+      float dv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) d8[q] += a.pd_delta[(int64_t)(b + q * a.TS) * C + cc];
+      for (int q = 0; q < 8; ++q) {
+        const int b = b0 + q * a.TS;
+        const int bc = b < a.nbs ? b : a.nbs - 1;
+        dv[q] = a.pd_delta[(int64_t)bc * C + cc];
       }
-      for (; b < a.nbs; b += a.TS) d8[0] += a.pd_delta[(int64_t)b * C + cc];
-      d = ((d8[0] + d8[1]) + (d8[2] + d8[3])) + ((d8[4] + d8[5]) + (d8[6] + d8[7]));
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d += (b0 + q * a.TS < a.nbs) ? dv[q] : 0.f;
     }
   }
   sh[0][tid] = g; sh[1][tid] = rr; sh[2][tid] = d;

@@ -42,6 +42,21 @@ class SchurComplementOperator(LinearOperator):
         res = (tmp - out)[self._lidx]                              # (:30)
         return res.squeeze(-1) if squeeze else res
 
+    def _solve(self, rhs, preconditioner=None, num_tridiag=0):
+        """S^-1 b without nesting: by block elimination the labelled part of Q^-1 [b; 0] IS S^-1 b, so one
+        HIP CG on the full precision replaces a CG on S whose every matvec hides another CG on Q_uu
+        (SURVEY.md section 8f-3)."""
+        from ..solvers import cg_solve
+        _lib.require_device(rhs)
+        squeeze = rhs.dim() == 1
+        v = _lib.f32c(rhs.unsqueeze(-1) if squeeze else rhs)
+        self._masks()
+        desc = self.base._descriptor()
+        full = torch.zeros(desc.n, v.shape[1], device=v.device, dtype=torch.float32)
+        full[self._lidx] = v
+        sol = cg_solve(desc, full)[0][self._lidx]
+        return sol.squeeze(-1) if squeeze else sol
+
     def _size(self):
         k = int(self.mask.sum())
         return torch.Size([k, k])

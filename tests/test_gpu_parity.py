@@ -679,3 +679,21 @@ def test_stochastic_gradients_large_n_branch(mgp, golden, dev):
     got = np.array([eps_t.grad.item(), kap_t.grad.item(), s_t.grad.item(), z_t.grad.item()])
     ref = g[p + "ml_grads"]
     assert (np.abs(got - ref) < 0.08 * np.abs(ref) + 0.02 * np.abs(ref).max()).all(), (got, ref)
+
+
+def test_schur_solve_by_block_elimination(mgp, golden, dev):
+    """S^-1 b from ONE CG on the full precision (labelled part of Q^-1 [b; 0]) equals the dense Schur solve."""
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 1, torch.tensor([[float(g["kappa"])]], device=dev))
+    mask = g["symmetric_schur_mask"]
+    S = mgp.operators.SchurComplementOperator(Q, T(mask, dev))
+    b = T(g["train_y"][mask], dev)
+    with mgp.settings.cg_tolerance(1e-7), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(4000):
+        x = S.solve(b)
+        Sx = S.matmul(x)
+    assert float((Sx - b).norm() / b.norm()) < 2e-4
+    Qd = Q.to_dense().double().cpu().numpy()
+    Sd = Qd[np.ix_(mask, mask)] - Qd[np.ix_(mask, ~mask)] @ np.linalg.solve(Qd[np.ix_(~mask, ~mask)], Qd[np.ix_(~mask, mask)])
+    ref = np.linalg.solve(Sd, g["train_y"][mask].astype(np.float64))
+    assert np.abs(x.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
