@@ -136,6 +136,7 @@ int mgp_spmm_set_group_hint(int lanes);      /* C == 1: lanes per row, one of 4,
 int mgp_spmm_set_rows_in_flight(int rows);   /* C == 1: rows a lane group loads at once: 1,2,4,8 */
 int mgp_spmm_set_entry_layout(int layout);   /* C == 1: 0 = 16-B per lane (default), 1 = lane-strided */
 int mgp_spmm_set_panel_mode(int on);         /* C == 1: column-panel sweep when the CSR has panels (experiment, default 0) */
+int mgp_spmm_set_block(int threads);         /* C == 1: workgroup size 256 (default) / 512 / 1024 */
 int mgp_spmm_set_stream_nt(int on);          /* C == 1: sc1 (L1-bypass) loads for the matrix stream (default 0) */
 int mgp_spmm_fused(const mgp_csr_t* L, const float* X, int C, float* Y, float a, float b,
                    const float* pre, const float* post, const float* base, float cb, float co,

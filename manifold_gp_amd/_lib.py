@@ -77,6 +77,7 @@ SIGNATURES = {
     "mgp_spmm_set_rows_in_flight": (c_int, [c_int]),
     "mgp_spmm_set_entry_layout": (c_int, [c_int]),
     "mgp_spmm_set_panel_mode": (c_int, [c_int]),
+    "mgp_spmm_set_block": (c_int, [c_int]),
     "mgp_spmm_set_stream_nt": (c_int, [c_int]),
     "mgp_spmm_fused": (c_int, [POINTER(CsrT), _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
                                c_float, _P, _P, _P]),

@@ -56,6 +56,7 @@ struct SpmmArgs {
 typedef int mgp_v4i __attribute__((ext_vector_type(4)));
 typedef float mgp_v4f __attribute__((ext_vector_type(4)));
 int g_stream_nt = 0;
+int g_spmv_block = 256;    // workgroup size of the C == 1 kernel (256 / 512 / 1024)
 
 // NT = true: buffer loads with the sc1 cache policy (served by L2, no L1 allocation).  The resource is
 // built from the wave-uniform array base; the entry index goes in the per-lane byte offset.
@@ -97,14 +98,14 @@ __device__ __forceinline__ float epilogue(const SpmmArgs& p, int64_t r, int c, f
 // then R shuffle reductions.  Three dependent memory phases per group instead of 3R: at N = 60k
 // the kernel is latency-bound (the matrix is cache resident), so bytes in flight per lane is
 // what sets the rate.  Rows longer than 4G entries take the (rare) remainder loop.
-template <int G, int R, bool PRE, bool NT>
-__global__ __launch_bounds__(kBlock) void spmv_kernel(SpmmArgs p) {
+template <int G, int R, bool PRE, bool NT, int BS>
+__global__ __launch_bounds__(BS) void spmv_kernel(SpmmArgs p) {
   if (p.skip && *p.skip) return;
   if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
   const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
   const int lane = threadIdx.x & (G - 1);
   const int grp = threadIdx.x / G;
-  constexpr int kGroups = kBlock / G;
+  constexpr int kGroups = BS / G;
   const int64_t r0 = (int64_t)lb * p.rows_per_block;
   int64_t r1 = r0 + p.rows_per_block;
   if (r1 > p.n) r1 = p.n;
@@ -190,14 +191,14 @@ __global__ __launch_bounds__(kBlock) void spmv_kernel(SpmmArgs p) {
     }
   }
   if (p.dot_partials) {
-    __shared__ float red[kBlock / MGP_WAVE];
+    __shared__ float red[BS / MGP_WAVE];
     dsum = mgp_wave_sum(dsum);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
     __syncthreads();
     if (threadIdx.x == 0) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < kBlock / MGP_WAVE; ++w) t += red[w];
+      for (int w = 0; w < BS / MGP_WAVE; ++w) t += red[w];
       p.dot_partials[lb] = t;
     }
   }
@@ -558,9 +559,9 @@ Plan make_plan(int64_t n, int rows_per_pass) {
 
 // C == 1 shape: lanes per row (4 entries per lane per pass) and rows in flight per lane group.
 // The host wrapper sets the lanes from the mean padded row length of the graph it built
-// (mgp_spmm_set_group_hint); 16 lanes x 4 rows suits k ~ 50.
+// (mgp_spmm_set_group_hint); measured best on the 60k and 500k graphs: 8 lanes x 1 row (tools/tune_spmv.py).
 int g_row_group_hint = 16;
-int g_rows_in_flight = 2;
+int g_rows_in_flight = 1;
 int g_entry_layout = 0;   // 0: 4 consecutive entries per lane (16-B loads), 1: lane-strided entries
 int g_panel_mode = 0;     // (experiment, off) sweep column panels when the CSR carries the panel structure
 bool g_panel_attr_set[2] = {false, false};
@@ -598,6 +599,14 @@ static int spmm_cols_group(int C) {
   return g;
 }
 
+extern "C" int mgp_spmm_set_block(int threads) {
+  if (threads != 256 && threads != 512 && threads != 1024) return MGP_ERR_ARG;
+  g_spmv_block = threads;
+  return MGP_OK;
+}
+
+static int spmv_block_threads() { return (g_entry_layout == 0 && !g_stream_nt) ? g_spmv_block : kBlock; }
+
 extern "C" int mgp_spmm_set_stream_nt(int on) {
   g_stream_nt = on ? 1 : 0;
   return MGP_OK;
@@ -621,7 +630,7 @@ int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
 
 extern "C" int mgp_spmm_dot_blocks(int64_t n, int C) {
   if (n <= 0 || C <= 0) return MGP_ERR_ARG;
-  int groups = (C == 1) ? (kBlock / g_row_group_hint) * spmv_rows_in_flight() : kBlock / spmm_cols_group(C) * 4;
+  int groups = (C == 1) ? (spmv_block_threads() / g_row_group_hint) * spmv_rows_in_flight() : kBlock / spmm_cols_group(C) * 4;
   return make_plan(n, groups).grid;
 }
 
@@ -630,9 +639,13 @@ static void launch_spmv(const SpmmArgs& a, int grid, hipStream_t st) {
   if (g_entry_layout == 1)
     hipLaunchKernelGGL((spmv_strided_kernel<G, R, PRE>), dim3(grid), dim3(kBlock), 0, st, a);
   else if (g_stream_nt)
-    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, true>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, true, 256>), dim3(grid), dim3(256), 0, st, a);
+  else if (g_spmv_block == 1024)
+    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, false, 1024>), dim3(grid), dim3(1024), 0, st, a);
+  else if (g_spmv_block == 512)
+    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, false, 512>), dim3(grid), dim3(512), 0, st, a);
   else
-    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, false>), dim3(grid), dim3(kBlock), 0, st, a);
+    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, false, 256>), dim3(grid), dim3(256), 0, st, a);
 }
 
 template <int G, bool PRE>
@@ -696,7 +709,7 @@ int mgp_spmm_fused_part(const mgp_csr_t* L, int64_t row_offset, const float* X, 
   } else if (C == 1) {
     const int G = g_row_group_hint;
     const int R = spmv_rows_in_flight();
-    Plan pl = make_plan(L->n, (kBlock / G) * R);
+    Plan pl = make_plan(L->n, (spmv_block_threads() / G) * R);
     p.rows_per_block = pl.rows_per_block;
     int rc = MGP_OK;
 #define MGP_SPMV_CASE(GG)                                                                     \

@@ -697,3 +697,57 @@ def test_schur_solve_by_block_elimination(mgp, golden, dev):
     Sd = Qd[np.ix_(mask, mask)] - Qd[np.ix_(mask, ~mask)] @ np.linalg.solve(Qd[np.ix_(~mask, ~mask)], Qd[np.ix_(~mask, mask)])
     ref = np.linalg.solve(Sd, g["train_y"][mask].astype(np.float64))
     assert np.abs(x.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+# ----------------------------------------------------------------------------- remaining section-8(a) rows
+@pytest.mark.parametrize("norm", NORMS)
+def test_operator_out_of_sample_vs_oracle(mgp, golden, dev, norm):
+    """GraphLaplacianOperator.out_of_sample (graph_laplacian_operator.py:146-157) called directly."""
+    from oracle.laplacian import LaplacianOracle
+    g = golden("dumbbell_k10_loop")
+    n = g["train_x"].shape[0]
+    op = _operator(mgp, g, dev, norm)
+    rng = np.random.default_rng(0)
+    phi = rng.normal(size=(n, 7)).astype(np.float32)
+    ev, ei = g["knn_test_D"], g["knn_test_I"].astype(np.int64)
+    out = op.out_of_sample(T(phi, dev), T(ev, dev), T(ei, dev)).cpu().numpy()
+    lo = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), norm, True, dtype=np.float64)
+    ref = lo.out_of_sample(phi.astype(np.float64), ev.astype(np.float64), ei)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-5 * np.abs(ref).max())
+
+
+def test_average_variance_vs_dense_inverse(mgp, golden, dev):
+    """PrecisionMaternOperator._average_variance (precision_matern_operator.py:45-53): mean of the
+    diagonal of Q^-1 over one-hot probes; with num_rand_vec >= d it is trace(Q^-1) / d exactly."""
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "randomwalk")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 1, torch.tensor([[float(g["kappa"])]], device=dev))
+    Qd = Q.to_dense().double()
+    ref_diag = torch.linalg.inv(0.5 * (Qd + Qd.t())).diagonal()
+    with mgp.settings.max_cholesky_size(2000):
+        full = Q._average_variance(num_rand_vec=10 ** 6)               # dense Cholesky branch, identity probes
+    assert abs(float(full) - float(ref_diag.mean())) < 1e-4 * float(ref_diag.mean())
+    torch.manual_seed(5)
+    with mgp.settings.max_cholesky_size(100), mgp.settings.cg_tolerance(1e-5), mgp.settings.cg_stop_mode(1), \
+            mgp.settings.max_cg_iterations(4000):
+        torch.manual_seed(5)
+        est = Q._average_variance(num_rand_vec=100)                     # HIP CG with 100 one-hot columns
+    assert abs(float(est) - float(ref_diag.mean())) < 0.25 * float(ref_diag.mean())   # Monte-Carlo (100 probes)
+
+
+def test_graph_variants_and_errors(mgp, golden, dev):
+    """NearestNeighbors.graph non-default flags (nearest_neighbors.py:39-55) and argument errors."""
+    g = golden("dumbbell_k10_loop")
+    x = T(g["train_x"], dev)
+    knn = mgp.utils.NearestNeighbors(x)
+    idx_d, val_d = knn.graph(10, symmetric=False)                          # directed list, column 0 dropped
+    assert idx_d.shape == (2, x.shape[0] * 9) and val_d.shape[0] == x.shape[0] * 9
+    assert torch.equal(idx_d[1].view(-1, 9).cpu(), torch.from_numpy(g["knn_I"][:, 1:].astype(np.int64)))
+    idx_s, val_s = knn.graph(10, self_loop=True)                           # keeps the self column
+    assert (idx_s[0] == idx_s[1]).sum() == x.shape[0]
+    with pytest.raises(ValueError):
+        knn.search(x[:, :1], 5)
+    with pytest.raises(ValueError):
+        knn.search(x, 0)
+    with pytest.raises(ValueError):
+        mgp.operators.GraphLaplacianOperator(val_d, idx_d, x.shape[0], torch.tensor([[0.5]], device=dev), "unnormalized")

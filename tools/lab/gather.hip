@@ -76,8 +76,9 @@ int main() {
   std::mt19937 rng(1);
   const char* names[] = {"uniform random over x", "random within +-64 of a per-wave base", "4 adjacent lanes share a 16-B slot (sorted, gap 1)",
                          "16 adjacent lanes share a 64-B line", "lane-consecutive (fully coalesced)", "all lanes of a wave the same address",
-                         "stride 16 floats (64 lanes -> 64 distinct lines, sequential)", "same-100-block random (61%) + uniform (39%)"};
-  for (int pat = 0; pat < 8; ++pat) {
+                         "stride 16 floats (64 lanes -> 64 distinct lines, sequential)", "same-100-block random (61%) + uniform (39%)",
+                         "same-100-block (61%) + one of 8 fixed other blocks per row block (39%)"};
+  for (int pat = 0; pat < 9; ++pat) {
     for (long e = 0; e < NE; ++e) {
       long wave = e / 64; int lane = e % 64;
       int base = (int)((wave * 97) % (NX - 2048)) + 1024;
@@ -90,7 +91,13 @@ int main() {
         case 4: v = base + lane; break;
         case 5: v = base; break;
         case 6: v = (base + lane * 16) % NX; break;
-        default: v = (rng() % 100 < 61) ? (base / 100) * 100 + (int)(rng() % 100) : (int)(rng() % NX); break;
+        case 7: v = (rng() % 100 < 61) ? (base / 100) * 100 + (int)(rng() % 100) : (int)(rng() % NX); break;
+        default: {
+          long row = e / 61; int B = (int)((row / 100) % 600);
+          if (rng() % 100 < 61) v = B * 100 + (int)(rng() % 100);
+          else { unsigned hb = (unsigned)(B * 2654435761u + (rng() % 8) * 40503u); v = (int)(hb % 600) * 100 + (int)(rng() % 100); }
+          break;
+        }
       }
       h[e] = v;
     }

@@ -10,40 +10,52 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def newest(pattern):
+    files = glob.glob(pattern)
+    return max(files, key=os.path.getmtime)
+
+
 def main(tag):
     base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    stats = list(csv.DictReader(open(glob.glob(base + "/trace/*/*_kernel_stats.csv")[0])))
+    stats = list(csv.DictReader(open(newest(base + "/trace/*/*_kernel_stats.csv"))))
     with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in stats[:32]:
             w.writerow([r["Name"][:150], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-    trace = list(csv.DictReader(open(glob.glob(base + "/trace/*/*_kernel_trace.csv")[0])))
+    trace = list(csv.DictReader(open(newest(base + "/trace/*/*_kernel_trace.csv"))))
+
+    import re
+
+    def hit(sub, name):
+        return re.search(sub, name) is not None
 
     def durs(sub, lo=2500):
-        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if sub in r["Kernel_Name"]]
+        d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in trace if hit(sub, r["Kernel_Name"])]
         return [x for x in d if x > lo]
-    f = list(csv.DictReader(open(glob.glob(base + "/pmc_fetch/*/*_counter_collection.csv")[0])))
-    wv = list(csv.DictReader(open(glob.glob(base + "/pmc_write/*/*_counter_collection.csv")[0])))
+    f = list(csv.DictReader(open(newest(base + "/pmc_fetch/*/*_counter_collection.csv"))))
+    wv = list(csv.DictReader(open(newest(base + "/pmc_write/*/*_counter_collection.csv"))))
 
     def med(rows, name, sub):
-        v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name and sub in r["Kernel_Name"]]
+        v = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name and hit(sub, r["Kernel_Name"])]
         v = [x for x in v if x > 1.0]
         return (statistics.median(v), len(v)) if v else (0.0, 0)
     res = {}
-    for k in ["spmv_kernel<8, 2, false", "spmv_kernel<8, 2, true", "cg_update_kernel", "cg_init_kernel"]:
+    pats = {"spmv_kernel (no pre-scaling)": r"spmv_kernel<\d+, \d+, false", "spmv_kernel (pre-scaled input)": r"spmv_kernel<\d+, \d+, true",
+            "cg_update_kernel": "cg_update_kernel", "cg_init_kernel": "cg_init_kernel"}
+    for label, k in pats.items():
         fs, n1 = med(f, "FETCH_SIZE", k)
         ws, _ = med(wv, "WRITE_SIZE", k)
         d = durs(k)
-        res[k] = dict(launches=n1, FETCH_SIZE_KB_median=fs, WRITE_SIZE_KB_median=ws,
+        res[label] = dict(launches=n1, FETCH_SIZE_KB_median=fs, WRITE_SIZE_KB_median=ws,
                       hbm_bytes_per_launch_corrected=int((2 * fs + ws) * 1024),
                       kernel_trace_median_ns=statistics.median(d) if d else None,
                       kernel_trace_launches=len(d))
     res["note"] = ("FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); "
                    "WRITE_SIZE as is; durations: non-skipped launches (> 2.5 us) from rocprofv3 --kernel-trace")
-    res["spmv_hbm_bytes_per_launch"] = res["spmv_kernel<8, 2, false"]["hbm_bytes_per_launch_corrected"]
+    res["spmv_hbm_bytes_per_launch"] = res["spmv_kernel (no pre-scaling)"]["hbm_bytes_per_launch_corrected"]
     json.dump(res, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
     for name in ("bench_trace.json", "bench_fetch.json"):
         src = os.path.join(base, name)

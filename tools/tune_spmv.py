@@ -32,27 +32,27 @@ def main():
     B = bench.spmm_bytes(g.n, g.M)
     shapes = [(L, G, R) for L in (0, 1) for G in (8, 16, 32, 64) for R in (1, 2, 4, 8) if R <= G]
     if a.quick:
-        shapes = [(0, 8, 1), (0, 8, 2), (0, 8, 4), (0, 16, 2), (0, 16, 4), (0, 16, 8), (0, 32, 4), (0, 32, 8)]
+        shapes = [(L, G, R) for L in (256, 512, 1024) for (G, R) in ((8, 1), (8, 2), (8, 4), (16, 2), (16, 4))]
     times = {s: [] for s in shapes}
     lib = _lib.lib()
     for rnd in range(a.rounds):
         for (L, G, R) in shapes:
             g.spmv_lanes = G
             lib.mgp_spmm_set_rows_in_flight(R)
-            lib.mgp_spmm_set_entry_layout(L)
+            if L >= 256:
+                lib.mgp_spmm_set_entry_layout(0)
+                lib.mgp_spmm_set_block(L)
+            else:
+                lib.mgp_spmm_set_entry_layout(L)
             import ctypes
             lib.mgp_spmm_set_group_hint(G)
             csr = sym.data.csr()
             out = torch.empty_like(v)
             st = _lib.stream()
             lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 10, None, st)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), a.reps, None, st)
-            e1.record()
-            torch.cuda.synchronize()
-            times[(L, G, R)].append(e0.elapsed_time(e1) / a.reps * 1e3)
+            ms = ctypes.c_float(0.0)
+            lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), a.reps, ctypes.byref(ms), st)
+            times[(L, G, R)].append(ms.value / a.reps * 1e3)
     out = []
     for s in shapes:
         t = sorted(times[s])
