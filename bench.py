@@ -257,9 +257,11 @@ def _main(quiet):
     t_k = time_spmv_kernel(wl)
     roof = dict(bound="hbm", achieved=round(B / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(B / t_k / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
-                kernel="spmv_kernel<%d,1,false,false,256> (fused CSR SpMV, C=1, %d lanes per row)" % (g.spmv_lanes, g.spmv_lanes),
+                kernel=("spmv_tile_kernel<false,%d> (fused CSR SpMV, C=1, %d-row tiles, x dictionary in LDS)"
+                        % (4 * g.tiles["rows"], g.tiles["rows"])) if g.tiles is not None else
+                       ("spmv_kernel<%d,1,false,false,256> (fused CSR SpMV, C=1, %d lanes per row)" % (g.spmv_lanes, g.spmv_lanes)),
                 bytes_per_launch=B, avg_launch_us=round(t_k * 1e6, 2),
-                note=("working set %.0f MB is Infinity-Cache resident; the kernel is gather-bound, see DESIGN.md"
+                note=("working set %.0f MB is Infinity-Cache resident; the kernel is latency-bound, see DESIGN.md"
                       if B < 2.5e8 else "working set %.0f MB streams from HBM") % (B / 1e6))
     # HBM bytes per launch from the PMC passes of the same command (tools/profile.sh ->
     # tools/summarize_profile.py): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE

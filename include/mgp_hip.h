@@ -84,6 +84,20 @@ int mgp_graph_from_coo(const int32_t* tri_row, const int32_t* tri_col, const flo
  * (rowptr[r] = segptr[r*P]); entry capacity <= 2n(k-1) + 4nP.  The C = 1 SpMV stages one panel of x
  * at a time in LDS (mgp_csr_t.segptr / panels / panel_width) instead of gathering from L2. */
 
+/* Row-tile column dictionaries for the C == 1 SpMV.  A tile is `tile_rows` consecutive rows of the padded
+ * CSR; tile_cols lists the distinct columns the tile references (ascending), lid maps every entry to
+ * its column's position in that list.  The SpMV stages x[tile_cols] in LDS once per tile, so the
+ * texture path sees one access per DISTINCT column instead of one per entry and the matrix stream
+ * shrinks to 6 bytes per entry.  No reference counterpart (the reference scatters with atomics,
+ * graph_laplacian_operator.py:117-120).
+ *   tile_ptr [ceil(n/tile_rows)+1], tile_cols [capacity nnz], lid [nnz]  (device, caller allocated)
+ *   total_cols / max_cols / max_entries: host outputs.  MGP_ERR_UNSUPPORTED when a tile references
+ *   more than 65536 distinct columns (use a smaller tile or leave the dictionaries off). */
+size_t mgp_graph_tiles_workspace_bytes(int64_t nnz);
+int mgp_graph_tiles(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t nnz, int tile_rows,
+                    int32_t* tile_ptr, int32_t* tile_cols, uint16_t* lid, int64_t* total_cols,
+                    int32_t* max_cols, int32_t* max_entries, void* work, size_t work_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Laplacian build: diffusion-maps normalisation of the kernel weights, fused row passes.
  * Replaces the cached properties adjacency_unnorm_mat / degree_unnorm_mat / adjacency_mat /
@@ -129,7 +143,19 @@ typedef struct {
   int32_t panels;          /* number of column panels (0 = no panel structure) */
   int32_t panel_width;
   int64_t ncols;           /* length of the vectors the columns index (0 = n; > n for a row slice) */
+  /* row-tile column dictionaries (mgp_graph_tiles); all NULL / 0 = gather straight from memory */
+  const int32_t* tile_ptr;   /* [ntiles + 1] offsets into tile_cols, ntiles = ceil(n / tile_rows) */
+  const int32_t* tile_cols;  /* distinct column ids of each tile, ascending */
+  const uint16_t* lid;       /* [nnz] position of every entry's column in its tile's list */
+  int32_t tile_rows;
+  int32_t tile_max_cols;     /* max over tiles of the list length (LDS floats per workgroup) */
+  int32_t tile_max_entries;  /* max over tiles of the padded entry count */
+  int32_t tile_reserved;
 } mgp_csr_t;
+
+/* workgroups that write dot partials for this CSR (format aware; use this one to size dot_partials) */
+int mgp_spmm_dot_blocks_csr(const mgp_csr_t* L, int C);
+int mgp_spmm_set_tile_mode(int on);          /* C == 1: use the tile dictionaries when present (default 1) */
 
 int mgp_spmm_dot_blocks(int64_t n, int C);   /* workgroups that write dot partials */
 int mgp_spmm_set_group_hint(int lanes);      /* C == 1: lanes per row, one of 4,8,16,32,64 */

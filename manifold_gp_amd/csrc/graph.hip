@@ -301,3 +301,135 @@ extern "C" size_t mgp_graph_coo_workspace_bytes(int64_t n, int64_t M, int panel_
   if (n <= 0 || panel_width < 0) return 0;
   return graph_bytes(2 * M > 0 ? 2 * M : 1, n, panels_for(n, panel_width));
 }
+
+// ------------------------------------------------------------------------------------------------
+// Row-tile column dictionaries for the C == 1 SpMV (spmm.hip: spmv_tile_kernel).
+// A tile = `tile_rows` consecutive rows.  For every tile: the ascending list of the DISTINCT columns
+// its entries reference (tile_cols[tile_ptr[t] .. tile_ptr[t+1])) and, per entry, the 16-bit position
+// of its column in that list (lid).  The SpMV stages x[tile_cols] in LDS once per tile and every
+// per-entry gather becomes a ds_read: on a k-NN graph a tile's rows share most of their neighbours,
+// so the texture-path accesses drop from one per entry to one per distinct column.
+namespace {
+
+__global__ void tile_keys(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n,
+                          int tile_rows, uint64_t* __restrict__ keys, int32_t* __restrict__ pos) {
+  const int lane = threadIdx.x & 15;
+  const int64_t g = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t r = g; r < n; r += ng) {
+    const uint64_t tile = (uint64_t)(r / tile_rows);
+    const int s = rowptr[r], e = rowptr[r + 1];
+    for (int i = s + lane; i < e; i += 16) {
+      keys[i] = (tile << 32) | (uint32_t)col[i];
+      pos[i] = i;
+    }
+  }
+}
+
+// tile_ptr[t] = number of distinct (tile, column) pairs before tile t
+__global__ void tile_starts(const uint64_t* __restrict__ keys, const int32_t* __restrict__ uidx,
+                            const int32_t* __restrict__ head, int64_t total, int64_t ntiles,
+                            int32_t* __restrict__ tile_ptr) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= ntiles;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t target = (uint64_t)t << 32;
+    int64_t lo = 0, hi = total;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    tile_ptr[t] = lo < total ? uidx[lo] : uidx[total - 1] + head[total - 1];
+  }
+}
+
+__global__ void tile_fill(const uint64_t* __restrict__ keys, const int32_t* __restrict__ pos,
+                          const int32_t* __restrict__ head, const int32_t* __restrict__ uidx,
+                          const int32_t* __restrict__ tile_ptr, int64_t total, int32_t* __restrict__ tile_cols,
+                          uint16_t* __restrict__ lid) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i];
+    const int32_t d = uidx[i] + head[i] - 1;          // index of this (tile, column) pair
+    if (head[i]) tile_cols[d] = (int32_t)(key & 0xffffffffu);
+    const int32_t local = d - tile_ptr[key >> 32];
+    lid[pos[i]] = (uint16_t)(local > 65535 ? 65535 : local);
+  }
+}
+
+__global__ void tile_extents(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tile_ptr, int64_t n,
+                             int tile_rows, int64_t ntiles, int32_t* __restrict__ maxima) {
+  int mc = 0, me = 0;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ntiles;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r0 = t * tile_rows;
+    const int64_t r1 = r0 + tile_rows < n ? r0 + tile_rows : n;
+    const int c = tile_ptr[t + 1] - tile_ptr[t];
+    const int e = rowptr[r1] - rowptr[r0];
+    mc = c > mc ? c : mc;
+    me = e > me ? e : me;
+  }
+  atomicMax(&maxima[0], mc);
+  atomicMax(&maxima[1], me);
+}
+
+size_t tile_bytes(int64_t nnz) {
+  size_t b = 2 * mgp_align(nnz * sizeof(uint64_t)) + 4 * mgp_align((nnz + 1) * sizeof(int32_t));
+  return b + cub_bytes_for(nnz) + 4096;
+}
+
+}  // namespace
+
+extern "C" size_t mgp_graph_tiles_workspace_bytes(int64_t nnz) { return nnz > 0 ? tile_bytes(nnz) : 0; }
+
+extern "C" int mgp_graph_tiles(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t nnz, int tile_rows,
+                               int32_t* tile_ptr, int32_t* tile_cols, uint16_t* lid, int64_t* total_cols,
+                               int32_t* max_cols, int32_t* max_entries, void* work, size_t work_bytes,
+                               void* stream) {
+  if (!rowptr || !col || !tile_ptr || !tile_cols || !lid || !total_cols || !max_cols || !max_entries || !work)
+    return MGP_ERR_ARG;
+  if (n <= 0 || nnz <= 0 || nnz > 0x7fffffff || tile_rows < 1) return MGP_ERR_ARG;
+  hipStream_t st = mgp_stream(stream);
+  const int64_t ntiles = mgp_cdiv(n, tile_rows);
+  MgpArena ar(work, work_bytes);
+  uint64_t* keys_a = ar.take<uint64_t>(nnz);
+  uint64_t* keys_b = ar.take<uint64_t>(nnz);
+  int32_t* pos_a = ar.take<int32_t>(nnz + 1);
+  int32_t* pos_b = ar.take<int32_t>(nnz + 1);
+  int32_t* head = ar.take<int32_t>(nnz + 1);
+  int32_t* uidx = ar.take<int32_t>(nnz + 1);
+  size_t cub_bytes = cub_bytes_for(nnz);
+  void* cub = ar.take<char>(cub_bytes);
+  int32_t* maxima = ar.take<int32_t>(2);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+
+  hipLaunchKernelGGL(tile_keys, dim3(grid_for(n * 16)), dim3(kBlock), 0, st, rowptr, col, n, tile_rows, keys_a, pos_a);
+  MGP_LAUNCH_CHECK();
+  hipcub::DoubleBuffer<uint64_t> kb(keys_a, keys_b);
+  hipcub::DoubleBuffer<int32_t> vb(pos_a, pos_b);
+  size_t tb = cub_bytes;
+  MGP_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub, tb, kb, vb, (int)nnz, 0, 32 + bits_for(ntiles + 1), st));
+  const uint64_t* keys = kb.Current();
+  const int32_t* pos = vb.Current();
+  hipLaunchKernelGGL(mark_heads, dim3(grid_for(nnz)), dim3(kBlock), 0, st, keys, nnz, head);
+  MGP_LAUNCH_CHECK();
+  tb = cub_bytes;
+  MGP_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, tb, head, uidx, (int)nnz, st));
+  hipLaunchKernelGGL(tile_starts, dim3(grid_for(ntiles + 1)), dim3(kBlock), 0, st, keys, uidx, head, nnz, ntiles,
+                     tile_ptr);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tile_fill, dim3(grid_for(nnz)), dim3(kBlock), 0, st, keys, pos, head, uidx, tile_ptr, nnz,
+                     tile_cols, lid);
+  MGP_LAUNCH_CHECK();
+  MGP_HIP_TRY(hipMemsetAsync(maxima, 0, 2 * sizeof(int32_t), st));
+  hipLaunchKernelGGL(tile_extents, dim3(grid_for(ntiles)), dim3(kBlock), 0, st, rowptr, tile_ptr, n, tile_rows, ntiles,
+                     maxima);
+  MGP_LAUNCH_CHECK();
+  int32_t h[2] = {0, 0}, last = 0;
+  MGP_HIP_TRY(hipMemcpyAsync(h, maxima, sizeof(h), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipMemcpyAsync(&last, tile_ptr + ntiles, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  *total_cols = last;
+  *max_cols = h[0];
+  *max_entries = h[1];
+  return h[0] > 65536 ? MGP_ERR_UNSUPPORTED : MGP_OK;
+}

@@ -461,6 +461,147 @@ __global__ __launch_bounds__(kPanelThreads) void spmv_panel_kernel(SpmmArgs p, c
   }
 }
 
+// ---------------------------------------------------------------- C == 1, row tiles + LDS dictionary
+// Counters on the 60k bench graph (profiles/r01_pmc_spmv.txt): the gather kernel above issues 3.9 M
+// texture-cache accesses per launch, 3 M of them the per-entry gathers of x -- one tag lookup per
+// lane per clock per CU, ~5 us of the 8.5 us launch -- although only 0.5 M requests go on to L2: the
+// kernel is bound by the L1 lookup rate, not by bytes.  Here a workgroup owns a tile of BS/4 rows, stages
+// the DISTINCT columns the tile references (mgp_graph_tiles: tile_cols) in LDS once -- a k-NN tile's
+// rows share most neighbours, so that is a few hundred gathers instead of thousands -- and every
+// per-entry gather becomes a ds_read through a 16-bit local id.  Stream: 4 B value + 2 B id per entry,
+// fully coalesced (lane q owns quad q of the tile's contiguous entry range, rows are padded to quads).
+//   phase 0  issue the stream loads of the first NQ quads per lane, row pointers, epilogue operands
+//   phase 1  xl[j] = pre * x[tile_cols[j]]                        -> barrier
+//   phase 2  part[q] = sum of the quad's 4 products (ds_read gathers) -> barrier
+//   phase 3  4 lanes per row add the row's quads, xor-shuffle, lane 0 runs the epilogue
+// The row sum order (quad-wise, then stride-4 lanes, then xor tree) does not depend on the tiling.
+struct TileArgs {
+  const int32_t* tile_ptr;
+  const int32_t* tile_cols;
+  const uint16_t* lid;
+  int64_t ntiles;
+  int tiles_per_block;
+  int max_cols;
+};
+
+typedef unsigned short mgp_v4h __attribute__((ext_vector_type(4)));
+
+template <bool PRE, int BS>
+__global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
+  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+  if (p.skip && *p.skip) return;
+  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
+  constexpr int TR = BS / 4;
+  constexpr int NQ = 4;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x, sub = tid & 3;
+  float* __restrict__ xl = tile_lds;
+  float* __restrict__ part = tile_lds + t.max_cols;
+  const float* __restrict__ x = p.X;
+  float dsum = 0.f;
+  const int64_t t0 = (int64_t)lb * t.tiles_per_block;
+  const int64_t t1 = t0 + t.tiles_per_block < t.ntiles ? t0 + t.tiles_per_block : t.ntiles;
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int64_t r0 = tile * TR;
+    const int64_t r1 = r0 + TR < p.n ? r0 + TR : p.n;
+    const int64_t row = r0 + (tid >> 2);
+    const bool valid = row < r1;
+    const int64_t rr = valid ? row : r0;
+    const int e0 = p.rowptr[r0], e1 = p.rowptr[r1];
+    const int rs = p.rowptr[rr], re = p.rowptr[rr + 1];
+    const int dp = t.tile_ptr[tile];
+    const int D = t.tile_ptr[tile + 1] - dp;
+    const int64_t grr = rr + p.goff;
+    float e_x = x[grr];
+    if (PRE) e_x *= p.pre[grr];
+    const float e_diag = p.diag[rr];
+    const float e_post = p.post ? p.post[grr] : 1.f;
+    const float e_base = p.base ? p.base[grr] : 0.f;
+    const float e_dotw = p.dotw ? p.dotw[grr] : 0.f;
+    const int qb = e0 >> 2, Q = (e1 - e0) >> 2;
+    // phase 0: unconditional (clamped) stream loads, all in flight before anything is consumed
+    mgp_v4f v[NQ];
+    mgp_v4h l[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int q = tid + k * BS;
+      const int qi = q < Q ? qb + q : 0;
+      v[k] = *reinterpret_cast<const mgp_v4f*>(p.vals + 4 * (int64_t)qi);
+      l[k] = *reinterpret_cast<const mgp_v4h*>(t.lid + 4 * (int64_t)qi);
+    }
+    // phase 1: dictionary -> LDS
+    for (int j0 = 0; j0 < D; j0 += NQ * BS) {
+      int c[NQ];
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        const int j = j0 + tid + k * BS;
+        c[k] = t.tile_cols[dp + (j < D ? j : 0)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float g[NQ];
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        g[k] = x[c[k]];
+        if (PRE) g[k] *= p.pre[c[k]];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        const int j = j0 + tid + k * BS;
+        if (j < D) xl[j] = g[k];
+      }
+    }
+    __syncthreads();
+    // phase 2: quad products
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int q = tid + k * BS;
+      if (q < Q) {
+        float s = v[k].x * xl[l[k].x];
+        s = fmaf(v[k].y, xl[l[k].y], s);
+        s = fmaf(v[k].z, xl[l[k].z], s);
+        s = fmaf(v[k].w, xl[l[k].w], s);
+        part[q] = s;
+      }
+    }
+    for (int q = tid + NQ * BS; q < Q; q += BS) {      // tiles with more than 16 * BS entries (rare)
+      const mgp_v4f vv = *reinterpret_cast<const mgp_v4f*>(p.vals + 4 * (int64_t)(qb + q));
+      const mgp_v4h ll = *reinterpret_cast<const mgp_v4h*>(t.lid + 4 * (int64_t)(qb + q));
+      float s = vv.x * xl[ll.x];
+      s = fmaf(vv.y, xl[ll.y], s);
+      s = fmaf(vv.z, xl[ll.z], s);
+      s = fmaf(vv.w, xl[ll.w], s);
+      part[q] = s;
+    }
+    __syncthreads();
+    // phase 3: rows
+    float acc = 0.f;
+    for (int i = (rs >> 2) - qb + sub, e = (re >> 2) - qb; i < e; i += 4) acc += part[i];
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (valid && sub == 0) {
+      const float lx = e_diag * e_x - acc;
+      const float tt = (p.a * e_x + p.b * lx) * e_post;
+      const float y = p.co * tt + p.cb * e_base;
+      p.Y[grr] = y;
+      dsum = fmaf(e_dotw, y, dsum);
+    }
+    if (tile + 1 < t1) __syncthreads();                // the next tile overwrites xl / part
+  }
+  if (p.dot_partials) {
+    __shared__ float red[BS / MGP_WAVE];
+    dsum = mgp_wave_sum(dsum);
+    if ((tid & 63) == 0) red[tid >> 6] = dsum;
+    __syncthreads();
+    if (tid == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < BS / MGP_WAVE; ++w) s += red[w];
+      p.dot_partials[lb] = s;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- C > 1
 // G lanes per row laid over columns; NACC column accumulators per lane (columns lane + a*G).
 template <int G, int NACC, bool PRE>
@@ -617,6 +758,29 @@ extern "C" int mgp_spmm_set_panel_mode(int on) {
   return MGP_OK;
 }
 
+int g_tile_mode = 1;
+
+extern "C" int mgp_spmm_set_tile_mode(int on) {
+  g_tile_mode = on ? 1 : 0;
+  return MGP_OK;
+}
+
+static size_t tile_lds_bytes(const mgp_csr_t* L) {
+  return ((size_t)L->tile_max_cols + (size_t)(L->tile_max_entries >> 2)) * sizeof(float);
+}
+
+static bool use_tiles(const mgp_csr_t* L, int C) {
+  return C == 1 && g_tile_mode && L->lid && L->tile_ptr && L->tile_cols &&
+         (L->tile_rows == 32 || L->tile_rows == 64 || L->tile_rows == 128) && tile_lds_bytes(L) <= 65536 - 64;
+}
+
+static int tile_grid(const mgp_csr_t* L, int* tiles_per_block) {
+  const int64_t ntiles = mgp_cdiv(L->n, L->tile_rows);
+  const int64_t tpb = mgp_cdiv(ntiles, kMaxGrid);
+  if (tiles_per_block) *tiles_per_block = (int)tpb;
+  return (int)mgp_cdiv(ntiles, tpb);
+}
+
 static bool use_panels(const mgp_csr_t* L, int C) {
   return C == 1 && g_panel_mode && L->segptr != nullptr && L->panels >= 1 && L->panel_width > 0 &&
          L->panel_width <= 32768 && (L->panel_width % 4) == 0;
@@ -625,7 +789,13 @@ static bool use_panels(const mgp_csr_t* L, int C) {
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (!L) return MGP_ERR_ARG;
   if (use_panels(L, C)) return (int)mgp_cdiv(L->n, kPanelRowsPerBlock);
+  if (use_tiles(L, C)) return tile_grid(L, nullptr);
   return mgp_spmm_dot_blocks(L->n, C);
+}
+
+extern "C" int mgp_spmm_dot_blocks_csr(const mgp_csr_t* L, int C) {
+  if (!L || L->n <= 0 || C <= 0) return MGP_ERR_ARG;
+  return mgp_spmm_dot_blocks_for(L, C);
 }
 
 extern "C" int mgp_spmm_dot_blocks(int64_t n, int C) {
@@ -706,6 +876,19 @@ int mgp_spmm_fused_part(const mgp_csr_t* L, int64_t row_offset, const float* X, 
     else if (stage) MGP_PANEL_LAUNCH(false, true);
     else MGP_PANEL_LAUNCH(false, false);
 #undef MGP_PANEL_LAUNCH
+  } else if (use_tiles(L, C)) {
+    TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols};
+    const int grid = tile_grid(L, &ta.tiles_per_block);
+    const size_t lds = tile_lds_bytes(L);
+#define MGP_TILE_LAUNCH(BS)                                                                              \
+  do {                                                                                                   \
+    if (pre) hipLaunchKernelGGL((spmv_tile_kernel<true, BS>), dim3(grid), dim3(BS), lds, st, p, ta);      \
+    else hipLaunchKernelGGL((spmv_tile_kernel<false, BS>), dim3(grid), dim3(BS), lds, st, p, ta);         \
+  } while (0)
+    if (L->tile_rows == 32) MGP_TILE_LAUNCH(128);
+    else if (L->tile_rows == 64) MGP_TILE_LAUNCH(256);
+    else MGP_TILE_LAUNCH(512);
+#undef MGP_TILE_LAUNCH
   } else if (C == 1) {
     const int G = g_row_group_hint;
     const int R = spmv_rows_in_flight();

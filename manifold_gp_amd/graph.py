@@ -17,6 +17,36 @@ PANEL_WIDTH = 32768        # columns of x staged in LDS at a time by the C == 1 
 MAX_PANELS = 4             # beyond this every workgroup would re-read too much of x: gather kernel
 
 
+TILE_ROWS = 64             # rows per SpMV tile (workgroup of 256 lanes); 32 / 64 / 128 are supported
+
+
+def build_tiles(n, rowptr, col, nnz, tile_rows=None):
+    """Row-tile column dictionaries for the C == 1 SpMV (mgp_graph_tiles).  Returns the dict that
+    _lib.csr_struct takes, or None when the graph has no entries / a tile does not fit the LDS budget."""
+    if nnz <= 0:
+        return None
+    dev = col.device
+    for rows in ([int(tile_rows)] if tile_rows else [TILE_ROWS, 32]):
+        ntiles = -(-n // rows)
+        tile_ptr = torch.empty(ntiles + 1, dtype=torch.int32, device=dev)
+        tile_cols = torch.empty(nnz, dtype=torch.int32, device=dev)
+        lid = torch.empty(nnz, dtype=torch.int16, device=dev)
+        wb = lib().mgp_graph_tiles_workspace_bytes(nnz)
+        work = _lib.workspace(wb, "graph", dev)
+        total, mc, me = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
+        rc = lib().mgp_graph_tiles(n, ptr(rowptr), ptr(col), nnz, rows, ptr(tile_ptr), ptr(tile_cols), ptr(lid),
+                                   ctypes.byref(total), ctypes.byref(mc), ctypes.byref(me), ptr(work), work.numel(),
+                                   stream())
+        if rc == -3:                      # MGP_ERR_UNSUPPORTED: a tile references > 65536 columns
+            continue
+        check(rc, "mgp_graph_tiles")
+        if (mc.value + me.value // 4) * 4 > 65536 - 64:
+            continue
+        return dict(tile_ptr=tile_ptr, tile_cols=tile_cols[:total.value].clone(), lid=lid, rows=rows,
+                    max_cols=mc.value, max_entries=me.value, total_cols=total.value)
+    return None
+
+
 def default_panel_width(n):
     """Column panels are an experiment that did not pay on MI355X (tools/tune_panels.py: every panel
     sweep costs 2-5 us of barriers and staging, more than the gathers it saves): off by default."""
@@ -24,7 +54,8 @@ def default_panel_width(n):
 
 
 class KnnGraph:
-    def __init__(self, n, tri_row, tri_col, tri_val, rowptr, col, d2, eid, segptr=None, panel_width=0):
+    def __init__(self, n, tri_row, tri_col, tri_val, rowptr, col, d2, eid, segptr=None, panel_width=0,
+                 tiles="auto"):
         self.n = int(n)
         self.tri_row, self.tri_col, self.tri_val = tri_row, tri_col, tri_val
         self.rowptr, self.col, self.d2, self.eid = rowptr, col, d2, eid
@@ -34,6 +65,9 @@ class KnnGraph:
         self.M = int(tri_val.shape[0])
         self.nnz = int(col.shape[0])
         self._edge_index = None
+        if isinstance(tiles, str):          # "auto": build on the device the CSR lives on (host tensors: none)
+            tiles = build_tiles(self.n, rowptr, col, self.nnz) if col.is_cuda else None
+        self.tiles = tiles
         # sub-wave group width for the C == 1 SpMV: 4 entries per lane per pass
         # measured on the 60k bench graph (tools/tune_spmv.py): 8 lanes x 2 rows in flight is the
         # fastest shape for mean rows of ~60 entries; wider groups only pay for much longer rows
@@ -46,6 +80,11 @@ class KnnGraph:
     @property
     def device(self):
         return self.tri_val.device
+
+    def csr_with(self, vals, diag):
+        """mgp_csr_t over this graph's structure with the given entry values / diagonal."""
+        return _lib.csr_struct(self.n, self.rowptr, self.col, vals, diag, self.segptr, self.panels, self.panel_width,
+                               tiles=self.tiles)
 
     @property
     def edge_index(self):
@@ -60,7 +99,7 @@ class KnnGraph:
 
     # ------------------------------------------------------------------ builders
     @classmethod
-    def from_knn(cls, D, I, panel_width=None):
+    def from_knn(cls, D, I, panel_width=None, tiles="auto"):
         """(D[n,k] f32, I[n,k] i32) on device -> KnnGraph via mgp_graph_build."""
         _lib.require_device(D, I)
         n, k = I.shape
@@ -87,10 +126,10 @@ class KnnGraph:
                                     ctypes.byref(nnz), ptr(work), work.numel(), stream()), "mgp_graph_build")
         M, nnz = M.value, nnz.value
         return cls(n, tri_row[:M].clone(), tri_col[:M].clone(), tri_val[:M].clone(), rowptr,
-                   col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone(), segptr, pw)
+                   col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone(), segptr, pw, tiles=tiles)
 
     @classmethod
-    def from_coo(cls, idx, val, n, panel_width=None):
+    def from_coo(cls, idx, val, n, panel_width=None, tiles="auto"):
         """Reference-style edge list (idx[2,M] any int dtype, val[M]) -> KnnGraph."""
         _lib.require_device(idx, val)
         dev = val.device
@@ -114,7 +153,7 @@ class KnnGraph:
                                        stream()), "mgp_graph_from_coo")
         nnz = nnz.value
         g = cls(n, tri_row, tri_col, tri_val, rowptr, col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone(),
-                segptr, pw)
+                segptr, pw, tiles=tiles)
         if idx.dtype == torch.int64:
             g._edge_index = idx
         return g
@@ -178,8 +217,7 @@ class LaplacianData:
         return self._tangent
 
     def csr(self):
-        g = self.graph
-        return _lib.csr_struct(g.n, g.rowptr, g.col, self.vals, self.diag, g.segptr, g.panels, g.panel_width)
+        return self.graph.csr_with(self.vals, self.diag)
 
     def edge_values(self, which):
         """0: W (adjacency_unnorm_mat), 1: A (adjacency_mat), 2: S (laplacian_triu) in COO order."""

@@ -89,8 +89,13 @@ def local_csr(lap_data, part, rank):
     if getattr(g, "segptr", None) is not None:
         P = g.panels
         segptr = (g.segptr[r0 * P:r1 * P + 1] - e0).contiguous()
+    tiles = None
+    gt = getattr(g, "tiles", None)
+    if gt is not None and e1 > e0 and r0 % gt["rows"] == 0 and (r1 - r0) % gt["rows"] == 0:
+        # the slice's tiles are whole tiles of the global graph: offsets into tile_cols stay absolute
+        tiles = dict(gt, tile_ptr=gt["tile_ptr"][r0 // gt["rows"]:r1 // gt["rows"] + 1].contiguous(), lid=gt["lid"][e0:e1])
     return dict(n_loc=part.n_loc, rowptr=rowptr, col=col, vals=vals, diag=diag, e0=e0, e1=e1, segptr=segptr,
-                panels=getattr(g, "panels", 0), panel_width=getattr(g, "panel_width", 0), ncols=g.n)
+                panels=getattr(g, "panels", 0), panel_width=getattr(g, "panel_width", 0), ncols=g.n, tiles=tiles)
 
 
 def local_operator_struct(desc, part, rank):
@@ -98,7 +103,8 @@ def local_operator_struct(desc, part, rank):
     loc = local_csr(desc.data, part, rank)
     op = desc.struct()
     op.L = _lib.csr_struct(loc["n_loc"], loc["rowptr"], loc["col"], loc["vals"], loc["diag"], loc["segptr"],
-                           loc["panels"] if loc["segptr"] is not None else 0, loc["panel_width"], loc["ncols"])
+                           loc["panels"] if loc["segptr"] is not None else 0, loc["panel_width"], loc["ncols"],
+                           tiles=loc["tiles"])
     return op, loc
 
 

@@ -478,7 +478,8 @@ def test_row_partitioned_spmm_tiles_the_full_product(mgp, golden, dev, P, C):
     for r in range(P):
         loc = local_csr(data, part, r)
         lc = _lib.csr_struct(loc["n_loc"], loc["rowptr"], loc["col"], loc["vals"], loc["diag"], loc["segptr"],
-                             loc["panels"] if loc["segptr"] is not None else 0, loc["panel_width"], loc["ncols"])
+                             loc["panels"] if loc["segptr"] is not None else 0, loc["panel_width"], loc["ncols"],
+                             tiles=loc["tiles"])
         _lib.check(lib.mgp_spmm_fused_rows(ctypes.byref(lc), part.range(r)[0], _lib.ptr(X), C, _lib.ptr(tiled), 1.5, 1.0,
                                            _lib.ptr(pre), _lib.ptr(pre), _lib.ptr(X), 0.5, 2.0, None, None,
                                            _lib.stream()), "mgp_spmm_fused_rows")
@@ -545,7 +546,7 @@ def test_panel_spmv_matches_gather_kernel(mgp, golden, dev, pw):
         lib.mgp_spmm_set_panel_mode(mode)
         csr = data.csr()
         y = torch.empty_like(x)
-        nb = lib.mgp_spmm_dot_blocks(n, 1) if (mode == 0 or not pw) else -(-n // 256)
+        nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), 1)
         part = torch.zeros(max(nb, 1), device=dev)
         _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(x), 1, _lib.ptr(y), 1.25, 1.0, _lib.ptr(pre), _lib.ptr(pre),
                                       _lib.ptr(base), 0.5, 2.0, _lib.ptr(x), _lib.ptr(part), _lib.stream()), "mgp_spmm_fused")
@@ -751,3 +752,108 @@ def test_graph_variants_and_errors(mgp, golden, dev):
         knn.search(x, 0)
     with pytest.raises(ValueError):
         mgp.operators.GraphLaplacianOperator(val_d, idx_d, x.shape[0], torch.tensor([[0.5]], device=dev), "unnormalized")
+
+
+def _tile_invariants(graph, tiles):
+    rows = tiles["rows"]
+    rowptr, col = graph.rowptr.cpu().numpy(), graph.col.cpu().numpy()
+    tp, tc = tiles["tile_ptr"].cpu().numpy(), tiles["tile_cols"].cpu().numpy()
+    lid = tiles["lid"].cpu().numpy().view(np.uint16).astype(np.int64)
+    ntiles = -(-graph.n // rows)
+    assert tp.shape[0] == ntiles + 1 and tp[0] == 0 and tp[-1] == tc.shape[0] == tiles["total_cols"]
+    mc = me = 0
+    for t in range(ntiles):
+        r0, r1 = t * rows, min((t + 1) * rows, graph.n)
+        e0, e1 = rowptr[r0], rowptr[r1]
+        want = np.unique(col[e0:e1])
+        got = tc[tp[t]:tp[t + 1]]
+        assert np.array_equal(got, want)                                  # distinct, ascending
+        assert np.array_equal(got[lid[e0:e1]], col[e0:e1])                # local id -> the entry's column
+        mc, me = max(mc, len(want)), max(me, e1 - e0)
+    assert (mc, me) == (tiles["max_cols"], tiles["max_entries"])
+
+
+@pytest.mark.parametrize("rows", [32, 64, 128])
+@pytest.mark.parametrize("name", ["dumbbell_k10_loop", "dumbbell_k50_noloop"])
+def test_tile_dictionary_spmv(mgp, golden, dev, name, rows):
+    """Row-tile column dictionaries (mgp_graph_tiles) and the LDS-staged C == 1 SpMV: structure
+    invariants, fp64 oracle, agreement with the gather kernel, dot partials, isolated rows."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.graph import KnnGraph, LaplacianData, build_tiles
+    from oracle.laplacian import LaplacianOracle
+    g = golden(name)
+    n = g["train_x"].shape[0]
+    idx, val = T(g["edge_index"].astype(np.int64), dev), T(g["edge_value"], dev)
+    graph = KnnGraph.from_coo(idx, val, n, tiles=None)
+    graph.tiles = build_tiles(n, graph.rowptr, graph.col, graph.nnz, tile_rows=rows)
+    assert graph.tiles is not None and graph.tiles["rows"] == rows
+    _tile_invariants(graph, graph.tiles)
+    data = LaplacianData(graph, float(g["eps"]), bool(g["self_loops"]))
+    lib = _lib.lib()
+    x = torch.randn(n, 1, device=dev)
+    pre = torch.rand(n, device=dev) + 0.5
+    base = torch.randn(n, 1, device=dev)
+    outs = {}
+    try:
+        for mode in (0, 1):
+            lib.mgp_spmm_set_tile_mode(mode)
+            csr = data.csr()
+            nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), 1)
+            assert nb == (-(-n // rows) if mode else lib.mgp_spmm_dot_blocks(n, 1))
+            part = torch.zeros(nb, device=dev)
+            y = torch.empty_like(x)
+            _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(x), 1, _lib.ptr(y), 1.25, 1.0, _lib.ptr(pre),
+                                          _lib.ptr(pre), _lib.ptr(base), 0.5, 2.0, _lib.ptr(x), _lib.ptr(part),
+                                          _lib.stream()), "mgp_spmm_fused")
+            y2 = torch.empty_like(x)                                    # no pre / post / base / dots
+            _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(x), 1, _lib.ptr(y2), 0.0, 1.0, None, None, None,
+                                          0.0, 1.0, None, None, _lib.stream()), "mgp_spmm_fused")
+            outs[mode] = (y.clone(), float(part.double().sum()), y2.clone())
+    finally:
+        lib.mgp_spmm_set_tile_mode(1)
+    lo = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "symmetric", data.self_loops, dtype=np.float64)
+    xs = pre.cpu().numpy().astype(np.float64)[:, None] * x.cpu().numpy()
+    ref = 0.5 * base.cpu().numpy() + 2.0 * pre.cpu().numpy()[:, None] * (1.25 * xs + lo.matmul(xs))
+    ref2 = lo.matmul(x.cpu().numpy().astype(np.float64))
+    tol = 4e-6 * np.abs(lo.diag).max() * np.abs(xs).max() * 2.0
+    for mode in (0, 1):
+        np.testing.assert_allclose(outs[mode][0].cpu().numpy(), ref, rtol=0, atol=tol)
+        np.testing.assert_allclose(outs[mode][2].cpu().numpy(), ref2, rtol=0, atol=tol)
+        assert abs(outs[mode][1] - float((x.cpu().double() * torch.from_numpy(ref)).sum())) < 1e-3 * np.abs(ref).max() * n ** 0.5
+
+
+def test_tile_dictionary_isolated_rows_and_long_range(mgp, dev):
+    """Edge list with isolated nodes (empty rows, empty tiles) and uniformly random long-range edges
+    (dictionary almost as long as the entry list): the tile SpMV equals the gather kernel's result
+    up to summation order and the fp64 dense product."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.graph import KnnGraph, LaplacianData
+    rng = np.random.default_rng(5)
+    n, M = 3000, 20000
+    r, c = rng.integers(0, 1500, M), rng.integers(0, 1500, M)         # nodes >= 1500 stay isolated
+    keep = r < c
+    pairs = np.unique(np.stack([r[keep], c[keep]], 1), axis=0)
+    idx = torch.from_numpy(pairs.T.copy()).to(dev)
+    val = torch.from_numpy(rng.random(len(pairs)).astype(np.float32) * 0.01).to(dev)
+    graph = KnnGraph.from_coo(idx, val, n)
+    assert graph.tiles is not None
+    _tile_invariants(graph, graph.tiles)
+    data = LaplacianData(graph, 0.1, True)
+    lib = _lib.lib()
+    x = torch.randn(n, 1, device=dev)
+    ys = []
+    try:
+        for mode in (0, 1):
+            lib.mgp_spmm_set_tile_mode(mode)
+            csr = data.csr()
+            y = torch.empty_like(x)
+            _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(x), 1, _lib.ptr(y), 0.0, 1.0, None, None, None, 0.0, 1.0,
+                                          None, None, _lib.stream()), "mgp_spmm_fused")
+            ys.append(y.cpu().double())
+    finally:
+        lib.mgp_spmm_set_tile_mode(1)
+    scale = float(data.diag.abs().max()) * float(x.abs().max())
+    assert float((ys[0] - ys[1]).abs().max()) < 1e-5 * scale
+    assert float(ys[1][1500:].abs().max()) <= float((data.diag[1500:].cpu().double() * x[1500:, 0].cpu().double()).abs().max()) + 1e-12

@@ -43,7 +43,8 @@ def main(tag):
         v = [x for x in v if x > 1.0]
         return (statistics.median(v), len(v)) if v else (0.0, 0)
     res = {}
-    pats = {"spmv_kernel (no pre-scaling)": r"spmv_kernel<\d+, \d+, false", "spmv_kernel (pre-scaled input)": r"spmv_kernel<\d+, \d+, true",
+    pats = {"spmv_kernel (no pre-scaling)": r"spmv_kernel<\d+, \d+, false|spmv_tile_kernel<false",
+            "spmv_kernel (pre-scaled input)": r"spmv_kernel<\d+, \d+, true|spmv_tile_kernel<true",
             "cg_update_kernel": "cg_update_kernel", "cg_init_kernel": "cg_init_kernel"}
     for label, k in pats.items():
         fs, n1 = med(f, "FETCH_SIZE", k)
