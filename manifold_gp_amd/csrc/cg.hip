@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void cg_init_kernel(CgArgs a, const float* 
   const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
   int64_t r1 = r0 + a.rows_per_block;
   if (r1 > a.n) r1 = a.n;
-  if (blockIdx.x == 0 && tid == 0) { a.state[0] = 1; a.state[1] = 0; a.state[2] = 0; }
+  if (blockIdx.x == 0 && tid == 0) { a.state[0] = 0; a.state[1] = 0; a.state[2] = 0; }   // the first apply ticks it to 1
   float g = 0.f, rr = 0.f;
   if (cc < a.C) {
     for (int64_t r = r0 + sl; r < r1; r += a.TS) {
@@ -126,18 +126,15 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   __shared__ float sh[3][kBlock];
   __shared__ float sh_alpha[kMaxC], sh_beta[kMaxC], sh_rel[kMaxC];
   __shared__ int sh_done;
-  // workgroup 0 may raise the flag while this launch runs: read it once per workgroup so that
-  // all waves of a workgroup take the same branch (every workgroup reaches the same decision)
-  if (threadIdx.x == 0) sh_done = a.state[1];
-  __syncthreads();
-  if (sh_done) return;
-  const int it = a.state[0];
-  const int par = it & 1, prev = par ^ 1;
+  __shared__ int sh_state[2];
   const int tid = threadIdx.x, cc = tid % a.TC, sl = tid / a.TC;
   const int C = a.C;
+  // Every first touch of a line in a kernel is served from beyond L2 (~0.7 us), so the prologue is ONE
+  // round trip: iteration counter + done flag, the dot partials of BOTH parities, gamma_old / alpha_old
+  // of both parities and this thread's first vector element are all requested before the first wait;
+  // the parity (a function of the iteration counter) only selects among values already in registers.
+  const int st_it = a.state[0], st_done = a.state[1];
 
-  // operands of this thread's first element: issued before the reduction so that their latency
-  // overlaps it (the kernel is a chain of dependent L2 round trips otherwise)
   const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
   int64_t r1 = r0 + a.rows_per_block;
   if (r1 > a.n) r1 = a.n;
@@ -154,25 +151,32 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
 
   // ---- every workgroup reduces the partials in the same fixed order: thread (sl, cc) sums
   // partials sl, sl+TS, ... of column cc with independent loads, LDS combines the TS slices
-  float g = 0.f, rr = 0.f, d = 0.f;
+  float g2[2] = {0.f, 0.f}, rr2[2] = {0.f, 0.f}, d = 0.f;
+  float go2[2] = {0.f, 0.f}, ao2[2] = {0.f, 0.f}, bb_old = 0.f;
   if (cc < C) {
-    const float* pg = a.pd_gamma + (int64_t)prev * a.nbv * C;
-    const float* pr = a.pd_rr + (int64_t)prev * a.nbv * C;
     // batches of 4 / 8 loads on clamped indices, masked afterwards: all in flight together
     for (int b0 = sl; b0 < a.nbv; b0 += 4 * a.TS) {
-      float gv[4], rv[4];
+      float gv[2][4], rv[2][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int b = b0 + q * a.TS;
-        const int bc = b < a.nbv ? b : a.nbv - 1;
-        gv[q] = pg[(int64_t)bc * C + cc];
-        rv[q] = pr[(int64_t)bc * C + cc];
+      for (int h = 0; h < 2; ++h) {
+        const float* pg = a.pd_gamma + (int64_t)h * a.nbv * C;
+        const float* pr = a.pd_rr + (int64_t)h * a.nbv * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int b = b0 + q * a.TS;
+          const int bc = b < a.nbv ? b : a.nbv - 1;
+          gv[h][q] = pg[(int64_t)bc * C + cc];
+          rv[h][q] = pr[(int64_t)bc * C + cc];
+        }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const bool on = b0 + q * a.TS < a.nbv;
-        g += on ? gv[q] : 0.f;
-        rr += on ? rv[q] : 0.f;
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool on = b0 + q * a.TS < a.nbv;
+          g2[h] += on ? gv[h][q] : 0.f;
+          rr2[h] += on ? rv[h][q] : 0.f;
+        }
       }
     }
     for (int b0 = sl; b0 < a.nbs; b0 += 8 * a.TS) {
@@ -187,11 +191,24 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
       for (int q = 0; q < 8; ++q) d += (b0 + q * a.TS < a.nbs) ? dv[q] : 0.f;
     }
   }
+  if (tid < C) {
+    go2[0] = a.gamma_old[tid]; go2[1] = a.gamma_old[C + tid];
+    ao2[0] = a.alpha_old[tid]; ao2[1] = a.alpha_old[C + tid];
+    bb_old = a.bb[tid];
+  }
+  // workgroup 0 may raise the done flag while this launch runs: one thread's view is published to
+  // the whole workgroup so that all its waves take the same branch
+  if (tid == 0) { sh_state[0] = st_it; sh_state[1] = st_done; }
+  __syncthreads();
+  if (sh_state[1]) return;
+  const int it = sh_state[0];
+  const int par = it & 1, prev = par ^ 1;
+  const float g = prev ? g2[1] : g2[0], rr = prev ? rr2[1] : rr2[0];
   sh[0][tid] = g; sh[1][tid] = rr; sh[2][tid] = d;
   reduce_slices<3>(sh, a.TC, a.TS, sl, cc);
   if (tid < C) {
     const float gamma = sh[0][tid], rr2 = sh[1][tid], delta = sh[2][tid];
-    const float bb = (it == 1) ? rr2 : a.bb[tid];
+    const float bb = (it == 1) ? rr2 : bb_old;
     const float rel = (bb > 0.f) ? sqrtf(rr2 / bb) : 0.f;
     sh_rel[tid] = rel;
     const bool frozen = (a.stop_mode == 0) ? (rel < 1e-10f) : (rel <= a.tol);
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
       if (it == 1) {
         alpha = (delta != 0.f) ? gamma / delta : 0.f;
       } else {
-        const float go = a.gamma_old[prev * C + tid], ao = a.alpha_old[prev * C + tid];
+        const float go = prev ? go2[1] : go2[0], ao = prev ? ao2[1] : ao2[0];
         beta = (go != 0.f) ? gamma / go : 0.f;
         const float den = delta - ((ao != 0.f) ? beta * gamma / ao : 0.f);
         alpha = (den != 0.f) ? gamma / den : 0.f;
@@ -279,6 +296,143 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   }
 }
 
+// ---- C == 1 specialisation of cg_update_kernel (the GP-mean solve).  Same arithmetic per element,
+// but built for latency: at N = 60k the kernel is a chain of dependent waits, not bandwidth.
+//   * ONE memory round trip: state, both parities of the gamma / rr partials (<= 2 per lane), the
+//     delta partials (<= 16 per lane), gamma_old / alpha_old of both parities and the lane's first
+//     vector element are all requested before the first wait;
+//   * TWO barriers: the wave sums of the five partial totals and the state words cross the
+//     workgroup through LDS once, then EVERY lane derives alpha, beta and the stopping decision
+//     redundantly (no broadcast round), and the new partials take the second barrier.
+// Summation order is fixed (lane slots in order, xor tree, (w0 + w1) + (w2 + w3)).
+constexpr int kC1GammaSlots = 2;    // nbv <= kMaxGridVec = 2 * 256
+constexpr int kC1DeltaSlots = 16;   // nbs <= 4096
+
+__global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
+  __shared__ float sh_w[kBlock / 64][5];
+  __shared__ float sh_o[kBlock / 64][2];
+  __shared__ int sh_state[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int st_it = a.state[0], st_done = a.state[1];
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.n) r1 = a.n;
+  const int64_t rf = r0 + tid;
+  const int64_t rs = rf < r1 ? rf : 0;
+  const float f_u = a.u[rs], f_p = a.p[rs], f_s = a.s[rs], f_w = a.w[rs], f_x = a.x[rs], f_r = a.r[rs];
+  const float l_m = (a.minv ? a.minv : a.x)[rs], l_pre = (a.us ? a.pre : a.x)[rs];
+  const float f_m = a.minv ? l_m : 1.f, f_pre = a.us ? l_pre : 1.f;
+  float gv[2][kC1GammaSlots], rv[2][kC1GammaSlots], dv[kC1DeltaSlots];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < kC1GammaSlots; ++q) {
+      const int b = tid + q * kBlock;
+      const int bc = b < a.nbv ? b : a.nbv - 1;
+      gv[h][q] = a.pd_gamma[(int64_t)h * a.nbv + bc];
+      rv[h][q] = a.pd_rr[(int64_t)h * a.nbv + bc];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kC1DeltaSlots; ++q) {
+    const int b = tid + q * kBlock;
+    dv[q] = a.pd_delta[b < a.nbs ? b : a.nbs - 1];
+  }
+  const float go0 = a.gamma_old[0], go1 = a.gamma_old[1], ao0 = a.alpha_old[0], ao1 = a.alpha_old[1];
+  const float bb_old = a.bb[0];
+  float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < kC1GammaSlots; ++q) {
+    const bool on = tid + q * kBlock < a.nbv;
+    t[0] += on ? gv[0][q] : 0.f; t[1] += on ? gv[1][q] : 0.f;
+    t[2] += on ? rv[0][q] : 0.f; t[3] += on ? rv[1][q] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < kC1DeltaSlots; ++q) t[4] += (tid + q * kBlock < a.nbs) ? dv[q] : 0.f;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) t[k] = mgp_wave_sum(t[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) sh_w[wave][k] = t[k];
+  }
+  // workgroup 0 may raise the done flag while this launch runs: one lane's view of the state is
+  // published so that all waves of a workgroup take the same branch
+  if (tid == 0) { sh_state[0] = st_it; sh_state[1] = st_done; }
+  __syncthreads();
+  if (sh_state[1]) return;
+  const int it = sh_state[0];
+  const int par = it & 1, prev = par ^ 1;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) t[k] = (sh_w[0][k] + sh_w[1][k]) + (sh_w[2][k] + sh_w[3][k]);
+  const float gamma = prev ? t[1] : t[0], rr2 = prev ? t[3] : t[2], delta = t[4];
+  const float bb = (it == 1) ? rr2 : bb_old;
+  const float rel = (bb > 0.f) ? sqrtf(rr2 / bb) : 0.f;
+  const bool frozen = (a.stop_mode == 0) ? (rel < 1e-10f) : (rel <= a.tol);
+  float alpha = 0.f, beta = 0.f;
+  if (!frozen) {
+    if (it == 1) {
+      alpha = (delta != 0.f) ? gamma / delta : 0.f;
+    } else {
+      const float go = prev ? go1 : go0, ao = prev ? ao1 : ao0;
+      beta = (go != 0.f) ? gamma / go : 0.f;
+      const float den = delta - ((ao != 0.f) ? beta * gamma / ao : 0.f);
+      alpha = (den != 0.f) ? gamma / den : 0.f;
+    }
+    if (!isfinite(alpha) || !isfinite(beta)) { alpha = 0.f; beta = 0.f; }
+  }
+  int done = 0, status = 0;
+  if (a.stop_mode == 0) {
+    if (it > a.min_iter && rel < a.tol) { done = 1; status = 1; }
+  } else if (rel <= a.tol) { done = 1; status = 1; }
+  if (!isfinite(rel)) { done = 1; status = 3; }
+  if (!done && it > a.max_iter) { done = 1; status = 2; }
+  if (blockIdx.x == 0 && tid == 0) {
+    a.gamma_old[par] = gamma;
+    a.alpha_old[par] = alpha;
+    if (it == 1) a.bb[0] = bb;
+    a.resid[0] = rel;
+    if (done) {
+      a.state[2] = status; a.state[1] = 1;
+      a.host_resid[0] = rel;
+      a.host_state[0] = it; a.host_state[2] = status;
+      __threadfence_system();
+      a.host_state[1] = 1;
+    }
+  }
+  if (done) return;
+
+  float ng = 0.f, nrr = 0.f;
+  for (int64_t r = rf; r < r1; r += kBlock) {
+    float un, po, so, wo, xo, ro, mo = 1.f, pr = 1.f;
+    if (r == rf) { un = f_u; po = f_p; so = f_s; wo = f_w; xo = f_x; ro = f_r; mo = f_m; pr = f_pre; }
+    else {
+      un = a.u[r]; po = a.p[r]; so = a.s[r]; wo = a.w[r]; xo = a.x[r]; ro = a.r[r];
+      if (a.minv) mo = a.minv[r];
+      if (a.us) pr = a.pre[r];
+    }
+    const float p = fmaf(beta, po, un);
+    const float s = fmaf(beta, so, wo);
+    a.p[r] = p;
+    a.s[r] = s;
+    a.x[r] = fmaf(alpha, p, xo);
+    const float rn = fmaf(-alpha, s, ro);
+    a.r[r] = rn;
+    float u2 = rn;
+    if (a.minv) { u2 = mo * rn; a.u[r] = u2; }
+    if (a.us) a.us[r] = pr * u2;
+    ng = fmaf(rn, u2, ng);
+    nrr = fmaf(rn, rn, nrr);
+  }
+  ng = mgp_wave_sum(ng);
+  nrr = mgp_wave_sum(nrr);
+  if (lane == 0) { sh_o[wave][0] = ng; sh_o[wave][1] = nrr; }
+  __syncthreads();
+  if (tid == 0) {
+    a.pd_gamma[(int64_t)par * a.nbv + blockIdx.x] = (sh_o[0][0] + sh_o[1][0]) + (sh_o[2][0] + sh_o[3][0]);
+    a.pd_rr[(int64_t)par * a.nbv + blockIdx.x] = (sh_o[0][1] + sh_o[1][1]) + (sh_o[2][1] + sh_o[3][1]);
+  }
+}
+
 // ---- iterative refinement (stop_mode 1, max_refine > 0): the recurrence residual of a single-
 // reduction CG drifts from the true residual on ill-conditioned systems in fp32; the true residual
 // R = B - A x is formed explicitly and, if it misses the tolerance, A d = R is solved and x += d.
@@ -334,10 +488,13 @@ struct CgPlan {
   float* pd_delta;
   hipStream_t stream;       // caller's stream: all work is enqueued here
   hipStream_t cap_stream;   // private stream used only to capture the iteration graph
-  hipGraphExec_t exec;        // `chunk` iterations
-  hipGraphExec_t exec_small;  // `chunk_small` iterations (first replay: short solves finish here)
-  bool has_graph;
-  int chunk, chunk_small;
+  hipGraphExec_t exec;        // `chunk` x (apply, update): continuation replays
+  hipGraph_t graph_first;     // cg_init + `len_first` x (apply, update): a short solve is ONE graph launch
+  hipGraphExec_t exec_first;
+  hipGraphNode_t init_node;   // the cg_init node of graph_first (its rhs argument is patched per solve)
+  bool has_graph, has_first;
+  int chunk, len_first;
+  int last_need;              // (apply, update) pairs the previous solve needed: len_first follows it
   int32_t* host_state;      // pinned
   float* host_resid;        // pinned
   float *xacc, *rbuf, *tbuf, *rpart;   // refinement: accumulated solution, residual rhs, A x, partials
@@ -364,13 +521,62 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   return b + 1024;
 }
 
-int enqueue_iteration(CgPlan* pl, hipStream_t st) {
-  hipLaunchKernelGGL(cg_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+// one CG step = operator apply (w = A u, partials of u . w, ticks the iteration counter; skipped once
+// converged) followed by the fused update kernel, which also takes the stopping decision: every
+// graph therefore ends right behind a decision and a solve that needs k steps runs exactly k bodies
+int enqueue_body(CgPlan* pl, hipStream_t st) {
+  MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
+                                  pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, pl->args.state + 1,
+                                  pl->args.state, pl->op_work, pl->op_work_bytes, st));
+  if (pl->C == 1 && pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock)
+    hipLaunchKernelGGL(cg_update_c1_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+  else
+    hipLaunchKernelGGL(cg_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
   MGP_LAUNCH_CHECK();
-  // w = A u ; partials of u . w ; skipped once converged ; ticks the iteration counter
-  return mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
-                                 pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, pl->args.state + 1,
-                                 pl->args.state, pl->op_work, pl->op_work_bytes, st);
+  return MGP_OK;
+}
+
+// (re)build the first graph: cg_init + len bodies.  Leaves has_first = false on any failure (the
+// solve then launches cg_init eagerly and replays the continuation graph).
+void capture_first(CgPlan* pl, int len) {
+  if (pl->exec_first) { (void)hipGraphExecDestroy(pl->exec_first); pl->exec_first = nullptr; }
+  if (pl->graph_first) { (void)hipGraphDestroy(pl->graph_first); pl->graph_first = nullptr; }
+  pl->has_first = false;
+  pl->len_first = len;
+  if (!pl->cap_stream || len < 1) return;
+  bool ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, pl->cap_stream, pl->args,
+                       (const float*)pl->args.x);   // placeholder rhs, patched before every launch
+    int rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
+    for (int i = 0; i < len && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
+    ok = (rc == MGP_OK && e2 == hipSuccess && graph != nullptr);
+    pl->graph_first = graph;
+  }
+  if (ok) {
+    size_t nroot = 1;
+    hipGraphNode_t root = nullptr;
+    ok = hipGraphGetRootNodes(pl->graph_first, &root, &nroot) == hipSuccess && nroot == 1 && root != nullptr;
+    hipGraphNodeType ty;
+    if (ok) ok = hipGraphNodeGetType(root, &ty) == hipSuccess && ty == hipGraphNodeTypeKernel;
+    pl->init_node = root;
+  }
+  if (ok) ok = hipGraphInstantiate(&pl->exec_first, pl->graph_first, nullptr, nullptr, 0) == hipSuccess;
+  (void)hipGetLastError();
+  pl->has_first = ok;
+}
+
+// point the cg_init node of the first graph at this solve's right-hand side
+bool patch_first_rhs(CgPlan* pl, const float* rhs) {
+  hipKernelNodeParams np;
+  memset(&np, 0, sizeof(np));
+  if (hipGraphKernelNodeGetParams(pl->init_node, &np) != hipSuccess) return false;
+  void* kp[2] = {(void*)&pl->args, (void*)&rhs};
+  np.kernelParams = kp;
+  np.extra = nullptr;
+  return hipGraphExecKernelNodeSetParams(pl->exec_first, pl->init_node, &np) == hipSuccess;
 }
 
 }  // namespace
@@ -399,7 +605,6 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   if (pl->prm.max_iter <= 0) pl->prm.max_iter = 1000;
   if (pl->prm.min_iter < 0) pl->prm.min_iter = 0;
   pl->chunk = pl->prm.check_every > 0 ? pl->prm.check_every : 10;
-  pl->chunk_small = pl->chunk < 4 ? pl->chunk : 4;
   pl->stream = mgp_stream(stream);
   const int64_t n = op->L.n * world;        // global vector length
   const size_t nc = (size_t)n * C;
@@ -448,20 +653,19 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   if (pl->prm.use_graph && !pl->is_dist) {   // collectives are enqueued eagerly (no capture)
     e = hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking);
     bool ok = (e == hipSuccess);
-    for (int which = 0; which < 2 && ok; ++which) {
-      const int len = which == 0 ? pl->chunk_small : pl->chunk;
-      ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-      if (!ok) break;
+    if (ok) ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
       int rc = MGP_OK;
-      for (int i = 0; i < len && rc == MGP_OK; ++i) rc = enqueue_iteration(pl, pl->cap_stream);
+      for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
       hipGraph_t graph = nullptr;
       hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
       ok = (rc == MGP_OK && e2 == hipSuccess && graph != nullptr);
-      if (ok) ok = hipGraphInstantiate(which == 0 ? &pl->exec_small : &pl->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+      if (ok) ok = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0) == hipSuccess;
       if (graph) (void)hipGraphDestroy(graph);
     }
     pl->has_graph = ok;
     (void)hipGetLastError();   // a failed capture falls back to eager launches
+    if (ok) capture_first(pl, pl->chunk < 4 ? pl->chunk : 4);
   }
   *plan_out = pl;
   return MGP_OK;
@@ -490,20 +694,22 @@ extern "C" int mgp_cg_plan_create_dist(const mgp_operator_t* op_local, int C, co
 static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   hipStream_t st = pl->stream;
   const size_t nc = (size_t)pl->args.n * pl->C;
-  hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, rhs);
-  MGP_LAUNCH_CHECK();
-  MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
-                                  pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, nullptr, nullptr, pl->op_work,
-                                  pl->op_work_bytes, st));
   pl->host_state[1] = 0;
-  int guard = 0;
   bool first = true;
+  if (pl->has_first && !patch_first_rhs(pl, rhs)) pl->has_first = false;
+  if (!pl->has_first) {
+    hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, rhs);
+    MGP_LAUNCH_CHECK();
+  }
+  int guard = 0;
   for (;;) {
-    const int len = first ? pl->chunk_small : pl->chunk;
-    if (pl->has_graph) {
-      MGP_HIP_TRY(hipGraphLaunch(first ? pl->exec_small : pl->exec, st));
+    if (first && pl->has_first) {
+      MGP_HIP_TRY(hipGraphLaunch(pl->exec_first, st));
+    } else if (pl->has_graph) {
+      MGP_HIP_TRY(hipGraphLaunch(pl->exec, st));
     } else {
-      for (int i = 0; i < len; ++i) MGP_TRY(enqueue_iteration(pl, st));
+      const int len = (first && pl->chunk > 4) ? 4 : pl->chunk;   // eager path: short solves stop early
+      for (int i = 0; i < len; ++i) MGP_TRY(enqueue_body(pl, st));
     }
     first = false;
     // the solution rides behind every chunk so that one synchronisation ends the solve; the
@@ -511,7 +717,15 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
     if (Xcopy) MGP_HIP_TRY(hipMemcpyAsync(Xcopy, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
     MGP_HIP_TRY(hipStreamSynchronize(st));
     if (pl->host_state[1]) break;
-    if (++guard > pl->prm.max_iter / pl->chunk_small + 4) break;
+    if (++guard > pl->prm.max_iter / (pl->chunk < 4 ? pl->chunk : 4) + 4) break;
+  }
+  // the first graph follows the workload: when two solves in a row needed the same number of steps and
+  // it is not the captured length, re-capture (a few hundred us, once) so that the next solve of
+  // this kind is exactly one graph launch with no skipped launches behind the stopping decision
+  if (pl->exec_first && pl->host_state[1]) {
+    const int need = pl->host_state[0];
+    if (need >= 1 && need <= 64 && need != pl->len_first && need == pl->last_need) capture_first(pl, need);
+    pl->last_need = need;
   }
   return MGP_OK;
 }
@@ -575,7 +789,8 @@ extern "C" int mgp_cg_plan_destroy(void* plan) {
   CgPlan* pl = static_cast<CgPlan*>(plan);
   if (!pl) return MGP_ERR_ARG;
   if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
-  if (pl->exec_small) (void)hipGraphExecDestroy(pl->exec_small);
+  if (pl->exec_first) (void)hipGraphExecDestroy(pl->exec_first);
+  if (pl->graph_first) (void)hipGraphDestroy(pl->graph_first);
   if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
   if (pl->host_state) (void)hipHostFree(pl->host_state);
   if (pl->host_resid) (void)hipHostFree(pl->host_resid);

@@ -489,67 +489,87 @@ typedef unsigned short mgp_v4h __attribute__((ext_vector_type(4)));
 template <bool PRE, int BS>
 __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
-  if (p.skip && *p.skip) return;
-  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
+  // the CG graph's skip flag / iteration tick: loaded here, consumed only after the first tile's
+  // metadata loads have been issued, so that the flag costs no round trip of its own
+  const int skipv = p.skip ? *p.skip : 0;
+  const int tickv = (p.tick && blockIdx.x == 0) ? *p.tick : 0;
   constexpr int TR = BS / 4;
   constexpr int NQ = 4;
   const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
   const int tid = threadIdx.x, sub = tid & 3;
   float* __restrict__ xl = tile_lds;
   float* __restrict__ part = tile_lds + t.max_cols;
+  // restrict-qualified read-only views: wave-uniform addresses become scalar (s_load) reads
   const float* __restrict__ x = p.X;
+  const float* __restrict__ prev = p.pre;
+  const int32_t* __restrict__ rowptr = p.rowptr;
+  const float* __restrict__ vals = p.vals;
+  const int32_t* __restrict__ tile_ptr = t.tile_ptr;
+  const uint32_t* __restrict__ tile_cols = reinterpret_cast<const uint32_t*>(t.tile_cols);
+  const uint16_t* __restrict__ lid = t.lid;
   float dsum = 0.f;
   const int64_t t0 = (int64_t)lb * t.tiles_per_block;
   const int64_t t1 = t0 + t.tiles_per_block < t.ntiles ? t0 + t.tiles_per_block : t.ntiles;
   for (int64_t tile = t0; tile < t1; ++tile) {
     const int64_t r0 = tile * TR;
     const int64_t r1 = r0 + TR < p.n ? r0 + TR : p.n;
-    const int64_t row = r0 + (tid >> 2);
-    const bool valid = row < r1;
-    const int64_t rr = valid ? row : r0;
-    const int e0 = p.rowptr[r0], e1 = p.rowptr[r1];
-    const int rs = p.rowptr[rr], re = p.rowptr[rr + 1];
-    const int dp = t.tile_ptr[tile];
-    const int D = t.tile_ptr[tile + 1] - dp;
-    const int64_t grr = rr + p.goff;
-    float e_x = x[grr];
-    if (PRE) e_x *= p.pre[grr];
-    const float e_diag = p.diag[rr];
-    const float e_post = p.post ? p.post[grr] : 1.f;
-    const float e_base = p.base ? p.base[grr] : 0.f;
-    const float e_dotw = p.dotw ? p.dotw[grr] : 0.f;
+    const int e0 = rowptr[r0], e1 = rowptr[r1];
+    const int dp = tile_ptr[tile];
+    const int D = tile_ptr[tile + 1] - dp;
     const int qb = e0 >> 2, Q = (e1 - e0) >> 2;
-    // phase 0: unconditional (clamped) stream loads, all in flight before anything is consumed
+    if (skipv) return;
+    // phase 0 (loads are retired in issue order, so the order below is the order they are needed in):
+    // dictionary ids first, then the matrix stream, then the row-phase operands -- all unconditional on
+    // clamped addresses, all in flight before the first wait
+    unsigned c[NQ];   // unsigned: a signed id is sign-extended right behind its load, i.e. waited for at once
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int j = tid + k * BS;
+      c[k] = (unsigned)tile_cols[j < D ? dp + j : 0];   // empty tile: dp may be one past the end
+    }
+    __builtin_amdgcn_sched_barrier(0);
     mgp_v4f v[NQ];
     mgp_v4h l[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       const int q = tid + k * BS;
       const int qi = q < Q ? qb + q : 0;
-      v[k] = *reinterpret_cast<const mgp_v4f*>(p.vals + 4 * (int64_t)qi);
-      l[k] = *reinterpret_cast<const mgp_v4h*>(t.lid + 4 * (int64_t)qi);
+      v[k] = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)qi);
+      l[k] = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)qi);
     }
-    // phase 1: dictionary -> LDS
-    for (int j0 = 0; j0 < D; j0 += NQ * BS) {
-      int c[NQ];
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 1: dictionary -> LDS (first NQ * BS columns from the ids loaded above)
+    float g[NQ];
 #pragma unroll
-      for (int k = 0; k < NQ; ++k) {
-        const int j = j0 + tid + k * BS;
-        c[k] = t.tile_cols[dp + (j < D ? j : 0)];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      float g[NQ];
+    for (int k = 0; k < NQ; ++k) {
+      g[k] = x[c[k]];
+      if (PRE) g[k] *= prev[c[k]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int64_t row = r0 + (tid >> 2);
+    const bool valid = row < r1;
+    const int64_t rr = valid ? row : r0;
+    const int64_t grr = rr + p.goff;
+    const int rs = rowptr[rr], re = rowptr[rr + 1];
+    float e_x = x[grr];
+    if (PRE) e_x *= prev[grr];
+    const float e_diag = p.diag[rr];
+    // nullable operands: unconditional load from a valid stand-in + select (no branch around a load)
+    const float l_post = (p.post ? p.post : x)[grr], l_base = (p.base ? p.base : x)[grr], l_dotw = (p.dotw ? p.dotw : x)[grr];
+    const float e_post = p.post ? l_post : 1.f;
+    const float e_base = p.base ? l_base : 0.f;
+    const float e_dotw = p.dotw ? l_dotw : 0.f;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k = 0; k < NQ; ++k) {
-        g[k] = x[c[k]];
-        if (PRE) g[k] *= p.pre[c[k]];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < NQ; ++k) {
-        const int j = j0 + tid + k * BS;
-        if (j < D) xl[j] = g[k];
-      }
+    for (int k = 0; k < NQ; ++k) {
+      const int j = tid + k * BS;
+      if (j < D) xl[j] = g[k];
+    }
+    for (int j = tid + NQ * BS; j < D; j += BS) {      // dictionaries longer than NQ * BS (rare)
+      const int cc = tile_cols[dp + j];
+      float gg = x[cc];
+      if (PRE) gg *= prev[cc];
+      xl[j] = gg;
     }
     __syncthreads();
     // phase 2: quad products
@@ -564,9 +584,9 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
         part[q] = s;
       }
     }
-    for (int q = tid + NQ * BS; q < Q; q += BS) {      // tiles with more than 16 * BS entries (rare)
-      const mgp_v4f vv = *reinterpret_cast<const mgp_v4f*>(p.vals + 4 * (int64_t)(qb + q));
-      const mgp_v4h ll = *reinterpret_cast<const mgp_v4h*>(t.lid + 4 * (int64_t)(qb + q));
+    for (int q = tid + NQ * BS; q < Q; q += BS) {      // tiles with more than 4 * NQ * BS entries (rare)
+      const mgp_v4f vv = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)(qb + q));
+      const mgp_v4h ll = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)(qb + q));
       float s = vv.x * xl[ll.x];
       s = fmaf(vv.y, xl[ll.y], s);
       s = fmaf(vv.z, xl[ll.z], s);
@@ -588,6 +608,7 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     }
     if (tile + 1 < t1) __syncthreads();                // the next tile overwrites xl / part
   }
+  if (p.tick && blockIdx.x == 0 && tid == 0 && !skipv) *p.tick = tickv + 1;
   if (p.dot_partials) {
     __shared__ float red[BS / MGP_WAVE];
     dsum = mgp_wave_sum(dsum);

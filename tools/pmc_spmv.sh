@@ -6,12 +6,11 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 i=0
 for grp in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_READ_sum" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
-           "TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_sum" \
            "SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum" \
-           "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_GATE_EN1_sum"; do
+           "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -- python3 tools/spmv_only.py > "$out/p$i.log" 2>&1 || echo "pass $i failed"
+  timeout -k 10 120 rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -- python3 tools/spmv_only.py > "$out/p$i.log" 2>&1 || echo "pass $i failed"
   echo "pass $i done"
 done
 python3 - <<'PY'
@@ -20,7 +19,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_spmv/p*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "spmv_kernel" in r["Kernel_Name"]:
+            if "spmv_" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
             v = v[5:] if len(v) > 10 else v
