@@ -231,7 +231,10 @@ int mgp_operator_apply_dot(const mgp_operator_t* op, const float* X, int C, floa
  *         when the mean over columns of ||r||_2 < tol; columns with ||r|| < 1e-10 freeze),
  *         mode 1 = every column ||r||_2 <= tol * ||b||_2
  *   out (host): iters, resid[C] relative residual norms (recurrence residual).
- * Synchronises `stream`. */
+ * A solve that needs k steps is ONE hipGraph launch (cg_init + k x (operator apply, fused update);
+ * the rhs pointer is patched into the graph, its length follows the previous solves).  The call
+ * returns when the stopping decision has reached the host (host-mapped flag); X is complete in
+ * stream order: consume it on `stream` or synchronise before reading it from elsewhere. */
 typedef struct {
   float tol;
   int32_t max_iter;

@@ -495,6 +495,7 @@ struct CgPlan {
   bool has_graph, has_first;
   int chunk, len_first;
   int last_need;              // (apply, update) pairs the previous solve needed: len_first follows it
+  const float* patched_rhs;   // rhs the cg_init node currently points at
   int32_t* host_state;      // pinned
   float* host_resid;        // pinned
   float *xacc, *rbuf, *tbuf, *rpart;   // refinement: accumulated solution, residual rhs, A x, partials
@@ -542,6 +543,7 @@ void capture_first(CgPlan* pl, int len) {
   if (pl->exec_first) { (void)hipGraphExecDestroy(pl->exec_first); pl->exec_first = nullptr; }
   if (pl->graph_first) { (void)hipGraphDestroy(pl->graph_first); pl->graph_first = nullptr; }
   pl->has_first = false;
+  pl->patched_rhs = nullptr;
   pl->len_first = len;
   if (!pl->cap_stream || len < 1) return;
   bool ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
@@ -570,13 +572,16 @@ void capture_first(CgPlan* pl, int len) {
 
 // point the cg_init node of the first graph at this solve's right-hand side
 bool patch_first_rhs(CgPlan* pl, const float* rhs) {
+  if (rhs == pl->patched_rhs) return true;
   hipKernelNodeParams np;
   memset(&np, 0, sizeof(np));
   if (hipGraphKernelNodeGetParams(pl->init_node, &np) != hipSuccess) return false;
   void* kp[2] = {(void*)&pl->args, (void*)&rhs};
   np.kernelParams = kp;
   np.extra = nullptr;
-  return hipGraphExecKernelNodeSetParams(pl->exec_first, pl->init_node, &np) == hipSuccess;
+  if (hipGraphExecKernelNodeSetParams(pl->exec_first, pl->init_node, &np) != hipSuccess) return false;
+  pl->patched_rhs = rhs;
+  return true;
 }
 
 }  // namespace
@@ -715,8 +720,18 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
     // the solution rides behind every chunk so that one synchronisation ends the solve; the
     // convergence flag / residuals arrive through host-mapped memory written by the update kernel
     if (Xcopy) MGP_HIP_TRY(hipMemcpyAsync(Xcopy, pl->args.x, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
-    MGP_HIP_TRY(hipStreamSynchronize(st));
-    if (pl->host_state[1]) break;
+    // The stopping decision arrives in host-mapped memory (written behind a system-scope fence by the
+    // update kernel): poll it instead of sleeping in hipStreamSynchronize -- at ~70 us per solve the
+    // wake-up latency of a blocking wait is a visible fraction.  Work queued behind the solve on the
+    // same stream (the X copy, the caller's kernels) stays ordered; a chunk that ends undecided is
+    // detected by the stream going idle.
+    volatile int32_t* flag = pl->host_state + 1;
+    while (!*flag) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) break;
+      if (q != hipErrorNotReady) return (int)q;
+    }
+    if (*flag) break;
     if (++guard > pl->prm.max_iter / (pl->chunk < 4 ? pl->chunk : 4) + 4) break;
   }
   // the first graph follows the workload: when two solves in a row needed the same number of steps and
@@ -724,7 +739,10 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   // this kind is exactly one graph launch with no skipped launches behind the stopping decision
   if (pl->exec_first && pl->host_state[1]) {
     const int need = pl->host_state[0];
-    if (need >= 1 && need <= 64 && need != pl->len_first && need == pl->last_need) capture_first(pl, need);
+    if (need >= 1 && need <= 64 && need != pl->len_first && need == pl->last_need) {
+      MGP_HIP_TRY(hipStreamSynchronize(st));   // the graph being replaced may still be draining
+      capture_first(pl, need);
+    }
     pl->last_need = need;
   }
   return MGP_OK;
