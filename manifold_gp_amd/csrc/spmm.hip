@@ -531,19 +531,29 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     mgp_v4f v[NQ];
     mgp_v4h l[NQ];
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
+    for (int k = 0; k < NQ / 2; ++k) {
       const int q = tid + k * BS;
       const int qi = q < Q ? qb + q : 0;
       v[k] = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)qi);
       l[k] = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)qi);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // phase 1: dictionary -> LDS (first NQ * BS columns from the ids loaded above)
+    // phase 1: dictionary -> LDS (first NQ * BS columns from the ids loaded above).  The gathers sit
+    // in the MIDDLE of the stream: loads retire in order, so the dictionary (and the first half of
+    // the stream) is complete while the second half is still arriving and the LDS work overlaps it.
     float g[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       g[k] = x[c[k]];
       if (PRE) g[k] *= prev[c[k]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = NQ / 2; k < NQ; ++k) {
+      const int q = tid + k * BS;
+      const int qi = q < Q ? qb + q : 0;
+      v[k] = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)qi);
+      l[k] = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)qi);
     }
     __builtin_amdgcn_sched_barrier(0);
     const int64_t row = r0 + (tid >> 2);
@@ -596,7 +606,15 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     __syncthreads();
     // phase 3: rows
     float acc = 0.f;
-    for (int i = (rs >> 2) - qb + sub, e = (re >> 2) - qb; i < e; i += 4) acc += part[i];
+    {
+      int i = (rs >> 2) - qb + sub;
+      const int e = (re >> 2) - qb;
+      for (; i + 12 < e; i += 16) {        // four independent ds_reads in flight per pass
+        const float a0 = part[i], a1 = part[i + 4], a2 = part[i + 8], a3 = part[i + 12];
+        acc += a0; acc += a1; acc += a2; acc += a3;
+      }
+      for (; i < e; i += 4) acc += part[i];
+    }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
     if (valid && sub == 0) {
