@@ -247,6 +247,10 @@ typedef struct {
 } mgp_cg_params_t;
 
 size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);
+/* C == 1, tile SpMV, nu >= 2, no preconditioner: fold the vector update into launch 0 of the next
+ * operator apply (one kernel less per step).  Experiment, default 0 (no gain measured at N = 60k);
+ * affects plans created afterwards. */
+int mgp_cg_set_fuse(int on);
 /* reusable solver: owns the captured iteration graph; `work` must outlive the plan */
 int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
                        const mgp_cg_params_t* params, void* work, size_t work_bytes, void* stream,

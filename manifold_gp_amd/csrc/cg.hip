@@ -28,6 +28,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxC = 256;
 constexpr int kMaxGridVec = 512;
+constexpr int kMaxPartials = 4096;   // capacity of the gamma / rr partial arrays (fused step: one slot per SpMV workgroup)
 
 struct CgArgs {
   int64_t n;
@@ -51,6 +52,7 @@ struct CgArgs {
   float tol;
   int max_iter, min_iter, stop_mode;
   int64_t rows_per_block;
+  float *rn, *sn;     // fused step only (else NULL): scratch for the new r / s, committed by the chain's last SpMV
 };
 
 // sh[k][sl * TC + cc] holds the partial of slice sl for column cc; result in sh[k][cc] for cc < TC.
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(kBlock) void cg_init_kernel(CgArgs a, const float* 
       const float u = a.minv ? a.minv[r] * b : b;
       a.x[i] = 0.f; a.p[i] = 0.f; a.s[i] = 0.f;
       a.r[i] = b;
+      if (a.rn) { a.rn[i] = b; a.sn[i] = 0.f; }
       if (a.minv) a.u[i] = u;
       if (a.us) a.us[i] = a.pre[r] * u;
       g = fmaf(b, u, g);
@@ -305,6 +308,13 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
 //     workgroup through LDS once, then EVERY lane derives alpha, beta and the stopping decision
 //     redundantly (no broadcast round), and the new partials take the second barrier.
 // Summation order is fixed (lane slots in order, xor tree, (w0 + w1) + (w2 + w3)).
+// C == 1 layout of the scalar block (plan_create_impl): fetched as one s_load_dwordx8.  Separate scalar
+// loads are not batched by hipcc (each is followed by lgkmcnt(0)): five of them cost five round trips.
+struct alignas(32) CgScalars {
+  float go0, go1, ao0, ao1, bb, resid;
+  int it, done;
+};
+
 constexpr int kC1GammaSlots = 2;    // nbv <= kMaxGridVec = 2 * 256
 constexpr int kC1DeltaSlots = 16;   // nbs <= 4096
 
@@ -313,7 +323,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   __shared__ float sh_o[kBlock / 64][2];
   __shared__ int sh_state[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int st_it = a.state[0], st_done = a.state[1];
+  const CgScalars sc = *reinterpret_cast<const CgScalars*>(a.gamma_old);
+  const int st_it = sc.it, st_done = sc.done;
   const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
   int64_t r1 = r0 + a.rows_per_block;
   if (r1 > a.n) r1 = a.n;
@@ -338,8 +349,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
     const int b = tid + q * kBlock;
     dv[q] = a.pd_delta[b < a.nbs ? b : a.nbs - 1];
   }
-  const float go0 = a.gamma_old[0], go1 = a.gamma_old[1], ao0 = a.alpha_old[0], ao1 = a.alpha_old[1];
-  const float bb_old = a.bb[0];
+  const float go0 = sc.go0, go1 = sc.go1, ao0 = sc.ao0, ao1 = sc.ao1;
+  const float bb_old = sc.bb;
   float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < kC1GammaSlots; ++q) {
@@ -433,6 +444,277 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   }
 }
 
+// ---- Fused CG step (C == 1, tile SpMV, single-chain operator with nu >= 2, no preconditioner).
+// update_k and the FIRST SpMV of apply_{k+1} in one launch: one launch floor (~2.7 us) and the update
+// kernel's own load chain less per step.  A workgroup owns the same 64-row tiles as spmv_tile_kernel.
+//   * decision: the gamma / rr / delta partials (one slot per workgroup of this grid) are re-reduced by
+//     every workgroup exactly as in cg_update_c1_kernel -> alpha, beta, stop;
+//   * the SpMV input u_new = r - alpha (w + beta s) is NOT read from memory: for every column of the
+//     tile's dictionary it is recomputed from the OLD r, w, s with the same two fmas the owner of that
+//     row uses, so the staged values are bit-identical to what the owner commits;
+//   * own rows: p, x are updated in place (nobody else reads them); the new r and s go to scratch
+//     (rn, sn) because other workgroups still gather the old ones -- the chain's last SpMV, which runs
+//     behind a kernel boundary, copies them back in its epilogue (MgpCommit);
+//   * output: t0 = tau xs + L xs (launch 0 of the operator chain) and the gamma = rr partials of r_new.
+typedef float cgf_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned short cgf_v4h __attribute__((ext_vector_type(4)));
+
+struct CgFuse {
+  const int32_t* rowptr;
+  const float* vals;
+  const float* diag;
+  const int32_t* tile_ptr;
+  const uint32_t* tile_cols;
+  const uint16_t* lid;
+  int64_t ntiles;
+  int tiles_per_block;
+  int max_cols;
+  float tau;
+  const float* pre;   // nullable (op->pre)
+  float* t0;          // output of the chain's launch 0
+  int nb;             // partial slots = workgroups of this grid
+  const float* rws;   // [n][4] = {r, w, s, pre} per row, published by the previous apply's last SpMV
+};
+
+__global__ __launch_bounds__(kBlock, 4) void cg_fused_step_kernel(CgArgs a, CgFuse f) {   // <= 128 VGPRs: 4 workgroups per CU, the 60k grid (938) in one round
+  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+  __shared__ float sh_w[kBlock / 64][5];
+  __shared__ float sh_o[kBlock / 64];
+  __shared__ int sh_state[2];
+  constexpr int TR = kBlock / 4, NQ = 4, BS = kBlock;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & 3;
+  float* __restrict__ xl = tile_lds;
+  float* __restrict__ part = tile_lds + f.max_cols;
+  const cgf_v4f* __restrict__ rws = reinterpret_cast<const cgf_v4f*>(f.rws);
+
+  // ---- round trip 1: state, scalars, partials (batches of 4 slots per lane, both parities)
+  const CgScalars sc = *reinterpret_cast<const CgScalars*>(a.gamma_old);
+  const int st_it = sc.it, st_done = sc.done;
+  const float go0 = sc.go0, go1 = sc.go1, ao0 = sc.ao0, ao1 = sc.ao1;
+  const float bb_old = sc.bb;
+  float t5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float gv0[4], gv1[4], rv0[4], rv1[4], dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int b = tid + q * kBlock;
+    const int bc = b < f.nb ? b : f.nb - 1;
+    gv0[q] = a.pd_gamma[bc]; gv1[q] = a.pd_gamma[f.nb + bc];
+    rv0[q] = a.pd_rr[bc];    rv1[q] = a.pd_rr[f.nb + bc];
+    dv[q] = a.pd_delta[bc];
+  }
+
+  float alpha = 0.f, beta = 0.f;
+  int par = 0;
+  float nrr = 0.f;
+  const int64_t t0i = (int64_t)lb * f.tiles_per_block;
+  const int64_t t1i = t0i + f.tiles_per_block < f.ntiles ? t0i + f.tiles_per_block : f.ntiles;
+  for (int64_t tile = t0i; tile < t1i; ++tile) {
+    const bool lead = tile == t0i;
+    const int64_t r0 = tile * TR;
+    const int64_t r1 = r0 + TR < a.n ? r0 + TR : a.n;
+    const int e0 = f.rowptr[r0], e1 = f.rowptr[r1];
+    const int dp = f.tile_ptr[tile];
+    const int D = f.tile_ptr[tile + 1] - dp;
+    const int qb = e0 >> 2, Q = (e1 - e0) >> 2;
+    // own row operands (round trip 1 as well: the row index needs no metadata)
+    const int64_t row = r0 + (tid >> 2);
+    const bool valid = row < r1;
+    const int64_t rr_ = valid ? row : r0;
+    const cgf_v4f o_rec = rws[rr_];
+    const float o_p = a.p[rr_], o_x = a.x[rr_], o_diag = f.diag[rr_];
+    const int rs = f.rowptr[rr_], re = f.rowptr[rr_ + 1];
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- round trip 2: dictionary ids + first half of the matrix stream
+    unsigned c[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int j = tid + k * BS;
+      c[k] = f.tile_cols[j < D ? dp + j : 0];
+    }
+    cgf_v4f v[NQ];
+    cgf_v4h l[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ / 2; ++k) {
+      const int q = tid + k * BS;
+      const int qi = q < Q ? qb + q : 0;
+      v[k] = *reinterpret_cast<const cgf_v4f*>(f.vals + 4 * (int64_t)qi);
+      l[k] = *reinterpret_cast<const cgf_v4h*>(f.lid + 4 * (int64_t)qi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (lead) {
+      // consume the partials while round trip 2 is in flight (more than 1024 slots: further batches).
+      // The empty asm pins the sums inside the loop body: they only depend on loop-invariant loads and
+      // would otherwise be hoisted above the tile's own loads, i.e. waited for first.
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("" : "+v"(gv0[q]), "+v"(gv1[q]), "+v"(rv0[q]), "+v"(rv1[q]), "+v"(dv[q]));
+        const bool on = tid + q * kBlock < f.nb;
+        t5[0] += on ? gv0[q] : 0.f; t5[1] += on ? gv1[q] : 0.f;
+        t5[2] += on ? rv0[q] : 0.f; t5[3] += on ? rv1[q] : 0.f;
+        t5[4] += on ? dv[q] : 0.f;
+      }
+      for (int b0 = 4 * kBlock; b0 < f.nb; b0 += 4 * kBlock) {
+        float g0[4], g1[4], q0[4], q1[4], d4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int b = b0 + tid + q * kBlock;
+          const int bc = b < f.nb ? b : f.nb - 1;
+          g0[q] = a.pd_gamma[bc]; g1[q] = a.pd_gamma[f.nb + bc];
+          q0[q] = a.pd_rr[bc];    q1[q] = a.pd_rr[f.nb + bc];
+          d4[q] = a.pd_delta[bc];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool on = b0 + tid + q * kBlock < f.nb;
+          t5[0] += on ? g0[q] : 0.f; t5[1] += on ? g1[q] : 0.f;
+          t5[2] += on ? q0[q] : 0.f; t5[3] += on ? q1[q] : 0.f;
+          t5[4] += on ? d4[q] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) t5[k] = mgp_wave_sum(t5[k]);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) sh_w[wave][k] = t5[k];
+      }
+      if (tid == 0) { sh_state[0] = st_it; sh_state[1] = st_done; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- round trip 3: {r, w, s, pre} records of the dictionary columns (one 16-byte gather per
+    // column); second half of the stream
+    cgf_v4f g4[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) g4[k] = rws[c[k]];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = NQ / 2; k < NQ; ++k) {
+      const int q = tid + k * BS;
+      const int qi = q < Q ? qb + q : 0;
+      v[k] = *reinterpret_cast<const cgf_v4f*>(f.vals + 4 * (int64_t)qi);
+      l[k] = *reinterpret_cast<const cgf_v4h*>(f.lid + 4 * (int64_t)qi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (lead) {
+      __syncthreads();
+      if (sh_state[1]) return;
+      const int it = sh_state[0];
+      par = it & 1;
+      const int prev = par ^ 1;
+      float tot[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) tot[k] = (sh_w[0][k] + sh_w[1][k]) + (sh_w[2][k] + sh_w[3][k]);
+      const float gamma = prev ? tot[1] : tot[0], rr2 = prev ? tot[3] : tot[2], delta = tot[4];
+      const float bb = (it == 1) ? rr2 : bb_old;
+      const float rel = (bb > 0.f) ? sqrtf(rr2 / bb) : 0.f;
+      const bool frozen = (a.stop_mode == 0) ? (rel < 1e-10f) : (rel <= a.tol);
+      if (!frozen) {
+        if (it == 1) {
+          alpha = (delta != 0.f) ? gamma / delta : 0.f;
+        } else {
+          const float go = prev ? go1 : go0, ao = prev ? ao1 : ao0;
+          beta = (go != 0.f) ? gamma / go : 0.f;
+          const float den = delta - ((ao != 0.f) ? beta * gamma / ao : 0.f);
+          alpha = (den != 0.f) ? gamma / den : 0.f;
+        }
+        if (!isfinite(alpha) || !isfinite(beta)) { alpha = 0.f; beta = 0.f; }
+      }
+      int done = 0, status = 0;
+      if (a.stop_mode == 0) {
+        if (it > a.min_iter && rel < a.tol) { done = 1; status = 1; }
+      } else if (rel <= a.tol) { done = 1; status = 1; }
+      if (!isfinite(rel)) { done = 1; status = 3; }
+      if (!done && it > a.max_iter) { done = 1; status = 2; }
+      if (blockIdx.x == 0 && tid == 0) {
+        a.gamma_old[par] = gamma;
+        a.alpha_old[par] = alpha;
+        if (it == 1) a.bb[0] = bb;
+        a.resid[0] = rel;
+        if (done) {
+          a.state[2] = status; a.state[1] = 1;
+          a.host_resid[0] = rel;
+          a.host_state[0] = it; a.host_state[2] = status;
+          __threadfence_system();
+          a.host_state[1] = 1;
+        }
+      }
+      if (done) return;
+    }
+    // ---- own rows: the vector update (same fma sequence as cg_update_c1_kernel)
+    const float p_new = fmaf(beta, o_p, o_rec.x);
+    const float s_new = fmaf(beta, o_rec.z, o_rec.y);
+    const float r_new = fmaf(-alpha, s_new, o_rec.x);
+    const float e_x = o_rec.w * r_new;
+    if (valid && sub == 0) {
+      a.p[rr_] = p_new;
+      a.x[rr_] = fmaf(alpha, p_new, o_x);
+      a.sn[rr_] = s_new;
+      a.rn[rr_] = r_new;
+      nrr = fmaf(r_new, r_new, nrr);
+    }
+    // ---- dictionary -> LDS
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int j = tid + k * BS;
+      const float sN = fmaf(beta, g4[k].z, g4[k].y);
+      const float rN = fmaf(-alpha, sN, g4[k].x);
+      if (j < D) xl[j] = g4[k].w * rN;
+    }
+    for (int j = tid + NQ * BS; j < D; j += BS) {
+      const cgf_v4f gg = rws[f.tile_cols[dp + j]];
+      const float sN = fmaf(beta, gg.z, gg.y);
+      const float rN = fmaf(-alpha, sN, gg.x);
+      xl[j] = gg.w * rN;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int q = tid + k * BS;
+      if (q < Q) {
+        float sq = v[k].x * xl[l[k].x];
+        sq = fmaf(v[k].y, xl[l[k].y], sq);
+        sq = fmaf(v[k].z, xl[l[k].z], sq);
+        sq = fmaf(v[k].w, xl[l[k].w], sq);
+        part[q] = sq;
+      }
+    }
+    for (int q = tid + NQ * BS; q < Q; q += BS) {
+      const cgf_v4f vv = *reinterpret_cast<const cgf_v4f*>(f.vals + 4 * (int64_t)(qb + q));
+      const cgf_v4h ll = *reinterpret_cast<const cgf_v4h*>(f.lid + 4 * (int64_t)(qb + q));
+      float sq = vv.x * xl[ll.x];
+      sq = fmaf(vv.y, xl[ll.y], sq);
+      sq = fmaf(vv.z, xl[ll.z], sq);
+      sq = fmaf(vv.w, xl[ll.w], sq);
+      part[q] = sq;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    {
+      int i = (rs >> 2) - qb + sub;
+      const int e = (re >> 2) - qb;
+      for (; i + 12 < e; i += 16) {
+        const float a0 = part[i], a1 = part[i + 4], a2 = part[i + 8], a3 = part[i + 12];
+        acc += a0; acc += a1; acc += a2; acc += a3;
+      }
+      for (; i < e; i += 4) acc += part[i];
+    }
+    acc = mgp_quad_sum(acc);
+    if (valid && sub == 0) {
+      const float lx = o_diag * e_x - acc;
+      f.t0[rr_] = f.tau * e_x + lx;        // a = tau, b = 1, co = 1: launch 0 of q2_chain
+    }
+    if (tile + 1 < t1i) __syncthreads();
+  }
+  nrr = mgp_wave_sum(nrr);
+  if (lane == 0) sh_o[wave] = nrr;
+  __syncthreads();
+  if (tid == 0) {
+    const float tsum = (sh_o[0] + sh_o[1]) + (sh_o[2] + sh_o[3]);
+    a.pd_gamma[(int64_t)par * f.nb + lb] = tsum;    // no preconditioner: gamma = r . r
+    a.pd_rr[(int64_t)par * f.nb + lb] = tsum;
+  }
+}
+
 // ---- iterative refinement (stop_mode 1, max_refine > 0): the recurrence residual of a single-
 // reduction CG drifts from the true residual on ill-conditioned systems in fp32; the true residual
 // R = B - A x is formed explicitly and, if it misses the tolerance, A d = R is solved and x += d.
@@ -496,6 +778,12 @@ struct CgPlan {
   int chunk, len_first;
   int last_need;              // (apply, update) pairs the previous solve needed: len_first follows it
   const float* patched_rhs;   // rhs the cg_init node currently points at
+  bool fused;                 // step = (chain tail, fused update + chain head) -- see cg_fused_step_kernel
+  CgFuse fuse;
+  int fgrid;
+  size_t flds;
+  float* t0;                  // output of the chain's launch 0 (first scratch buffer of op_work)
+  float* rws;                 // fused step: [n][4] row records {r, w, s, pre}
   int32_t* host_state;      // pinned
   float* host_resid;        // pinned
   float *xacc, *rbuf, *tbuf, *rpart;   // refinement: accumulated solution, residual rhs, A x, partials
@@ -514,18 +802,30 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   const int nbs = mgp_spmm_dot_blocks_for(&op->L, C) * world;
   size_t b = 10 * nc;                                  // x r u w p s us + refinement xacc rbuf tbuf
   b += 4 * nc + 256;                                   // operator chain scratch (global length)
-  b += 4 * mgp_align((size_t)kMaxGridVec * C * sizeof(float));   // pd_gamma[2], pd_rr[2]
+  b += 4 * mgp_align((size_t)kMaxPartials * C * sizeof(float));  // pd_gamma[2], pd_rr[2]
+  b += 6 * nc;                                         // fused step: rn, sn, row records [n][4]
   b += mgp_align((size_t)nbs * C * sizeof(float));              // pd_delta
-  b += 6 * mgp_align((size_t)C * sizeof(float));                // gamma_old[2] alpha_old[2] bb resid
-  b += mgp_align(16 * sizeof(int));
+  b += mgp_align((6 * (size_t)C + 16) * sizeof(float));          // gamma_old[2] alpha_old[2] bb resid state
   b += mgp_align((size_t)256 * C * 2 * sizeof(float));          // refinement partials
   return b + 1024;
 }
 
+int g_cg_fuse = 0;   // measured at N = 60k: step 16.3 us fused vs 16.3 us unfused -- off until it wins
+
 // one CG step = operator apply (w = A u, partials of u . w, ticks the iteration counter; skipped once
 // converged) followed by the fused update kernel, which also takes the stopping decision: every
-// graph therefore ends right behind a decision and a solve that needs k steps runs exactly k bodies
+// graph therefore ends right behind a decision and a solve that needs k steps runs exactly k bodies.
+// Fused form: the update kernel also runs launch 0 of the NEXT apply, so a body is (launches 1..nu-1 of
+// the chain, fused step) and the solve opens with a plain launch 0 (enqueue_head).
 int enqueue_body(CgPlan* pl, hipStream_t st) {
+  if (pl->fused) {
+    const MgpCommit cm{pl->args.rn, pl->args.sn, pl->op.pre, pl->rws};
+    MGP_TRY(mgp_operator_apply_tail(&pl->op, pl->args.rn, 1, pl->args.w, pl->args.rn, pl->pd_delta, pl->args.state + 1,
+                                    pl->args.state, &cm, pl->op_work, pl->op_work_bytes, st));
+    hipLaunchKernelGGL(cg_fused_step_kernel, dim3(pl->fgrid), dim3(kBlock), pl->flds, st, pl->args, pl->fuse);
+    MGP_LAUNCH_CHECK();
+    return MGP_OK;
+  }
   MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
                                   pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, pl->args.state + 1,
                                   pl->args.state, pl->op_work, pl->op_work_bytes, st));
@@ -535,6 +835,15 @@ int enqueue_body(CgPlan* pl, hipStream_t st) {
     hipLaunchKernelGGL(cg_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
+}
+
+// behind cg_init (fused form only): launch 0 of the first apply, t0 = tau xs + L xs with xs = pre (.) b
+int enqueue_head(CgPlan* pl, hipStream_t st) {
+  if (!pl->fused) return MGP_OK;
+  const float tau = 2.0f * (float)pl->op.nu / (pl->op.kappa * pl->op.kappa);
+  const float* in = pl->args.us ? pl->args.us : pl->args.r;
+  return mgp_spmm_fused_part(&pl->op.L, 0, in, 1, pl->t0, tau, 1.0f, nullptr, nullptr, nullptr, 0.f, 1.0f, nullptr, nullptr,
+                             nullptr, nullptr, st);
 }
 
 // (re)build the first graph: cg_init + len bodies.  Leaves has_first = false on any failure (the
@@ -551,6 +860,7 @@ void capture_first(CgPlan* pl, int len) {
     hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, pl->cap_stream, pl->args,
                        (const float*)pl->args.x);   // placeholder rhs, patched before every launch
     int rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
+    if (rc == MGP_OK) rc = enqueue_head(pl, pl->cap_stream);
     for (int i = 0; i < len && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
     hipGraph_t graph = nullptr;
     const hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
@@ -631,21 +941,46 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   int64_t nbv = mgp_cdiv(n, rpb);
   if (nbv > kMaxGridVec) { rpb = mgp_cdiv(mgp_cdiv(n, kMaxGridVec), a.TS) * a.TS; nbv = mgp_cdiv(n, rpb); }
   a.rows_per_block = rpb; a.nbv = (int)nbv;
-  a.pd_gamma = ar.take<float>(2 * (size_t)kMaxGridVec * C);
-  a.pd_rr = ar.take<float>(2 * (size_t)kMaxGridVec * C);
+  a.pd_gamma = ar.take<float>(2 * (size_t)kMaxPartials * C);
+  a.pd_rr = ar.take<float>(2 * (size_t)kMaxPartials * C);
   pl->nb_loc = mgp_spmm_dot_blocks_for(&op->L, C);
   a.nbs = pl->nb_loc * world;
   pl->pd_delta = ar.take<float>((size_t)a.nbs * C);
   a.pd_delta = pl->pd_delta;
-  a.gamma_old = ar.take<float>(2 * (size_t)C);
-  a.alpha_old = ar.take<float>(2 * (size_t)C);
-  a.bb = ar.take<float>(C);
-  a.resid = ar.take<float>(C);
-  a.state = ar.take<int>(16);
+  // one contiguous block: for C == 1 {gamma_old[2], alpha_old[2], bb, resid, state[0], state[1]} are 32
+  // consecutive bytes, which the C == 1 kernels fetch with a single scalar load (CgScalars)
+  float* blk = ar.take<float>(6 * (size_t)C + 16);
+  a.gamma_old = blk;
+  a.alpha_old = blk + 2 * (size_t)C;
+  a.bb = blk + 4 * (size_t)C;
+  a.resid = blk + 5 * (size_t)C;
+  a.state = reinterpret_cast<int*>(blk + 6 * (size_t)C);
   pl->xacc = ar.take<float>(nc); pl->rbuf = ar.take<float>(nc); pl->tbuf = ar.take<float>(nc);
   pl->rpart = ar.take<float>((size_t)256 * C * 2);
   a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter;
   a.stop_mode = pl->prm.stop_mode;
+  a.rn = nullptr; a.sn = nullptr;
+  pl->fused = false;
+  {
+    int fg = 0, ftpb = 0;
+    size_t fl = 0;
+    if (g_cg_fuse && C == 1 && !dist && !minv && mgp_operator_tail_supported(op) && op->L.tile_rows == kBlock / 4 &&
+        mgp_tile_plan(&op->L, 1, &fg, &ftpb, &fl) && fg <= kMaxPartials) {
+      pl->fused = true;
+      pl->fgrid = fg;
+      pl->flds = fl;
+      a.rn = ar.take<float>(nc); a.sn = ar.take<float>(nc);
+      pl->rws = ar.take<float>(4 * nc);
+      // cg_init and the partial arrays follow the SpMV grid: one slot per workgroup of the fused kernel
+      a.nbv = fg; a.rows_per_block = (int64_t)ftpb * (kBlock / 4);
+      const float tau = 2.0f * (float)op->nu / (op->kappa * op->kappa);
+      pl->t0 = mgp_operator_first_out(op, 1, pl->op_work, pl->op_work_bytes);
+      pl->fuse = CgFuse{op->L.rowptr, op->L.vals, op->L.diag, op->L.tile_ptr,
+                        reinterpret_cast<const uint32_t*>(op->L.tile_cols), op->L.lid,
+                        mgp_cdiv(op->L.n, (int64_t)op->L.tile_rows), ftpb, op->L.tile_max_cols, tau, op->pre, pl->t0, fg, pl->rws};
+      if (!pl->t0) pl->fused = false;
+    }
+  }
   if (!ar.ok()) { delete pl; return MGP_ERR_WORKSPACE; }
   hipError_t e = hipHostMalloc((void**)&pl->host_state, 16 * sizeof(int32_t), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_resid, (size_t)C * sizeof(float), hipHostMallocMapped);
@@ -673,6 +1008,11 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
     if (ok) capture_first(pl, pl->chunk < 4 ? pl->chunk : 4);
   }
   *plan_out = pl;
+  return MGP_OK;
+}
+
+extern "C" int mgp_cg_set_fuse(int on) {
+  g_cg_fuse = on ? 1 : 0;
   return MGP_OK;
 }
 
@@ -705,6 +1045,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   if (!pl->has_first) {
     hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, rhs);
     MGP_LAUNCH_CHECK();
+    MGP_TRY(enqueue_head(pl, st));
   }
   int guard = 0;
   for (;;) {

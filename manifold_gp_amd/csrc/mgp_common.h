@@ -54,9 +54,31 @@ __device__ __forceinline__ int mgp_xcd_block(int pb, int grid) {
   return start + i;
 }
 
+// Cross-lane sums on the VALU (DPP) instead of __shfl_xor, which hipcc lowers to ds_bpermute_b32: a
+// 6-level xor tree is 6 dependent LDS-pipe round trips (~0.1 us each in a latency-bound kernel).
+//   row_shr:1,2,4,8 build 16-lane row totals in lane 15 of every row, row_bcast15 / row_bcast31 carry
+//   them across the four rows, lane 63 ends up with the wave total, readlane broadcasts it.
+// Fixed order, every lane gets the same value.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float mgp_dpp_add(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
+  return v + __builtin_bit_cast(float, moved);
+}
+
 __device__ __forceinline__ float mgp_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = mgp_dpp_add<0x111, 0xf>(v);   // row_shr:1
+  v = mgp_dpp_add<0x112, 0xf>(v);   // row_shr:2
+  v = mgp_dpp_add<0x114, 0xf>(v);   // row_shr:4
+  v = mgp_dpp_add<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of each row holds the row total
+  v = mgp_dpp_add<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+  v = mgp_dpp_add<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3 -> lane 63 holds the total
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// sum over the 4 lanes of a quad, result in all 4 (same order as xor 1 then xor 2)
+__device__ __forceinline__ float mgp_quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
   return v;
 }
 

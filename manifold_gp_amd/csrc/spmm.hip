@@ -49,6 +49,7 @@ struct SpmmArgs {
   int* tick;         // nullable: workgroup 0 adds 1 when the launch is not skipped
   int64_t goff;      // row partition: CSR rows are local [0, n), vectors are global -> row r is
                      // element r + goff of X / Y / pre / post / base / dotw (0 on one GPU)
+  MgpCommit commit;  // tile kernel only: packed row record written in the epilogue (fused CG step)
 };
 
 // Streaming (read-once) matrix entries: non-temporal 16-byte loads bypass the 32 KB L1, which is then
@@ -569,6 +570,8 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     const float e_post = p.post ? l_post : 1.f;
     const float e_base = p.base ? l_base : 0.f;
     const float e_dotw = p.dotw ? l_dotw : 0.f;
+    const float l_cp0 = (p.commit.pack4 ? p.commit.src0 : x)[grr], l_cp1 = (p.commit.pack4 ? p.commit.src1 : x)[grr];
+    const float l_cp2 = ((p.commit.pack4 && p.commit.pre) ? p.commit.pre : x)[grr];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
@@ -615,14 +618,18 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
       }
       for (; i < e; i += 4) acc += part[i];
     }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
+    acc = mgp_quad_sum(acc);
     if (valid && sub == 0) {
       const float lx = e_diag * e_x - acc;
       const float tt = (p.a * e_x + p.b * lx) * e_post;
       const float y = p.co * tt + p.cb * e_base;
       p.Y[grr] = y;
       dsum = fmaf(e_dotw, y, dsum);
+      if (p.commit.pack4) {
+        mgp_v4f rec;
+        rec.x = l_cp0; rec.y = y; rec.z = l_cp1; rec.w = p.commit.pre ? l_cp2 : 1.f;
+        *reinterpret_cast<mgp_v4f*>(p.commit.pack4 + 4 * grr) = rec;
+      }
     }
     if (tile + 1 < t1) __syncthreads();                // the next tile overwrites xl / part
   }
@@ -804,6 +811,8 @@ extern "C" int mgp_spmm_set_tile_mode(int on) {
   return MGP_OK;
 }
 
+int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, size_t* lds_bytes);
+
 static size_t tile_lds_bytes(const mgp_csr_t* L) {
   return ((size_t)L->tile_max_cols + (size_t)(L->tile_max_entries >> 2)) * sizeof(float);
 }
@@ -823,6 +832,14 @@ static int tile_grid(const mgp_csr_t* L, int* tiles_per_block) {
 static bool use_panels(const mgp_csr_t* L, int C) {
   return C == 1 && g_panel_mode && L->segptr != nullptr && L->panels >= 1 && L->panel_width > 0 &&
          L->panel_width <= 32768 && (L->panel_width % 4) == 0;
+}
+
+int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, size_t* lds_bytes) {
+  if (!L || !use_tiles(L, C)) return 0;
+  const int g = tile_grid(L, tiles_per_block);
+  if (grid) *grid = g;
+  if (lds_bytes) *lds_bytes = tile_lds_bytes(L);
+  return 1;
 }
 
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
@@ -889,12 +906,24 @@ int mgp_spmm_fused_ex(const mgp_csr_t* L, const float* X, int C, float* Y, float
 int mgp_spmm_fused_part(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
                         const float* pre, const float* post, const float* base, float cb, float co,
                         const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream) {
+  return mgp_spmm_fused_commit(L, row_offset, X, C, Y, a, b, pre, post, base, cb, co, dotw, dot_partials, skip, tick,
+                               nullptr, stream);
+}
+
+int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
+                          const float* pre, const float* post, const float* base, float cb, float co,
+                          const float* dotw, float* dot_partials, const int* skip, int* tick,
+                          const MgpCommit* commit, void* stream) {
   if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !X || !Y) return MGP_ERR_ARG;
   if (L->n <= 0 || C <= 0 || C > 256) return C > 256 ? MGP_ERR_UNSUPPORTED : MGP_ERR_ARG;
   if (X == Y) return MGP_ERR_ARG;  // rows gather other rows of X: never in place
   hipStream_t st = mgp_stream(stream);
   SpmmArgs p{L->n, L->rowptr, L->col, L->vals, L->diag, X, Y, C, a, b, pre, post, base, cb, co,
-             dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset};
+             dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset, MgpCommit{nullptr, nullptr, nullptr, nullptr}};
+  if (commit) {
+    if (!use_tiles(L, C) || (use_panels(L, C))) return MGP_ERR_UNSUPPORTED;   // row copies ride in the tile kernel only
+    p.commit = *commit;
+  }
   if (use_panels(L, C)) {
     const int grid = (int)mgp_cdiv(L->n, kPanelRowsPerBlock);
     const int64_t ncols = L->ncols > 0 ? L->ncols : L->n;

@@ -857,3 +857,47 @@ def test_tile_dictionary_isolated_rows_and_long_range(mgp, dev):
     scale = float(data.diag.abs().max()) * float(x.abs().max())
     assert float((ys[0] - ys[1]).abs().max()) < 1e-5 * scale
     assert float(ys[1][1500:].abs().max()) <= float((data.diag[1500:].cpu().double() * x[1500:, 0].cpu().double()).abs().max()) + 1e-12
+
+
+@pytest.mark.parametrize("nu", [2, 3])
+@pytest.mark.parametrize("form", [0, 2])
+@pytest.mark.parametrize("norm", NORMS)
+def test_cg_fused_step_matches_unfused(mgp, golden, dev, norm, form, nu):
+    """C == 1 solves with the vector update folded into launch 0 of the next operator apply
+    (cg_fused_step_kernel) against the three-kernel step: same iteration count (+-1), same solution
+    to fp32 round-off, true residual at tolerance, masked (Schur-block) pre/post vectors included;
+    repeated solves exercise the single-graph path and its re-capture."""
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.solvers import CgPlan
+    g = golden("dumbbell_k10_loop")
+    lap = _operator(mgp, g, dev, norm)
+    Q = mgp.operators.PrecisionMaternOperator(lap, nu, torch.tensor([[float(g["kappa"])]], device=dev))
+    desc = Q._descriptor()
+    desc = desc.with_(scale=0.7, form=2, noise=1e-2) if form == 2 else desc
+    n = lap.shape[0]
+    y = T(g["train_y"], dev).view(-1, 1).contiguous()
+    y2 = torch.randn(n, 1, device=dev)
+    lib = _lib.lib()
+    out = {}
+    try:
+        for fuse in (0, 1):
+            lib.mgp_cg_set_fuse(fuse)
+            plan = CgPlan(desc, 1, tol=1e-6, max_iter=20000, stop_mode=1, check_every=8)
+            sols = []
+            for rhs in (y, y, y2, y, y):                      # pointer changes, repeats -> graph re-capture
+                x = plan.solve(rhs).clone()
+                sols.append((x, plan.iters, plan.status))
+            out[fuse] = sols
+            plan.close()
+    finally:
+        lib.mgp_cg_set_fuse(0)
+    for (x0, it0, st0), (x1, it1, st1), rhs in zip(out[0], out[1], (y, y, y2, y, y)):
+        assert st0 == 1 and st1 == 1
+        assert abs(it0 - it1) <= max(1, it0 // 50), (it0, it1)
+        scale = float(x0.abs().max())
+        r1 = desc.apply(x1) - rhs
+        r0 = desc.apply(x0) - rhs
+        assert float(r1.norm() / rhs.norm()) < max(5e-6, 3 * float(r0.norm() / rhs.norm()))
+        assert float((x0 - x1).abs().max()) < 2e-4 * scale, (float((x0 - x1).abs().max()), scale)
+    # the same right-hand side solved three times gives bitwise the same answer
+    assert torch.equal(out[1][0][0], out[1][1][0]) and torch.equal(out[1][0][0], out[1][3][0])
