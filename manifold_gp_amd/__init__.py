@@ -4,6 +4,7 @@ inference path behind the reference's plugin surface:
     manifold_gp_amd.kernels    <->  manifold_gp.kernels    (RiemannMaternKernel)
     manifold_gp_amd.operators  <->  manifold_gp.operators  (GraphLaplacianOperator, ...)
     manifold_gp_amd.utils      <->  manifold_gp.utils      (NearestNeighbors, bump_function)
+    manifold_gp_amd.models     <->  manifold_gp.models     (RiemannGP: precision / hybrid posterior)
 
 All arithmetic runs in hand-written gfx950 HIP kernels (manifold_gp_amd/csrc) loaded through the
 C-ABI of include/mgp_hip.h; there is no CPU fallback.  `install_as_manifold_gp()` aliases the three
@@ -14,7 +15,7 @@ import sys
 
 from . import _compat
 from ._compat import settings
-from . import kernels, operators, utils  # noqa: F401
+from . import kernels, operators, utils, models  # noqa: F401
 
 __version__ = "0.1.0"
 
@@ -28,7 +29,7 @@ def install_as_manifold_gp(force=False):
         base = types.ModuleType("manifold_gp")
         base.__path__ = []
         sys.modules["manifold_gp"] = base
-    for name, mod in (("kernels", kernels), ("operators", operators), ("utils", utils)):
+    for name, mod in (("kernels", kernels), ("operators", operators), ("utils", utils), ("models", models)):
         sys.modules["manifold_gp." + name] = mod
         setattr(base, name, mod)
     return base

@@ -901,3 +901,68 @@ def test_cg_fused_step_matches_unfused(mgp, golden, dev, norm, form, nu):
         assert float((x0 - x1).abs().max()) < 2e-4 * scale, (float((x0 - x1).abs().max()), scale)
     # the same right-hand side solved three times gives bitwise the same answer
     assert torch.equal(out[1][0][0], out[1][1][0]) and torch.equal(out[1][0][0], out[1][3][0])
+
+
+@pytest.mark.parametrize("norm", NORMS)
+def test_riemann_gp_posterior_and_hybrid(mgp, golden, dev, norm):
+    """RiemannGP (manifold_gp/models/riemann_gp.py:10-75): Woodbury posterior on device against the
+    fp64 oracle on the same spectral features, modulation = bump of the 1-NN distance, hybrid blend
+    with a Euclidean base model, and the precision() wrapper chain."""
+    from manifold_gp_amd.models import EuclideanGP, GaussianLikelihood, RiemannGP, ScaleKernel
+    from manifold_gp_amd import operators as O
+    from oracle.knn import knn_search
+    from oracle.solvers import gp_posterior_lowrank
+    from oracle.spectral import bump_function as bump_oracle
+    g = golden("dumbbell_k10_loop")
+    x = T(g["train_x"], dev)
+    y = T(g["train_y"], dev)
+    m = int(g["modes"])
+    s, noise = 0.7, 1e-2
+    kern = mgp.kernels.RiemannMaternKernel(nu=2, x=x, nearest_neighbors=int(g["k"]), laplacian_normalization=norm,
+                                           num_modes=m, bump_scale=float(g["bump"][0]), bump_decay=float(g["bump"][1])).to(dev)
+    kern.initialize(graphbandwidth=float(g["eps"]), lengthscale=float(g["kappa"]))
+    lik = GaussianLikelihood(noise).to(dev)
+    model = RiemannGP(x, y, lik, ScaleKernel(kern, s).to(dev)).to(dev)
+    model.eval()
+    rng = np.random.default_rng(3)
+    xt_np = g["train_x"][rng.choice(x.shape[0], 40, replace=False)] + rng.normal(scale=0.02, size=(40, x.shape[1])).astype(np.float32)
+    xt_np[:5] += 5.0                                            # far from the data: outside the bump support
+    xt = T(xt_np, dev)
+    model.posterior(xt)
+    Z, Zs = kern.features(x).cpu().numpy(), kern.features(xt).cpu().numpy()
+    mean_o, cov_o, _ = gp_posterior_lowrank(Z, g["train_y"], Zs, s, noise)
+    scale = max(np.abs(mean_o).max(), 1e-6)
+    np.testing.assert_allclose(model.posterior_mean.cpu().numpy(), mean_o, rtol=0, atol=2e-4 * scale)
+    np.testing.assert_allclose(model.posterior_covar.cpu().numpy(), cov_o, rtol=0, atol=2e-4 * max(np.abs(cov_o).max(), 1e-6))
+    assert float(model.posterior_mean[:5].abs().max()) == 0.0 and float(model.posterior_covar[:5, :5].abs().max()) == 0.0
+    # noisy posterior adds the noise on the diagonal (riemann_gp.py:46)
+    model.posterior(xt, noisy_posterior=True)
+    np.testing.assert_allclose(model.posterior_covar.cpu().numpy(), cov_o + noise * np.eye(40), rtol=0,
+                               atol=2e-4 * max(np.abs(cov_o).max(), noise))
+    # modulation: bump of the distance to the nearest training point (riemann_gp.py:41-43)
+    d1, _ = knn_search(g["train_x"], xt_np, 1)
+    mod_o = bump_oracle(np.sqrt(d1[:, 0]), float(g["bump"][0]) * float(g["eps"]), float(g["bump"][1]))
+    np.testing.assert_allclose(model.modulation(xt).cpu().numpy(), mod_o, rtol=0, atol=1e-5)
+    assert mod_o[:5].max() == 0.0 and (mod_o[5:] > 0.5).sum() > 10
+    # hybrid posterior (riemann_gp.py:48-75)
+    base = EuclideanGP(x[::4], y[::4], GaussianLikelihood(noise).to(dev), lengthscale=0.5, outputscale=1.0)
+    model.posterior(xt, base_model=base)
+    b = base(xt)
+    w = 1.0 - mod_o
+    np.testing.assert_allclose(model.posterior_mean.cpu().numpy(), mean_o + w * b.mean.cpu().numpy(), rtol=0, atol=3e-4 * scale)
+    np.testing.assert_allclose(model.posterior_covar.cpu().numpy(),
+                               cov_o + np.outer(w, w) * b.covariance_matrix.cpu().numpy(), rtol=0, atol=3e-4)
+    np.testing.assert_allclose(model.posterior_stddev.cpu().numpy(),
+                               np.sqrt(np.clip(np.diag(cov_o), 0, None)) + w * b.stddev.cpu().numpy(), rtol=0, atol=2e-3)
+    # precision(): Schur (if labelled) -> Scale -> Noise (riemann_gp.py:32-39)
+    Qn = model.precision()
+    assert isinstance(Qn, O.NoiseWrapperOperator) and isinstance(model.precision(noise=False), O.ScaleWrapperOperator)
+    labeled = torch.zeros(x.shape[0], dtype=torch.bool, device=dev)
+    labeled[::3] = True
+    semi = RiemannGP(x[labeled], y[labeled], lik, ScaleKernel(kern, s).to(dev), labeled=labeled)
+    Qs = semi.precision(noise=False)
+    assert isinstance(Qs, O.ScaleWrapperOperator) and Qs.shape[0] == int(labeled.sum())
+    v = torch.randn(x.shape[0], device=dev)
+    with torch.no_grad():
+        ref = s * kern.precision().matmul(v)
+        assert float((model.precision(noise=False).matmul(v) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())

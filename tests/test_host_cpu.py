@@ -151,6 +151,15 @@ def test_operator_exports_match_reference_names():
     import importlib
     assert importlib.import_module("manifold_gp.kernels").RiemannMaternKernel is mgp.kernels.RiemannMaternKernel
     assert importlib.import_module("manifold_gp.operators").GraphLaplacianOperator is mgp.operators.GraphLaplacianOperator
+    assert importlib.import_module("manifold_gp.models").RiemannGP is mgp.models.RiemannGP
+    # RiemannGP surface of manifold_gp/models/riemann_gp.py:10-75
+    for name in ("precision", "modulation", "posterior", "posterior_mean", "posterior_covar", "posterior_stddev",
+                 "base_kernel", "eval"):
+        assert hasattr(mgp.models.RiemannGP, name), name
+    lik = mgp.models.GaussianLikelihood(0.03)
+    assert abs(float(lik.noise) - 0.03) < 1e-6
+    with pytest.raises(RuntimeError):                          # host tensors: no CPU path
+        mgp.models.RiemannGP(torch.zeros(4, 2), torch.zeros(4), lik, object())
     import sys
     for k in [k for k in sys.modules if k == "manifold_gp" or k.startswith("manifold_gp.")]:
         del sys.modules[k]
