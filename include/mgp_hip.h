@@ -284,6 +284,10 @@ typedef struct {
   uint64_t seed;
 } mgp_lanczos_params_t;
 
+/* host-only helper of the block eigensolver: eigendecomposition of a small dense symmetric matrix in
+ * fp64 (Householder tridiagonalisation + implicit QL).  A [n x n] row-major, evals ascending,
+ * eigenvectors = columns of V [n x n] row-major.  No device work. */
+int mgp_host_symeig(int n, const double* A, double* evals, double* V);
 size_t mgp_lanczos_workspace_bytes(int64_t n, int m, const mgp_lanczos_params_t* p);
 int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals,
                          float* evecs, float* resid, int32_t* info, void* work, size_t work_bytes,

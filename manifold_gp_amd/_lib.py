@@ -72,6 +72,7 @@ SIGNATURES = {
     "mgp_spmm_dot_blocks_csr": (c_int, [POINTER(CsrT), c_int]),
     "mgp_spmm_set_tile_mode": (c_int, [c_int]),
     "mgp_cg_set_fuse": (c_int, [c_int]),
+    "mgp_host_symeig": (c_int, [c_int, _P, _P, _P]),
     "mgp_graph_build": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, POINTER(c_int64), _P, _P, _P, _P, _P,
                                 POINTER(c_int64), _P, c_size_t, _P]),
     "mgp_graph_coo_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),

@@ -157,7 +157,7 @@ def test_operator_exports_match_reference_names():
                  "base_kernel", "eval"):
         assert hasattr(mgp.models.RiemannGP, name), name
     lik = mgp.models.GaussianLikelihood(0.03)
-    assert abs(float(lik.noise) - 0.03) < 1e-6
+    assert abs(float(lik.noise.detach()) - 0.03) < 1e-6
     with pytest.raises(RuntimeError):                          # host tensors: no CPU path
         mgp.models.RiemannGP(torch.zeros(4, 2), torch.zeros(4), lik, object())
     import sys
@@ -182,3 +182,29 @@ def test_synthetic_workloads_are_deterministic():
     assert x1.min() >= -0.5 and x1.max() <= 0.5
     eps, eps_min = synth.bandwidth_rule(np.array([0.1, 0.4]), 0.05)
     assert abs(eps_min - np.sqrt(0.4 / (-4 * np.log(1e-4)))) < 1e-9 and eps == eps_min
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64, 125])
+def test_host_symeig_matches_lapack(n):
+    """The small dense fp64 eigensolver inside the block eigensolver (host-only entry of the C-ABI):
+    eigenvalues, orthonormality and reconstruction against numpy, including a rank-deficient Gram
+    matrix (clustered / zero eigenvalues, the case Rayleigh-Ritz hands it)."""
+    from manifold_gp_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(n)
+    mats = [rng.standard_normal((n, n))]
+    B = rng.standard_normal((n, max(1, n // 3)))
+    mats.append(B @ B.T)                                        # rank-deficient PSD
+    mats.append(np.diag(np.repeat([1.0, 1.0 + 1e-12, 5.0], -(-n // 3))[:n]))   # (nearly) degenerate diagonal
+    for M in mats:
+        A = np.ascontiguousarray(0.5 * (M + M.T))
+        ev = np.empty(n)
+        V = np.empty((n, n))
+        rc = lib.mgp_host_symeig(n, A.ctypes.data, ev.ctypes.data, V.ctypes.data)
+        assert rc == 0
+        ref = np.linalg.eigvalsh(A)
+        scale = max(np.abs(ref).max(), 1e-300)
+        assert np.all(np.diff(ev) >= 0)
+        np.testing.assert_allclose(ev, ref, rtol=0, atol=1e-12 * scale * n)
+        np.testing.assert_allclose(V.T @ V, np.eye(n), rtol=0, atol=1e-12 * n)
+        np.testing.assert_allclose(V @ np.diag(ev) @ V.T, A, rtol=0, atol=1e-12 * scale * n)
