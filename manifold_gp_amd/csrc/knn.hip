@@ -30,53 +30,94 @@ constexpr int kMaxKp = 2048;
 constexpr int kMaxDimLds = 4096;
 
 // ------------------------------------------------------------------ 1. distance tiles
+// VEC = true (d % 4 == 0): 16-byte global loads, the next feature chunk is fetched into registers while
+// the current one is consumed (one exposed global round trip per tile instead of one per chunk).
+// The 8x8 micro-tile is computed on float2 pairs so that hipcc emits v_pk_add_f32 / v_pk_fma_f32: two
+// IEEE fp32 results per lane per instruction, i.e. the packed-math VALU rate -- same roundings, same
+// order over the features as the scalar form, so the selection bound gamma is unchanged.
+typedef float knn_v2f __attribute__((ext_vector_type(2)));
+
+template <bool VEC>
 __global__ __launch_bounds__(kBlock) void dist_tile_kernel(const float* __restrict__ db, int64_t N, int d,
                                                            const float* __restrict__ q, int64_t nq,
                                                            float* __restrict__ out, int64_t ld) {
-  __shared__ float Qs[kDK][kTile + 4];
-  __shared__ float Ps[kDK][kTile + 4];
+  __shared__ __attribute__((aligned(16))) float Qs[kDK][kTile + 4];
+  __shared__ __attribute__((aligned(16))) float Ps[kDK][kTile + 4];
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
   const int64_t p0 = (int64_t)blockIdx.x * kTile, q0 = (int64_t)blockIdx.y * kTile;
-  float acc[8][8];
+  knn_v2f acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = knn_v2f{0.f, 0.f};
+
+  // VEC staging: float4 f -> (row = f / 4, kq = f % 4): rows of 64 contiguous bytes, 2 float4 per lane
+  // per matrix; rows past the end are clamped (their results are never stored)
+  float4 rq[2], rp[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = tid + h * kBlock;
+      const int row = f >> 2, kq = f & 3;
+      const int64_t qr = (q0 + row < nq) ? q0 + row : nq - 1;
+      const int64_t pr = (p0 + row < N) ? p0 + row : N - 1;
+      const int kg = k0 + 4 * kq;
+      if (kg < d) {
+        rq[h] = *reinterpret_cast<const float4*>(q + qr * d + kg);
+        rp[h] = *reinterpret_cast<const float4*>(db + pr * d + kg);
+      } else {
+        rq[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rp[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  if (VEC) fetch(0);
 
   for (int k0 = 0; k0 < d; k0 += kDK) {
-    // stage: element e -> (row = e / 16, kk = e % 16): 64 contiguous bytes per row
+    if (VEC) {
 #pragma unroll
-    for (int e = tid; e < kTile * kDK; e += kBlock) {
-      const int row = e >> 4, kk = e & 15;
-      const int kg = k0 + kk;
-      float qv = 0.f, pv = 0.f;
-      if (kg < d) {
-        if (q0 + row < nq) qv = q[(q0 + row) * d + kg];
-        if (p0 + row < N) pv = db[(p0 + row) * d + kg];
+      for (int h = 0; h < 2; ++h) {
+        const int f = tid + h * kBlock;
+        const int row = f >> 2, kq = 4 * (f & 3);
+        Qs[kq + 0][row] = rq[h].x; Qs[kq + 1][row] = rq[h].y; Qs[kq + 2][row] = rq[h].z; Qs[kq + 3][row] = rq[h].w;
+        Ps[kq + 0][row] = rp[h].x; Ps[kq + 1][row] = rp[h].y; Ps[kq + 2][row] = rp[h].z; Ps[kq + 3][row] = rp[h].w;
       }
-      Qs[kk][row] = qv;
-      Ps[kk][row] = pv;
+    } else {
+      // element e -> (row = e / 16, kk = e % 16): 64 contiguous bytes per row
+#pragma unroll
+      for (int e = tid; e < kTile * kDK; e += kBlock) {
+        const int row = e >> 4, kk = e & 15;
+        const int kg = k0 + kk;
+        float qv = 0.f, pv = 0.f;
+        if (kg < d) {
+          if (q0 + row < nq) qv = q[(q0 + row) * d + kg];
+          if (p0 + row < N) pv = db[(p0 + row) * d + kg];
+        }
+        Qs[kk][row] = qv;
+        Ps[kk][row] = pv;
+      }
     }
     __syncthreads();
+    if (VEC && k0 + kDK < d) fetch(k0 + kDK);      // in flight during the 16 feature steps below
 #pragma unroll
     for (int kk = 0; kk < kDK; ++kk) {
-      float qa[8], pa[8];
       const float4 q_lo = *reinterpret_cast<const float4*>(&Qs[kk][ty * 8]);
       const float4 q_hi = *reinterpret_cast<const float4*>(&Qs[kk][ty * 8 + 4]);
       const float4 p_lo = *reinterpret_cast<const float4*>(&Ps[kk][tx * 8]);
       const float4 p_hi = *reinterpret_cast<const float4*>(&Ps[kk][tx * 8 + 4]);
-      qa[0] = q_lo.x; qa[1] = q_lo.y; qa[2] = q_lo.z; qa[3] = q_lo.w;
-      qa[4] = q_hi.x; qa[5] = q_hi.y; qa[6] = q_hi.z; qa[7] = q_hi.w;
-      pa[0] = p_lo.x; pa[1] = p_lo.y; pa[2] = p_lo.z; pa[3] = p_lo.w;
-      pa[4] = p_hi.x; pa[5] = p_hi.y; pa[6] = p_hi.z; pa[7] = p_hi.w;
+      const float qa[8] = {q_lo.x, q_lo.y, q_lo.z, q_lo.w, q_hi.x, q_hi.y, q_hi.z, q_hi.w};
+      const knn_v2f pa[4] = {knn_v2f{p_lo.x, p_lo.y}, knn_v2f{p_lo.z, p_lo.w}, knn_v2f{p_hi.x, p_hi.y},
+                             knn_v2f{p_hi.z, p_hi.w}};
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < 8; ++i) {
+        const knn_v2f qq = knn_v2f{qa[i], qa[i]};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float df = qa[i] - pa[j];
-          acc[i][j] = fmaf(df, df, acc[i][j]);
+        for (int j = 0; j < 4; ++j) {
+          const knn_v2f df = qq - pa[j];
+          acc[i][j] = __builtin_elementwise_fma(df, df, acc[i][j]);
         }
+      }
     }
     __syncthreads();
   }
@@ -87,12 +128,12 @@ __global__ __launch_bounds__(kBlock) void dist_tile_kernel(const float* __restri
     const int64_t pc = p0 + tx * 8;
     float* o = out + qr * ld + pc;
     if (pc + 8 <= N) {
-      *reinterpret_cast<float4*>(o) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
-      *reinterpret_cast<float4*>(o + 4) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+      *reinterpret_cast<float4*>(o) = make_float4(acc[i][0].x, acc[i][0].y, acc[i][1].x, acc[i][1].y);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(acc[i][2].x, acc[i][2].y, acc[i][3].x, acc[i][3].y);
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (pc + j < N) o[j] = acc[i][j];
+        if (pc + j < N) o[j] = (j & 1) ? acc[i][j >> 1].y : acc[i][j >> 1].x;
     }
   }
 }
@@ -369,7 +410,8 @@ extern "C" int mgp_knn_search(const float* db, int64_t N, int d, const float* q,
     const int64_t rows = (n - q0) < qc ? (n - q0) : qc;
     ++n_chunks;
     dim3 grid((unsigned)mgp_cdiv(N, kTile), (unsigned)mgp_cdiv(rows, kTile));
-    hipLaunchKernelGGL(dist_tile_kernel, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
+    if (d % 4 == 0) hipLaunchKernelGGL(dist_tile_kernel<true>, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
+    else hipLaunchKernelGGL(dist_tile_kernel<false>, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
     MGP_LAUNCH_CHECK();
     SelectArgs a{slab, ld, N, db, q + q0 * d, d, k, Kp0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, gamma};
     MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
