@@ -142,7 +142,26 @@ __global__ __launch_bounds__(kBlock) void dist_tile_kernel(const float* __restri
 // exact oracle distance: fp64, ascending feature order, no contraction (oracle/knn_oracle.c)
 __device__ __forceinline__ double oracle_d2(const float* __restrict__ qrow, const float* __restrict__ xrow, int d) {
   double acc = 0.0;
-  for (int j = 0; j < d; ++j) {
+  int j = 0;
+  if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(xrow) & 15) == 0)) {
+    // 32 features per pass: the 8 x 16-byte loads are issued before the (strictly sequential, oracle-
+    // ordered) accumulation consumes them, so the chain waits for memory once per pass, not per feature
+    for (; j + 32 <= d; j += 32) {
+      float4 x4[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x4[u] = *reinterpret_cast<const float4*>(xrow + j + 4 * u);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float xs[4] = {x4[u].x, x4[u].y, x4[u].z, x4[u].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const double df = __dsub_rn((double)qrow[j + 4 * u + t], (double)xs[t]);
+          acc = __dadd_rn(acc, __dmul_rn(df, df));
+        }
+      }
+    }
+  }
+  for (; j < d; ++j) {
     const double df = __dsub_rn((double)qrow[j], (double)xrow[j]);
     acc = __dadd_rn(acc, __dmul_rn(df, df));
   }
@@ -188,6 +207,31 @@ struct SelectArgs {
   double gamma;
 };
 
+// Visit every key of a slab row: 4 x 16-byte loads per lane are issued before the first key is used.
+// With one 4-byte load per iteration the histogram's LDS atomic forces a wait per key and the row
+// scan is a chain of ~230 dependent HBM round trips per pass (measured 3.5 ms per 3200-row chunk).
+template <class F>
+__device__ __forceinline__ void for_each_key(const uint32_t* __restrict__ keys, int64_t N, int tid, F f) {
+  const int64_t nq = N >> 2;
+  const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(keys);
+  for (int64_t b0 = 0; b0 < nq; b0 += 4 * kBlock) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t qi = b0 + tid + u * kBlock;
+      v[u] = k4[qi < nq ? qi : nq - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t qi = b0 + tid + u * kBlock;
+      if (qi < nq) {
+        f(v[u].x, 4 * qi); f(v[u].y, 4 * qi + 1); f(v[u].z, 4 * qi + 2); f(v[u].w, 4 * qi + 3);
+      }
+    }
+  }
+  for (int64_t i = (nq << 2) + tid; i < N; i += kBlock) f(keys[i], i);
+}
+
 // ------------------------------------------------------------------ 2. select + re-rank
 __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   __shared__ int hist[2048];
@@ -214,10 +258,10 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
       const int nb = 1 << nbits[ps];
       for (int i = tid; i < nb; i += kBlock) hist[i] = 0;
       __syncthreads();
-      for (int64_t i = tid; i < N; i += kBlock) {
-        const uint32_t key = keys[i];
-        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shifts[ps]) & (nb - 1)], 1);
-      }
+      const int sh = shifts[ps];
+      for_each_key(keys, N, tid, [&](uint32_t key, int64_t) {
+        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> sh) & (nb - 1)], 1);
+      });
       __syncthreads();
       // 256 threads x (nb/256) bins: find the bin holding the rank-th key
       const int per = nb / kBlock;
@@ -247,8 +291,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   for (int i = tid; i < Kp; i += kBlock) { cand_idx[i] = INT_MAX; cand_d[i] = INFINITY; }
   __syncthreads();
   if (want < N) {
-    for (int64_t i = tid; i < N; i += kBlock) {
-      const uint32_t key = keys[i];
+    for_each_key(keys, N, tid, [&](uint32_t key, int64_t i) {
       if (key < T) {
         const int slot = atomicAdd(&sh_cnt_lt, 1);
         cand_idx[slot] = (int)i;
@@ -256,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
         const int e = atomicAdd(&sh_cnt_eq, 1);
         if (e < rank) cand_idx[want - 1 - e] = (int)i;
       }
-    }
+    });
   } else {
     for (int i = tid; i < want; i += kBlock) cand_idx[i] = i;
   }
