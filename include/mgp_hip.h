@@ -47,8 +47,13 @@ int mgp_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes); /* hipGet
  * Distances/ties follow the rule in oracle/knn_oracle.c (fp64 sum in ascending feature order,
  * no FMA contraction, lower index wins exact ties): fp32 tiles select a padded candidate set,
  * an fp64 re-rank orders it, a per-row bound check proves the set sufficient, rows that fail
- * are redone with a wider set and finally by an exact fp64 scan.  Synchronises `stream`.
- * stats (nullable, host int64[4]): rows redone wide, rows redone exact, chunks, candidates K'. */
+ * are redone with a wider set and finally by an exact fp64 scan.  For d <= 3 and N >= 4096 no
+ * N x n distance slab is formed: points are Morton-sorted, a window around the query gives a provable
+ * upper bound on its k-th neighbour distance, one fused streaming pass keeps the points under that
+ * bound and the fp64 re-rank orders them (knn_lowd.hip); rows whose candidate list overflows go
+ * through the slab pipeline.  Same results bit for bit.  Synchronises `stream`.
+ * stats (nullable, host int64[4]): rows redone wide, rows redone exact, chunks, candidates K'
+ * (-1 when the low-dimensional path ran; [0] then counts its overflow rows). */
 size_t mgp_knn_workspace_bytes(int64_t N, int64_t n, int d, int k);
 int mgp_knn_search(const float* db, int64_t N, int d, const float* q, int64_t n, int k,
                    float* D, int32_t* I, void* work, size_t work_bytes, int64_t* stats,

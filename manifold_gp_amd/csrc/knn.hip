@@ -19,7 +19,9 @@
 //      fp64 distances to every point + k rounds of (d, index) arg-min.
 #include <math.h>
 #include <limits.h>
+#include <vector>
 #include "mgp_common.h"
+#include "mgp_internal.h"
 
 namespace {
 
@@ -415,7 +417,7 @@ int next_pow2(int v) {
 
 }  // namespace
 
-extern "C" size_t mgp_knn_workspace_bytes(int64_t N, int64_t n, int d, int k) {
+static size_t bruteforce_bytes(int64_t N, int64_t n, int d, int k) {
   if (N <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
   const int64_t ld = mgp_cdiv(N, 4) * 4;
   const int64_t qc = chunk_rows(N, n);
@@ -426,11 +428,12 @@ extern "C" size_t mgp_knn_workspace_bytes(int64_t N, int64_t n, int d, int k) {
   return b + 1024;
 }
 
-extern "C" int mgp_knn_search(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
-                              int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream) {
+// the slab pipeline (any d): distance tiles -> radix select -> fp64 re-rank -> sufficiency check
+int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
+                       int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream) {
   if (!db || !q || !D || !I || !work) return MGP_ERR_ARG;
   if (N <= 0 || n <= 0 || d <= 0 || k <= 0 || k > N || k > 1024 || N > INT_MAX) return MGP_ERR_ARG;
-  if (work_bytes < mgp_knn_workspace_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
+  if (work_bytes < bruteforce_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
   hipStream_t st = mgp_stream(stream);
   const int64_t ld = mgp_cdiv(N, 4) * 4;
   const int64_t qc = chunk_rows(N, n);
@@ -490,5 +493,67 @@ extern "C" int mgp_knn_search(const float* db, int64_t N, int d, const float* q,
   }
   MGP_HIP_TRY(hipStreamSynchronize(st));
   if (stats) { stats[0] = n_wide; stats[1] = n_exact; stats[2] = n_chunks; stats[3] = Kp0; }
+  return MGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Public entry: d <= 3 and N >= 4096 take the slab-free path of knn_lowd.hip; its (rare) overflow rows,
+// and every other shape, go through the slab pipeline above.
+namespace {
+
+int64_t fallback_rows(int64_t n) {          // rows the low-d path may hand back per round
+  int64_t r = n / 8;
+  if (r < 4096) r = 4096;
+  return r < n ? r : n;
+}
+
+}  // namespace
+
+extern "C" size_t mgp_knn_workspace_bytes(int64_t N, int64_t n, int d, int k) {
+  if (N <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
+  if (!mgp_knn_lowd_eligible(N, n, d, k)) return bruteforce_bytes(N, n, d, k);
+  const int64_t fr = fallback_rows(n);
+  size_t b = bruteforce_bytes(N, fr, d, k) + mgp_knn_lowd_workspace_bytes(N, n, d, k);
+  b += mgp_align((size_t)fr * d * sizeof(float)) + 2 * mgp_align((size_t)fr * k * sizeof(float)) +
+       mgp_align((size_t)fr * sizeof(int32_t));
+  return b + 1024;
+}
+
+extern "C" int mgp_knn_search(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
+                              int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream) {
+  if (!db || !q || !D || !I || !work) return MGP_ERR_ARG;
+  if (N <= 0 || n <= 0 || d <= 0 || k <= 0 || k > N || k > 1024 || N > INT_MAX) return MGP_ERR_ARG;
+  if (work_bytes < mgp_knn_workspace_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
+  if (!mgp_knn_lowd_eligible(N, n, d, k)) return mgp_knn_bruteforce(db, N, d, q, n, k, D, I, work, work_bytes, stats, stream);
+
+  hipStream_t st = mgp_stream(stream);
+  const int64_t fr = fallback_rows(n);
+  MgpArena ar(work, work_bytes);
+  const size_t bf_bytes = bruteforce_bytes(N, fr, d, k);
+  void* bf_work = ar.take<char>(bf_bytes);
+  const size_t ld_bytes = mgp_knn_lowd_workspace_bytes(N, n, d, k);
+  void* ld_work = ar.take<char>(ld_bytes);
+  float* qsub = ar.take<float>((size_t)fr * d);
+  float* Dsub = ar.take<float>((size_t)fr * k);
+  int32_t* Isub = ar.take<int32_t>((size_t)fr * k);
+  int32_t* rows_dev = ar.take<int32_t>(fr);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+
+  std::vector<int32_t> over;
+  MGP_TRY(mgp_knn_lowd(db, N, d, q, n, k, D, I, ld_work, ld_bytes, &over, stream));
+  int64_t st_wide = 0, st_exact = 0, st_chunks = 0;
+  for (size_t o0 = 0; o0 < over.size(); o0 += (size_t)fr) {
+    const int64_t m = (int64_t)std::min<size_t>((size_t)fr, over.size() - o0);
+    MGP_HIP_TRY(hipMemcpyAsync(rows_dev, over.data() + o0, (size_t)m * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    MGP_TRY(mgp_knn_gather_rows(q, rows_dev, m, d, qsub, stream));
+    int64_t s4[4] = {0, 0, 0, 0};
+    MGP_TRY(mgp_knn_bruteforce(db, N, d, qsub, m, k, Dsub, Isub, bf_work, bf_bytes, s4, stream));
+    MGP_TRY(mgp_knn_scatter_rows(Dsub, Isub, rows_dev, m, k, D, I, stream));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    st_wide += s4[0]; st_exact += s4[1]; st_chunks += s4[2];
+  }
+  // stats: [0] rows redone by the slab pipeline (low-d overflow + its own wide retries), [1] exact rows,
+  // [2] slab chunks, [3] -1 marks the low-d path
+  if (stats) { stats[0] = (int64_t)over.size() + st_wide; stats[1] = st_exact; stats[2] = st_chunks; stats[3] = -1; }
   return MGP_OK;
 }

@@ -1,5 +1,6 @@
 // Internal (non-exported) entry points shared between the translation units of libmgp_hip.
 #pragma once
+#include <vector>
 #include "mgp_hip.h"
 
 // mgp_spmm_fused plus: `skip` (device flag: the launch is a no-op when non-zero) and `tick`
@@ -66,3 +67,14 @@ float* mgp_operator_first_out(const mgp_operator_t* op, int C, void* work, size_
 int mgp_operator_apply_tail(const mgp_operator_t* op, const float* X, int C, float* Y, const float* dotw,
                             float* dot_partials, const int* skip, int* tick, const MgpCommit* commit, void* work,
                             size_t work_bytes, void* stream);
+
+// k-NN internals (knn.hip / knn_lowd.hip)
+int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
+                       int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream);
+int mgp_knn_lowd_eligible(int64_t N, int64_t n, int d, int k);
+size_t mgp_knn_lowd_workspace_bytes(int64_t N, int64_t n, int d, int k);
+int mgp_knn_lowd(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D, int32_t* I, void* work,
+                 size_t work_bytes, std::vector<int32_t>* over_rows, void* stream);
+int mgp_knn_gather_rows(const float* src, const int32_t* rows_dev, int64_t m, int w, float* dst, void* stream);
+int mgp_knn_scatter_rows(const float* Ds, const int32_t* Is, const int32_t* rows_dev, int64_t m, int k, float* D,
+                         int32_t* I, void* stream);

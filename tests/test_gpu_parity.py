@@ -966,3 +966,36 @@ def test_riemann_gp_posterior_and_hybrid(mgp, golden, dev, norm):
     with torch.no_grad():
         ref = s * kern.precision().matmul(v)
         assert float((model.precision(noise=False).matmul(v) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_knn_lowdim_slab_free_path_vs_oracle(mgp, dev, d):
+    """d <= 3, N >= 4096: Morton window threshold + fused filter + fp64 re-rank (knn_lowd.hip), bit-exact
+    against the oracle: random cloud with clusters, lattice with masses of exact ties, duplicates,
+    queries outside the bounding box, several k; self search and separate queries."""
+    from oracle import knn as oknn
+    rng = np.random.default_rng(10 + d)
+    n = 6000
+    cloud = rng.normal(size=(n, d)).astype(np.float32)
+    cloud[: n // 3] = cloud[: n // 3] * 0.01 + 3.0                     # a dense cluster
+    side = int(round(n ** (1.0 / d))) + 1
+    grids = np.meshgrid(*[np.arange(side, dtype=np.float32)] * d, indexing="ij")
+    lattice = np.stack([g.ravel() for g in grids], 1)[:n]
+    lattice = np.concatenate([lattice, lattice[:50]])                  # duplicates on top of exact ties
+    for name, x in (("cloud", cloud), ("lattice", lattice)):
+        q = np.concatenate([x[:400], (x[:40] * 3.0 + 10.0).astype(np.float32)])     # in-set and far outside
+        nn = mgp.utils.NearestNeighbors(T(x, dev))
+        for k in (1, 7, 50, 64, 128):
+            Dr, Ir = oknn.knn_search(x, q, k)
+            D, I = nn.search(T(q, dev), k)
+            assert nn.last_stats["candidates"] == -1, "low-d path not taken"
+            assert np.array_equal(I.cpu().numpy(), Ir), (name, k)
+            assert np.array_equal(D.cpu().numpy(), Dr), (name, k)
+        Dr, Ir = oknn.knn_search(x, x, 16)                             # self search (graph build shape)
+        D, I = nn.search(T(x, dev), 16)
+        assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), name
+    # k too large for the window (4k > 1024) falls back to the slab pipeline
+    nn = mgp.utils.NearestNeighbors(T(cloud, dev))
+    Dr, Ir = oknn.knn_search(cloud, cloud[:64], 300)
+    D, I = nn.search(T(cloud[:64], dev), 300)
+    assert nn.last_stats["candidates"] > 0 and np.array_equal(I.cpu().numpy(), Ir)
