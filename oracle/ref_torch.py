@@ -85,3 +85,20 @@ def torch_cg(matmul, b, tol, max_iter, jacobi=None):
         p = z + (rz_new / rz) * p
         rz = rz_new
     return x, it
+
+
+def torch_laplacian_from_edges(val, idx, n, eps, self_loops=True):
+    """graph_laplacian_operator.py:52-106 in differentiable torch ops (exp, scatter_add, gathers): the
+    reference's cached properties as functions of the bandwidth `eps` (a tensor that may require grad).
+    Returns (diag [n], triu [M], degree [n]) of L_sym, i.e. what TorchCooLaplacian takes."""
+    val = torch.as_tensor(val, dtype=torch.float32)
+    idx = torch.as_tensor(idx, dtype=torch.int64)
+    w = torch.exp(-val / (4.0 * eps * eps))                                   # :56
+    ones = torch.ones(n) if self_loops else torch.zeros(n)
+    dt = ones.index_add(0, idx[0], w).index_add(0, idx[1], w)                 # :62-69
+    a = w / (dt[idx[0]] * dt[idx[1]])                                         # :75
+    self_a = dt.pow(-2) if self_loops else torch.zeros(n)
+    deg = self_a.index_add(0, idx[0], a).index_add(0, idx[1], a)              # :81-88
+    diag = (1.0 - self_a / deg) / (eps * eps) if self_loops else torch.ones(n) / (eps * eps)   # :94-97
+    triu = a / (deg[idx[0]].sqrt() * deg[idx[1]].sqrt()) / (eps * eps)        # :105-106 (stored positive)
+    return diag, triu, deg
