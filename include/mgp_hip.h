@@ -72,22 +72,15 @@ int mgp_knn_search(const float* db, int64_t N, int d, const float* q, int64_t n,
  *                   *nnz = rowptr[n].  A (i,i) edge (duplicate points) appears twice in row i,
  *                   exactly as the reference scatters it twice.
  * Synchronises `stream` (needs M on the host). */
-size_t mgp_graph_workspace_bytes(int64_t n, int k, int panel_width);
-int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int k, int panel_width,
-                    int32_t* tri_row, int32_t* tri_col, float* tri_val, int64_t* M,
-                    int32_t* rowptr, int32_t* segptr, int32_t* col, float* d2, int32_t* eid,
+size_t mgp_graph_workspace_bytes(int64_t n, int k);
+int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int k, int32_t* tri_row, int32_t* tri_col,
+                    float* tri_val, int64_t* M, int32_t* rowptr, int32_t* col, float* d2, int32_t* eid,
                     int64_t* nnz, void* work, size_t work_bytes, void* stream);
 /* same CSR from an existing reference-style edge list (idx[2,M] given as two i32 arrays) */
-size_t mgp_graph_coo_workspace_bytes(int64_t n, int64_t M, int panel_width);
+size_t mgp_graph_coo_workspace_bytes(int64_t n, int64_t M);
 int mgp_graph_from_coo(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val,
-                       int64_t M, int64_t n, int panel_width, int32_t* rowptr, int32_t* segptr,
-                       int32_t* col, float* d2, int32_t* eid, int64_t* nnz, void* work,
-                       size_t work_bytes, void* stream);
-/* Column panels (panel_width > 0, a multiple of 4; 0 = none): every row is additionally split into
- * P = ceil(n / panel_width) segments by column panel, each segment padded to MGP_PAD entries (padding
- * column = first column of the panel); segptr i32 [n*P + 1] holds the segment starts
- * (rowptr[r] = segptr[r*P]); entry capacity <= 2n(k-1) + 4nP.  The C = 1 SpMV stages one panel of x
- * at a time in LDS (mgp_csr_t.segptr / panels / panel_width) instead of gathering from L2. */
+                       int64_t M, int64_t n, int32_t* rowptr, int32_t* col, float* d2, int32_t* eid,
+                       int64_t* nnz, void* work, size_t work_bytes, void* stream);
 
 /* Row-tile column dictionaries for the C == 1 SpMV.  A tile is `tile_rows` consecutive rows of the padded
  * CSR; tile_cols lists the distinct columns the tile references (ascending), lid maps every entry to
@@ -144,9 +137,6 @@ typedef struct {
   const int32_t* col;
   const float* vals;
   const float* diag;
-  const int32_t* segptr;   /* nullable: column-panel segment starts [n*panels + 1] (mgp_graph_build) */
-  int32_t panels;          /* number of column panels (0 = no panel structure) */
-  int32_t panel_width;
   int64_t ncols;           /* length of the vectors the columns index (0 = n; > n for a row slice) */
   /* row-tile column dictionaries (mgp_graph_tiles); all NULL / 0 = gather straight from memory */
   const int32_t* tile_ptr;   /* [ntiles + 1] offsets into tile_cols, ntiles = ceil(n / tile_rows) */
@@ -164,11 +154,7 @@ int mgp_spmm_set_tile_mode(int on);          /* C == 1: use the tile dictionarie
 
 int mgp_spmm_dot_blocks(int64_t n, int C);   /* workgroups that write dot partials */
 int mgp_spmm_set_group_hint(int lanes);      /* C == 1: lanes per row, one of 4,8,16,32,64 */
-int mgp_spmm_set_rows_in_flight(int rows);   /* C == 1: rows a lane group loads at once: 1,2,4,8 */
-int mgp_spmm_set_entry_layout(int layout);   /* C == 1: 0 = 16-B per lane (default), 1 = lane-strided */
-int mgp_spmm_set_panel_mode(int on);         /* C == 1: column-panel sweep when the CSR has panels (experiment, default 0) */
-int mgp_spmm_set_block(int threads);         /* C == 1: workgroup size 256 (default) / 512 / 1024 */
-int mgp_spmm_set_stream_nt(int on);          /* C == 1: sc1 (L1-bypass) loads for the matrix stream (default 0) */
+int mgp_spmm_set_rows_in_flight(int rows);   /* C == 1 fallback kernel: rows a lane group loads at once: 1,2,4,8 */
 int mgp_spmm_fused(const mgp_csr_t* L, const float* X, int C, float* Y, float a, float b,
                    const float* pre, const float* post, const float* base, float cb, float co,
                    const float* dotw, float* dot_partials, void* stream);

@@ -35,7 +35,7 @@ class MgpError(RuntimeError):
 
 class CsrT(Structure):
     _fields_ = [("n", c_int64), ("rowptr", c_void_p), ("col", c_void_p), ("vals", c_void_p),
-                ("diag", c_void_p), ("segptr", c_void_p), ("panels", c_int32), ("panel_width", c_int32),
+                ("diag", c_void_p),
                 ("ncols", c_int64), ("tile_ptr", c_void_p), ("tile_cols", c_void_p), ("lid", c_void_p),
                 ("tile_rows", c_int32), ("tile_max_cols", c_int32), ("tile_max_entries", c_int32),
                 ("tile_reserved", c_int32)]
@@ -65,7 +65,7 @@ SIGNATURES = {
     "mgp_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
     "mgp_knn_search": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, _P, _P, c_size_t,
                                POINTER(c_int64), _P]),
-    "mgp_graph_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "mgp_graph_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mgp_graph_tiles_workspace_bytes": (c_size_t, [c_int64]),
     "mgp_graph_tiles": (c_int, [c_int64, _P, _P, c_int64, c_int, _P, _P, _P, POINTER(c_int64), POINTER(c_int32),
                                 POINTER(c_int32), _P, c_size_t, _P]),
@@ -73,10 +73,10 @@ SIGNATURES = {
     "mgp_spmm_set_tile_mode": (c_int, [c_int]),
     "mgp_cg_set_fuse": (c_int, [c_int]),
     "mgp_host_symeig": (c_int, [c_int, _P, _P, _P]),
-    "mgp_graph_build": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P, _P, POINTER(c_int64), _P, _P, _P, _P, _P,
+    "mgp_graph_build": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, POINTER(c_int64), _P, _P, _P, _P,
                                 POINTER(c_int64), _P, c_size_t, _P]),
-    "mgp_graph_coo_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
-    "mgp_graph_from_coo": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, _P, _P, _P, POINTER(c_int64), _P,
+    "mgp_graph_coo_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "mgp_graph_from_coo": (c_int, [_P, _P, _P, c_int64, c_int64, _P, _P, _P, _P, POINTER(c_int64), _P,
                                    c_size_t, _P]),
     "mgp_laplacian_build": (c_int, [c_int64, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mgp_laplacian_tangent": (c_int, [c_int64, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -84,10 +84,6 @@ SIGNATURES = {
     "mgp_spmm_dot_blocks": (c_int, [c_int64, c_int]),
     "mgp_spmm_set_group_hint": (c_int, [c_int]),
     "mgp_spmm_set_rows_in_flight": (c_int, [c_int]),
-    "mgp_spmm_set_entry_layout": (c_int, [c_int]),
-    "mgp_spmm_set_panel_mode": (c_int, [c_int]),
-    "mgp_spmm_set_block": (c_int, [c_int]),
-    "mgp_spmm_set_stream_nt": (c_int, [c_int]),
     "mgp_spmm_fused": (c_int, [POINTER(CsrT), _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
                                c_float, _P, _P, _P]),
     "mgp_spmm_fused_rows": (c_int, [POINTER(CsrT), c_int64, _P, c_int, _P, c_float, c_float, _P, _P, _P, c_float,
@@ -196,11 +192,10 @@ def workspace(nbytes, tag, device):
     return buf
 
 
-def csr_struct(n, rowptr, col, vals, diag, segptr=None, panels=0, panel_width=0, ncols=0, tiles=None):
+def csr_struct(n, rowptr, col, vals, diag, ncols=0, tiles=None):
     """tiles: None or the dict KnnGraph.tiles holds (tile_ptr, tile_cols, lid tensors + rows / max_cols /
     max_entries)."""
-    s = CsrT(int(n), rowptr.data_ptr(), col.data_ptr(), vals.data_ptr(), diag.data_ptr(),
-             segptr.data_ptr() if segptr is not None else None, int(panels), int(panel_width), int(ncols))
+    s = CsrT(int(n), rowptr.data_ptr(), col.data_ptr(), vals.data_ptr(), diag.data_ptr(), int(ncols))
     if tiles is not None:
         s.tile_ptr, s.tile_cols, s.lid = tiles["tile_ptr"].data_ptr(), tiles["tile_cols"].data_ptr(), tiles["lid"].data_ptr()
         s.tile_rows, s.tile_max_cols, s.tile_max_entries = tiles["rows"], tiles["max_cols"], tiles["max_entries"]

@@ -98,7 +98,8 @@ __device__ __forceinline__ void reduce_slices(float (*sh)[kBlock], int TC, int T
 __global__ __launch_bounds__(kBlock) void cg_init_kernel(CgArgs a, const float* __restrict__ B) {
   __shared__ float sh[2][kBlock];
   const int tid = threadIdx.x, cc = tid % a.TC, sl = tid / a.TC;
-  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int64_t r0 = (int64_t)lb * a.rows_per_block;
   int64_t r1 = r0 + a.rows_per_block;
   if (r1 > a.n) r1 = a.n;
   if (blockIdx.x == 0 && tid == 0) { a.state[0] = 0; a.state[1] = 0; a.state[2] = 0; }   // the first apply ticks it to 1
@@ -325,7 +326,10 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const CgScalars sc = *reinterpret_cast<const CgScalars*>(a.gamma_old);
   const int st_it = sc.it, st_done = sc.done;
-  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  // same block -> XCD -> row-range mapping as the SpMV kernels (mgp_xcd_block): the vector slices this
+  // workgroup writes are the ones the SpMV workgroups of the same XCD read next, and vice versa
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int64_t r0 = (int64_t)lb * a.rows_per_block;
   int64_t r1 = r0 + a.rows_per_block;
   if (r1 > a.n) r1 = a.n;
   const int64_t rf = r0 + tid;
@@ -439,8 +443,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   if (lane == 0) { sh_o[wave][0] = ng; sh_o[wave][1] = nrr; }
   __syncthreads();
   if (tid == 0) {
-    a.pd_gamma[(int64_t)par * a.nbv + blockIdx.x] = (sh_o[0][0] + sh_o[1][0]) + (sh_o[2][0] + sh_o[3][0]);
-    a.pd_rr[(int64_t)par * a.nbv + blockIdx.x] = (sh_o[0][1] + sh_o[1][1]) + (sh_o[2][1] + sh_o[3][1]);
+    a.pd_gamma[(int64_t)par * a.nbv + lb] = (sh_o[0][0] + sh_o[1][0]) + (sh_o[2][0] + sh_o[3][0]);
+    a.pd_rr[(int64_t)par * a.nbv + lb] = (sh_o[0][1] + sh_o[1][1]) + (sh_o[2][1] + sh_o[3][1]);
   }
 }
 

@@ -77,53 +77,39 @@ __global__ void expand_both_directions(const int32_t* __restrict__ tri_row, cons
   }
 }
 
-// Segment t = (row r = t / P, column panel p = t % P): segstart[t] = first sorted position whose key
-// >= (r, p * PW).  P = 1 gives plain row starts.
-__global__ void seg_search(const uint64_t* __restrict__ keys, int64_t total, int64_t n, int P, int PW,
-                           int32_t* __restrict__ segstart) {
-  const int64_t T = n * P;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= T;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    const uint64_t r = (uint64_t)(t / P), p = (uint64_t)(t % P);
-    const uint64_t target = (t == T) ? ((uint64_t)n << 32) : ((r << 32) | (p * (uint64_t)PW));
+// rowstart[r] = first sorted position whose key >= (r, 0)
+__global__ void row_search(const uint64_t* __restrict__ keys, int64_t total, int64_t n, int32_t* __restrict__ rowstart) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r <= n; r += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t target = (uint64_t)r << 32;
     int64_t lo = 0, hi = total;
     while (lo < hi) {
       int64_t mid = (lo + hi) >> 1;
       if (keys[mid] < target) lo = mid + 1; else hi = mid;
     }
-    segstart[t] = (int32_t)lo;
+    rowstart[r] = (int32_t)lo;
   }
 }
 
-__global__ void padded_counts(const int32_t* __restrict__ segstart, int64_t T, int32_t* __restrict__ cnt) {
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= T;
-       t += (int64_t)gridDim.x * blockDim.x) {
-    if (t == T) { cnt[t] = 0; continue; }
-    const int c = segstart[t + 1] - segstart[t];
-    cnt[t] = (c + MGP_PAD - 1) / MGP_PAD * MGP_PAD;
+__global__ void padded_counts(const int32_t* __restrict__ rowstart, int64_t n, int32_t* __restrict__ cnt) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r <= n; r += (int64_t)gridDim.x * blockDim.x) {
+    if (r == n) { cnt[r] = 0; continue; }
+    const int c = rowstart[r + 1] - rowstart[r];
+    cnt[r] = (c + MGP_PAD - 1) / MGP_PAD * MGP_PAD;
   }
-}
-
-__global__ void rowptr_from_segptr(const int32_t* __restrict__ segptr, int64_t n, int P, int32_t* __restrict__ rowptr) {
-  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r <= n; r += (int64_t)gridDim.x * blockDim.x)
-    rowptr[r] = segptr[r * P];
 }
 
 __global__ void fill_csr(const uint64_t* __restrict__ keys, const int32_t* __restrict__ eids,
-                         const float* __restrict__ tri_val, const int32_t* __restrict__ segstart,
-                         const int32_t* __restrict__ segptr, int64_t n, int P, int PW, int32_t* __restrict__ col,
+                         const float* __restrict__ tri_val, const int32_t* __restrict__ rowstart,
+                         const int32_t* __restrict__ rowptr, int64_t n, int32_t* __restrict__ col,
                          float* __restrict__ d2, int32_t* __restrict__ eid) {
-  // one 16-lane group per segment: copy the sorted entries, then write the padding.  Padding entries
-  // sit inside the segment's column panel (col = first column of the panel, or the row itself when
-  // there are no panels), d2 = +inf (weight 0), eid = -1.
+  // one 16-lane group per row: copy the sorted entries, then write the padding (col = the row itself,
+  // d2 = +inf -> weight 0, eid = -1)
   const int lane = threadIdx.x & 15;
   const int64_t g = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
   const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
-  const int64_t T = n * P;
-  for (int64_t t = g; t < T; t += ng) {
-    const int s = segstart[t], cnt = segstart[t + 1] - s;
-    const int o = segptr[t], cap = segptr[t + 1] - o;
-    const int32_t padcol = P > 1 ? (int32_t)((t % P) * PW) : (int32_t)t;
+  for (int64_t r = g; r < n; r += ng) {
+    const int s = rowstart[r], cnt = rowstart[r + 1] - s;
+    const int o = rowptr[r], cap = rowptr[r + 1] - o;
     for (int i = lane; i < cap; i += 16) {
       if (i < cnt) {
         const uint64_t key = keys[s + i];
@@ -132,7 +118,7 @@ __global__ void fill_csr(const uint64_t* __restrict__ keys, const int32_t* __res
         d2[o + i] = tri_val[e];
         eid[o + i] = e;
       } else {
-        col[o + i] = padcol;
+        col[o + i] = (int32_t)r;
         d2[o + i] = INFINITY;
         eid[o + i] = -1;
       }
@@ -143,7 +129,7 @@ __global__ void fill_csr(const uint64_t* __restrict__ keys, const int32_t* __res
 struct GraphWork {
   uint64_t *keys_a, *keys_b;
   float *vals_a, *vals_b;     // also reused as int32 payload
-  int32_t *head, *uidx, *rowstart, *cnt, *segtmp;
+  int32_t *head, *uidx, *rowstart, *cnt;
   void* cub;
   size_t cub_bytes;
 };
@@ -162,21 +148,17 @@ size_t cub_bytes_for(int64_t items) {
   return mgp_align(m + 1024);
 }
 
-int panels_for(int64_t n, int panel_width) { return panel_width > 0 ? (int)mgp_cdiv(n, panel_width) : 1; }
-
-size_t graph_bytes(int64_t items, int64_t n, int P) {
-  const int64_t T = n * P;
+size_t graph_bytes(int64_t items, int64_t n) {
   size_t b = 0;
   b += 2 * mgp_align(items * sizeof(uint64_t));
   b += 2 * mgp_align(items * sizeof(float));
   b += 2 * mgp_align((items + 1) * sizeof(int32_t));
-  b += 3 * mgp_align((T + 2) * sizeof(int32_t));
-  b += cub_bytes_for(items > T + 2 ? items : T + 2);
+  b += 2 * mgp_align((n + 2) * sizeof(int32_t));
+  b += cub_bytes_for(items > n + 2 ? items : n + 2);
   return b + 4096;
 }
 
-bool carve(GraphWork& w, void* work, size_t bytes, int64_t items, int64_t n, int P) {
-  const int64_t T = n * P;
+bool carve(GraphWork& w, void* work, size_t bytes, int64_t items, int64_t n) {
   MgpArena ar(work, bytes);
   w.keys_a = ar.take<uint64_t>(items);
   w.keys_b = ar.take<uint64_t>(items);
@@ -184,10 +166,9 @@ bool carve(GraphWork& w, void* work, size_t bytes, int64_t items, int64_t n, int
   w.vals_b = ar.take<float>(items);
   w.head = ar.take<int32_t>(items + 1);
   w.uidx = ar.take<int32_t>(items + 1);
-  w.rowstart = ar.take<int32_t>(T + 2);
-  w.cnt = ar.take<int32_t>(T + 2);
-  w.segtmp = ar.take<int32_t>(T + 2);
-  w.cub_bytes = cub_bytes_for(items > T + 2 ? items : T + 2);
+  w.rowstart = ar.take<int32_t>(n + 2);
+  w.cnt = ar.take<int32_t>(n + 2);
+  w.cub_bytes = cub_bytes_for(items > n + 2 ? items : n + 2);
   w.cub = ar.take<char>(w.cub_bytes);
   return ar.ok();
 }
@@ -198,14 +179,11 @@ int bits_for(int64_t n) {
   return b;
 }
 
-// tri_* (device, sorted unique) -> padded CSR (rows split into P column panels of width PW, every
-// segment padded to 4 entries).  keys_a/keys_b/vals_* are scratch of >= 2M items.
+// tri_* (device, sorted unique) -> padded CSR (every row padded to 4 entries).  keys_a/keys_b/vals_* are
+// scratch of >= 2M items.
 int csr_from_tri(GraphWork& w, const int32_t* tri_row, const int32_t* tri_col, const float* tri_val,
-                 int64_t M, int64_t n, int PW, int32_t* rowptr, int32_t* segptr, int32_t* col, float* d2,
-                 int32_t* eid, int64_t* nnz, hipStream_t st) {
-  const int P = panels_for(n, PW);
-  const int64_t T = n * P;
-  int32_t* sp = segptr ? segptr : w.segtmp;
+                 int64_t M, int64_t n, int32_t* rowptr, int32_t* col, float* d2, int32_t* eid, int64_t* nnz,
+                 hipStream_t st) {
   const int64_t items = 2 * M;
   if (items > 0) {
     hipLaunchKernelGGL(expand_both_directions, dim3(grid_for(M)), dim3(kBlock), 0, st, tri_row, tri_col, M,
@@ -217,22 +195,20 @@ int csr_from_tri(GraphWork& w, const int32_t* tri_row, const int32_t* tri_col, c
     MGP_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w.cub, tb, kb, vb, (int)items, 0, 32 + bits_for(n), st));
     const uint64_t* keys = kb.Current();
     const int32_t* eids = vb.Current();
-    hipLaunchKernelGGL(seg_search, dim3(grid_for(T + 1)), dim3(kBlock), 0, st, keys, items, n, P, PW, w.rowstart);
+    hipLaunchKernelGGL(row_search, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, keys, items, n, w.rowstart);
     MGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(padded_counts, dim3(grid_for(T + 1)), dim3(kBlock), 0, st, w.rowstart, T, w.cnt);
+    hipLaunchKernelGGL(padded_counts, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, w.rowstart, n, w.cnt);
     MGP_LAUNCH_CHECK();
     tb = w.cub_bytes;
-    MGP_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.cub, tb, w.cnt, sp, (int)(T + 1), st));
-    hipLaunchKernelGGL(fill_csr, dim3(grid_for(T * 16)), dim3(kBlock), 0, st, keys, eids, tri_val, w.rowstart, sp, n,
-                       P, PW, col, d2, eid);
+    MGP_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.cub, tb, w.cnt, rowptr, (int)(n + 1), st));
+    hipLaunchKernelGGL(fill_csr, dim3(grid_for(n * 16)), dim3(kBlock), 0, st, keys, eids, tri_val, w.rowstart, rowptr, n,
+                       col, d2, eid);
     MGP_LAUNCH_CHECK();
   } else {
-    MGP_HIP_TRY(hipMemsetAsync(sp, 0, (T + 1) * sizeof(int32_t), st));
+    MGP_HIP_TRY(hipMemsetAsync(rowptr, 0, (n + 1) * sizeof(int32_t), st));
   }
-  hipLaunchKernelGGL(rowptr_from_segptr, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, sp, n, P, rowptr);
-  MGP_LAUNCH_CHECK();
   int32_t last = 0;
-  MGP_HIP_TRY(hipMemcpyAsync(&last, sp + T, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipMemcpyAsync(&last, rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   MGP_HIP_TRY(hipStreamSynchronize(st));
   *nnz = last;
   return MGP_OK;
@@ -240,25 +216,21 @@ int csr_from_tri(GraphWork& w, const int32_t* tri_row, const int32_t* tri_col, c
 
 }  // namespace
 
-extern "C" size_t mgp_graph_workspace_bytes(int64_t n, int k, int panel_width) {
-  if (n <= 0 || k < 2 || panel_width < 0) return 0;
-  return graph_bytes(2 * n * (int64_t)(k - 1), n, panels_for(n, panel_width));
+extern "C" size_t mgp_graph_workspace_bytes(int64_t n, int k) {
+  if (n <= 0 || k < 2) return 0;
+  return graph_bytes(2 * n * (int64_t)(k - 1), n);
 }
 
-extern "C" int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int k, int panel_width,
-                               int32_t* tri_row, int32_t* tri_col, float* tri_val, int64_t* M, int32_t* rowptr,
-                               int32_t* segptr, int32_t* col, float* d2, int32_t* eid, int64_t* nnz, void* work,
-                               size_t work_bytes, void* stream) {
+extern "C" int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int k, int32_t* tri_row, int32_t* tri_col,
+                               float* tri_val, int64_t* M, int32_t* rowptr, int32_t* col, float* d2, int32_t* eid,
+                               int64_t* nnz, void* work, size_t work_bytes, void* stream) {
   if (!D || !I || !tri_row || !tri_col || !tri_val || !M || !rowptr || !col || !d2 || !eid || !nnz || !work)
     return MGP_ERR_ARG;
   if (n <= 0 || k < 2 || n * (int64_t)(k - 1) * 2 > 0x7fffffff) return MGP_ERR_ARG;
-  if (panel_width < 0 || (panel_width % 4) != 0) return MGP_ERR_ARG;
-  const int P = panels_for(n, panel_width);
-  if (n * (int64_t)P > 0x7ffffff0) return MGP_ERR_ARG;
   hipStream_t st = mgp_stream(stream);
   const int64_t total = n * (int64_t)(k - 1);
   GraphWork w;
-  if (!carve(w, work, work_bytes, 2 * total, n, P)) return MGP_ERR_WORKSPACE;
+  if (!carve(w, work, work_bytes, 2 * total, n)) return MGP_ERR_WORKSPACE;
 
   hipLaunchKernelGGL(make_directed_keys, dim3(grid_for(total)), dim3(kBlock), 0, st, D, I, n, k, w.keys_a, w.vals_a);
   MGP_LAUNCH_CHECK();
@@ -280,26 +252,22 @@ extern "C" int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int 
   MGP_HIP_TRY(hipMemcpyAsync(&last_head, w.head + (total - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
   MGP_HIP_TRY(hipStreamSynchronize(st));
   *M = (int64_t)last_idx + last_head;
-  return csr_from_tri(w, tri_row, tri_col, tri_val, *M, n, panel_width, rowptr, segptr, col, d2, eid, nnz, st);
+  return csr_from_tri(w, tri_row, tri_col, tri_val, *M, n, rowptr, col, d2, eid, nnz, st);
 }
 
 extern "C" int mgp_graph_from_coo(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val,
-                                  int64_t M, int64_t n, int panel_width, int32_t* rowptr, int32_t* segptr,
-                                  int32_t* col, float* d2, int32_t* eid, int64_t* nnz, void* work,
-                                  size_t work_bytes, void* stream) {
+                                  int64_t M, int64_t n, int32_t* rowptr, int32_t* col, float* d2, int32_t* eid,
+                                  int64_t* nnz, void* work, size_t work_bytes, void* stream) {
   if (!tri_row || !tri_col || !tri_val || !rowptr || !col || !d2 || !eid || !nnz || !work) return MGP_ERR_ARG;
-  if (n <= 0 || M < 0 || 2 * M > 0x7fffffff || panel_width < 0 || (panel_width % 4) != 0) return MGP_ERR_ARG;
-  const int P = panels_for(n, panel_width);
-  if (n * (int64_t)P > 0x7ffffff0) return MGP_ERR_ARG;
+  if (n <= 0 || M < 0 || 2 * M > 0x7fffffff) return MGP_ERR_ARG;
   GraphWork w;
-  if (!carve(w, work, work_bytes, 2 * M > 0 ? 2 * M : 1, n, P)) return MGP_ERR_WORKSPACE;
-  return csr_from_tri(w, tri_row, tri_col, tri_val, M, n, panel_width, rowptr, segptr, col, d2, eid, nnz,
-                      mgp_stream(stream));
+  if (!carve(w, work, work_bytes, 2 * M > 0 ? 2 * M : 1, n)) return MGP_ERR_WORKSPACE;
+  return csr_from_tri(w, tri_row, tri_col, tri_val, M, n, rowptr, col, d2, eid, nnz, mgp_stream(stream));
 }
 
-extern "C" size_t mgp_graph_coo_workspace_bytes(int64_t n, int64_t M, int panel_width) {
-  if (n <= 0 || panel_width < 0) return 0;
-  return graph_bytes(2 * M > 0 ? 2 * M : 1, n, panels_for(n, panel_width));
+extern "C" size_t mgp_graph_coo_workspace_bytes(int64_t n, int64_t M) {
+  if (n <= 0) return 0;
+  return graph_bytes(2 * M > 0 ? 2 * M : 1, n);
 }
 
 // ------------------------------------------------------------------------------------------------

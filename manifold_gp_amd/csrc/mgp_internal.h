@@ -32,7 +32,7 @@ int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X
 // 1 when the C == 1 tile kernel would run on L; launch geometry of that kernel
 int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, size_t* lds_bytes);
 
-// workgroups that write dot partials for this CSR (depends on whether the panel kernel is used)
+// workgroups that write dot partials for this CSR (depends on whether the tile kernel is used)
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C);
 
 // operator chain with the same hooks on its LAST SpMM

@@ -10,16 +10,17 @@
 // elementwise launches, by ONE launch without atomics over a full symmetric CSR.
 //
 // gfx950 mapping
-//   * rows are padded to 4 entries and 16-byte aligned, so every lane issues
-//     global_load_dwordx4 for 4 column ids and 4 values (coalesced 1 KiB per wave-instruction);
-//   * C == 1: a row is owned by a G-lane sub-wave group (G in 4..64 chosen from the mean row
-//     length), partial products are reduced with wave shuffles inside the group;
-//   * C  > 1: a row is owned by G = pow2(min(C,64)) lanes laid over the right-hand-side
-//     columns; the group loads G (col,val) pairs coalesced and broadcasts them one by one
-//     (readlane -> scalar base address when G = 64), so every X row is read as one contiguous
-//     burst; dot partials go through LDS across the groups of a workgroup;
-//   * the grid is capped (<= 1024 workgroups, contiguous row ranges per workgroup) and remapped
-//     so that each XCD streams one contiguous slice of rows and keeps its slice of x in its L2.
+//   * rows are padded to 4 entries and 16-byte aligned: every stream load is a 16-byte load;
+//   * C == 1, default: spmv_tile_kernel -- 64-row tiles, the distinct columns of a tile staged in LDS
+//     once (dictionary built by mgp_graph_tiles), per-entry gathers are ds_reads through 16-bit ids;
+//   * C == 1, fallback (no dictionaries): spmv_kernel -- a row is owned by a G-lane sub-wave group
+//     (G in 4..64 from the mean row length), gathers go to memory, shuffle reduction in the group;
+//   * C  > 1: spmm_kernel -- a row is owned by G = pow2(min(C,64)) lanes laid over the right-hand-
+//     side columns; the group loads G (col,val) pairs coalesced and broadcasts them (readlane ->
+//     scalar base address when G = 64), 8 entries' X rows in flight per pass, every X row read as one
+//     contiguous burst; dot partials go through LDS across the groups of a workgroup;
+//   * grids are capped (<= 4096 workgroups, contiguous row ranges per workgroup) and remapped so
+//     that each XCD streams one contiguous slice of rows (mgp_xcd_block).
 #include "mgp_common.h"
 #include "mgp_internal.h"
 
@@ -52,33 +53,15 @@ struct SpmmArgs {
   MgpCommit commit;  // tile kernel only: packed row record written in the epilogue (fused CG step)
 };
 
-// Streaming (read-once) matrix entries: non-temporal 16-byte loads bypass the 32 KB L1, which is then
-// left to the gathered x lines (a k-NN row block re-uses the x lines of its few neighbour blocks).
 typedef int mgp_v4i __attribute__((ext_vector_type(4)));
 typedef float mgp_v4f __attribute__((ext_vector_type(4)));
-int g_stream_nt = 0;
-int g_spmv_block = 256;    // workgroup size of the C == 1 kernel (256 / 512 / 1024)
 
-// NT = true: buffer loads with the sc1 cache policy (served by L2, no L1 allocation).  The resource is
-// built from the wave-uniform array base; the entry index goes in the per-lane byte offset.
-template <bool NT>
 __device__ __forceinline__ int4 load_col4(const int32_t* base, int idx) {
-  if (NT) {
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, 0x7fffffff, 0x00020000);
-    const mgp_v4i v = __builtin_bit_cast(mgp_v4i, __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 4, 0, 16));
-    return make_int4(v.x, v.y, v.z, v.w);
-  }
   const mgp_v4i v = *reinterpret_cast<const mgp_v4i*>(base + idx);
   return make_int4(v.x, v.y, v.z, v.w);
 }
 
-template <bool NT>
 __device__ __forceinline__ float4 load_val4(const float* base, int idx) {
-  if (NT) {
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, (short)0, 0x7fffffff, 0x00020000);
-    const mgp_v4f v = __builtin_bit_cast(mgp_v4f, __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 4, 0, 16));
-    return make_float4(v.x, v.y, v.z, v.w);
-  }
   const mgp_v4f v = *reinterpret_cast<const mgp_v4f*>(base + idx);
   return make_float4(v.x, v.y, v.z, v.w);
 }
@@ -99,8 +82,9 @@ __device__ __forceinline__ float epilogue(const SpmmArgs& p, int64_t r, int c, f
 // then R shuffle reductions.  Three dependent memory phases per group instead of 3R: at N = 60k
 // the kernel is latency-bound (the matrix is cache resident), so bytes in flight per lane is
 // what sets the rate.  Rows longer than 4G entries take the (rare) remainder loop.
-template <int G, int R, bool PRE, bool NT, int BS>
-__global__ __launch_bounds__(BS) void spmv_kernel(SpmmArgs p) {
+template <int G, int R, bool PRE>
+__global__ __launch_bounds__(kBlock) void spmv_kernel(SpmmArgs p) {
+  constexpr int BS = kBlock;
   if (p.skip && *p.skip) return;
   if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
   const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
@@ -140,8 +124,8 @@ __global__ __launch_bounds__(BS) void spmv_kernel(SpmmArgs p) {
       const int i = s[t] + 4 * lane;
       const bool on = i < s[t + 1];
       const int ii = on ? i : 0;
-      c[t] = load_col4<NT>(p.col, ii);
-      const float4 vv = load_val4<NT>(p.vals, ii);
+      c[t] = load_col4(p.col, ii);
+      const float4 vv = load_val4(p.vals, ii);
       v[t] = make_float4(on ? vv.x : 0.f, on ? vv.y : 0.f, on ? vv.z : 0.f, on ? vv.w : 0.f);
     }
     // keep the phases apart: all 2R stream loads are in flight before the first gather issues
@@ -167,8 +151,8 @@ __global__ __launch_bounds__(BS) void spmv_kernel(SpmmArgs p) {
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       for (int i = s[t] + 4 * lane + 4 * G; i < s[t + 1]; i += 4 * G) {
-        const int4 cc = load_col4<NT>(p.col, i);
-        const float4 vv = load_val4<NT>(p.vals, i);
+        const int4 cc = load_col4(p.col, i);
+        const float4 vv = load_val4(p.vals, i);
         float x0 = x[cc.x], x1 = x[cc.y], x2 = x[cc.z], x3 = x[cc.w];
         if (PRE) { x0 *= p.pre[cc.x]; x1 *= p.pre[cc.y]; x2 *= p.pre[cc.z]; x3 *= p.pre[cc.w]; }
         acc[t] = fmaf(vv.x, x0, acc[t]);
@@ -200,263 +184,6 @@ __global__ __launch_bounds__(BS) void spmv_kernel(SpmmArgs p) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < BS / MGP_WAVE; ++w) t += red[w];
-      p.dot_partials[lb] = t;
-    }
-  }
-}
-
-// ---------------------------------------------------------------- C == 1, lane-strided entries
-// Same ownership (G lanes x R rows) but lane l reads entries l, l+G, l+2G, ... of a row with 4-byte
-// loads: one gather instruction then covers G CONSECUTIVE sorted column ids of a row, which mostly
-// fall into a few cache lines of x, so the texture unit merges them into few L2 requests.  With
-// 16-byte-per-lane loads every lane of a gather instruction sits 4 entries apart and nearly every
-// lane pulls its own 64-B line: measured on the 60k graph the L2 -> L1 gather traffic (not HBM, not
-// latency) is what bounds the kernel.
-template <int G, int R, bool PRE>
-__global__ __launch_bounds__(kBlock) void spmv_strided_kernel(SpmmArgs p) {
-  if (p.skip && *p.skip) return;
-  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
-  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
-  const int lane = threadIdx.x & (G - 1);
-  const int grp = threadIdx.x / G;
-  constexpr int kGroups = kBlock / G;
-  const int64_t r0 = (int64_t)lb * p.rows_per_block;
-  int64_t r1 = r0 + p.rows_per_block;
-  if (r1 > p.n) r1 = p.n;
-  const float* __restrict__ x = p.X;
-  float dsum = 0.f;
-  for (int64_t rb = r0 + (int64_t)grp * R; rb < r1; rb += (int64_t)kGroups * R) {
-    int s[R + 1];
-#pragma unroll
-    for (int t = 0; t <= R; ++t) {
-      const int64_t rr = rb + t;
-      s[t] = p.rowptr[rr < r1 ? rr : r1];
-    }
-    const int64_t myr = rb + lane;
-    const bool mine = lane < R && myr < r1;
-    const int64_t er = mine ? myr : r0;
-    const int64_t ger = er + p.goff;
-    float e_x = x[ger];
-    if (PRE) e_x *= p.pre[ger];
-    const float e_diag = p.diag[er];
-    const float e_post = p.post ? p.post[ger] : 1.f;
-    const float e_base = p.base ? p.base[ger] : 0.f;
-    const float e_dotw = p.dotw ? p.dotw[ger] : 0.f;
-    int c[R];
-    float v[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      const int i = s[t] + lane;
-      const bool on = i < s[t + 1];
-      const int ii = on ? i : 0;
-      c[t] = p.col[ii];
-      const float vv = p.vals[ii];
-      v[t] = on ? vv : 0.f;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float xg[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      xg[t] = x[c[t]];
-      if (PRE) xg[t] *= p.pre[c[t]];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    float acc[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) acc[t] = v[t] * xg[t];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      for (int i = s[t] + lane + G; i < s[t + 1]; i += G) {
-        const int cc = p.col[i];
-        float xv = x[cc];
-        if (PRE) xv *= p.pre[cc];
-        acc[t] = fmaf(p.vals[i], xv, acc[t]);
-      }
-    }
-    float my_acc = 0.f;
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      const float tot = mgp_group_sum<G>(acc[t]);
-      if (lane == t) my_acc = tot;
-    }
-    if (mine) {
-      const float lx = e_diag * e_x - my_acc;
-      const float tt = (p.a * e_x + p.b * lx) * e_post;
-      const float y = p.co * tt + p.cb * e_base;
-      p.Y[myr + p.goff] = y;
-      dsum = fmaf(e_dotw, y, dsum);
-    }
-  }
-  if (p.dot_partials) {
-    __shared__ float red[kBlock / MGP_WAVE];
-    dsum = mgp_wave_sum(dsum);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = dsum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < kBlock / MGP_WAVE; ++w) t += red[w];
-      p.dot_partials[lb] = t;
-    }
-  }
-}
-
-// ---------------------------------------------------------------- C == 1, x panels staged in LDS
-// Measured (tools/lab/gather.hip): 4-byte gathers that miss the 32 KB L1 cost one 128-B line fill
-// each -- ~0.5 gathers per clock per CU -- and that, not HBM, bounds the kernels above on graphs with
-// long-range edges (39 % of the 60k bench graph).  Here the rows are additionally split by COLUMN
-// PANEL (mgp_graph_build: segptr), a workgroup of 1024 lanes stages one panel of x (<= 32768 columns =
-// 128 KB, already multiplied by `pre`) in LDS with coalesced 16-byte loads and every gather becomes a
-// ds_read.  Row ownership: 8 lanes x 2 rows per lane group, 256 rows per workgroup; the first-pass
-// stream loads of a panel are issued before the barrier that publishes the panel; panels in which
-// the workgroup has no entries are skipped (banded graphs touch 1-3 panels).
-constexpr int kPanelThreads = 1024;
-constexpr int kPanelLanes = 8;
-constexpr int kPanelRowsPerGroup = 2;
-constexpr int kPanelRowsPerBlock = kPanelThreads / kPanelLanes * kPanelRowsPerGroup;   // 256
-
-// STAGE = true: panel in LDS.  STAGE = false: same panel-major sweep but the gathers go to global
-// memory; the workgroup's waves stay in the same panel (one barrier per panel), so during a panel the
-// CU only touches a PW-column window of x -- with PW * 4 B <= the 32 KB L1 the long-range gathers hit
-// L1 after the first touch of a line (cache blocking) instead of paying one line fill each.
-template <bool PRE, bool STAGE>
-__global__ __launch_bounds__(kPanelThreads) void spmv_panel_kernel(SpmmArgs p, const int32_t* __restrict__ segptr,
-                                                                   int P, int PW, int64_t ncols) {
-  extern __shared__ __attribute__((aligned(16))) float xs[];
-  if (p.skip && *p.skip) return;
-  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
-  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
-  const int tid = threadIdx.x;
-  const int lane = tid & (kPanelLanes - 1);
-  const int grp = tid / kPanelLanes;
-  constexpr int R = kPanelRowsPerGroup;
-  const int64_t rb = (int64_t)lb * kPanelRowsPerBlock + (int64_t)grp * R;
-  const float* __restrict__ x = p.X;
-  // epilogue operands of "my" row, in flight from the start
-  const int64_t myr = rb + lane;
-  const bool mine = lane < R && myr < p.n;
-  const int64_t er = mine ? myr : 0;
-  const int64_t ger = er + p.goff;
-  float e_x = x[ger];
-  if (PRE) e_x *= p.pre[ger];
-  const float e_diag = p.diag[er];
-  const float e_post = p.post ? p.post[ger] : 1.f;
-  const float e_base = p.base ? p.base[ger] : 0.f;
-  const float e_dotw = p.dotw ? p.dotw[ger] : 0.f;
-
-  float acc[R];
-#pragma unroll
-  for (int t = 0; t < R; ++t) acc[t] = 0.f;
-
-  for (int pnl = 0; pnl < P; ++pnl) {
-    int s[R], e[R];
-    bool any = false;
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      const int64_t r = rb + t;
-      const bool valid = r < p.n;
-      const int64_t q = (valid ? r : 0) * P + pnl;
-      const int a0 = segptr[q], a1 = segptr[q + 1];
-      s[t] = valid ? a0 : 0;
-      e[t] = valid ? a1 : 0;
-      any |= e[t] > s[t];
-    }
-    // barrier 1: nobody still reads the previous panel; also votes whether this panel is needed
-    if (!__syncthreads_or(any ? 1 : 0)) continue;
-    const int64_t c0 = (int64_t)pnl * PW;
-    const int width = (int)((ncols - c0) < PW ? (ncols - c0) : PW);
-    // stage the panel: all (up to 8) 16-byte loads of a lane are issued before the first LDS store
-    // (a load -> store loop makes hipcc wait for every load in turn: 8 serial L2 round trips)
-    constexpr int kStage = STAGE ? 32768 / (kPanelThreads * 4) : 0;   // 8 float4 per lane for a full panel
-    float4 stage[kStage > 0 ? kStage : 1];
-    const int wsafe = width >= 4 ? width - 4 : 0;
-#pragma unroll
-    for (int k = 0; k < kStage; ++k) {
-      const int i = (tid + k * kPanelThreads) * 4;
-      const int ii = i < wsafe ? i : wsafe;                 // clamped: unconditional load
-      float4 v4 = *reinterpret_cast<const float4*>(x + c0 + ii);
-      if (PRE) {
-        const float4 s4 = *reinterpret_cast<const float4*>(p.pre + c0 + ii);
-        v4.x *= s4.x; v4.y *= s4.y; v4.z *= s4.z; v4.w *= s4.w;
-      }
-      stage[k] = v4;
-    }
-    // first pass of the stream loads does not depend on the panel: in flight across barrier 2
-    int4 c[R];
-    float4 v[R];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      const int i = s[t] + 4 * lane;
-      const bool on = i < e[t];
-      const int ii = on ? i : 0;
-      const int4 cc = *reinterpret_cast<const int4*>(p.col + ii);
-      const float4 vv = *reinterpret_cast<const float4*>(p.vals + ii);
-      const int cb = (int)c0;
-      c[t] = make_int4(on ? cc.x - cb : 0, on ? cc.y - cb : 0, on ? cc.z - cb : 0, on ? cc.w - cb : 0);
-      v[t] = make_float4(on ? vv.x : 0.f, on ? vv.y : 0.f, on ? vv.z : 0.f, on ? vv.w : 0.f);
-    }
-#pragma unroll
-    for (int k = 0; k < kStage; ++k) {
-      const int i = (tid + k * kPanelThreads) * 4;
-      if (i + 4 <= width) *reinterpret_cast<float4*>(xs + i) = stage[k];
-    }
-    (void)wsafe;
-    if (STAGE && tid < (width & 3)) {                       // ragged tail (width not a multiple of 4)
-      const int k = (width & ~3) + tid;
-      xs[k] = PRE ? x[c0 + k] * p.pre[c0 + k] : x[c0 + k];
-    }
-    if (STAGE) __syncthreads();   // barrier 2: the panel is published
-    const float* __restrict__ xp = STAGE ? xs : (x + c0);
-    const float* __restrict__ pp = p.pre + c0;
-    auto gx = [&](int j) -> float {
-      float r = xp[j];
-      if (PRE && !STAGE) r *= pp[j];
-      return r;
-    };
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      float a = acc[t];
-      const float g0 = gx(c[t].x), g1 = gx(c[t].y), g2 = gx(c[t].z), g3 = gx(c[t].w);
-      a = fmaf(v[t].x, g0, a);
-      a = fmaf(v[t].y, g1, a);
-      a = fmaf(v[t].z, g2, a);
-      a = fmaf(v[t].w, g3, a);
-      for (int i = s[t] + 4 * lane + 4 * kPanelLanes; i < e[t]; i += 4 * kPanelLanes) {
-        const int4 cc = *reinterpret_cast<const int4*>(p.col + i);
-        const float4 vv = *reinterpret_cast<const float4*>(p.vals + i);
-        const int cb = (int)c0;
-        const float h0 = gx(cc.x - cb), h1 = gx(cc.y - cb), h2 = gx(cc.z - cb), h3 = gx(cc.w - cb);
-        a = fmaf(vv.x, h0, a);
-        a = fmaf(vv.y, h1, a);
-        a = fmaf(vv.z, h2, a);
-        a = fmaf(vv.w, h3, a);
-      }
-      acc[t] = a;
-    }
-  }
-  float my_acc = 0.f;
-#pragma unroll
-  for (int t = 0; t < R; ++t) {
-    const float tot = mgp_group_sum<kPanelLanes>(acc[t]);
-    if (lane == t) my_acc = tot;
-  }
-  float dsum = 0.f;
-  if (mine) {
-    const float lx = e_diag * e_x - my_acc;
-    const float tt = (p.a * e_x + p.b * lx) * e_post;
-    const float y = p.co * tt + p.cb * e_base;
-    p.Y[myr + p.goff] = y;
-    dsum = e_dotw * y;
-  }
-  if (p.dot_partials) {
-    __shared__ float red[kPanelThreads / MGP_WAVE];
-    dsum = mgp_wave_sum(dsum);
-    if ((tid & 63) == 0) red[tid >> 6] = dsum;
-    __syncthreads();
-    if (tid == 0) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < kPanelThreads / MGP_WAVE; ++w) t += red[w];
       p.dot_partials[lb] = t;
     }
   }
@@ -764,10 +491,6 @@ Plan make_plan(int64_t n, int rows_per_pass) {
 // (mgp_spmm_set_group_hint); measured best on the 60k and 500k graphs: 8 lanes x 1 row (tools/tune_spmv.py).
 int g_row_group_hint = 16;
 int g_rows_in_flight = 1;
-int g_entry_layout = 0;   // 0: 4 consecutive entries per lane (16-B loads), 1: lane-strided entries
-int g_panel_mode = 0;     // (experiment, off) sweep column panels when the CSR carries the panel structure
-bool g_panel_attr_set[2] = {false, false};
-int g_panel_stage_min_width = 16384;   // panels at least this wide are staged in LDS, narrower ones rely on L1
 
 }  // namespace
 
@@ -783,12 +506,6 @@ extern "C" int mgp_spmm_set_rows_in_flight(int rows) {
   return MGP_OK;
 }
 
-extern "C" int mgp_spmm_set_entry_layout(int layout) {
-  if (layout != 0 && layout != 1) return MGP_ERR_ARG;
-  g_entry_layout = layout;
-  return MGP_OK;
-}
-
 static int spmv_rows_in_flight() {
   int r = g_rows_in_flight;
   if (r > g_row_group_hint) r = g_row_group_hint;   // lane t finishes row t: needs R <= G
@@ -799,24 +516,6 @@ static int spmm_cols_group(int C) {
   int g = 4;
   while (g < C && g < 64) g <<= 1;
   return g;
-}
-
-extern "C" int mgp_spmm_set_block(int threads) {
-  if (threads != 256 && threads != 512 && threads != 1024) return MGP_ERR_ARG;
-  g_spmv_block = threads;
-  return MGP_OK;
-}
-
-static int spmv_block_threads() { return (g_entry_layout == 0 && !g_stream_nt) ? g_spmv_block : kBlock; }
-
-extern "C" int mgp_spmm_set_stream_nt(int on) {
-  g_stream_nt = on ? 1 : 0;
-  return MGP_OK;
-}
-
-extern "C" int mgp_spmm_set_panel_mode(int on) {
-  g_panel_mode = on ? 1 : 0;
-  return MGP_OK;
 }
 
 int g_tile_mode = 1;
@@ -844,11 +543,6 @@ static int tile_grid(const mgp_csr_t* L, int* tiles_per_block) {
   return (int)mgp_cdiv(ntiles, tpb);
 }
 
-static bool use_panels(const mgp_csr_t* L, int C) {
-  return C == 1 && g_panel_mode && L->segptr != nullptr && L->panels >= 1 && L->panel_width > 0 &&
-         L->panel_width <= 32768 && (L->panel_width % 4) == 0;
-}
-
 int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, size_t* lds_bytes) {
   if (!L || !use_tiles(L, C)) return 0;
   const int g = tile_grid(L, tiles_per_block);
@@ -859,7 +553,6 @@ int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, si
 
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (!L) return MGP_ERR_ARG;
-  if (use_panels(L, C)) return (int)mgp_cdiv(L->n, kPanelRowsPerBlock);
   if (use_tiles(L, C)) return tile_grid(L, nullptr);
   return mgp_spmm_dot_blocks(L->n, C);
 }
@@ -871,22 +564,13 @@ extern "C" int mgp_spmm_dot_blocks_csr(const mgp_csr_t* L, int C) {
 
 extern "C" int mgp_spmm_dot_blocks(int64_t n, int C) {
   if (n <= 0 || C <= 0) return MGP_ERR_ARG;
-  int groups = (C == 1) ? (spmv_block_threads() / g_row_group_hint) * spmv_rows_in_flight() : kBlock / spmm_cols_group(C) * 4;
+  int groups = (C == 1) ? (kBlock / g_row_group_hint) * spmv_rows_in_flight() : kBlock / spmm_cols_group(C) * 4;
   return make_plan(n, groups).grid;
 }
 
 template <int G, int R, bool PRE>
 static void launch_spmv(const SpmmArgs& a, int grid, hipStream_t st) {
-  if (g_entry_layout == 1)
-    hipLaunchKernelGGL((spmv_strided_kernel<G, R, PRE>), dim3(grid), dim3(kBlock), 0, st, a);
-  else if (g_stream_nt)
-    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, true, 256>), dim3(grid), dim3(256), 0, st, a);
-  else if (g_spmv_block == 1024)
-    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, false, 1024>), dim3(grid), dim3(1024), 0, st, a);
-  else if (g_spmv_block == 512)
-    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, false, 512>), dim3(grid), dim3(512), 0, st, a);
-  else
-    hipLaunchKernelGGL((spmv_kernel<G, R, PRE, false, 256>), dim3(grid), dim3(256), 0, st, a);
+  hipLaunchKernelGGL((spmv_kernel<G, R, PRE>), dim3(grid), dim3(kBlock), 0, st, a);
 }
 
 template <int G, bool PRE>
@@ -936,30 +620,10 @@ int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X
   SpmmArgs p{L->n, L->rowptr, L->col, L->vals, L->diag, X, Y, C, a, b, pre, post, base, cb, co,
              dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset, MgpCommit{nullptr, nullptr, nullptr, nullptr}};
   if (commit) {
-    if (!use_tiles(L, C) || (use_panels(L, C))) return MGP_ERR_UNSUPPORTED;   // row copies ride in the tile kernel only
+    if (!use_tiles(L, C)) return MGP_ERR_UNSUPPORTED;   // the row records ride in the tile kernel only
     p.commit = *commit;
   }
-  if (use_panels(L, C)) {
-    const int grid = (int)mgp_cdiv(L->n, kPanelRowsPerBlock);
-    const int64_t ncols = L->ncols > 0 ? L->ncols : L->n;
-    const bool stage = L->panel_width >= g_panel_stage_min_width;
-    const size_t lds = stage ? (size_t)L->panel_width * sizeof(float) : 0;
-    const int which = pre ? 1 : 0;
-    if (stage && !g_panel_attr_set[which]) {
-      const void* fn = pre ? reinterpret_cast<const void*>(&spmv_panel_kernel<true, true>)
-                           : reinterpret_cast<const void*>(&spmv_panel_kernel<false, true>);
-      MGP_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 32768 * (int)sizeof(float)));
-      g_panel_attr_set[which] = true;
-    }
-#define MGP_PANEL_LAUNCH(PP, SS)                                                                            \
-  hipLaunchKernelGGL((spmv_panel_kernel<PP, SS>), dim3(grid), dim3(kPanelThreads), lds, st, p, L->segptr, \
-                     L->panels, L->panel_width, ncols)
-    if (pre && stage) MGP_PANEL_LAUNCH(true, true);
-    else if (pre) MGP_PANEL_LAUNCH(true, false);
-    else if (stage) MGP_PANEL_LAUNCH(false, true);
-    else MGP_PANEL_LAUNCH(false, false);
-#undef MGP_PANEL_LAUNCH
-  } else if (use_tiles(L, C)) {
+  if (use_tiles(L, C)) {
     TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols};
     const int grid = tile_grid(L, &ta.tiles_per_block);
     const size_t lds = tile_lds_bytes(L);
@@ -975,7 +639,7 @@ int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X
   } else if (C == 1) {
     const int G = g_row_group_hint;
     const int R = spmv_rows_in_flight();
-    Plan pl = make_plan(L->n, (spmv_block_threads() / G) * R);
+    Plan pl = make_plan(L->n, (kBlock / G) * R);
     p.rows_per_block = pl.rows_per_block;
     int rc = MGP_OK;
 #define MGP_SPMV_CASE(GG)                                                                     \

@@ -13,10 +13,6 @@ from . import _lib
 from ._lib import check, lib, ptr, stream
 
 
-PANEL_WIDTH = 32768        # columns of x staged in LDS at a time by the C == 1 SpMV (128 KB of fp32)
-MAX_PANELS = 4             # beyond this every workgroup would re-read too much of x: gather kernel
-
-
 TILE_ROWS = 64             # rows per SpMV tile (workgroup of 256 lanes); 32 / 64 / 128 are supported
 
 
@@ -47,21 +43,11 @@ def build_tiles(n, rowptr, col, nnz, tile_rows=None):
     return None
 
 
-def default_panel_width(n):
-    """Column panels are an experiment that did not pay on MI355X (tools/tune_panels.py: every panel
-    sweep costs 2-5 us of barriers and staging, more than the gathers it saves): off by default."""
-    return 0
-
-
 class KnnGraph:
-    def __init__(self, n, tri_row, tri_col, tri_val, rowptr, col, d2, eid, segptr=None, panel_width=0,
-                 tiles="auto"):
+    def __init__(self, n, tri_row, tri_col, tri_val, rowptr, col, d2, eid, tiles="auto"):
         self.n = int(n)
         self.tri_row, self.tri_col, self.tri_val = tri_row, tri_col, tri_val
         self.rowptr, self.col, self.d2, self.eid = rowptr, col, d2, eid
-        self.segptr = segptr
-        self.panel_width = int(panel_width) if segptr is not None else 0
-        self.panels = -(-self.n // self.panel_width) if self.panel_width > 0 else 0
         self.M = int(tri_val.shape[0])
         self.nnz = int(col.shape[0])
         self._edge_index = None
@@ -83,8 +69,7 @@ class KnnGraph:
 
     def csr_with(self, vals, diag):
         """mgp_csr_t over this graph's structure with the given entry values / diagonal."""
-        return _lib.csr_struct(self.n, self.rowptr, self.col, vals, diag, self.segptr, self.panels, self.panel_width,
-                               tiles=self.tiles)
+        return _lib.csr_struct(self.n, self.rowptr, self.col, vals, diag, tiles=self.tiles)
 
     @property
     def edge_index(self):
@@ -99,18 +84,15 @@ class KnnGraph:
 
     # ------------------------------------------------------------------ builders
     @classmethod
-    def from_knn(cls, D, I, panel_width=None, tiles="auto"):
+    def from_knn(cls, D, I, tiles="auto"):
         """(D[n,k] f32, I[n,k] i32) on device -> KnnGraph via mgp_graph_build."""
         _lib.require_device(D, I)
         n, k = I.shape
         dev = D.device
         D = _lib.f32c(D)
         I = I.to(torch.int32).contiguous()
-        pw = default_panel_width(n) if panel_width is None else int(panel_width)
-        P = -(-n // pw) if pw > 0 else 1
         cap_e = n * (k - 1)
-        cap_z = 2 * cap_e + 4 * n * P
-        segptr = torch.empty(n * P + 1, dtype=torch.int32, device=dev) if pw > 0 else None
+        cap_z = 2 * cap_e + 4 * n
         tri_row = torch.empty(cap_e, dtype=torch.int32, device=dev)
         tri_col = torch.empty(cap_e, dtype=torch.int32, device=dev)
         tri_val = torch.empty(cap_e, dtype=torch.float32, device=dev)
@@ -118,18 +100,18 @@ class KnnGraph:
         col = torch.empty(cap_z, dtype=torch.int32, device=dev)
         d2 = torch.empty(cap_z, dtype=torch.float32, device=dev)
         eid = torch.empty(cap_z, dtype=torch.int32, device=dev)
-        wb = lib().mgp_graph_workspace_bytes(n, k, pw)
+        wb = lib().mgp_graph_workspace_bytes(n, k)
         work = _lib.workspace(wb, "graph", dev)
         M, nnz = ctypes.c_int64(0), ctypes.c_int64(0)
-        check(lib().mgp_graph_build(ptr(D), ptr(I), n, k, pw, ptr(tri_row), ptr(tri_col), ptr(tri_val),
-                                    ctypes.byref(M), ptr(rowptr), ptr(segptr), ptr(col), ptr(d2), ptr(eid),
+        check(lib().mgp_graph_build(ptr(D), ptr(I), n, k, ptr(tri_row), ptr(tri_col), ptr(tri_val),
+                                    ctypes.byref(M), ptr(rowptr), ptr(col), ptr(d2), ptr(eid),
                                     ctypes.byref(nnz), ptr(work), work.numel(), stream()), "mgp_graph_build")
         M, nnz = M.value, nnz.value
         return cls(n, tri_row[:M].clone(), tri_col[:M].clone(), tri_val[:M].clone(), rowptr,
-                   col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone(), segptr, pw, tiles=tiles)
+                   col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone(), tiles=tiles)
 
     @classmethod
-    def from_coo(cls, idx, val, n, panel_width=None, tiles="auto"):
+    def from_coo(cls, idx, val, n, tiles="auto"):
         """Reference-style edge list (idx[2,M] any int dtype, val[M]) -> KnnGraph."""
         _lib.require_device(idx, val)
         dev = val.device
@@ -137,23 +119,20 @@ class KnnGraph:
         tri_row = idx[0].to(torch.int32).contiguous()
         tri_col = idx[1].to(torch.int32).contiguous()
         tri_val = _lib.f32c(val.reshape(-1))
-        pw = default_panel_width(n) if panel_width is None else int(panel_width)
-        P = -(-n // pw) if pw > 0 else 1
-        cap_z = 2 * M + 4 * n * P
-        segptr = torch.empty(n * P + 1, dtype=torch.int32, device=dev) if pw > 0 else None
+        cap_z = 2 * M + 4 * n
         rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
         col = torch.empty(cap_z, dtype=torch.int32, device=dev)
         d2 = torch.empty(cap_z, dtype=torch.float32, device=dev)
         eid = torch.empty(cap_z, dtype=torch.int32, device=dev)
-        wb = lib().mgp_graph_coo_workspace_bytes(n, M, pw)
+        wb = lib().mgp_graph_coo_workspace_bytes(n, M)
         work = _lib.workspace(wb, "graph", dev)
         nnz = ctypes.c_int64(0)
-        check(lib().mgp_graph_from_coo(ptr(tri_row), ptr(tri_col), ptr(tri_val), M, n, pw, ptr(rowptr), ptr(segptr),
+        check(lib().mgp_graph_from_coo(ptr(tri_row), ptr(tri_col), ptr(tri_val), M, n, ptr(rowptr),
                                        ptr(col), ptr(d2), ptr(eid), ctypes.byref(nnz), ptr(work), work.numel(),
                                        stream()), "mgp_graph_from_coo")
         nnz = nnz.value
         g = cls(n, tri_row, tri_col, tri_val, rowptr, col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone(),
-                segptr, pw, tiles=tiles)
+                tiles=tiles)
         if idx.dtype == torch.int64:
             g._edge_index = idx
         return g

@@ -64,13 +64,7 @@ def pad_graph(graph, n_pad):
         return graph
     extra = n_pad - graph.n
     rowptr = torch.cat([graph.rowptr, graph.rowptr[-1:].expand(extra)])
-    segptr, pw = None, 0
-    if graph.segptr is not None and -(-n_pad // graph.panel_width) == graph.panels:
-        # same number of column panels after padding: the new (empty) rows add `panels` segment starts each
-        segptr = torch.cat([graph.segptr, graph.segptr[-1:].expand(extra * graph.panels)])
-        pw = graph.panel_width
-    g = KnnGraph(n_pad, graph.tri_row, graph.tri_col, graph.tri_val, rowptr, graph.col, graph.d2, graph.eid,
-                 segptr, pw)
+    g = KnnGraph(n_pad, graph.tri_row, graph.tri_col, graph.tri_val, rowptr, graph.col, graph.d2, graph.eid)
     g.spmv_lanes = graph.spmv_lanes
     return g
 
@@ -85,25 +79,19 @@ def local_csr(lap_data, part, rank):
     col = g.col[e0:e1] if e1 > e0 else torch.zeros(4, dtype=torch.int32, device=g.device)
     vals = lap_data.vals[e0:e1] if e1 > e0 else torch.zeros(4, dtype=torch.float32, device=g.device)
     diag = lap_data.diag[r0:r1].contiguous()
-    segptr = None
-    if getattr(g, "segptr", None) is not None:
-        P = g.panels
-        segptr = (g.segptr[r0 * P:r1 * P + 1] - e0).contiguous()
     tiles = None
     gt = getattr(g, "tiles", None)
     if gt is not None and e1 > e0 and r0 % gt["rows"] == 0 and (r1 - r0) % gt["rows"] == 0:
         # the slice's tiles are whole tiles of the global graph: offsets into tile_cols stay absolute
         tiles = dict(gt, tile_ptr=gt["tile_ptr"][r0 // gt["rows"]:r1 // gt["rows"] + 1].contiguous(), lid=gt["lid"][e0:e1])
-    return dict(n_loc=part.n_loc, rowptr=rowptr, col=col, vals=vals, diag=diag, e0=e0, e1=e1, segptr=segptr,
-                panels=getattr(g, "panels", 0), panel_width=getattr(g, "panel_width", 0), ncols=g.n, tiles=tiles)
+    return dict(n_loc=part.n_loc, rowptr=rowptr, col=col, vals=vals, diag=diag, e0=e0, e1=e1, ncols=g.n, tiles=tiles)
 
 
 def local_operator_struct(desc, part, rank):
     """mgp_operator_t for the local rows of a Descriptor built on the padded graph."""
     loc = local_csr(desc.data, part, rank)
     op = desc.struct()
-    op.L = _lib.csr_struct(loc["n_loc"], loc["rowptr"], loc["col"], loc["vals"], loc["diag"], loc["segptr"],
-                           loc["panels"] if loc["segptr"] is not None else 0, loc["panel_width"], loc["ncols"],
+    op.L = _lib.csr_struct(loc["n_loc"], loc["rowptr"], loc["col"], loc["vals"], loc["diag"], loc["ncols"],
                            tiles=loc["tiles"])
     return op, loc
 

@@ -477,8 +477,7 @@ def test_row_partitioned_spmm_tiles_the_full_product(mgp, golden, dev, P, C):
     tiled = torch.full_like(X, float("nan"))
     for r in range(P):
         loc = local_csr(data, part, r)
-        lc = _lib.csr_struct(loc["n_loc"], loc["rowptr"], loc["col"], loc["vals"], loc["diag"], loc["segptr"],
-                             loc["panels"] if loc["segptr"] is not None else 0, loc["panel_width"], loc["ncols"],
+        lc = _lib.csr_struct(loc["n_loc"], loc["rowptr"], loc["col"], loc["vals"], loc["diag"], loc["ncols"],
                              tiles=loc["tiles"])
         _lib.check(lib.mgp_spmm_fused_rows(ctypes.byref(lc), part.range(r)[0], _lib.ptr(X), C, _lib.ptr(tiled), 1.5, 1.0,
                                            _lib.ptr(pre), _lib.ptr(pre), _lib.ptr(X), 0.5, 2.0, None, None,
@@ -514,51 +513,6 @@ def test_distributed_plan_world1_matches_single_gpu(mgp, golden, dev):
     r1 = desc.apply(xs) - T(g["train_y"], dev)
     assert float(r.norm() / y.norm()) < max(1e-4, 3 * float(r1.norm() / y.norm()))
     plan.close()
-
-
-@pytest.mark.parametrize("pw", [0, 256, 512, 4096])
-def test_panel_spmv_matches_gather_kernel(mgp, golden, dev, pw):
-    """C == 1 SpMV with x panels staged in LDS (several panel widths -> 1..7 panels) against the
-    gather kernel and the fp64 oracle; fused epilogue, pre/post scalings and dot partials included."""
-    import ctypes
-    from manifold_gp_amd import _lib
-    from manifold_gp_amd.graph import KnnGraph, LaplacianData
-    from oracle.laplacian import LaplacianOracle
-    g = golden("dumbbell_k10_loop")
-    n = g["train_x"].shape[0]
-    idx, val = T(g["edge_index"].astype(np.int64), dev), T(g["edge_value"], dev)
-    graph = KnnGraph.from_coo(idx, val, n, panel_width=pw)
-    assert graph.panels == (-(-n // pw) if pw else 0)
-    if pw:
-        sp = graph.segptr.cpu().numpy()
-        assert np.array_equal(sp[::graph.panels], graph.rowptr.cpu().numpy()) and (np.diff(sp) >= 0).all() and (sp % 4 == 0).all()
-        col = graph.col.cpu().numpy()
-        for t_ in (0, 5, len(sp) - 2):                      # columns of a segment stay inside its panel
-            seg = col[sp[t_]:sp[t_ + 1]]
-            assert ((seg // pw) == (t_ % graph.panels)).all()
-    data = LaplacianData(graph, float(g["eps"]), True)
-    lib = _lib.lib()
-    x = torch.randn(n, 1, device=dev)
-    pre = torch.rand(n, device=dev) + 0.5
-    base = torch.randn(n, 1, device=dev)
-    outs = {}
-    for mode in (0, 1):
-        lib.mgp_spmm_set_panel_mode(mode)
-        csr = data.csr()
-        y = torch.empty_like(x)
-        nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), 1)
-        part = torch.zeros(max(nb, 1), device=dev)
-        _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(x), 1, _lib.ptr(y), 1.25, 1.0, _lib.ptr(pre), _lib.ptr(pre),
-                                      _lib.ptr(base), 0.5, 2.0, _lib.ptr(x), _lib.ptr(part), _lib.stream()), "mgp_spmm_fused")
-        outs[mode] = (y.clone(), float(part.sum()))
-    lib.mgp_spmm_set_panel_mode(1)
-    lo = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "symmetric", True, dtype=np.float64)
-    xs = (pre.cpu().numpy().astype(np.float64)[:, None] * x.cpu().numpy())
-    ref = 0.5 * base.cpu().numpy() + 2.0 * pre.cpu().numpy()[:, None] * (1.25 * xs + lo.matmul(xs))
-    tol = 4e-6 * np.abs(lo.diag).max() * np.abs(xs).max() * 2.0
-    for mode in (0, 1):
-        np.testing.assert_allclose(outs[mode][0].cpu().numpy(), ref, rtol=0, atol=tol)
-        assert abs(outs[mode][1] - float((x.cpu().double() * torch.from_numpy(ref)).sum())) < 1e-3 * np.abs(ref).max() * n ** 0.5
 
 
 def test_slq_logdet_vs_dense(mgp, golden, dev):

@@ -34,11 +34,11 @@ def test_library_exports_every_header_symbol():
 def test_struct_layouts_match_c_abi():
     """mgp_csr_t / mgp_operator_t / params structs: sizes as the C compiler lays them out."""
     from manifold_gp_amd import _lib
-    assert ctypes.sizeof(_lib.CsrT) == 104
-    assert ctypes.sizeof(_lib.OperatorT) == 104 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
+    assert ctypes.sizeof(_lib.CsrT) == 88
+    assert ctypes.sizeof(_lib.OperatorT) == 88 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
     assert ctypes.sizeof(_lib.CgParamsT) == 28
     assert ctypes.sizeof(_lib.LanczosParamsT) == 24
-    assert _lib.OperatorT.pre.offset == 104 and _lib.OperatorT.nu.offset == 120
+    assert _lib.OperatorT.pre.offset == 88 and _lib.OperatorT.nu.offset == 104
 
 
 def test_argument_errors_without_gpu():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time the C == 1 fused SpMV for every (lanes per row, rows in flight) shape on the bench graph
+"""Time the C == 1 gather (fallback) SpMV for every (lanes per row, rows in flight) shape on the bench graph
 (interleaved rounds in one process, cdna_hip_programming.md rule 24).  GPU box only."""
 import argparse
 import json
@@ -30,20 +30,17 @@ def main():
     sym = lap._symmetric_twin()
     v = torch.rand(g.n, 1, device=dev)
     B = bench.spmm_bytes(g.n, g.M)
-    shapes = [(L, G, R) for L in (0, 1) for G in (8, 16, 32, 64) for R in (1, 2, 4, 8) if R <= G]
+    shapes = [(0, G, R) for G in (8, 16, 32, 64) for R in (1, 2, 4, 8) if R <= G]
     if a.quick:
-        shapes = [(L, G, R) for L in (256, 512, 1024) for (G, R) in ((8, 1), (8, 2), (8, 4), (16, 2), (16, 4))]
+        shapes = [(0, G, R) for (G, R) in ((8, 1), (8, 2), (8, 4), (16, 2), (16, 4))]
+    lib_ = _lib.lib()
+    lib_.mgp_spmm_set_tile_mode(0)          # this tool tunes the gather (fallback) kernel
     times = {s: [] for s in shapes}
     lib = _lib.lib()
     for rnd in range(a.rounds):
         for (L, G, R) in shapes:
             g.spmv_lanes = G
             lib.mgp_spmm_set_rows_in_flight(R)
-            if L >= 256:
-                lib.mgp_spmm_set_entry_layout(0)
-                lib.mgp_spmm_set_block(L)
-            else:
-                lib.mgp_spmm_set_entry_layout(L)
             import ctypes
             lib.mgp_spmm_set_group_hint(G)
             csr = sym.data.csr()
