@@ -469,6 +469,104 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------- C in {4, 8, 12, 16}
+// Lanes are laid over ENTRIES, not over columns.  spmm_kernel above broadcasts every (col, val) pair to
+// the lanes of a row group with __shfl, which hipcc lowers to ds_bpermute_b32: two LDS-pipe round trips
+// per entry, ~45 us per launch at N = 60k for any C <= 16.  Here a row is owned by one 16-lane DPP row;
+// LPE = 1 / 2 / 4 adjacent lanes share one entry and each loads ONE 16-byte quarter of the X row of its
+// column (adjacent lanes -> one 64-byte texture access per entry), multiplies and accumulates its own
+// partial sums over the passes of the row; at the end of the row the partials of the lanes holding the
+// same quarter are summed with DPP row rotations (8, 4, 2, 1 down to LPE): no LDS, no broadcast.
+// Lanes 0 .. C/4-1 then hold the row's C results, run the epilogue and store 16 bytes each.
+template <int ROT>
+__device__ __forceinline__ float dpp_ror_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + ROT, 0xf, 0xf, true));
+}
+
+template <int LPE>
+__device__ __forceinline__ float row16_class_sum(float v) {   // sum over lanes l, l + LPE, l + 2 LPE, ... of a DPP row
+  v = dpp_ror_add<8>(v);
+  if (LPE <= 4) v = dpp_ror_add<4>(v);
+  if (LPE <= 2) v = dpp_ror_add<2>(v);
+  if (LPE <= 1) v = dpp_ror_add<1>(v);
+  return v;
+}
+
+template <int C4, bool PRE>
+__global__ __launch_bounds__(kBlock) void spmm_row16_kernel(SpmmArgs p) {
+  if (p.skip && *p.skip) return;
+  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
+  constexpr int C = 4 * C4, G = 16, kGroups = kBlock / G;
+  constexpr int LPE = C4 == 1 ? 1 : (C4 == 2 ? 2 : 4);   // lanes per entry
+  constexpr int EP = G / LPE;                            // entries per pass of a row group
+  constexpr int U = 4;                                   // passes in flight
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int lane = threadIdx.x & (G - 1);
+  const int grp = threadIdx.x / G;
+  const int q = lane % LPE, el = lane / LPE;
+  const bool qon = q < C4;                               // C = 12: the fourth lane of an entry idles
+  const int64_t r0 = (int64_t)lb * p.rows_per_block;
+  int64_t r1 = r0 + p.rows_per_block;
+  if (r1 > p.n) r1 = p.n;
+  const mgp_v4f* __restrict__ X4 = reinterpret_cast<const mgp_v4f*>(p.X);
+  mgp_v4f dsum = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0 + grp; r < r1; r += kGroups) {
+    const int s = p.rowptr[r], e = p.rowptr[r + 1];
+    mgp_v4f acc = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+    for (int i0 = s; i0 < e; i0 += U * EP) {
+      int cj[U];
+      float vj[U];
+      mgp_v4f xr[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * EP + el;
+        const bool on = i < e;
+        const int ii = on ? i : s;               // clamped: unconditional loads (s < e here)
+        const int cc = p.col[ii];
+        const float vv = p.vals[ii];
+        cj[u] = cc;
+        vj[u] = on ? vv : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (PRE) vj[u] *= p.pre[cj[u]];
+        xr[u] = X4[(int64_t)cj[u] * C4 + (qon ? q : 0)];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        acc.x = fmaf(vj[u], xr[u].x, acc.x); acc.y = fmaf(vj[u], xr[u].y, acc.y);
+        acc.z = fmaf(vj[u], xr[u].z, acc.z); acc.w = fmaf(vj[u], xr[u].w, acc.w);
+      }
+    }
+    acc.x = row16_class_sum<LPE>(acc.x); acc.y = row16_class_sum<LPE>(acc.y);
+    acc.z = row16_class_sum<LPE>(acc.z); acc.w = row16_class_sum<LPE>(acc.w);
+    if (el == 0 && qon) {                        // lanes 0 .. C4-1: columns 4q .. 4q+3 of this row
+      const int64_t gr = r + p.goff;
+      const float prer = PRE ? p.pre[gr] : 1.f;
+      const mgp_v4f xin = X4[gr * C4 + q];
+      mgp_v4f y;
+      y.x = epilogue(p, r, 4 * q + 0, xin.x * prer, acc.x); y.y = epilogue(p, r, 4 * q + 1, xin.y * prer, acc.y);
+      y.z = epilogue(p, r, 4 * q + 2, xin.z * prer, acc.z); y.w = epilogue(p, r, 4 * q + 3, xin.w * prer, acc.w);
+      *reinterpret_cast<mgp_v4f*>(p.Y + gr * C + 4 * q) = y;
+      if (p.dotw) {
+        const float* dw = p.dotw + gr * C + 4 * q;
+        dsum.x = fmaf(dw[0], y.x, dsum.x); dsum.y = fmaf(dw[1], y.y, dsum.y);
+        dsum.z = fmaf(dw[2], y.z, dsum.z); dsum.w = fmaf(dw[3], y.w, dsum.w);
+      }
+    }
+  }
+  if (p.dot_partials) {
+    __shared__ float red[kGroups][16];
+    if (el == 0 && qon) { red[grp][4 * q] = dsum.x; red[grp][4 * q + 1] = dsum.y; red[grp][4 * q + 2] = dsum.z; red[grp][4 * q + 3] = dsum.w; }
+    __syncthreads();
+    if (threadIdx.x < C) {
+      float t = 0.f;
+      for (int g = 0; g < kGroups; ++g) t += red[g][threadIdx.x];
+      p.dot_partials[(int64_t)lb * C + threadIdx.x] = t;
+    }
+  }
+}
+
 struct Plan {
   int grid;
   int64_t rows_per_block;
@@ -518,6 +616,14 @@ static int spmm_cols_group(int C) {
   return g;
 }
 
+// rows a workgroup covers per pass (the grid / dot-partial count follows from it).  C in {4,8,12,16}
+// uses 64 whichever kernel runs (the row16 kernel needs 16-byte aligned X, the generic one does not)
+static int spmm_rows_per_pass(int C) {
+  if (C == 1) return (kBlock / g_row_group_hint) * spmv_rows_in_flight();
+  if (C <= 16 && (C & 3) == 0) return (kBlock / 16) * 4;
+  return kBlock / spmm_cols_group(C) * 4;
+}
+
 int g_tile_mode = 1;
 
 extern "C" int mgp_spmm_set_tile_mode(int on) {
@@ -564,8 +670,7 @@ extern "C" int mgp_spmm_dot_blocks_csr(const mgp_csr_t* L, int C) {
 
 extern "C" int mgp_spmm_dot_blocks(int64_t n, int C) {
   if (n <= 0 || C <= 0) return MGP_ERR_ARG;
-  int groups = (C == 1) ? (kBlock / g_row_group_hint) * spmv_rows_in_flight() : kBlock / spmm_cols_group(C) * 4;
-  return make_plan(n, groups).grid;
+  return make_plan(n, spmm_rows_per_pass(C)).grid;
 }
 
 template <int G, int R, bool PRE>
@@ -656,10 +761,23 @@ int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X
     }
 #undef MGP_SPMV_CASE
     MGP_TRY(rc);
+  } else if (C <= 16 && (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15) == 0) {
+    Plan pl = make_plan(L->n, spmm_rows_per_pass(C));
+    p.rows_per_block = pl.rows_per_block;
+#define MGP_ROW16_LAUNCH(C4)                                                                                   \
+  do {                                                                                                         \
+    if (pre) hipLaunchKernelGGL((spmm_row16_kernel<C4, true>), dim3(pl.grid), dim3(kBlock), 0, st, p);          \
+    else hipLaunchKernelGGL((spmm_row16_kernel<C4, false>), dim3(pl.grid), dim3(kBlock), 0, st, p);             \
+  } while (0)
+    if (C == 4) MGP_ROW16_LAUNCH(1);
+    else if (C == 8) MGP_ROW16_LAUNCH(2);
+    else if (C == 12) MGP_ROW16_LAUNCH(3);
+    else MGP_ROW16_LAUNCH(4);
+#undef MGP_ROW16_LAUNCH
   } else {
     const int G = spmm_cols_group(C);
     const int nacc = (int)mgp_cdiv(C, G);
-    Plan pl = make_plan(L->n, (kBlock / G) * 4);
+    Plan pl = make_plan(L->n, spmm_rows_per_pass(C));
     p.rows_per_block = pl.rows_per_block;
 #define MGP_SPMM_LAUNCH(GG, NA)                                    \
   do {                                                             \

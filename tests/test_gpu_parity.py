@@ -155,7 +155,7 @@ def test_reference_pass_criterion(mgp, golden, dev, norm):
     assert ref_round_equal(op.diagonal().cpu().numpy(), g[p + "diag"])
 
 
-@pytest.mark.parametrize("C", [1, 2, 3, 7, 16, 33, 64, 100, 130, 256, 300])
+@pytest.mark.parametrize("C", [1, 2, 3, 4, 7, 8, 12, 16, 33, 64, 100, 130, 256, 300])
 def test_spmm_column_counts_vs_oracle(mgp, golden, dev, C):
     from oracle.laplacian import LaplacianOracle
     g = golden("dumbbell_k10_loop")
