@@ -91,10 +91,28 @@ int mgp_graph_from_coo(const int32_t* tri_row, const int32_t* tri_col, const flo
  *   tile_ptr [ceil(n/tile_rows)+1], tile_cols [capacity nnz], lid [nnz]  (device, caller allocated)
  *   total_cols / max_cols / max_entries: host outputs.  MGP_ERR_UNSUPPORTED when a tile references
  *   more than 65536 distinct columns (use a smaller tile or leave the dictionaries off). */
-size_t mgp_graph_tiles_workspace_bytes(int64_t nnz);
+size_t mgp_graph_tiles_workspace_bytes(int64_t n, int64_t nnz);
+/* row_order (nullable): a permutation of the rows; tile t then holds rows row_order[64 t .. 64 t + 63]
+ * (locality order for inputs that arrive unordered).  With it the tile view is a second CSR in that
+ * order: tile_rowptr [n+1] (entry offsets), emap [nnz] (tile-order entry -> entry of the CSR: gather
+ * the values through it, mgp_csr_t.tile_vals), lid in tile order; column ids stay the original ones. */
 int mgp_graph_tiles(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t nnz, int tile_rows,
-                    int32_t* tile_ptr, int32_t* tile_cols, uint16_t* lid, int64_t* total_cols,
-                    int32_t* max_cols, int32_t* max_entries, void* work, size_t work_bytes, void* stream);
+                    const int32_t* row_order, int32_t* tile_rowptr, int32_t* emap, int32_t* tile_ptr,
+                    int32_t* tile_cols, uint16_t* lid, int64_t* total_cols, int32_t* max_cols,
+                    int32_t* max_entries, void* work, size_t work_bytes, void* stream);
+
+/* Breadth-first (Cuthill-McKee style) locality order of the graph: order [n] = node ids level by level,
+ * a level sorted by (position of the first-numbered parent, node id); components are appended one
+ * after the other.  Deterministic.  For inputs whose node order carries no locality (random point
+ * order) the tile dictionaries built on this order recover the reuse a spatially sorted input has.
+ * Synchronises `stream` (one host round trip per BFS level). */
+/* Morton (Z-curve) order of points with d <= 3: int32 [n] permutation, ascending code.  The cheaper and
+ * tighter alternative to the BFS order when coordinates of low dimension are at hand.  Synchronises. */
+size_t mgp_morton_order_workspace_bytes(int64_t n);
+int mgp_morton_order(const float* x, int64_t n, int d, int32_t* order, void* work, size_t work_bytes, void* stream);
+size_t mgp_graph_bfs_workspace_bytes(int64_t n);
+int mgp_graph_bfs_order(int64_t n, const int32_t* rowptr, const int32_t* col, int32_t* order, void* work,
+                        size_t work_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Laplacian build: diffusion-maps normalisation of the kernel weights, fused row passes.
@@ -146,6 +164,10 @@ typedef struct {
   int32_t tile_max_cols;     /* max over tiles of the list length (LDS floats per workgroup) */
   int32_t tile_max_entries;  /* max over tiles of the padded entry count */
   int32_t tile_reserved;
+  /* tiles over a row ORDER (mgp_graph_tiles with row_order): all NULL = tile t is rows 64 t .. 64 t + 63 */
+  const int32_t* tile_rowptr;  /* [n+1] entry offsets in tile order */
+  const float* tile_vals;      /* [nnz] vals gathered through emap */
+  const int32_t* tile_rowid;   /* [n] original row of every tile-order position (= row_order) */
 } mgp_csr_t;
 
 /* workgroups that write dot partials for this CSR (format aware; use this one to size dot_partials) */

@@ -38,7 +38,8 @@ class CsrT(Structure):
                 ("diag", c_void_p),
                 ("ncols", c_int64), ("tile_ptr", c_void_p), ("tile_cols", c_void_p), ("lid", c_void_p),
                 ("tile_rows", c_int32), ("tile_max_cols", c_int32), ("tile_max_entries", c_int32),
-                ("tile_reserved", c_int32)]
+                ("tile_reserved", c_int32), ("tile_rowptr", c_void_p), ("tile_vals", c_void_p),
+                ("tile_rowid", c_void_p)]
 
 
 class OperatorT(Structure):
@@ -66,9 +67,13 @@ SIGNATURES = {
     "mgp_knn_search": (c_int, [_P, c_int64, c_int, _P, c_int64, c_int, _P, _P, _P, c_size_t,
                                POINTER(c_int64), _P]),
     "mgp_graph_workspace_bytes": (c_size_t, [c_int64, c_int]),
-    "mgp_graph_tiles_workspace_bytes": (c_size_t, [c_int64]),
-    "mgp_graph_tiles": (c_int, [c_int64, _P, _P, c_int64, c_int, _P, _P, _P, POINTER(c_int64), POINTER(c_int32),
-                                POINTER(c_int32), _P, c_size_t, _P]),
+    "mgp_graph_tiles_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "mgp_graph_tiles": (c_int, [c_int64, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, POINTER(c_int64),
+                                POINTER(c_int32), POINTER(c_int32), _P, c_size_t, _P]),
+    "mgp_morton_order_workspace_bytes": (c_size_t, [c_int64]),
+    "mgp_morton_order": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _P]),
+    "mgp_graph_bfs_workspace_bytes": (c_size_t, [c_int64]),
+    "mgp_graph_bfs_order": (c_int, [c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "mgp_spmm_dot_blocks_csr": (c_int, [POINTER(CsrT), c_int]),
     "mgp_spmm_set_tile_mode": (c_int, [c_int]),
     "mgp_cg_set_fuse": (c_int, [c_int]),
@@ -192,11 +197,15 @@ def workspace(nbytes, tag, device):
     return buf
 
 
-def csr_struct(n, rowptr, col, vals, diag, ncols=0, tiles=None):
+def csr_struct(n, rowptr, col, vals, diag, ncols=0, tiles=None, tile_vals=None):
     """tiles: None or the dict KnnGraph.tiles holds (tile_ptr, tile_cols, lid tensors + rows / max_cols /
-    max_entries)."""
+    max_entries; for tiles over a row order also tile_rowptr / rowid / emap).  tile_vals: `vals` gathered
+    through tiles["emap"] -- required with ordered tiles, which are otherwise left out of the struct."""
     s = CsrT(int(n), rowptr.data_ptr(), col.data_ptr(), vals.data_ptr(), diag.data_ptr(), int(ncols))
-    if tiles is not None:
+    if tiles is not None and (tiles.get("rowid") is None or tile_vals is not None):
         s.tile_ptr, s.tile_cols, s.lid = tiles["tile_ptr"].data_ptr(), tiles["tile_cols"].data_ptr(), tiles["lid"].data_ptr()
         s.tile_rows, s.tile_max_cols, s.tile_max_entries = tiles["rows"], tiles["max_cols"], tiles["max_entries"]
+        if tiles.get("rowid") is not None:
+            s.tile_rowptr, s.tile_rowid = tiles["tile_rowptr"].data_ptr(), tiles["rowid"].data_ptr()
+            s.tile_vals = tile_vals.data_ptr()
     return s

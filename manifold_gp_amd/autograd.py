@@ -32,7 +32,7 @@ def _spmm(data, X, a, b, pre, post, base, cb, co, tangent=False):
     check(lib().mgp_spmm_set_group_hint(g.spmv_lanes), "mgp_spmm_set_group_hint")
     if tangent:
         t = data.tangent()
-        csr = g.csr_with(t.d_vals, t.d_diag)
+        csr = g.csr_with(t.d_vals, t.d_diag, t.d_vals_t)
     else:
         csr = data.csr()
     X = _lib.f32c(X)

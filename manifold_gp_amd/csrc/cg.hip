@@ -478,6 +478,7 @@ struct CgFuse {
   float* t0;          // output of the chain's launch 0
   int nb;             // partial slots = workgroups of this grid
   const float* rws;   // [n][4] = {r, w, s, pre} per row, published by the previous apply's last SpMV
+  const int32_t* rowid;   // nullable: tiles over a row order (rowptr / vals are then the tile-order arrays)
 };
 
 __global__ __launch_bounds__(kBlock, 4) void cg_fused_step_kernel(CgArgs a, CgFuse f) {   // <= 128 VGPRs: 4 workgroups per CU, the 60k grid (938) in one round
@@ -524,10 +525,11 @@ __global__ __launch_bounds__(kBlock, 4) void cg_fused_step_kernel(CgArgs a, CgFu
     // own row operands (round trip 1 as well: the row index needs no metadata)
     const int64_t row = r0 + (tid >> 2);
     const bool valid = row < r1;
-    const int64_t rr_ = valid ? row : r0;
+    const int64_t pr_ = valid ? row : r0;                                  // position in the tile order
+    const int64_t rr_ = f.rowid ? (int64_t)f.rowid[pr_] : pr_;             // row of the vectors
     const cgf_v4f o_rec = rws[rr_];
     const float o_p = a.p[rr_], o_x = a.x[rr_], o_diag = f.diag[rr_];
-    const int rs = f.rowptr[rr_], re = f.rowptr[rr_ + 1];
+    const int rs = f.rowptr[pr_], re = f.rowptr[pr_ + 1];
     __builtin_amdgcn_sched_barrier(0);
     // ---- round trip 2: dictionary ids + first half of the matrix stream
     unsigned c[NQ];
@@ -979,9 +981,10 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
       a.nbv = fg; a.rows_per_block = (int64_t)ftpb * (kBlock / 4);
       const float tau = 2.0f * (float)op->nu / (op->kappa * op->kappa);
       pl->t0 = mgp_operator_first_out(op, 1, pl->op_work, pl->op_work_bytes);
-      pl->fuse = CgFuse{op->L.rowptr, op->L.vals, op->L.diag, op->L.tile_ptr,
-                        reinterpret_cast<const uint32_t*>(op->L.tile_cols), op->L.lid,
-                        mgp_cdiv(op->L.n, (int64_t)op->L.tile_rows), ftpb, op->L.tile_max_cols, tau, op->pre, pl->t0, fg, pl->rws};
+      pl->fuse = CgFuse{op->L.tile_rowptr ? op->L.tile_rowptr : op->L.rowptr, op->L.tile_vals ? op->L.tile_vals : op->L.vals,
+                        op->L.diag, op->L.tile_ptr, reinterpret_cast<const uint32_t*>(op->L.tile_cols), op->L.lid,
+                        mgp_cdiv(op->L.n, (int64_t)op->L.tile_rows), ftpb, op->L.tile_max_cols, tau, op->pre, pl->t0, fg, pl->rws,
+                        op->L.tile_rowid};
       if (!pl->t0) pl->fused = false;
     }
   }

@@ -279,6 +279,33 @@ extern "C" size_t mgp_graph_coo_workspace_bytes(int64_t n, int64_t M) {
 // so the texture-path accesses drop from one per entry to one per distinct column.
 namespace {
 
+// ordered tiles: position p of the tile order holds original row row_order[p]
+__global__ void order_lengths(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ row_order, int64_t n,
+                              int32_t* __restrict__ len) {
+  for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p <= n; p += (int64_t)gridDim.x * blockDim.x)
+    len[p] = p < n ? rowptr[row_order[p] + 1] - rowptr[row_order[p]] : 0;
+}
+
+// keys / entry map in tile order: entry i of position p <- entry rowptr[row_order[p]] + i of the CSR
+__global__ void tile_keys_ordered(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                  const int32_t* __restrict__ row_order, const int32_t* __restrict__ tile_rowptr,
+                                  int64_t n, int tile_rows, uint64_t* __restrict__ keys, int32_t* __restrict__ pos,
+                                  int32_t* __restrict__ emap) {
+  const int lane = threadIdx.x & 15;
+  const int64_t g = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t p = g; p < n; p += ng) {
+    const uint64_t tile = (uint64_t)(p / tile_rows);
+    const int src = rowptr[row_order[p]];
+    const int dst = tile_rowptr[p], cnt = tile_rowptr[p + 1] - dst;
+    for (int i = lane; i < cnt; i += 16) {
+      keys[dst + i] = (tile << 32) | (uint32_t)col[src + i];
+      pos[dst + i] = dst + i;
+      emap[dst + i] = src + i;
+    }
+  }
+}
+
 __global__ void tile_keys(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n,
                           int tile_rows, uint64_t* __restrict__ keys, int32_t* __restrict__ pos) {
   const int lane = threadIdx.x & 15;
@@ -324,7 +351,7 @@ __global__ void tile_fill(const uint64_t* __restrict__ keys, const int32_t* __re
   }
 }
 
-__global__ void tile_extents(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ tile_ptr, int64_t n,
+__global__ void tile_extents(const int32_t* __restrict__ rowptr /* in tile order */, const int32_t* __restrict__ tile_ptr, int64_t n,
                              int tile_rows, int64_t ntiles, int32_t* __restrict__ maxima) {
   int mc = 0, me = 0;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < ntiles;
@@ -340,38 +367,54 @@ __global__ void tile_extents(const int32_t* __restrict__ rowptr, const int32_t* 
   atomicMax(&maxima[1], me);
 }
 
-size_t tile_bytes(int64_t nnz) {
-  size_t b = 2 * mgp_align(nnz * sizeof(uint64_t)) + 4 * mgp_align((nnz + 1) * sizeof(int32_t));
-  return b + cub_bytes_for(nnz) + 4096;
+size_t tile_bytes(int64_t n, int64_t nnz) {
+  const int64_t items = nnz > n + 2 ? nnz : n + 2;      // some scratch doubles as per-row storage
+  size_t b = 2 * mgp_align(items * sizeof(uint64_t)) + 4 * mgp_align((items + 1) * sizeof(int32_t));
+  return b + cub_bytes_for(items) + 4096;
 }
 
 }  // namespace
 
-extern "C" size_t mgp_graph_tiles_workspace_bytes(int64_t nnz) { return nnz > 0 ? tile_bytes(nnz) : 0; }
+extern "C" size_t mgp_graph_tiles_workspace_bytes(int64_t n, int64_t nnz) { return (n > 0 && nnz > 0) ? tile_bytes(n, nnz) : 0; }
 
 extern "C" int mgp_graph_tiles(int64_t n, const int32_t* rowptr, const int32_t* col, int64_t nnz, int tile_rows,
-                               int32_t* tile_ptr, int32_t* tile_cols, uint16_t* lid, int64_t* total_cols,
-                               int32_t* max_cols, int32_t* max_entries, void* work, size_t work_bytes,
-                               void* stream) {
+                               const int32_t* row_order, int32_t* tile_rowptr, int32_t* emap, int32_t* tile_ptr,
+                               int32_t* tile_cols, uint16_t* lid, int64_t* total_cols, int32_t* max_cols,
+                               int32_t* max_entries, void* work, size_t work_bytes, void* stream) {
   if (!rowptr || !col || !tile_ptr || !tile_cols || !lid || !total_cols || !max_cols || !max_entries || !work)
     return MGP_ERR_ARG;
+  if (row_order && (!tile_rowptr || !emap)) return MGP_ERR_ARG;
   if (n <= 0 || nnz <= 0 || nnz > 0x7fffffff || tile_rows < 1) return MGP_ERR_ARG;
   hipStream_t st = mgp_stream(stream);
   const int64_t ntiles = mgp_cdiv(n, tile_rows);
   MgpArena ar(work, work_bytes);
-  uint64_t* keys_a = ar.take<uint64_t>(nnz);
-  uint64_t* keys_b = ar.take<uint64_t>(nnz);
-  int32_t* pos_a = ar.take<int32_t>(nnz + 1);
-  int32_t* pos_b = ar.take<int32_t>(nnz + 1);
-  int32_t* head = ar.take<int32_t>(nnz + 1);
-  int32_t* uidx = ar.take<int32_t>(nnz + 1);
-  size_t cub_bytes = cub_bytes_for(nnz);
+  const int64_t items = nnz > n + 2 ? nnz : n + 2;
+  uint64_t* keys_a = ar.take<uint64_t>(items);
+  uint64_t* keys_b = ar.take<uint64_t>(items);
+  int32_t* pos_a = ar.take<int32_t>(items + 1);
+  int32_t* pos_b = ar.take<int32_t>(items + 1);
+  int32_t* head = ar.take<int32_t>(items + 1);
+  int32_t* uidx = ar.take<int32_t>(items + 1);
+  size_t cub_bytes = cub_bytes_for(items);
   void* cub = ar.take<char>(cub_bytes);
   int32_t* maxima = ar.take<int32_t>(2);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
 
-  hipLaunchKernelGGL(tile_keys, dim3(grid_for(n * 16)), dim3(kBlock), 0, st, rowptr, col, n, tile_rows, keys_a, pos_a);
-  MGP_LAUNCH_CHECK();
+  const int32_t* rp_tile = rowptr;          // row pointers in tile order
+  if (row_order) {
+    // lengths of the rows in tile order -> tile_rowptr (head is free scratch of >= n + 1 ints here)
+    hipLaunchKernelGGL(order_lengths, dim3(grid_for(n + 1)), dim3(kBlock), 0, st, rowptr, row_order, n, head);
+    MGP_LAUNCH_CHECK();
+    size_t tb0 = cub_bytes;
+    MGP_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(cub, tb0, head, tile_rowptr, (int)(n + 1), st));
+    hipLaunchKernelGGL(tile_keys_ordered, dim3(grid_for(n * 16)), dim3(kBlock), 0, st, rowptr, col, row_order, tile_rowptr,
+                       n, tile_rows, keys_a, pos_a, emap);
+    MGP_LAUNCH_CHECK();
+    rp_tile = tile_rowptr;
+  } else {
+    hipLaunchKernelGGL(tile_keys, dim3(grid_for(n * 16)), dim3(kBlock), 0, st, rowptr, col, n, tile_rows, keys_a, pos_a);
+    MGP_LAUNCH_CHECK();
+  }
   hipcub::DoubleBuffer<uint64_t> kb(keys_a, keys_b);
   hipcub::DoubleBuffer<int32_t> vb(pos_a, pos_b);
   size_t tb = cub_bytes;
@@ -389,7 +432,7 @@ extern "C" int mgp_graph_tiles(int64_t n, const int32_t* rowptr, const int32_t* 
                      tile_cols, lid);
   MGP_LAUNCH_CHECK();
   MGP_HIP_TRY(hipMemsetAsync(maxima, 0, 2 * sizeof(int32_t), st));
-  hipLaunchKernelGGL(tile_extents, dim3(grid_for(ntiles)), dim3(kBlock), 0, st, rowptr, tile_ptr, n, tile_rows, ntiles,
+  hipLaunchKernelGGL(tile_extents, dim3(grid_for(ntiles)), dim3(kBlock), 0, st, rp_tile, tile_ptr, n, tile_rows, ntiles,
                      maxima);
   MGP_LAUNCH_CHECK();
   int32_t h[2] = {0, 0}, last = 0;
@@ -400,4 +443,142 @@ extern "C" int mgp_graph_tiles(int64_t n, const int32_t* rowptr, const int32_t* 
   *max_cols = h[0];
   *max_entries = h[1];
   return h[0] > 65536 ? MGP_ERR_UNSUPPORTED : MGP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Locality order for inputs that arrive unordered (random point order: a 64-row tile then references
+// ~64 x row-length distinct columns and the dictionary SpMV degenerates to one gather per entry).
+// Breadth-first (Cuthill-McKee style) numbering of the k-NN graph: level by level, the nodes of a level
+// sorted by (position of their first-numbered parent, node id).  Works for any ambient dimension, needs
+// only the CSR.  Deterministic: the parent of a node is the MINIMUM position among its numbered
+// neighbours (atomicMin), ties broken by node id in the per-level radix sort.
+namespace {
+
+__global__ void bfs_expand(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                           const int32_t* __restrict__ frontier, int fcount, int base,
+                           const int32_t* __restrict__ pos, uint32_t* __restrict__ pkey,
+                           int32_t* __restrict__ cand, int32_t* __restrict__ ccount) {
+  const int lane = threadIdx.x & 15;
+  const int64_t g = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 4;
+  const int64_t ng = ((int64_t)gridDim.x * blockDim.x) >> 4;
+  for (int64_t f = g; f < fcount; f += ng) {
+    const int v = frontier[f];
+    const uint32_t mypos = (uint32_t)(base + f);
+    for (int i = rowptr[v] + lane, e = rowptr[v + 1]; i < e; i += 16) {
+      const int c = col[i];
+      if (pos[c] >= 0) continue;                       // numbered already (incl. padding entries: c == v)
+      const uint32_t old = atomicMin(&pkey[c], mypos);
+      if (old == 0xffffffffu) cand[atomicAdd(ccount, 1)] = c;   // first touch: c joins the next level once
+    }
+  }
+}
+
+__global__ void bfs_keys(const int32_t* __restrict__ cand, int m, const uint32_t* __restrict__ pkey,
+                         uint64_t* __restrict__ keys) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+    keys[i] = ((uint64_t)pkey[cand[i]] << 32) | (uint32_t)cand[i];
+}
+
+__global__ void bfs_number(const uint64_t* __restrict__ keys, int m, int base, int32_t* __restrict__ pos,
+                           int32_t* __restrict__ frontier, int32_t* __restrict__ order) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const int v = (int)(keys[i] & 0xffffffffu);
+    pos[v] = base + i;
+    frontier[i] = v;
+    order[base + i] = v;
+  }
+}
+
+__global__ void bfs_first_unvisited(const int32_t* __restrict__ pos, int64_t n, int from, int32_t* __restrict__ out) {
+  for (int64_t i = from + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (pos[i] < 0) { atomicMin(out, (int32_t)i); return; }
+}
+
+__global__ void bfs_seed(int32_t v, int base, int32_t* __restrict__ pos, int32_t* __restrict__ frontier,
+                         int32_t* __restrict__ order) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { pos[v] = base; frontier[0] = v; order[base] = v; }
+}
+
+__global__ void bfs_append_rest(int32_t* __restrict__ pos, int64_t n, int32_t* __restrict__ order, int32_t* __restrict__ counter) {
+  // level cap reached (pathological diameter): the remaining nodes are appended behind the numbered ones
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    if (pos[i] < 0) { const int p = atomicAdd(counter, 1); pos[i] = p; order[p] = (int32_t)i; }
+}
+
+}  // namespace
+
+extern "C" size_t mgp_graph_bfs_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  size_t b = 3 * mgp_align((size_t)n * sizeof(int32_t)) + mgp_align((size_t)n * sizeof(uint32_t));
+  b += 2 * mgp_align((size_t)n * sizeof(uint64_t)) + cub_bytes_for(n) + mgp_align(64);
+  return b + 4096;
+}
+
+extern "C" int mgp_graph_bfs_order(int64_t n, const int32_t* rowptr, const int32_t* col, int32_t* order, void* work,
+                                   size_t work_bytes, void* stream) {
+  if (!rowptr || !col || !order || !work || n <= 0 || n > 0x7fffffff) return MGP_ERR_ARG;
+  if (work_bytes < mgp_graph_bfs_workspace_bytes(n)) return MGP_ERR_WORKSPACE;
+  hipStream_t st = mgp_stream(stream);
+  MgpArena ar(work, work_bytes);
+  int32_t* pos = ar.take<int32_t>(n);
+  int32_t* frontier = ar.take<int32_t>(n);
+  int32_t* cand = ar.take<int32_t>(n);
+  uint32_t* pkey = ar.take<uint32_t>(n);
+  uint64_t* keys_a = ar.take<uint64_t>(n);
+  uint64_t* keys_b = ar.take<uint64_t>(n);
+  const size_t cub_bytes = cub_bytes_for(n);
+  void* cub = ar.take<char>(cub_bytes);
+  int32_t* counters = ar.take<int32_t>(16);      // [0] candidates of the level, [1] first unvisited
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  MGP_HIP_TRY(hipMemsetAsync(pos, 0xff, (size_t)n * sizeof(int32_t), st));
+  MGP_HIP_TRY(hipMemsetAsync(pkey, 0xff, (size_t)n * sizeof(uint32_t), st));
+  int numbered = 0, fcount = 0, fbase = 0, scan_from = 0;
+  int64_t levels = 0;
+  const int64_t level_cap = 200000;
+  while (numbered < n) {
+    if (fcount == 0) {                               // next component: seed = smallest unnumbered node
+      int32_t big = 0x7fffffff;
+      MGP_HIP_TRY(hipMemcpyAsync(counters + 1, &big, sizeof(int32_t), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(bfs_first_unvisited, dim3(grid_for(n - scan_from)), dim3(kBlock), 0, st, pos, n, scan_from, counters + 1);
+      MGP_LAUNCH_CHECK();
+      int32_t seed = 0;
+      MGP_HIP_TRY(hipMemcpyAsync(&seed, counters + 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      MGP_HIP_TRY(hipStreamSynchronize(st));
+      if (seed >= n) break;
+      hipLaunchKernelGGL(bfs_seed, dim3(1), dim3(64), 0, st, seed, numbered, pos, frontier, order);
+      MGP_LAUNCH_CHECK();
+      scan_from = seed + 1;
+      fbase = numbered;
+      fcount = 1;
+      numbered += 1;
+      continue;
+    }
+    if (++levels > level_cap) break;
+    MGP_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(int32_t), st));
+    hipLaunchKernelGGL(bfs_expand, dim3(grid_for((int64_t)fcount * 16)), dim3(kBlock), 0, st, rowptr, col, frontier, fcount,
+                       fbase, pos, pkey, cand, counters);
+    MGP_LAUNCH_CHECK();
+    int32_t m = 0;
+    MGP_HIP_TRY(hipMemcpyAsync(&m, counters, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    if (m > 0) {
+      hipLaunchKernelGGL(bfs_keys, dim3(grid_for(m)), dim3(kBlock), 0, st, cand, m, pkey, keys_a);
+      MGP_LAUNCH_CHECK();
+      hipcub::DoubleBuffer<uint64_t> kb(keys_a, keys_b);
+      size_t tb = cub_bytes;
+      MGP_HIP_TRY(hipcub::DeviceRadixSort::SortKeys(cub, tb, kb, m, 0, 64, st));
+      hipLaunchKernelGGL(bfs_number, dim3(grid_for(m)), dim3(kBlock), 0, st, kb.Current(), m, numbered, pos, frontier, order);
+      MGP_LAUNCH_CHECK();
+    }
+    fbase = numbered;
+    fcount = m;
+    numbered += m;
+  }
+  if (numbered < n) {
+    MGP_HIP_TRY(hipMemcpyAsync(counters, &numbered, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(bfs_append_rest, dim3(grid_for(n)), dim3(kBlock), 0, st, pos, n, order, counters);
+    MGP_LAUNCH_CHECK();
+  }
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  return MGP_OK;
 }

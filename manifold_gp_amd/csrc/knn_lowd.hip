@@ -412,3 +412,49 @@ int mgp_knn_scatter_rows(const float* Ds, const int32_t* Is, const int32_t* rows
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
+
+// Morton (Z-curve) order of points with d <= 3: the row order handed to mgp_graph_tiles when the input
+// order carries no locality (graph.py); same codes as the k-NN path above.
+extern "C" size_t mgp_morton_order_workspace_bytes(int64_t n) {
+  if (n <= 0) return 0;
+  return 2 * mgp_align((size_t)n * sizeof(uint64_t)) + mgp_align((size_t)n * sizeof(int32_t)) + cub_sort_bytes(n) +
+         mgp_align((size_t)1024 * 6 * sizeof(float)) + 4096;
+}
+
+extern "C" int mgp_morton_order(const float* x, int64_t n, int d, int32_t* order, void* work, size_t work_bytes,
+                                void* stream) {
+  if (!x || !order || !work || n <= 0 || n > INT_MAX || d < 1 || d > 3) return MGP_ERR_ARG;
+  if (work_bytes < mgp_morton_order_workspace_bytes(n)) return MGP_ERR_WORKSPACE;
+  hipStream_t st = mgp_stream(stream);
+  MgpArena ar(work, work_bytes);
+  uint64_t* codes_a = ar.take<uint64_t>(n);
+  uint64_t* codes_b = ar.take<uint64_t>(n);
+  int32_t* idx_a = ar.take<int32_t>(n);
+  const size_t cub_bytes = cub_sort_bytes(n);
+  void* cub = ar.take<char>(cub_bytes);
+  float* boxpart = ar.take<float>(1024 * 6);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  const int bgrid = (int)std::min<int64_t>(1024, mgp_cdiv(n, kBlock));
+  hipLaunchKernelGGL(minmax_kernel, dim3(bgrid), dim3(kBlock), 0, st, x, n, d, boxpart);
+  MGP_LAUNCH_CHECK();
+  std::vector<float> hp((size_t)bgrid * 6);
+  MGP_HIP_TRY(hipMemcpyAsync(hp.data(), boxpart, hp.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  Box box;
+  for (int a = 0; a < 3; ++a) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int b = 0; b < bgrid; ++b) { lo = std::min(lo, hp[(size_t)b * 6 + a]); hi = std::max(hi, hp[(size_t)b * 6 + 3 + a]); }
+    if (!(hi > lo) || !std::isfinite(lo) || !std::isfinite(hi)) { box.lo[a] = std::isfinite(lo) ? lo : 0.f; box.inv[a] = 0.f; }
+    else { box.lo[a] = lo; box.inv[a] = 2097151.0f / (hi - lo); }
+  }
+  hipLaunchKernelGGL(codes_kernel, dim3(grid_for(n)), dim3(kBlock), 0, st, x, n, d, box, codes_a, idx_a);
+  MGP_LAUNCH_CHECK();
+  hipcub::DoubleBuffer<uint64_t> kb(codes_a, codes_b);
+  hipcub::DoubleBuffer<int32_t> vb(idx_a, order);
+  size_t tb = cub_bytes;
+  MGP_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(cub, tb, kb, vb, (int)n, 0, 63, st));
+  if (vb.Current() != order)
+    MGP_HIP_TRY(hipMemcpyAsync(order, vb.Current(), (size_t)n * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  return MGP_OK;
+}

@@ -210,6 +210,10 @@ struct TileArgs {
   int64_t ntiles;
   int tiles_per_block;
   int max_cols;
+  // tiles over a row order (all NULL: position p of the tile order is row p of the CSR)
+  const int32_t* rowptr_t;
+  const float* vals_t;
+  const int32_t* rowid;
 };
 
 typedef unsigned short mgp_v4h __attribute__((ext_vector_type(4)));
@@ -230,8 +234,8 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
   // restrict-qualified read-only views: wave-uniform addresses become scalar (s_load) reads
   const float* __restrict__ x = p.X;
   const float* __restrict__ prev = p.pre;
-  const int32_t* __restrict__ rowptr = p.rowptr;
-  const float* __restrict__ vals = p.vals;
+  const int32_t* __restrict__ rowptr = t.rowptr_t ? t.rowptr_t : p.rowptr;   // CSR in tile order
+  const float* __restrict__ vals = t.vals_t ? t.vals_t : p.vals;
   const int32_t* __restrict__ tile_ptr = t.tile_ptr;
   const uint32_t* __restrict__ tile_cols = reinterpret_cast<const uint32_t*>(t.tile_cols);
   const uint16_t* __restrict__ lid = t.lid;
@@ -286,9 +290,10 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     __builtin_amdgcn_sched_barrier(0);
     const int64_t row = r0 + (tid >> 2);
     const bool valid = row < r1;
-    const int64_t rr = valid ? row : r0;
+    const int64_t pr = valid ? row : r0;                                 // position in the tile order
+    const int64_t rr = t.rowid ? (int64_t)t.rowid[pr] : pr;              // row of the CSR / of the vectors
     const int64_t grr = rr + p.goff;
-    const int rs = rowptr[rr], re = rowptr[rr + 1];
+    const int rs = rowptr[pr], re = rowptr[pr + 1];
     float e_x = x[grr];
     if (PRE) e_x *= prev[grr];
     const float e_diag = p.diag[rr];
@@ -638,6 +643,8 @@ static size_t tile_lds_bytes(const mgp_csr_t* L) {
 }
 
 static bool use_tiles(const mgp_csr_t* L, int C) {
+  const int ord = (L->tile_rowptr != nullptr) + (L->tile_vals != nullptr) + (L->tile_rowid != nullptr);
+  if (ord != 0 && ord != 3) return false;      // an ordered tile view is all three arrays or none
   return C == 1 && g_tile_mode && L->lid && L->tile_ptr && L->tile_cols &&
          (L->tile_rows == 32 || L->tile_rows == 64 || L->tile_rows == 128) && tile_lds_bytes(L) <= 65536 - 64;
 }
@@ -729,7 +736,8 @@ int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X
     p.commit = *commit;
   }
   if (use_tiles(L, C)) {
-    TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols};
+    TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
+                L->tile_rowptr, L->tile_vals, L->tile_rowid};
     const int grid = tile_grid(L, &ta.tiles_per_block);
     const size_t lds = tile_lds_bytes(L);
 #define MGP_TILE_LAUNCH(BS)                                                                              \

@@ -16,9 +16,23 @@ from ._lib import check, lib, ptr, stream
 TILE_ROWS = 64             # rows per SpMV tile (workgroup of 256 lanes); 32 / 64 / 128 are supported
 
 
-def build_tiles(n, rowptr, col, nnz, tile_rows=None):
+REORDER_BELOW_REUSE = 3.0  # entries per distinct tile column under which a locality order is tried
+
+
+def bfs_order(n, rowptr, col):
+    """Breadth-first locality order of the graph (mgp_graph_bfs_order): int32 [n] permutation."""
+    order = torch.empty(n, dtype=torch.int32, device=col.device)
+    wb = lib().mgp_graph_bfs_workspace_bytes(n)
+    work = _lib.workspace(wb, "graph", col.device)
+    check(lib().mgp_graph_bfs_order(n, ptr(rowptr), ptr(col), ptr(order), ptr(work), work.numel(), stream()),
+          "mgp_graph_bfs_order")
+    return order
+
+
+def build_tiles(n, rowptr, col, nnz, tile_rows=None, order=None):
     """Row-tile column dictionaries for the C == 1 SpMV (mgp_graph_tiles).  Returns the dict that
-    _lib.csr_struct takes, or None when the graph has no entries / a tile does not fit the LDS budget."""
+    _lib.csr_struct takes, or None when the graph has no entries / a tile does not fit the LDS budget.
+    order: optional int32 [n] row permutation (tiles over that order; adds tile_rowptr / emap / rowid)."""
     if nnz <= 0:
         return None
     dev = col.device
@@ -27,24 +41,55 @@ def build_tiles(n, rowptr, col, nnz, tile_rows=None):
         tile_ptr = torch.empty(ntiles + 1, dtype=torch.int32, device=dev)
         tile_cols = torch.empty(nnz, dtype=torch.int32, device=dev)
         lid = torch.empty(nnz, dtype=torch.int16, device=dev)
-        wb = lib().mgp_graph_tiles_workspace_bytes(nnz)
+        tile_rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev) if order is not None else None
+        emap = torch.empty(nnz, dtype=torch.int32, device=dev) if order is not None else None
+        wb = lib().mgp_graph_tiles_workspace_bytes(n, nnz)
         work = _lib.workspace(wb, "graph", dev)
         total, mc, me = ctypes.c_int64(0), ctypes.c_int32(0), ctypes.c_int32(0)
-        rc = lib().mgp_graph_tiles(n, ptr(rowptr), ptr(col), nnz, rows, ptr(tile_ptr), ptr(tile_cols), ptr(lid),
-                                   ctypes.byref(total), ctypes.byref(mc), ctypes.byref(me), ptr(work), work.numel(),
-                                   stream())
+        rc = lib().mgp_graph_tiles(n, ptr(rowptr), ptr(col), nnz, rows, ptr(order), ptr(tile_rowptr), ptr(emap),
+                                   ptr(tile_ptr), ptr(tile_cols), ptr(lid), ctypes.byref(total), ctypes.byref(mc),
+                                   ctypes.byref(me), ptr(work), work.numel(), stream())
         if rc == -3:                      # MGP_ERR_UNSUPPORTED: a tile references > 65536 columns
             continue
         check(rc, "mgp_graph_tiles")
         if (mc.value + me.value // 4) * 4 > 65536 - 64:
             continue
-        return dict(tile_ptr=tile_ptr, tile_cols=tile_cols[:total.value].clone(), lid=lid, rows=rows,
-                    max_cols=mc.value, max_entries=me.value, total_cols=total.value)
+        t = dict(tile_ptr=tile_ptr, tile_cols=tile_cols[:total.value].clone(), lid=lid, rows=rows,
+                 max_cols=mc.value, max_entries=me.value, total_cols=total.value, reuse=nnz / max(total.value, 1))
+        if order is not None:
+            t.update(tile_rowptr=tile_rowptr, emap=emap.long(), rowid=order)
+        return t
     return None
 
 
+def morton_order(x):
+    """Z-curve order of points with d <= 3 (mgp_morton_order): int32 [n] permutation."""
+    n, d = x.shape
+    order = torch.empty(n, dtype=torch.int32, device=x.device)
+    wb = lib().mgp_morton_order_workspace_bytes(n)
+    work = _lib.workspace(wb, "graph", x.device)
+    check(lib().mgp_morton_order(ptr(_lib.f32c(x)), n, d, ptr(order), ptr(work), work.numel(), stream()),
+          "mgp_morton_order")
+    return order
+
+
+def build_tiles_auto(n, rowptr, col, nnz, points=None):
+    """Tiles in the given row order; when that order carries no locality (few entries per distinct tile
+    column) a locality order is tried and kept if it helps: the Z-curve of the points when they have
+    d <= 3 coordinates, else a breadth-first order of the graph."""
+    t = build_tiles(n, rowptr, col, nnz)
+    if t is None or t["reuse"] >= REORDER_BELOW_REUSE or n < 4 * TILE_ROWS:
+        return t
+    if points is not None and points.dim() == 2 and points.shape[1] <= 3 and points.shape[0] == n:
+        order = morton_order(points)
+    else:
+        order = bfs_order(n, rowptr, col)
+    t2 = build_tiles(n, rowptr, col, nnz, order=order)
+    return t2 if (t2 is not None and t2["reuse"] > 1.3 * t["reuse"]) else t
+
+
 class KnnGraph:
-    def __init__(self, n, tri_row, tri_col, tri_val, rowptr, col, d2, eid, tiles="auto"):
+    def __init__(self, n, tri_row, tri_col, tri_val, rowptr, col, d2, eid, tiles="auto", points=None):
         self.n = int(n)
         self.tri_row, self.tri_col, self.tri_val = tri_row, tri_col, tri_val
         self.rowptr, self.col, self.d2, self.eid = rowptr, col, d2, eid
@@ -52,7 +97,7 @@ class KnnGraph:
         self.nnz = int(col.shape[0])
         self._edge_index = None
         if isinstance(tiles, str):          # "auto": build on the device the CSR lives on (host tensors: none)
-            tiles = build_tiles(self.n, rowptr, col, self.nnz) if col.is_cuda else None
+            tiles = build_tiles_auto(self.n, rowptr, col, self.nnz, points) if col.is_cuda else None
         self.tiles = tiles
         # sub-wave group width for the C == 1 SpMV: 4 entries per lane per pass
         # measured on the 60k bench graph (tools/tune_spmv.py): 8 lanes x 2 rows in flight is the
@@ -67,9 +112,16 @@ class KnnGraph:
     def device(self):
         return self.tri_val.device
 
-    def csr_with(self, vals, diag):
-        """mgp_csr_t over this graph's structure with the given entry values / diagonal."""
-        return _lib.csr_struct(self.n, self.rowptr, self.col, vals, diag, tiles=self.tiles)
+    def csr_with(self, vals, diag, tile_vals=None):
+        """mgp_csr_t over this graph's structure with the given entry values / diagonal (tile_vals: the
+        values in tile order when the tiles follow a row order, see tile_values)."""
+        return _lib.csr_struct(self.n, self.rowptr, self.col, vals, diag, tiles=self.tiles, tile_vals=tile_vals)
+
+    def tile_values(self, vals):
+        """`vals` gathered into tile order (None when the tiles are in row order)."""
+        if self.tiles is None or self.tiles.get("rowid") is None:
+            return None
+        return vals.index_select(0, self.tiles["emap"])
 
     @property
     def edge_index(self):
@@ -84,7 +136,7 @@ class KnnGraph:
 
     # ------------------------------------------------------------------ builders
     @classmethod
-    def from_knn(cls, D, I, tiles="auto"):
+    def from_knn(cls, D, I, tiles="auto", points=None):
         """(D[n,k] f32, I[n,k] i32) on device -> KnnGraph via mgp_graph_build."""
         _lib.require_device(D, I)
         n, k = I.shape
@@ -108,7 +160,7 @@ class KnnGraph:
                                     ctypes.byref(nnz), ptr(work), work.numel(), stream()), "mgp_graph_build")
         M, nnz = M.value, nnz.value
         return cls(n, tri_row[:M].clone(), tri_col[:M].clone(), tri_val[:M].clone(), rowptr,
-                   col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone(), tiles=tiles)
+                   col[:nnz].clone(), d2[:nnz].clone(), eid[:nnz].clone(), tiles=tiles, points=points)
 
     @classmethod
     def from_coo(cls, idx, val, n, tiles="auto"):
@@ -175,6 +227,7 @@ class LaplacianData:
                                         ptr(self.diag), ptr(self.dsqrt), ptr(self.dinvsqrt), ptr(self.vals),
                                         stream()), "mgp_laplacian_build")
         self._edge = {}
+        self.vals_t = graph.tile_values(self.vals)       # tiles over a locality order stream their own copy
 
     def tangent(self):
         """d/d eps of every array of this object (mgp_laplacian_tangent), cached."""
@@ -192,11 +245,12 @@ class LaplacianData:
                                               ptr(self.degree_unnorm), ptr(self.degree), ptr(self.diag),
                                               ptr(t.d_degree_unnorm), ptr(t.d_degree), ptr(t.d_diag), ptr(t.d_dsqrt),
                                               ptr(t.d_dinvsqrt), ptr(t.d_vals), stream()), "mgp_laplacian_tangent")
+            t.d_vals_t = g.tile_values(t.d_vals)
             self._tangent = t
         return self._tangent
 
     def csr(self):
-        return self.graph.csr_with(self.vals, self.diag)
+        return self.graph.csr_with(self.vals, self.diag, self.vals_t)
 
     def edge_values(self, which):
         """0: W (adjacency_unnorm_mat), 1: A (adjacency_mat), 2: S (laplacian_triu) in COO order."""

@@ -64,7 +64,10 @@ def pad_graph(graph, n_pad):
         return graph
     extra = n_pad - graph.n
     rowptr = torch.cat([graph.rowptr, graph.rowptr[-1:].expand(extra)])
-    g = KnnGraph(n_pad, graph.tri_row, graph.tri_col, graph.tri_val, rowptr, graph.col, graph.d2, graph.eid)
+    # row-order tiles only: a rank's slice must be whole tiles of the global graph (local_csr)
+    from .graph import build_tiles
+    tiles = build_tiles(n_pad, rowptr, graph.col, graph.nnz) if graph.col.is_cuda else None
+    g = KnnGraph(n_pad, graph.tri_row, graph.tri_col, graph.tri_val, rowptr, graph.col, graph.d2, graph.eid, tiles=tiles)
     g.spmv_lanes = graph.spmv_lanes
     return g
 
@@ -81,7 +84,7 @@ def local_csr(lap_data, part, rank):
     diag = lap_data.diag[r0:r1].contiguous()
     tiles = None
     gt = getattr(g, "tiles", None)
-    if gt is not None and e1 > e0 and r0 % gt["rows"] == 0 and (r1 - r0) % gt["rows"] == 0:
+    if gt is not None and gt.get("rowid") is None and e1 > e0 and r0 % gt["rows"] == 0 and (r1 - r0) % gt["rows"] == 0:
         # the slice's tiles are whole tiles of the global graph: offsets into tile_cols stay absolute
         tiles = dict(gt, tile_ptr=gt["tile_ptr"][r0 // gt["rows"]:r1 // gt["rows"] + 1].contiguous(), lid=gt["lid"][e0:e1])
     return dict(n_loc=part.n_loc, rowptr=rowptr, col=col, vals=vals, diag=diag, e0=e0, e1=e1, ncols=g.n, tiles=tiles)

@@ -57,7 +57,7 @@ class NearestNeighbors():
         val, idx = self.search(self.x, k, nprobe)
         n = self.x.shape[0]
         if symmetric and not self_loop:
-            self.knn_graph = KnnGraph.from_knn(val, idx.to(torch.int32))
+            self.knn_graph = KnnGraph.from_knn(val, idx.to(torch.int32), points=self.x if self.x.shape[1] <= 3 else None)
             return self.knn_graph.edge_index, self.knn_graph.edge_value
         # non-default variants: plain torch index bookkeeping (no arithmetic), as
         # nearest_neighbors.py:42-53

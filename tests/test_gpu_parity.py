@@ -953,3 +953,100 @@ def test_knn_lowdim_slab_free_path_vs_oracle(mgp, dev, d):
     Dr, Ir = oknn.knn_search(cloud, cloud[:64], 300)
     D, I = nn.search(T(cloud[:64], dev), 300)
     assert nn.last_stats["candidates"] > 0 and np.array_equal(I.cpu().numpy(), Ir)
+
+
+def test_locality_order_for_unordered_inputs(mgp, dev):
+    """Points in random order: the row-order tiles have no column reuse, KnnGraph switches to tiles over a
+    breadth-first order (mgp_graph_bfs_order + ordered mgp_graph_tiles).  Checks: the order is a
+    permutation, reuse recovers, the tile invariants hold in tile order, the SpMV (all epilogue features)
+    equals the gather kernel, CG / fused CG solve to tolerance, gradients still work."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.graph import LaplacianData, bfs_order, build_tiles
+    from manifold_gp_amd.solvers import CgPlan
+    from tools import synth
+    n = 20000
+    x_np, y_np = synth.swiss_roll(n, seed=3, order="random")
+    x = T(x_np, dev)
+    knn = mgp.utils.NearestNeighbors(x)
+    knn.graph(16)
+    g = knn.knn_graph
+    plain = build_tiles(g.n, g.rowptr, g.col, g.nnz)
+    assert plain["reuse"] < 1.5                                   # random order: nothing to share
+    t = g.tiles
+    assert t.get("rowid") is not None, "locality order not applied"
+    assert t["reuse"] > 4 * plain["reuse"]
+    order = t["rowid"].cpu().numpy()
+    assert np.array_equal(np.sort(order), np.arange(n))
+    from manifold_gp_amd.graph import morton_order
+    assert np.array_equal(morton_order(x).cpu().numpy(), order)                        # d = 3: Z-curve of the points
+    b1, b2 = bfs_order(g.n, g.rowptr, g.col).cpu().numpy(), bfs_order(g.n, g.rowptr, g.col).cpu().numpy()
+    assert np.array_equal(b1, b2) and np.array_equal(np.sort(b1), np.arange(n))     # graph-only order: deterministic
+    tb = build_tiles(g.n, g.rowptr, g.col, g.nnz, order=T(b1, dev).int())
+    assert tb["reuse"] > 3 * plain["reuse"]
+    # invariants in tile order
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    trp, emap = t["tile_rowptr"].cpu().numpy(), t["emap"].cpu().numpy()
+    tp, tc = t["tile_ptr"].cpu().numpy(), t["tile_cols"].cpu().numpy()
+    lid = t["lid"].cpu().numpy().view(np.uint16).astype(np.int64)
+    assert np.array_equal(np.diff(trp), np.diff(rowptr)[order]) and np.array_equal(np.sort(emap), np.arange(g.nnz))
+    for tile in (0, 7, len(tp) - 2):
+        p0, p1 = tile * t["rows"], min((tile + 1) * t["rows"], n)
+        e0, e1 = trp[p0], trp[p1]
+        cols = col[emap[e0:e1]]
+        assert np.array_equal(tc[tp[tile]:tp[tile + 1]], np.unique(cols))
+        assert np.array_equal(tc[tp[tile]:tp[tile + 1]][lid[e0:e1]], cols)
+    # SpMV with every epilogue feature against the gather kernel
+    data = LaplacianData(g, 0.35, True)
+    lib = _lib.lib()
+    v = torch.randn(n, 1, device=dev)
+    pre = torch.rand(n, device=dev) + 0.5
+    base = torch.randn(n, 1, device=dev)
+    outs = []
+    try:
+        for mode in (0, 1):
+            lib.mgp_spmm_set_tile_mode(mode)
+            csr = data.csr()
+            nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), 1)
+            part = torch.zeros(nb, device=dev)
+            yv = torch.empty_like(v)
+            _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(yv), 1.25, 1.0, _lib.ptr(pre),
+                                          _lib.ptr(pre), _lib.ptr(base), 0.5, 2.0, _lib.ptr(v), _lib.ptr(part),
+                                          _lib.stream()), "mgp_spmm_fused")
+            outs.append((yv.clone(), float(part.double().sum())))
+    finally:
+        lib.mgp_spmm_set_tile_mode(1)
+    scale = float(outs[0][0].abs().max())
+    assert float((outs[0][0] - outs[1][0]).abs().max()) < 1e-5 * scale
+    assert abs(outs[0][1] - outs[1][1]) < 1e-4 * scale * n ** 0.5
+    # CG (three-kernel step and fused step) on the ordered tiles
+    lap = mgp.operators.GraphLaplacianOperator(knn.edge_value if hasattr(knn, "edge_value") else g.edge_value, g.edge_index, n,
+                                               torch.tensor([[0.35]], device=dev), "randomwalk", graph=g)
+    Q = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[1.5]], device=dev))
+    desc = Q._descriptor().with_(scale=0.7, form=2, noise=1e-2)
+    y = T(y_np, dev).view(-1, 1).contiguous()
+    sols = []
+    try:
+        for fuse in (0, 1):
+            lib.mgp_cg_set_fuse(fuse)
+            plan = CgPlan(desc, 1, tol=1e-6, max_iter=20000, stop_mode=1)
+            sol = plan.solve(y).clone()
+            assert plan.status == 1
+            r = desc.apply(sol) - y
+            assert float(r.norm() / y.norm()) < 2e-5
+            sols.append(sol)
+            plan.close()
+    finally:
+        lib.mgp_cg_set_fuse(0)
+    assert float((sols[0] - sols[1]).abs().max()) < 2e-4 * float(sols[0].abs().max())
+    # gradient wrt the bandwidth through the ordered tiles (tangent values take the same entry map)
+    eps = torch.tensor([[0.35]], device=dev, requires_grad=True)
+    op = mgp.operators.GraphLaplacianOperator(g.edge_value, g.edge_index, n, eps, "symmetric", graph=g)
+    loss = (op.matmul(v) * v).sum()
+    loss.backward()
+    h = 1e-3
+    with torch.no_grad():
+        fp = (mgp.operators.GraphLaplacianOperator(g.edge_value, g.edge_index, n, torch.tensor([[0.35 + h]], device=dev), "symmetric", graph=g).matmul(v) * v).sum()
+        fm = (mgp.operators.GraphLaplacianOperator(g.edge_value, g.edge_index, n, torch.tensor([[0.35 - h]], device=dev), "symmetric", graph=g).matmul(v) * v).sum()
+    fd = float((fp - fm) / (2 * h))
+    assert abs(float(eps.grad) - fd) < 2e-2 * abs(fd)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from manifold_gp_amd import _lib  # noqa: E402
-from manifold_gp_amd.graph import build_tiles  # noqa: E402
+from manifold_gp_amd.graph import bfs_order, build_tiles  # noqa: E402
 
 
 def main():
@@ -43,12 +43,24 @@ def main():
         d = (t["tile_ptr"][1:] - t["tile_ptr"][:-1]).float()
         stats["tile%d" % rows] = dict(total_cols=t["total_cols"], max_cols=t["max_cols"], max_entries=t["max_entries"],
                                       mean_cols=round(float(d.mean()), 1), reuse=round(g.nnz / max(t["total_cols"], 1), 2))
+    # tiles over a breadth-first locality order (what KnnGraph picks for unordered inputs)
+    import time
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    order = bfs_order(g.n, g.rowptr, g.col)
+    torch.cuda.synchronize(); t_bfs = time.perf_counter() - t0
+    tb = build_tiles(g.n, g.rowptr, g.col, g.nnz, tile_rows=64, order=order)
+    if tb is not None:
+        variants["tile64_bfs"] = tb
+        d = (tb["tile_ptr"][1:] - tb["tile_ptr"][:-1]).float()
+        stats["tile64_bfs"] = dict(total_cols=tb["total_cols"], max_cols=tb["max_cols"], mean_cols=round(float(d.mean()), 1),
+                                   reuse=round(g.nnz / max(tb["total_cols"], 1), 2), bfs_order_ms=round(t_bfs * 1e3, 1))
     times = {k: [] for k in variants}
     ref = None
     for rnd in range(a.rounds):
         for name, t in variants.items():
             g.tiles = t
             lib.mgp_spmm_set_tile_mode(1 if t is not None else 0)
+            sym.data.vals_t = g.tile_values(sym.data.vals)
             csr = sym.data.csr()
             out = torch.empty_like(v)
             st = _lib.stream()
