@@ -346,6 +346,9 @@ struct EigWork {
 int block_size_for(int m, const mgp_lanczos_params_t* p) {
   int b = (p && p->max_basis > 0) ? p->max_basis : m + std::max(m / 4, 16);
   if (b < m + 2) b = m + 2;
+  // a multiple of 4 unless the caller fixed the size: block rows are then 16-byte aligned, which the SpMM
+  // and the MFMA rotation kernel exploit (C = 128 runs faster than C = 125)
+  if (!(p && p->max_basis > 0)) b = (b + 3) / 4 * 4;
   return b;
 }
 
