@@ -165,17 +165,17 @@ __global__ void copy_cols_kernel(const float* __restrict__ V, int64_t n, int ld,
 // eigensolver, against ~20 ms for the cyclic Jacobi it replaces (which made the host the bottleneck of
 // mgp_lanczos_smallest once the SpMM was fixed).  A [n x n] row-major symmetric (destroyed); evals
 // ascending; eigenvectors = columns of V (row-major [n x n]).
-void tred2(int n, double* V, double* d, double* e) {
-  for (int j = 0; j < n; ++j) d[j] = V[(size_t)(n - 1) * n + j];
+void tred2(int n, int ld, double* V, double* d, double* e) {
+  for (int j = 0; j < n; ++j) d[j] = V[(size_t)(n - 1) * ld + j];
   for (int i = n - 1; i > 0; --i) {
     double scale = 0.0, h = 0.0;
     for (int k = 0; k < i; ++k) scale += fabs(d[k]);
     if (scale == 0.0) {
       e[i] = d[i - 1];
       for (int j = 0; j < i; ++j) {
-        d[j] = V[(size_t)(i - 1) * n + j];
-        V[(size_t)i * n + j] = 0.0;
-        V[(size_t)j * n + i] = 0.0;
+        d[j] = V[(size_t)(i - 1) * ld + j];
+        V[(size_t)i * ld + j] = 0.0;
+        V[(size_t)j * ld + i] = 0.0;
       }
     } else {
       for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
@@ -188,11 +188,11 @@ void tred2(int n, double* V, double* d, double* e) {
       for (int j = 0; j < i; ++j) e[j] = 0.0;
       for (int j = 0; j < i; ++j) {
         f = d[j];
-        V[(size_t)j * n + i] = f;
-        g = e[j] + V[(size_t)j * n + j] * f;
+        V[(size_t)j * ld + i] = f;
+        g = e[j] + V[(size_t)j * ld + j] * f;
         for (int k = j + 1; k <= i - 1; ++k) {
-          g += V[(size_t)k * n + j] * d[k];
-          e[k] += V[(size_t)k * n + j] * f;
+          g += V[(size_t)k * ld + j] * d[k];
+          e[k] += V[(size_t)k * ld + j] * f;
         }
         e[j] = g;
       }
@@ -203,36 +203,36 @@ void tred2(int n, double* V, double* d, double* e) {
       for (int j = 0; j < i; ++j) {
         f = d[j];
         g = e[j];
-        for (int k = j; k <= i - 1; ++k) V[(size_t)k * n + j] -= (f * e[k] + g * d[k]);
-        d[j] = V[(size_t)(i - 1) * n + j];
-        V[(size_t)i * n + j] = 0.0;
+        for (int k = j; k <= i - 1; ++k) V[(size_t)k * ld + j] -= (f * e[k] + g * d[k]);
+        d[j] = V[(size_t)(i - 1) * ld + j];
+        V[(size_t)i * ld + j] = 0.0;
       }
     }
     d[i] = h;
   }
   for (int i = 0; i < n - 1; ++i) {   // accumulate the transformations
-    V[(size_t)(n - 1) * n + i] = V[(size_t)i * n + i];
-    V[(size_t)i * n + i] = 1.0;
+    V[(size_t)(n - 1) * ld + i] = V[(size_t)i * ld + i];
+    V[(size_t)i * ld + i] = 1.0;
     const double h = d[i + 1];
     if (h != 0.0) {
-      for (int k = 0; k <= i; ++k) d[k] = V[(size_t)k * n + (i + 1)] / h;
+      for (int k = 0; k <= i; ++k) d[k] = V[(size_t)k * ld + (i + 1)] / h;
       for (int j = 0; j <= i; ++j) {
         double g = 0.0;
-        for (int k = 0; k <= i; ++k) g += V[(size_t)k * n + (i + 1)] * V[(size_t)k * n + j];
-        for (int k = 0; k <= i; ++k) V[(size_t)k * n + j] -= g * d[k];
+        for (int k = 0; k <= i; ++k) g += V[(size_t)k * ld + (i + 1)] * V[(size_t)k * ld + j];
+        for (int k = 0; k <= i; ++k) V[(size_t)k * ld + j] -= g * d[k];
       }
     }
-    for (int k = 0; k <= i; ++k) V[(size_t)k * n + (i + 1)] = 0.0;
+    for (int k = 0; k <= i; ++k) V[(size_t)k * ld + (i + 1)] = 0.0;
   }
   for (int j = 0; j < n; ++j) {
-    d[j] = V[(size_t)(n - 1) * n + j];
-    V[(size_t)(n - 1) * n + j] = 0.0;
+    d[j] = V[(size_t)(n - 1) * ld + j];
+    V[(size_t)(n - 1) * ld + j] = 0.0;
   }
-  V[(size_t)(n - 1) * n + (n - 1)] = 1.0;
+  V[(size_t)(n - 1) * ld + (n - 1)] = 1.0;
   e[0] = 0.0;
 }
 
-void tql2(int n, double* V, double* d, double* e) {
+void tql2(int n, int ld, double* V, double* d, double* e) {
   for (int i = 1; i < n; ++i) e[i - 1] = e[i];
   e[n - 1] = 0.0;
   double f = 0.0, tst1 = 0.0;
@@ -275,9 +275,9 @@ void tql2(int n, double* V, double* d, double* e) {
           p = c * d[i] - s * g;
           d[i + 1] = h + s * (c * g + s * d[i]);
           for (int k = 0; k < n; ++k) {
-            h = V[(size_t)k * n + i + 1];
-            V[(size_t)k * n + i + 1] = s * V[(size_t)k * n + i] + c * h;
-            V[(size_t)k * n + i] = c * V[(size_t)k * n + i] - s * h;
+            h = V[(size_t)k * ld + i + 1];
+            V[(size_t)k * ld + i + 1] = s * V[(size_t)k * ld + i] + c * h;
+            V[(size_t)k * ld + i] = c * V[(size_t)k * ld + i] - s * h;
           }
         }
         p = -s * s2 * c3 * el1 * e[l] / dl1;
@@ -292,27 +292,26 @@ void tql2(int n, double* V, double* d, double* e) {
 
 void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& evals, std::vector<double>& V) {
   // (name kept from the Jacobi days: every caller wants "eigh of a small symmetric matrix")
-  V = A;
+  // The work matrix has a padded leading dimension: tred2 / tql2 walk columns, and with ld = n a
+  // power-of-two n (block sizes 128, 256) maps a whole column onto a handful of L1 sets of the host
+  // CPU -- measured 4-6x slower than n +- 4.
+  const int ld = (n % 16 == 0) ? n + 3 : n;
+  std::vector<double> W((size_t)n * ld);
   for (int i = 0; i < n; ++i)      // use the symmetric part
-    for (int j = i + 1; j < n; ++j) {
-      const double v = 0.5 * (V[(size_t)i * n + j] + V[(size_t)j * n + i]);
-      V[(size_t)i * n + j] = v;
-      V[(size_t)j * n + i] = v;
-    }
+    for (int j = 0; j < n; ++j) W[(size_t)i * ld + j] = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
   std::vector<double> d(n), e(n);
-  if (n == 1) { evals.assign(1, V[0]); V[0] = 1.0; return; }
-  tred2(n, V.data(), d.data(), e.data());
-  tql2(n, V.data(), d.data(), e.data());
+  if (n == 1) { evals.assign(1, W[0]); V.assign(1, 1.0); return; }
+  tred2(n, ld, W.data(), d.data(), e.data());
+  tql2(n, ld, W.data(), d.data(), e.data());
   std::vector<int> order(n);
   for (int i = 0; i < n; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
   evals.resize(n);
-  std::vector<double> Vs((size_t)n * n);
+  V.assign((size_t)n * n, 0.0);
   for (int j = 0; j < n; ++j) {
     evals[j] = d[order[j]];
-    for (int k = 0; k < n; ++k) Vs[(size_t)k * n + j] = V[(size_t)k * n + order[j]];
+    for (int k = 0; k < n; ++k) V[(size_t)k * n + j] = W[(size_t)k * ld + order[j]];
   }
-  V.swap(Vs);
 }
 
 // symmetric tridiagonal (alpha[k], beta[k-1]) eigenvalues + first components of eigenvectors
@@ -344,7 +343,7 @@ struct EigWork {
 };
 
 int block_size_for(int m, const mgp_lanczos_params_t* p) {
-  int b = (p && p->max_basis > 0) ? p->max_basis : m + std::max(m / 4, 16);
+  int b = (p && p->max_basis > 0) ? p->max_basis : m + std::max(m / 2, 32);   // measured: 100 -> 152 halves the SpMM count of 125
   if (b < m + 2) b = m + 2;
   // a multiple of 4 unless the caller fixed the size: block rows are then 16-byte aligned, which the SpMM
   // and the MFMA rotation kernel exploit (C = 128 runs faster than C = 125)
