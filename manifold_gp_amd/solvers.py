@@ -281,6 +281,21 @@ def lowrank_cg(Z, y, outputscale, noise, tol=1e-6, max_iter=500):
     return x, it
 
 
+def lowrank_solve(Z, y, outputscale, noise):
+    """(outputscale Z Z^T + noise I)^-1 y by Woodbury on the m x m root (fp64 Gram + Cholesky through
+    torch: library GEMM / POTRF on a 100 x 100 matrix, not a hot op) -- the direct form of lowrank_cg and
+    what gpytorch does for a LowRankRootAddedDiagLinearOperator."""
+    _lib.require_device(Z, y)
+    Zd = Z.double()
+    G = Zd.t() @ Zd
+    m = G.shape[0]
+    C = G + (noise / outputscale) * torch.eye(m, dtype=torch.float64, device=G.device)
+    Lc = torch.linalg.cholesky(C)
+    v = y.double()
+    t = torch.cholesky_solve((Zd.t() @ v).reshape(m, -1), Lc).reshape((m,) + tuple(v.shape[1:]))
+    return ((v - Zd @ t) / noise).float()
+
+
 def kernel_block(Z1, Z2, scale=1.0):
     """K = scale * Z1 Z2^T on the fp32 MFMA."""
     _lib.require_device(Z1, Z2)

@@ -396,7 +396,7 @@ def test_spectral_posterior_vs_woodbury_fp64(mgp, golden, dev):
     """Posterior mean / variance with K = s Z Z^T + noise I: CG on device vs the fp64 Woodbury
     closed form (what gpytorch evaluates for the reference), 1e-4 relative."""
     from oracle.solvers import gp_posterior_lowrank
-    from manifold_gp_amd.solvers import kernel_block, lowrank_cg
+    from manifold_gp_amd.solvers import kernel_block, lowrank_cg, lowrank_solve
     g = golden("dumbbell_k10_loop")
     kern = mgp.kernels.RiemannMaternKernel(nu=2, x=T(g["train_x"], dev), nearest_neighbors=10,
                                            laplacian_normalization="randomwalk", num_modes=50).to(dev)
@@ -410,6 +410,8 @@ def test_spectral_posterior_vs_woodbury_fp64(mgp, golden, dev):
     ref_mean, ref_cov, ref_alpha = gp_posterior_lowrank(Z.cpu().numpy(), g["train_y"], Zt.cpu().numpy(), s, noise)
     assert np.abs(mean.cpu().numpy() - ref_mean).max() < 1e-4 * max(np.abs(ref_mean).max(), 1e-3)
     assert np.abs(alpha.cpu().numpy() - ref_alpha).max() < 1e-4 * np.abs(ref_alpha).max()
+    alpha_w = lowrank_solve(Z, y, s, noise)                       # direct (Woodbury) form of the same solve
+    assert np.abs(alpha_w.cpu().numpy() - ref_alpha).max() < 1e-5 * np.abs(ref_alpha).max()
 
 
 # ----------------------------------------------------------------------------- full-size properties

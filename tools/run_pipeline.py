@@ -14,7 +14,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import manifold_gp_amd as mgp  # noqa: E402
-from manifold_gp_amd.solvers import cg_solve, kernel_block, lowrank_cg  # noqa: E402
+from manifold_gp_amd.solvers import cg_solve, kernel_block, lowrank_cg, lowrank_solve  # noqa: E402
 from tools import synth  # noqa: E402
 
 
@@ -62,6 +62,9 @@ def main():
     (alpha, its), t = timed(lambda: lowrank_cg(Z, y, hp["outputscale"], hp["noise"], tol=1e-6))
     res["posterior_covariance_form_lowrank_cg_ms"] = round(t, 2)
     res["lowrank_cg_iters"] = its
+    alpha_w, t = timed(lambda: lowrank_solve(Z, y, hp["outputscale"], hp["noise"]))
+    res["posterior_covariance_form_woodbury_ms"] = round(t, 2)
+    res["woodbury_vs_cg_rel_diff"] = float((alpha_w - alpha).abs().max() / alpha.abs().max())
     mean_t = K @ alpha
     res["spectral_posterior_test_rmse"] = float((mean_t - yt).square().mean().sqrt())
     Q = kern.precision()
