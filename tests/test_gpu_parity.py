@@ -1052,3 +1052,21 @@ def test_locality_order_for_unordered_inputs(mgp, dev):
         fm = (mgp.operators.GraphLaplacianOperator(g.edge_value, g.edge_index, n, torch.tensor([[0.35 - h]], device=dev), "symmetric", graph=g).matmul(v) * v).sum()
     fd = float((fp - fm) / (2 * h))
     assert abs(float(eps.grad) - fd) < 2e-2 * abs(fd)
+
+
+def test_example_walkthrough_runs(mgp, dev):
+    """examples/dumbbell_supervised.py: the reference's notebook flow under the reference's module names."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "dumbbell_supervised.py")
+    spec = importlib.util.spec_from_file_location("dumbbell_supervised", path)
+    mod = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(mod)
+        out = mod.main(quiet=True)
+    finally:
+        for k in [k for k in sys.modules if k == "manifold_gp" or k.startswith("manifold_gp.")]:
+            del sys.modules[k]
+    assert out["precision_solve_residual"] < 1e-4 and np.isfinite(out["test_rmse"]) and out["test_rmse"] < 1.0
+    assert out["mean_std"] > 0 and out["eigen_max_residual"] < 1e-2
