@@ -1,7 +1,8 @@
-"""Hot-path subset of manifold_gp.utils (manifold_gp/utils/__init__.py:3-18): NearestNeighbors and
-bump_function.  Dataset loaders, plotting and the training harness are out of scope (SURVEY.md
-section 2)."""
+"""Hot-path subset of manifold_gp.utils (manifold_gp/utils/__init__.py:3-18): NearestNeighbors,
+bump_function and the precision-form training loop `manifold_informed_train`.  Dataset loaders and
+plotting are out of scope."""
 from .nearest_neighbors import NearestNeighbors
 from .torch_utils import bump_function
+from .train_model import manifold_informed_train
 
-__all__ = ["NearestNeighbors", "bump_function"]
+__all__ = ["NearestNeighbors", "bump_function", "manifold_informed_train"]

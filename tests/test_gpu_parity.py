@@ -1070,3 +1070,34 @@ def test_example_walkthrough_runs(mgp, dev):
             del sys.modules[k]
     assert out["precision_solve_residual"] < 1e-4 and np.isfinite(out["test_rmse"]) and out["test_rmse"] < 1.0
     assert out["mean_std"] > 0 and out["eigen_max_residual"] < 1e-2
+
+
+@pytest.mark.parametrize("max_cholesky", [4000, 100])
+def test_manifold_informed_train_loop(mgp, golden, dev, max_cholesky):
+    """train_model.py:49-113 on the HIP path: the precision-form loss and its gradients wrt noise, output
+    scale, length scale and graph bandwidth drive an optimiser; dense-Cholesky branch (exact) and the
+    iterative branch (HIP CG + stochastic Lanczos with surrogate gradients)."""
+    from manifold_gp_amd.models import GaussianLikelihood, RiemannGP, ScaleKernel
+    from manifold_gp_amd.utils import manifold_informed_train
+    g = golden("dumbbell_k10_loop")
+    x, y = T(g["train_x"], dev), T(g["train_y"], dev)
+    kern = mgp.kernels.RiemannMaternKernel(nu=1, x=x, nearest_neighbors=int(g["k"]), laplacian_normalization="randomwalk",
+                                           num_modes=20).to(dev)
+    kern.initialize(graphbandwidth=float(g["eps"]) * 2.0, lengthscale=1.0)
+    model = RiemannGP(x, y, GaussianLikelihood(1e-2).to(dev), ScaleKernel(kern, 1.0).to(dev)).to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in params]
+    opt = torch.optim.Adam(params, lr=2e-2)
+    losses = []
+
+    class Rec:                                  # records the loss of every epoch through the scheduler hook
+        def step(self, loss):
+            losses.append(float(loss.detach()))
+    torch.manual_seed(0)
+    last = manifold_informed_train(model, opt, max_iter=5, tolerance=0.0, num_rand_vec=16, max_cholesky=max_cholesky,
+                                   cg_tolerance=1e-4, cg_max_iter=4000, scheduler=Rec())
+    assert len(losses) == 6 and all(np.isfinite(losses)) and np.isfinite(last)
+    moved = [float((p.detach() - b).abs().max()) for p, b in zip(params, before)]
+    assert sum(m > 1e-4 for m in moved) >= 3, moved             # noise, output scale, length scale / bandwidth
+    if max_cholesky >= 4000:
+        assert losses[-1] < losses[0]                             # exact gradients: the loss goes down
