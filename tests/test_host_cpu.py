@@ -34,11 +34,11 @@ def test_library_exports_every_header_symbol():
 def test_struct_layouts_match_c_abi():
     """mgp_csr_t / mgp_operator_t / params structs: sizes as the C compiler lays them out."""
     from manifold_gp_amd import _lib
-    assert ctypes.sizeof(_lib.CsrT) == 88
-    assert ctypes.sizeof(_lib.OperatorT) == 88 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
+    assert ctypes.sizeof(_lib.CsrT) == 112
+    assert ctypes.sizeof(_lib.OperatorT) == 112 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
     assert ctypes.sizeof(_lib.CgParamsT) == 28
     assert ctypes.sizeof(_lib.LanczosParamsT) == 24
-    assert _lib.OperatorT.pre.offset == 88 and _lib.OperatorT.nu.offset == 104
+    assert _lib.OperatorT.pre.offset == 112 and _lib.OperatorT.nu.offset == 128
 
 
 def test_argument_errors_without_gpu():
@@ -209,3 +209,23 @@ def test_host_symeig_matches_lapack(n):
         np.testing.assert_allclose(ev, ref, rtol=0, atol=1e-12 * scale * n)
         np.testing.assert_allclose(V.T @ V, np.eye(n), rtol=0, atol=1e-12 * n)
         np.testing.assert_allclose(V @ np.diag(ev) @ V.T, A, rtol=0, atol=1e-12 * scale * n)
+
+
+def test_struct_fields_mirror_header_and_integration_stub():
+    """Field for field: the typedef structs of include/mgp_hip.h, the ctypes Structures of _lib.py and the
+    binding shown in INTEGRATION.md (a stale stub makes the C side read past a shorter struct)."""
+    from manifold_gp_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "mgp_hip.h")).read()
+
+    def c_fields(name):
+        body = re.search(r"typedef struct \{(.*?)\}\s*" + name + r"\s*;", hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return [re.search(r"(\w+)\s*$", decl.strip()).group(1) for decl in body.split(";") if decl.strip()]
+
+    for cname, cls in (("mgp_csr_t", _lib.CsrT), ("mgp_operator_t", _lib.OperatorT), ("mgp_cg_params_t", _lib.CgParamsT),
+                       ("mgp_lanczos_params_t", _lib.LanczosParamsT)):
+        assert c_fields(cname) == [f[0] for f in cls._fields_], cname
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    stub = re.search(r"class mgp_csr_t\(ctypes\.Structure\):(.*?)\n\n", doc, re.S).group(1)
+    assert re.findall(r'\("(\w+)",', stub) == [f[0] for f in _lib.CsrT._fields_]
