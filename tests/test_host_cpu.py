@@ -219,7 +219,7 @@ def test_struct_fields_mirror_header_and_integration_stub():
     hdr = open(os.path.join(root, "include", "mgp_hip.h")).read()
 
     def c_fields(name):
-        body = re.search(r"typedef struct \{(.*?)\}\s*" + name + r"\s*;", hdr, re.S).group(1)
+        body = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\}\s*" + name + r"\s*;", hdr, re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         return [re.search(r"(\w+)\s*$", decl.strip()).group(1) for decl in body.split(";") if decl.strip()]
 
