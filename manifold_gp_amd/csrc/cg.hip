@@ -784,6 +784,8 @@ struct CgPlan {
   int chunk, len_first;
   int last_need;              // (apply, update) pairs the previous solve needed: len_first follows it
   const float* patched_rhs;   // rhs the cg_init node currently points at
+  int solves;                 // run_cg calls so far (graphs are captured at the second one)
+  bool graphs_tried;
   bool fused;                 // step = (chain tail, fused update + chain head) -- see cg_fused_step_kernel
   CgFuse fuse;
   int fgrid;
@@ -907,6 +909,32 @@ extern "C" size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C) {
   return cg_bytes(op, C);
 }
 
+// Graphs are captured at the SECOND solve of a plan: capture + instantiate cost ~20-30 ms, more than a
+// whole solve, and plans built for a one-off solve (every epoch of a training loop has new operator
+// values, hence a new plan) never earn it back.  The first solve runs the same launches eagerly.
+static void capture_graphs(CgPlan* pl) {
+  pl->graphs_tried = true;
+  if (!pl->prm.use_graph || pl->is_dist) return;   // collectives are enqueued eagerly (no capture)
+  hipError_t e = hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking);
+  bool ok = (e == hipSuccess);
+  if (ok) ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    int rc = MGP_OK;
+    for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
+    hipGraph_t graph = nullptr;
+    hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
+    ok = (rc == MGP_OK && e2 == hipSuccess && graph != nullptr);
+    if (ok) ok = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+  }
+  pl->has_graph = ok;
+  (void)hipGetLastError();   // a failed capture falls back to eager launches
+  if (ok) {
+    int len = pl->last_need >= 1 && pl->last_need <= 64 ? pl->last_need : (pl->chunk < 4 ? pl->chunk : 4);
+    capture_first(pl, len);
+  }
+}
+
 static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, const mgp_cg_params_t* params,
                             const MgpDist* dist, void* work, size_t work_bytes, void* stream, void** plan_out) {
   if (!op || !params || !work || !plan_out) return MGP_ERR_ARG;
@@ -942,10 +970,13 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   a.us = op->pre ? usbuf : nullptr;
   pl->op_work_bytes = 4 * mgp_align(nc * sizeof(float)) + 256;
   pl->op_work = ar.take<char>(pl->op_work_bytes);
-  // contiguous row ranges per workgroup, at most kMaxGridVec workgroups
+  // contiguous row ranges per workgroup, at most kMaxGridVec workgroups.  C > 1: every workgroup of the
+  // update kernel re-reduces ALL dot partials of ALL columns (nbv x (2 nbv + nbs) x C loads per launch),
+  // so the grid is kept small -- 128 workgroups still cover N C >> 32k elements
+  const int max_grid_vec = (C == 1) ? kMaxGridVec : 128;
   int64_t rpb = a.TS;
   int64_t nbv = mgp_cdiv(n, rpb);
-  if (nbv > kMaxGridVec) { rpb = mgp_cdiv(mgp_cdiv(n, kMaxGridVec), a.TS) * a.TS; nbv = mgp_cdiv(n, rpb); }
+  if (nbv > max_grid_vec) { rpb = mgp_cdiv(mgp_cdiv(n, max_grid_vec), a.TS) * a.TS; nbv = mgp_cdiv(n, rpb); }
   a.rows_per_block = rpb; a.nbv = (int)nbv;
   a.pd_gamma = ar.take<float>(2 * (size_t)kMaxPartials * C);
   a.pd_rr = ar.take<float>(2 * (size_t)kMaxPartials * C);
@@ -997,23 +1028,6 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&pl->dev_true_rel, pl->host_true_rel, 0);
   if (e != hipSuccess) { delete pl; return (int)e; }
 
-  if (pl->prm.use_graph && !pl->is_dist) {   // collectives are enqueued eagerly (no capture)
-    e = hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking);
-    bool ok = (e == hipSuccess);
-    if (ok) ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-    if (ok) {
-      int rc = MGP_OK;
-      for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
-      hipGraph_t graph = nullptr;
-      hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
-      ok = (rc == MGP_OK && e2 == hipSuccess && graph != nullptr);
-      if (ok) ok = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0) == hipSuccess;
-      if (graph) (void)hipGraphDestroy(graph);
-    }
-    pl->has_graph = ok;
-    (void)hipGetLastError();   // a failed capture falls back to eager launches
-    if (ok) capture_first(pl, pl->chunk < 4 ? pl->chunk : 4);
-  }
   *plan_out = pl;
   return MGP_OK;
 }
@@ -1048,6 +1062,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   const size_t nc = (size_t)pl->args.n * pl->C;
   pl->host_state[1] = 0;
   bool first = true;
+  if (pl->solves++ >= 1 && !pl->graphs_tried) capture_graphs(pl);
   if (pl->has_first && !patch_first_rhs(pl, rhs)) pl->has_first = false;
   if (!pl->has_first) {
     hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, rhs);
@@ -1085,9 +1100,9 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   // the first graph follows the workload: when two solves in a row needed the same number of steps and
   // it is not the captured length, re-capture (a few hundred us, once) so that the next solve of
   // this kind is exactly one graph launch with no skipped launches behind the stopping decision
-  if (pl->exec_first && pl->host_state[1]) {
+  if (pl->host_state[1]) {
     const int need = pl->host_state[0];
-    if (need >= 1 && need <= 64 && need != pl->len_first && need == pl->last_need) {
+    if (pl->exec_first && need >= 1 && need <= 64 && need != pl->len_first && need == pl->last_need) {
       MGP_HIP_TRY(hipStreamSynchronize(st));   // the graph being replaced may still be draining
       capture_first(pl, need);
     }

@@ -446,9 +446,12 @@ def test_full_size_properties_60k(mgp, dev):
     sol, its, res = cg_solve(desc, y, tol=1e-6, stop_mode=1)
     r = desc.apply(sol) - y
     assert float(r.norm() / y.norm()) < 5e-6 and its < 200
-    # graph replay and eager launches give the same bits
+    # graph replay and eager launches give the same bits (a plan captures its graphs at its second
+    # solve: the cached plan behind cg_solve is used three times here)
+    sol_b, _, _ = cg_solve(desc, y, tol=1e-6, stop_mode=1)
+    sol_c, _, _ = cg_solve(desc, y, tol=1e-6, stop_mode=1)
     sol2, _, _ = cg_solve(desc, y, tol=1e-6, stop_mode=1, use_graph=False)
-    assert torch.equal(sol, sol2)
+    assert torch.equal(sol, sol2) and torch.equal(sol_b, sol2) and torch.equal(sol_c, sol2)
 
 
 # ----------------------------------------------------------------------------- row partition (multi-GPU path)
