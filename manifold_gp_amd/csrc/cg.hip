@@ -12,9 +12,11 @@
 //   * dot products are per-workgroup partials reduced again, in a fixed order, by every
 //     workgroup of the consuming kernel: no atomics, no separate reduction launch, bitwise
 //     reproducible, and a kernel boundary (~1.5 us) is the only synchronisation;
-//   * the iteration index and the convergence flag live in device memory, so `check_every`
-//     iterations are captured once into a hipGraph and replayed; after convergence the remaining
-//     launches of a replay return at their first instruction;
+//   * the iteration index and the convergence flag live in device memory, so whole solves are
+//     hipGraphs: cg_init + k x (apply, update) is ONE launch (rhs pointer patched into the graph, k
+//     follows the previous solves), longer solves continue with `check_every`-step graphs; launches
+//     behind the stopping decision return after their first loads; graphs are captured at a plan's
+//     second solve; the host polls the host-mapped decision word instead of sleeping on the stream;
 //   * column freezing / stopping follow linear_cg (stop_mode 0) or a per-column relative
 //     residual (stop_mode 1).
 #include <math.h>
