@@ -313,6 +313,12 @@ int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* 
  * and from the stochastic-Lanczos-quadrature log-determinant of inv_quad_logdet
  * (train_model.py:68).  q0 [n] device start vector; alpha[steps], beta[steps] host;
  * Q_out (nullable) device [steps, n], row j = q_j.  Synchronises `stream`. */
+/* P independent Lanczos runs at once (the probes of the stochastic log-determinant): Q0 [n, P] row-major,
+ * P <= 16, steps <= 47; alpha / beta host [steps][P].  Same arithmetic per column as mgp_lanczos_tridiag,
+ * one P-column SpMM chain per step instead of P single-vector chains.  Synchronises `stream`. */
+size_t mgp_lanczos_tridiag_block_workspace_bytes(const mgp_operator_t* op, int P, int steps);
+int mgp_lanczos_tridiag_block(const mgp_operator_t* op, const float* Q0, int P, int steps, float* alpha, float* beta,
+                              void* work, size_t work_bytes, void* stream);
 size_t mgp_lanczos_tridiag_workspace_bytes(const mgp_operator_t* op, int steps);
 int mgp_lanczos_tridiag(const mgp_operator_t* op, const float* q0, int steps, float* alpha,
                         float* beta, float* Q_out, void* work, size_t work_bytes, void* stream);

@@ -78,6 +78,9 @@ SIGNATURES = {
     "mgp_spmm_set_tile_mode": (c_int, [c_int]),
     "mgp_cg_set_fuse": (c_int, [c_int]),
     "mgp_host_symeig": (c_int, [c_int, _P, _P, _P]),
+    "mgp_lanczos_tridiag_block_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int, c_int]),
+    "mgp_lanczos_tridiag_block": (c_int, [POINTER(OperatorT), _P, c_int, c_int, POINTER(c_float), POINTER(c_float), _P,
+                                         c_size_t, _P]),
     "mgp_graph_build": (c_int, [_P, _P, c_int64, c_int, _P, _P, _P, POINTER(c_int64), _P, _P, _P, _P,
                                 POINTER(c_int64), _P, c_size_t, _P]),
     "mgp_graph_coo_workspace_bytes": (c_size_t, [c_int64, c_int64]),

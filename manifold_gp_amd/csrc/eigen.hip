@@ -646,6 +646,185 @@ __global__ __launch_bounds__(kBlock) void lz_normalize_kernel(const float* __res
 
 }  // namespace
 
+// ---------------------------------------------------------------- block of independent Lanczos runs
+// P start vectors at once (the probes of the stochastic log-determinant): every vector is an [n, P]
+// row-major block, every coefficient a P-vector, the operator apply is ONE P-column SpMM chain.  The runs
+// stay independent (no coupling between columns) -- this is batching, not block Lanczos: it divides the
+// launch count by P, and the single-vector version is launch-bound (11 launches per step).
+namespace {
+
+constexpr int kBlzMaxNq = 48;    // basis vectors kept for re-orthogonalisation (steps + 1 <= this; 48 KB of LDS)
+constexpr int kBlzMaxP = 16;
+
+// partial[blk][i][p] = sum_{r in chunk} W[r,p] * Q_i[r,p],  i < nq
+__global__ __launch_bounds__(kBlock) void blz_dots_kernel(const float* __restrict__ W, const float* __restrict__ Q,
+                                                          int64_t n, int P, int nq, int64_t rows_per_block,
+                                                          float* __restrict__ partial) {
+  extern __shared__ float sh[];                 // [nq][RL][P]
+  const int RL = kBlock / P;
+  const int p = threadIdx.x % P, rl = threadIdx.x / P;
+  const bool on = rl < RL;
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  const int64_t stride = n * P;
+  for (int i0 = 0; i0 < nq; i0 += 8) {          // 8 basis vectors per sweep over the chunk (registers)
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (on)
+      for (int64_t r = r0 + rl; r < r1; r += RL) {
+        const float w = W[r * P + p];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < nq) acc[u] = fmaf(w, Q[(int64_t)(i0 + u) * stride + r * P + p], acc[u]);
+      }
+    if (on)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u < nq) sh[((i0 + u) * RL + rl) * P + p] = acc[u];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < nq * P; e += kBlock) {
+    const int i = e / P, pp = e % P;
+    float t = 0.f;
+    for (int k = 0; k < RL; ++k) t += sh[(i * RL + k) * P + pp];
+    partial[((int64_t)blockIdx.x * nq + i) * P + pp] = t;
+  }
+}
+
+// h[i][p] = sum_blk partial; W -= sum_i h[i][p] Q_i; alpha[p] (+)= h[nq-1][p]; norm partials of the new W
+__global__ __launch_bounds__(kBlock) void blz_update_kernel(float* __restrict__ W, const float* __restrict__ Q, int64_t n,
+                                                            int P, int nq, int64_t rows_per_block,
+                                                            const float* __restrict__ partial, int nblk,
+                                                            float* __restrict__ alpha_row, int accumulate,
+                                                            float* __restrict__ norm_partial) {
+  extern __shared__ float sh[];                 // h [nq][P], then reduction scratch [RL][P]
+  float* h = sh;
+  float* red = sh + nq * P;
+  const int RL = kBlock / P;
+  for (int e = threadIdx.x; e < nq * P; e += kBlock) {
+    float t = 0.f;
+    for (int bI = 0; bI < nblk; ++bI) t += partial[(int64_t)bI * nq * P + e];
+    h[e] = t;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && (int)threadIdx.x < P) {
+    const float a = h[(nq - 1) * P + threadIdx.x];
+    alpha_row[threadIdx.x] = accumulate ? alpha_row[threadIdx.x] + a : a;
+  }
+  const int p = threadIdx.x % P, rl = threadIdx.x / P;
+  const bool on = rl < RL;
+  const int64_t r0 = blockIdx.x * rows_per_block;
+  int64_t r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  const int64_t stride = n * P;
+  float nn = 0.f;
+  if (on)
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+      float v = W[r * P + p];
+      for (int i = 0; i < nq; ++i) v = fmaf(-h[i * P + p], Q[(int64_t)i * stride + r * P + p], v);
+      W[r * P + p] = v;
+      nn = fmaf(v, v, nn);
+    }
+  if (on) red[rl * P + p] = nn;
+  __syncthreads();
+  if ((int)threadIdx.x < P) {
+    float t = 0.f;
+    for (int k = 0; k < RL; ++k) t += red[k * P + threadIdx.x];
+    norm_partial[(int64_t)blockIdx.x * P + threadIdx.x] = t;
+  }
+}
+
+// beta[p] = sqrt(sum_blk norm_partial[blk][p]); Qnext = W / beta  (a zero column stays zero)
+__global__ __launch_bounds__(kBlock) void blz_normalize_kernel(const float* __restrict__ W, float* __restrict__ Qnext,
+                                                               int64_t n, int P, const float* __restrict__ norm_partial,
+                                                               int nblk, float* __restrict__ beta_row) {
+  __shared__ float inv[kBlzMaxP];
+  if ((int)threadIdx.x < P) {
+    float t = 0.f;
+    for (int bI = 0; bI < nblk; ++bI) t += norm_partial[(int64_t)bI * P + threadIdx.x];
+    const float b = sqrtf(t);
+    inv[threadIdx.x] = b > 0.f ? 1.0f / b : 0.f;
+    if (blockIdx.x == 0) beta_row[threadIdx.x] = b;
+  }
+  __syncthreads();
+  const int64_t total = n * P;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x)
+    Qnext[e] = W[e] * inv[e % P];
+}
+
+}  // namespace
+
+extern "C" size_t mgp_lanczos_tridiag_block_workspace_bytes(const mgp_operator_t* op, int P, int steps) {
+  if (!op || steps <= 0 || steps + 1 > kBlzMaxNq || P <= 0 || P > kBlzMaxP || op->L.n <= 0) return 0;
+  const int64_t n = op->L.n;
+  size_t s = mgp_align((size_t)(steps + 1) * n * P * sizeof(float));   // Q
+  s += mgp_align((size_t)n * P * sizeof(float));                       // W
+  s += mgp_operator_workspace_bytes(op, P);
+  s += mgp_align((size_t)256 * (steps + 1) * P * sizeof(float));        // dot partials
+  s += mgp_align((size_t)256 * P * sizeof(float));                      // norm partials
+  s += 2 * mgp_align((size_t)(steps + 1) * P * sizeof(float));          // alpha, beta
+  return s + 4096;
+}
+
+// Q0 [n, P] start vectors (columns need not be normalised).  alpha / beta: host [steps][P].
+extern "C" int mgp_lanczos_tridiag_block(const mgp_operator_t* op, const float* Q0, int P, int steps, float* alpha,
+                                         float* beta, void* work, size_t work_bytes, void* stream) {
+  if (!op || !Q0 || !alpha || !beta || !work || steps <= 0 || P <= 0) return MGP_ERR_ARG;
+  if (P > kBlzMaxP || steps + 1 > kBlzMaxNq) return MGP_ERR_UNSUPPORTED;
+  if (work_bytes < mgp_lanczos_tridiag_block_workspace_bytes(op, P, steps)) return MGP_ERR_WORKSPACE;
+  const int64_t n = op->L.n;
+  hipStream_t st = mgp_stream(stream);
+  MgpArena ar(work, work_bytes);
+  float* Q = ar.take<float>((size_t)(steps + 1) * n * P);
+  float* W = ar.take<float>((size_t)n * P);
+  const size_t owb = mgp_operator_workspace_bytes(op, P);
+  void* ow = ar.take<char>(owb);
+  float* dpart = ar.take<float>((size_t)256 * (steps + 1) * P);
+  float* npart = ar.take<float>((size_t)256 * P);
+  float* d_alpha = ar.take<float>((size_t)(steps + 1) * P);
+  float* d_beta = ar.take<float>((size_t)(steps + 1) * P);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  const int RL = kBlock / P;
+  int64_t nblk = std::min<int64_t>(256, mgp_cdiv(n, 4 * RL));
+  if (nblk < 1) nblk = 1;
+  const int64_t rpb = mgp_cdiv(n, nblk);
+  nblk = mgp_cdiv(n, rpb);
+  const int egrid = (int)std::min<int64_t>(2048, mgp_cdiv(n * P, kBlock));
+  const int64_t blockf = n * P;
+
+  // q_0 = Q0 / column norms: one update launch with a zero coefficient gives the norm partials
+  MGP_HIP_TRY(hipMemcpyAsync(W, Q0, blockf * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipMemcpyAsync(Q, Q0, blockf * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipMemsetAsync(dpart, 0, (size_t)256 * P * sizeof(float), st));
+  MGP_HIP_TRY(hipMemsetAsync(d_alpha, 0, (size_t)(steps + 1) * P * sizeof(float), st));
+  hipLaunchKernelGGL(blz_update_kernel, dim3((int)nblk), dim3(kBlock), (size_t)(P + RL * P) * sizeof(float), st, W, Q, n, P, 1,
+                     rpb, dpart, (int)nblk, d_alpha + (size_t)steps * P, 0, npart);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(blz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, W, Q, n, P, npart, (int)nblk,
+                     d_beta + (size_t)steps * P);
+  MGP_LAUNCH_CHECK();
+  for (int j = 0; j < steps; ++j) {
+    float* qj = Q + (int64_t)j * blockf;
+    MGP_TRY(mgp_operator_apply_ex(op, qj, P, W, nullptr, nullptr, nullptr, nullptr, ow, owb, stream));
+    const int nq = j + 1;
+    for (int pass = 0; pass < 2; ++pass) {   // classical Gram-Schmidt against q_0..q_j, twice
+      hipLaunchKernelGGL(blz_dots_kernel, dim3((int)nblk), dim3(kBlock), (size_t)nq * RL * P * sizeof(float), st, W, Q, n, P,
+                         nq, rpb, dpart);
+      MGP_LAUNCH_CHECK();
+      hipLaunchKernelGGL(blz_update_kernel, dim3((int)nblk), dim3(kBlock), (size_t)(nq * P + RL * P) * sizeof(float), st, W,
+                         Q, n, P, nq, rpb, dpart, (int)nblk, d_alpha + (size_t)j * P, pass, npart);
+      MGP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(blz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, W, Q + (int64_t)(j + 1) * blockf, n, P, npart,
+                       (int)nblk, d_beta + (size_t)j * P);
+    MGP_LAUNCH_CHECK();
+  }
+  MGP_HIP_TRY(hipMemcpyAsync(alpha, d_alpha, (size_t)steps * P * sizeof(float), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipMemcpyAsync(beta, d_beta, (size_t)steps * P * sizeof(float), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  return MGP_OK;
+}
+
 extern "C" size_t mgp_lanczos_tridiag_workspace_bytes(const mgp_operator_t* op, int steps) {
   if (!op || steps <= 0 || op->L.n <= 0) return 0;
   const int64_t n = op->L.n;

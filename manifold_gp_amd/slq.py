@@ -32,6 +32,24 @@ def lanczos_tridiag(desc, q0, steps):
     return np.array(alpha, dtype=np.float64), np.array(beta, dtype=np.float64)
 
 
+def lanczos_tridiag_block(desc, Q0, steps):
+    """P independent Lanczos runs at once (mgp_lanczos_tridiag_block): Q0 [n, P], P <= 16.
+    Returns alpha [steps, P], beta [steps, P] (float64 numpy)."""
+    _lib.require_device(Q0)
+    Q0 = _lib.f32c(Q0)
+    P = Q0.shape[1]
+    op = desc.struct()
+    wb = lib().mgp_lanczos_tridiag_block_workspace_bytes(ctypes.byref(op), P, int(steps))
+    if wb == 0:
+        raise RuntimeError("mgp_lanczos_tridiag_block: unsupported shape (P = %d, steps = %d)" % (P, steps))
+    work = _lib.workspace(wb, "lanczos_tridiag", Q0.device)
+    alpha = (ctypes.c_float * (steps * P))()
+    beta = (ctypes.c_float * (steps * P))()
+    check(lib().mgp_lanczos_tridiag_block(ctypes.byref(op), ptr(Q0), P, int(steps), alpha, beta, ptr(work), work.numel(),
+                                          stream()), "mgp_lanczos_tridiag_block")
+    return (np.array(alpha, dtype=np.float64).reshape(steps, P), np.array(beta, dtype=np.float64).reshape(steps, P))
+
+
 def _quadrature_log(alpha, beta):
     k = len(alpha)
     # an (almost) zero beta means the Krylov space is exhausted: truncate there
@@ -57,8 +75,18 @@ def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
     gen = torch.Generator(device="cpu").manual_seed(seed)
     dev = desc.data.graph.device
     total = 0.0
-    for _ in range(num_probes):
-        z = (torch.randint(0, 2, (n,), generator=gen).float() * 2 - 1).to(dev)
-        a, b = lanczos_tridiag(desc, z, steps)
-        total += _quadrature_log(a, b)
+    if steps + 1 <= 48:
+        # all probes as columns of one block (batches of <= 16, a multiple of 4 columns so that the SpMM
+        # takes its 16-byte-row kernel): the runs are independent, the launch count drops by the batch size
+        num_probes = -(-num_probes // 4) * 4
+        Z = (torch.randint(0, 2, (n, num_probes), generator=gen).float() * 2 - 1).to(dev)
+        for c0 in range(0, num_probes, 16):
+            a, b = lanczos_tridiag_block(desc, Z[:, c0:c0 + 16].contiguous(), steps)
+            for p in range(a.shape[1]):
+                total += _quadrature_log(a[:, p], b[:, p])
+    else:
+        for _ in range(num_probes):
+            z = (torch.randint(0, 2, (n,), generator=gen).float() * 2 - 1).to(dev)
+            a, b = lanczos_tridiag(desc, z, steps)
+            total += _quadrature_log(a, b)
     return torch.tensor(n * total / num_probes, dtype=torch.float32, device=dev)

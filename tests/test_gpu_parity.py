@@ -1104,3 +1104,23 @@ def test_manifold_informed_train_loop(mgp, golden, dev, max_cholesky):
     assert sum(m > 1e-4 for m in moved) >= 3, moved             # noise, output scale, length scale / bandwidth
     if max_cholesky >= 4000:
         assert losses[-1] < losses[0]                             # exact gradients: the loss goes down
+
+
+def test_lanczos_tridiag_block_matches_single_runs(mgp, golden, dev):
+    """mgp_lanczos_tridiag_block: P probes as columns of one block give, column by column, the tridiagonal
+    of the single-vector routine (same arithmetic up to summation order)."""
+    from manifold_gp_amd.slq import lanczos_tridiag, lanczos_tridiag_block
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[float(g["kappa"])]], device=dev))
+    desc = mgp.operators.NoiseWrapperOperator(mgp.operators.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev)),
+                                              torch.tensor(1e-2, device=dev))._descriptor()
+    n = lap.shape[0]
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    Z = (torch.randint(0, 2, (n, 8), generator=gen).float() * 2 - 1).to(dev)
+    steps = 12
+    A, B = lanczos_tridiag_block(desc, Z, steps)
+    for p in (0, 3, 7):
+        a, b = lanczos_tridiag(desc, Z[:, p].contiguous(), steps)
+        np.testing.assert_allclose(A[:, p], a, rtol=2e-3, atol=2e-3 * np.abs(a).max())
+        np.testing.assert_allclose(B[:, p], b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
