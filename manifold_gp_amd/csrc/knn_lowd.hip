@@ -162,11 +162,15 @@ __global__ __launch_bounds__(kBlock) void window_threshold_kernel(const float4* 
   if (lane == 0 && qi_raw < n) T[qi] = a[k - 1] * inflate;
 }
 
-// ---- phase B: fused distance + filter, one query per lane, points broadcast from LDS
+// ---- phase B: fused distance + filter, one query per lane, points broadcast from LDS.
+// gridDim.y > 1 (few queries against many points, e.g. out-of-sample features of a small test batch):
+// the point range is split over blockIdx.y so that the pass still fills the chip; the lanes of the
+// segments then share a query's candidate list through an atomic slot counter (the list order is
+// irrelevant, phase C sorts by (d64, index)).  gridDim.y == 1: private counters, no atomics.
 __global__ __launch_bounds__(kBlock) void filter_kernel(const float4* __restrict__ xs, int64_t N,
                                                         const float* __restrict__ q, int64_t n, int d,
                                                         const float* __restrict__ T, int32_t* __restrict__ cand,
-                                                        int32_t* __restrict__ cnt) {
+                                                        int32_t* __restrict__ cnt, int64_t seg) {
   __shared__ float4 pts[kChunk];
   const int tid = threadIdx.x;
   const int64_t qi_raw = (int64_t)blockIdx.x * kBlock + tid;
@@ -175,26 +179,30 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(const float4* __restrict
   const float qx = q[qi * d], qy = d > 1 ? q[qi * d + 1] : 0.f, qz = d > 2 ? q[qi * d + 2] : 0.f;
   const float thr = live ? T[qi] : -1.f;
   int32_t* __restrict__ mine = cand + qi * kCap;
+  const bool shared_list = gridDim.y > 1;
+  const int64_t p_begin = (int64_t)blockIdx.y * seg;
+  const int64_t p_end = p_begin + seg < N ? p_begin + seg : N;
   int c = 0;
-  for (int64_t c0 = 0; c0 < N; c0 += kChunk) {
+  for (int64_t c0 = p_begin; c0 < p_end; c0 += kChunk) {
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < kChunk / kBlock; ++t) {
       const int64_t j = c0 + tid + t * kBlock;
       // points past the end sit infinitely far away
-      pts[tid + t * kBlock] = j < N ? xs[j] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+      pts[tid + t * kBlock] = j < p_end ? xs[j] : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
     }
     __syncthreads();
 #pragma unroll 8
     for (int p = 0; p < kChunk; ++p) {
       const float dd = d2_f32(qx, qy, qz, pts[p]);
       if (dd <= thr) {
-        if (c < kCap) mine[c] = (int32_t)(c0 + p);
+        const int slot = shared_list ? atomicAdd(&cnt[qi], 1) : c;
+        if (slot < kCap) mine[slot] = (int32_t)(c0 + p);
         ++c;
       }
     }
   }
-  if (live) cnt[qi] = c;
+  if (live && !shared_list) cnt[qi] = c;
 }
 
 __device__ __forceinline__ bool pair_less(double d1, int i1, double d2, int i2) {
@@ -381,7 +389,15 @@ int mgp_knn_lowd(const float* db, int64_t N, int d, const float* q, int64_t n, i
   MGP_LAUNCH_CHECK();
 
   // B. fused filter, C. exact re-rank
-  hipLaunchKernelGGL(filter_kernel, dim3((unsigned)mgp_cdiv(n, kBlock)), dim3(kBlock), 0, st, xs, N, q, n, d, T, cand, cnt);
+  // enough workgroups to fill the chip: split the point range when there are few query blocks
+  const int64_t qblocks = mgp_cdiv(n, kBlock);
+  int64_t segs = 1;
+  if (qblocks < 1024) segs = std::min<int64_t>(mgp_cdiv(1024, qblocks), std::max<int64_t>(1, N / (8 * kChunk)));
+  if (segs > 1) MGP_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int32_t), st));
+  const int64_t seg_len = mgp_cdiv(mgp_cdiv(N, segs), (int64_t)kChunk) * kChunk;     // whole LDS chunks per segment
+  segs = mgp_cdiv(N, seg_len);
+  hipLaunchKernelGGL(filter_kernel, dim3((unsigned)qblocks, (unsigned)segs), dim3(kBlock), 0, st, xs, N, q, n, d, T, cand, cnt,
+                     seg_len);
   MGP_LAUNCH_CHECK();
   MGP_HIP_TRY(hipMemsetAsync(over_count, 0, sizeof(int32_t), st));
   hipLaunchKernelGGL(rerank_kernel, dim3(qgrid), dim3(kBlock), 0, st, xs, perm, q, n, d, k, cand, cnt, D, I, over_list,

@@ -1124,3 +1124,19 @@ def test_lanczos_tridiag_block_matches_single_runs(mgp, golden, dev):
         a, b = lanczos_tridiag(desc, Z[:, p].contiguous(), steps)
         np.testing.assert_allclose(A[:, p], a, rtol=2e-3, atol=2e-3 * np.abs(a).max())
         np.testing.assert_allclose(B[:, p], b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
+
+
+def test_knn_lowdim_few_queries_split_point_range(mgp, dev):
+    """Few queries against many points (out-of-sample features of a small batch): the fused filter splits
+    the point range over several workgroups that share the candidate lists; still bit-exact."""
+    from oracle import knn as oknn
+    rng = np.random.default_rng(21)
+    x = rng.normal(size=(40000, 3)).astype(np.float32)
+    x[:5000] = np.round(x[:5000] * 4) / 4                      # a lattice part: exact ties
+    q = np.concatenate([x[:100], rng.normal(size=(200, 3)).astype(np.float32)])
+    nn = mgp.utils.NearestNeighbors(T(x, dev))
+    for k in (1, 20, 64):
+        Dr, Ir = oknn.knn_search(x, q, k)
+        D, I = nn.search(T(q, dev), k)
+        assert nn.last_stats["candidates"] == -1
+        assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), k
