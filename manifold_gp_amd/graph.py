@@ -99,9 +99,8 @@ class KnnGraph:
         if isinstance(tiles, str):          # "auto": build on the device the CSR lives on (host tensors: none)
             tiles = build_tiles_auto(self.n, rowptr, col, self.nnz, points) if col.is_cuda else None
         self.tiles = tiles
-        # sub-wave group width for the C == 1 SpMV: 4 entries per lane per pass
-        # measured on the 60k bench graph (tools/tune_spmv.py): 8 lanes x 2 rows in flight is the
-        # fastest shape for mean rows of ~60 entries; wider groups only pay for much longer rows
+        # sub-wave group width of the fallback (gather) C == 1 SpMV: 4 entries per lane per pass; 8 lanes
+        # measured best for mean rows of ~60 entries (tools/tune_spmv.py), wider groups only for longer rows
         mean_row = self.nnz / max(self.n, 1)
         lanes = 8
         while lanes < 64 and lanes * 16 < mean_row:
