@@ -765,6 +765,58 @@ __global__ void refine_accumulate_kernel(float* __restrict__ xacc, const float* 
     xacc[i] = first ? x[i] : xacc[i] + x[i];
 }
 
+// ---- fp64 refinement (single GPU): the accumulated solution and the true residual live in fp64
+__global__ void refine_accumulate64_kernel(double* __restrict__ xacc, const float* __restrict__ x, int64_t total, int first) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    xacc[i] = first ? (double)x[i] : xacc[i] + (double)x[i];
+}
+
+// R = B - T (fp64) -> next right-hand side in fp32; partial[blk][c] = {sum R^2, sum B^2} in fp64
+__global__ __launch_bounds__(kBlock) void refine_residual64_kernel(const float* __restrict__ B, const double* __restrict__ T,
+                                                                   float* __restrict__ R, int64_t n, int C,
+                                                                   double* __restrict__ partial) {
+  __shared__ double sh[2][kBlock];
+  int TC = 1;
+  while (TC < C) TC <<= 1;
+  const int TS = kBlock / TC;
+  const int tid = threadIdx.x, cc = tid % TC, sl = tid / TC;
+  double rr = 0.0, bb = 0.0;
+  if (cc < C) {
+    for (int64_t r = (int64_t)blockIdx.x * TS + sl; r < n; r += (int64_t)gridDim.x * TS) {
+      const int64_t i = r * C + cc;
+      const double b = (double)B[i], d = b - T[i];
+      R[i] = (float)d;
+      rr += d * d;
+      bb += b * b;
+    }
+  }
+  sh[0][tid] = rr; sh[1][tid] = bb;
+  __syncthreads();
+  if (tid < TC && tid < C) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < TS; ++k) { s0 += sh[0][k * TC + tid]; s1 += sh[1][k * TC + tid]; }
+    partial[((int64_t)blockIdx.x * C + tid) * 2 + 0] = s0;
+    partial[((int64_t)blockIdx.x * C + tid) * 2 + 1] = s1;
+  }
+}
+
+__global__ void refine_finalize64_kernel(const double* __restrict__ partial, int nblk, int C, float* __restrict__ host_rel) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double rr = 0.0, bb = 0.0;
+    for (int b = 0; b < nblk; ++b) { rr += partial[((int64_t)b * C + c) * 2]; bb += partial[((int64_t)b * C + c) * 2 + 1]; }
+    host_rel[c] = bb > 0.0 ? (float)sqrt(rr / bb) : 0.f;
+  }
+}
+
+__global__ void refine_publish64_kernel(const double* __restrict__ xacc, float* __restrict__ x, float* __restrict__ X2,
+                                        int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = (float)xacc[i];
+    x[i] = v;
+    if (X2) X2[i] = v;
+  }
+}
+
 struct CgPlan {
   mgp_operator_t op;
   MgpDist dist;             // row partition (is_dist): op.L holds the local rows only
@@ -797,6 +849,7 @@ struct CgPlan {
   int32_t* host_state;      // pinned
   float* host_resid;        // pinned
   float *xacc, *rbuf, *tbuf, *rpart;   // refinement: accumulated solution, residual rhs, A x, partials
+  double *xacc64, *t64, *work64, *rpart64;   // single GPU: the same in fp64 (true residual from an fp64 apply)
   float* host_true_rel;     // host-mapped [C]: true relative residuals
   float* dev_true_rel;
 };
@@ -817,6 +870,7 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   b += mgp_align((size_t)nbs * C * sizeof(float));              // pd_delta
   b += mgp_align((6 * (size_t)C + 16) * sizeof(float));          // gamma_old[2] alpha_old[2] bb resid state
   b += mgp_align((size_t)256 * C * 2 * sizeof(float));          // refinement partials
+  b += 6 * 2 * nc + mgp_align((size_t)256 * C * 2 * sizeof(double));   // fp64 refinement: xacc, A x, 4 chain buffers
   return b + 1024;
 }
 
@@ -996,6 +1050,8 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   a.state = reinterpret_cast<int*>(blk + 6 * (size_t)C);
   pl->xacc = ar.take<float>(nc); pl->rbuf = ar.take<float>(nc); pl->tbuf = ar.take<float>(nc);
   pl->rpart = ar.take<float>((size_t)256 * C * 2);
+  pl->xacc64 = ar.take<double>(nc); pl->t64 = ar.take<double>(nc); pl->work64 = ar.take<double>(4 * nc);
+  pl->rpart64 = ar.take<double>((size_t)256 * C * 2);
   a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter;
   a.stop_mode = pl->prm.stop_mode;
   a.rn = nullptr; a.sn = nullptr;
@@ -1130,22 +1186,35 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
   int total_iters = 0, last_status = 0;
   const float* rhs = B;
   const int egrid = (int)(mgp_cdiv((int64_t)nc, kBlock) > 2048 ? 2048 : mgp_cdiv((int64_t)nc, kBlock));
+  const bool f64 = !pl->is_dist;     // single GPU: accumulate x and form the true residual in fp64
+  const int rgrid = 256;
   for (int ref = 0; ref <= max_refine; ++ref) {
     MGP_TRY(run_cg(pl, rhs, nullptr));
     total_iters += pl->host_state[0] - 1;
     last_status = pl->host_state[2];
-    hipLaunchKernelGGL(refine_accumulate_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->xacc, pl->args.x, (int64_t)nc,
-                       ref == 0 ? 1 : 0);
-    MGP_LAUNCH_CHECK();
-    // true residual R = B - A xacc
-    MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->xacc, nullptr, pl->C, pl->tbuf,
-                                    nullptr, nullptr, 0, nullptr, nullptr, pl->op_work, pl->op_work_bytes, st));
-    const int rgrid = 256;
-    hipLaunchKernelGGL(refine_residual_kernel, dim3(rgrid), dim3(kBlock), 0, st, B, pl->tbuf, pl->rbuf, pl->args.n,
-                       pl->C, pl->rpart);
-    MGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(refine_finalize_kernel, dim3(1), dim3(kBlock), 0, st, pl->rpart, rgrid, pl->C, pl->dev_true_rel);
-    MGP_LAUNCH_CHECK();
+    if (f64) {
+      hipLaunchKernelGGL(refine_accumulate64_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->xacc64, pl->args.x, (int64_t)nc,
+                         ref == 0 ? 1 : 0);
+      MGP_LAUNCH_CHECK();
+      MGP_TRY(mgp_operator_apply_f64(&pl->op, pl->xacc64, pl->C, pl->t64, pl->work64, st));
+      hipLaunchKernelGGL(refine_residual64_kernel, dim3(rgrid), dim3(kBlock), 0, st, B, pl->t64, pl->rbuf, pl->args.n, pl->C,
+                         pl->rpart64);
+      MGP_LAUNCH_CHECK();
+      hipLaunchKernelGGL(refine_finalize64_kernel, dim3(1), dim3(kBlock), 0, st, pl->rpart64, rgrid, pl->C, pl->dev_true_rel);
+      MGP_LAUNCH_CHECK();
+    } else {
+      hipLaunchKernelGGL(refine_accumulate_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->xacc, pl->args.x, (int64_t)nc,
+                         ref == 0 ? 1 : 0);
+      MGP_LAUNCH_CHECK();
+      // true residual R = B - A xacc
+      MGP_TRY(mgp_operator_apply_dist(&pl->op, &pl->dist, pl->xacc, nullptr, pl->C, pl->tbuf, nullptr, nullptr, 0, nullptr,
+                                      nullptr, pl->op_work, pl->op_work_bytes, st));
+      hipLaunchKernelGGL(refine_residual_kernel, dim3(rgrid), dim3(kBlock), 0, st, B, pl->tbuf, pl->rbuf, pl->args.n,
+                         pl->C, pl->rpart);
+      MGP_LAUNCH_CHECK();
+      hipLaunchKernelGGL(refine_finalize_kernel, dim3(1), dim3(kBlock), 0, st, pl->rpart, rgrid, pl->C, pl->dev_true_rel);
+      MGP_LAUNCH_CHECK();
+    }
     MGP_HIP_TRY(hipStreamSynchronize(st));
     bool ok = true;
     for (int c = 0; c < pl->C; ++c) ok = ok && (pl->host_true_rel[c] <= 2.0f * pl->prm.tol);
@@ -1153,8 +1222,13 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
     rhs = pl->rbuf;
   }
   // publish the accumulated solution in the plan buffer (mgp_cg_plan_x) and, if asked, in X
-  MGP_HIP_TRY(hipMemcpyAsync(pl->args.x, pl->xacc, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if (X) MGP_HIP_TRY(hipMemcpyAsync(X, pl->xacc, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (f64) {
+    hipLaunchKernelGGL(refine_publish64_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->xacc64, pl->args.x, X, (int64_t)nc);
+    MGP_LAUNCH_CHECK();
+  } else {
+    MGP_HIP_TRY(hipMemcpyAsync(pl->args.x, pl->xacc, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (X) MGP_HIP_TRY(hipMemcpyAsync(X, pl->xacc, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
   MGP_HIP_TRY(hipStreamSynchronize(st));
   if (iters) *iters = total_iters;
   if (status) *status = last_status;

@@ -78,3 +78,6 @@ int mgp_knn_lowd(const float* db, int64_t N, int d, const float* q, int64_t n, i
 int mgp_knn_gather_rows(const float* src, const int32_t* rows_dev, int64_t m, int w, float* dst, void* stream);
 int mgp_knn_scatter_rows(const float* Ds, const int32_t* Is, const int32_t* rows_dev, int64_t m, int k, float* D,
                          int32_t* I, void* stream);
+
+// fp64 operator apply from the fp32 matrix (true residual of the CG refinement); work64 = 4 n C doubles
+int mgp_operator_apply_f64(const mgp_operator_t* op, const double* X, int C, double* Y, double* work64, void* stream);

@@ -158,6 +158,77 @@ int mgp_operator_apply_tail(const mgp_operator_t* op, const float* X, int C, flo
   return q2_chain(op, nullptr, 0, X, nullptr, C, Y, X, 1.f, op->noise, t0, t1, &hk, stream);
 }
 
+// ---------------------------------------------------------------- fp64 apply (iterative refinement only)
+// Y = cb base + co post (.) (a xs + b (diag (.) xs - S xs)), xs = pre (.) X, everything accumulated in
+// fp64 from the fp32 matrix: used once per refinement round of the CG to form the TRUE residual, so that
+// the refined solution is accurate to fp32 round-off in the FORWARD error even when cond(A) eps32 is
+// large (N = 1M swiss roll: 1e-3).  One lane per (row, column); not a hot kernel.
+namespace {
+
+__global__ void spmm_f64_kernel(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                const float* __restrict__ vals, const float* __restrict__ diag,
+                                const double* __restrict__ X, double* __restrict__ Y, int C, double a, double b,
+                                const float* __restrict__ pre, const float* __restrict__ post,
+                                const double* __restrict__ base, double cb, double co) {
+  const int64_t total = n * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C;
+    const int c = (int)(i % C);
+    double acc = 0.0;
+    for (int e = rowptr[r], e1 = rowptr[r + 1]; e < e1; ++e) {
+      const int j = col[e];
+      double xj = X[(int64_t)j * C + c];
+      if (pre) xj *= (double)pre[j];
+      acc += (double)vals[e] * xj;
+    }
+    double xs = X[i];
+    if (pre) xs *= (double)pre[r];
+    double t = a * xs + b * ((double)diag[r] * xs - acc);
+    if (post) t *= (double)post[r];
+    Y[i] = (base ? cb * base[i] : 0.0) + co * t;
+  }
+}
+
+int q2_chain_f64(const mgp_operator_t* op, const double* X, int C, double* Y, const double* base, double cb, double co,
+                 double* t0, double* t1, hipStream_t st) {
+  const double tau = 2.0 * (double)op->nu / ((double)op->kappa * (double)op->kappa);
+  const int64_t n = op->L.n;
+  int64_t grid = mgp_cdiv(n * C, 256);
+  if (grid > 65535 * 4) grid = 65535 * 4;
+  const double* in = X;
+  for (int s = 0; s < op->nu; ++s) {
+    const bool first = (s == 0), last = (s == op->nu - 1);
+    double* out = last ? Y : ((s & 1) ? t1 : t0);
+    hipLaunchKernelGGL(spmm_f64_kernel, dim3((unsigned)grid), dim3(256), 0, st, n, op->L.rowptr, op->L.col, op->L.vals,
+                       op->L.diag, in, out, C, tau, 1.0, first ? op->pre : nullptr, last ? op->post : nullptr,
+                       last ? base : nullptr, cb, last ? co * (double)op->scale : 1.0);
+    MGP_LAUNCH_CHECK();
+    in = out;
+  }
+  return MGP_OK;
+}
+
+}  // namespace
+
+// work64: 4 buffers of n * C doubles
+int mgp_operator_apply_f64(const mgp_operator_t* op, const double* X, int C, double* Y, double* work64, void* stream) {
+  MGP_TRY(check_op(op));
+  if (!X || !Y || !work64 || C <= 0) return MGP_ERR_ARG;
+  hipStream_t st = mgp_stream(stream);
+  const size_t nc = (size_t)op->L.n * C;
+  double *t0 = work64, *t1 = work64 + nc, *ua = work64 + 2 * nc, *ub = work64 + 3 * nc;
+  const double noise = (double)op->noise;
+  switch (op->form) {
+    case 0: return q2_chain_f64(op, X, C, Y, nullptr, 0.0, 1.0, t0, t1, st);
+    case 2: return q2_chain_f64(op, X, C, Y, X, 1.0, noise, t0, t1, st);
+    case 1:
+      MGP_TRY(q2_chain_f64(op, X, C, ua, X, 1.0, -noise, t0, t1, st));
+      MGP_TRY(q2_chain_f64(op, ua, C, ub, X, 1.0, -noise, t0, t1, st));
+      return q2_chain_f64(op, ub, C, Y, nullptr, 0.0, 1.0, t0, t1, st);
+  }
+  return MGP_ERR_ARG;
+}
+
 extern "C" int mgp_operator_apply(const mgp_operator_t* op, const float* X, int C, float* Y, void* work,
                                   size_t work_bytes, void* stream) {
   return mgp_operator_apply_ex(op, X, C, Y, nullptr, nullptr, nullptr, nullptr, work, work_bytes, stream);
