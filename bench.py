@@ -277,7 +277,7 @@ def _main(quiet):
                 scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                 config=dict(workload=wl["name"], nodes=g.n, edges=g.M, nnz_padded=g.nnz, rhs_columns=1,
                             system="A = I + noise*outputscale*Q, Q=(2nu/kappa^2 I + L)^nu x D",
-                            cg_tol=args.tol, cg_iters=its, cg_rel_residual=resid, cg_true_residual=true_res,
+                            cg_tol=args.tol, cg_iters=its, cg_rel_residual=resid, cg_true_residual_fp32_apply=true_res,
                             spmv_per_solve=spmvs_per_solve, eps=wl["eps"], knn_graph_build_s=round(wl["t_graph"], 3)),
                 cg_solve_ms=round(dt / args.steps * 1e3, 4), roofline=roof)
     if not args.no_cpu_baseline:

@@ -279,7 +279,7 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
                                 rhs_columns=1, parallelism="rows of L partitioned over %d ranks, vectors replicated, "
                                 "one grouped RCCL all-gather per SpMV" % world,
                                 cg_tol=args.tol, cg_iters=its, cg_rel_residual=max(plan.resid),
-                                cg_true_residual=true_res, spmv_per_solve=spmvs, eps=wl["eps"]),
+                                cg_true_residual_fp32_apply=true_res, spmv_per_solve=spmvs, eps=wl["eps"]),
                     cg_solve_ms=round(dt / args.steps * 1e3, 4),
                     roofline=dict(bound="hbm", achieved=round(value / world, 1), peak=hbm_peak, unit="GB/s",
                                   frac=round(value / world / hbm_peak, 4), traffic=None,
