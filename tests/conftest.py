@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no libmgp_hip.so (built artefacts are not tracked): build it once, exactly as
+    __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU)."""
+    so = os.path.join(ROOT, "manifold_gp_amd", "libmgp_hip.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.check_call(["bash", os.path.join(ROOT, "manifold_gp_amd", "csrc", "build.sh")])
+
+
 @pytest.fixture(scope="session")
 def golden():
     def _load(name):
