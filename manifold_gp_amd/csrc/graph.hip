@@ -534,7 +534,7 @@ extern "C" int mgp_graph_bfs_order(int64_t n, const int32_t* rowptr, const int32
   MGP_HIP_TRY(hipMemsetAsync(pkey, 0xff, (size_t)n * sizeof(uint32_t), st));
   int numbered = 0, fcount = 0, fbase = 0, scan_from = 0;
   int64_t levels = 0;
-  const int64_t level_cap = 200000;
+  const int64_t level_cap = 20000;   // one host round trip per level: bounds the setup cost on chain-like graphs (<~ 1 s)
   while (numbered < n) {
     if (fcount == 0) {                               // next component: seed = smallest unnumbered node
       int32_t big = 0x7fffffff;
