@@ -10,6 +10,42 @@ from .. import _lib
 from .._compat import LinearOperator
 
 
+class _SchurMatmul(torch.autograd.Function):
+    """S(theta) v with gradients.  With w = Q_uu^-1 Q_ul v and the full-length vectors V = [v; -w],
+    U = [g; -z] (z = Q_uu^-1 Q_ul g), u^T S v = U^T Q V and, because w and z are stationary points of
+    that bilinear form, d(g^T S v)/d theta = U^T (dQ/d theta) V with U, V held fixed: one more inner solve
+    and one differentiable precision matmul in the backward pass, no differentiation through the CG.
+    The rhs gradient is S g (S is symmetric for the symmetric precision operators of the reference)."""
+
+    @staticmethod
+    def forward(ctx, v, op, *hyper):
+        from .._compat import settings
+        # the backward pass runs outside the caller's settings context: keep the solver settings of the
+        # forward pass for the inner solve of the backward pass
+        ctx.cg = dict(tol=settings.cg_tolerance.value(), max_iter=settings.max_cg_iterations.value(),
+                      stop_mode=settings.cg_stop_mode.value())
+        res, V = op._apply_parts(v, **ctx.cg)
+        ctx.op = op
+        ctx.save_for_backward(V, *hyper)
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        op = ctx.op
+        V = ctx.saved_tensors[0]
+        hyper = ctx.saved_tensors[1:]
+        Sg, U = op._apply_parts(_lib.f32c(g), **ctx.cg)
+        grads = [None] * len(hyper)
+        need = [i for i, h in enumerate(hyper) if h.requires_grad and ctx.needs_input_grad[2 + i]]
+        if need:
+            with torch.enable_grad():
+                val = (U * op.base._matmul(V)).sum()
+                out = torch.autograd.grad(val, [hyper[i] for i in need], allow_unused=True)
+            for i, gi in zip(need, out):
+                grads[i] = gi
+        return (Sg if ctx.needs_input_grad[0] else None, None, *grads)
+
+
 class SchurComplementOperator(LinearOperator):
     def __init__(self, base, mask):
         super().__init__(base, mask)
@@ -26,20 +62,34 @@ class SchurComplementOperator(LinearOperator):
             self._lidx = torch.nonzero(m, as_tuple=False).squeeze(-1)
         return self._fmask
 
-    def _matmul(self, rhs):
+    def _hyper_tensors(self):
+        return getattr(self.base, "_hyper_tensors", lambda: [])()
+
+    def _apply_parts(self, v, **cg_kw):
+        """(S v [k, C], V [n, C]) with V = [v on the labelled nodes; -Q_uu^-1 Q_ul v on the others]."""
         from ..solvers import cg_solve
+        with torch.no_grad():
+            ml, mu = self._masks()
+            desc = self.base._descriptor()
+            n = desc.n
+            full = torch.zeros(n, v.shape[1], device=v.device, dtype=torch.float32)
+            full[self._lidx] = v
+            tmp = desc.masked(col_mask=ml).apply(full)                 # Q[:, l] v           (:27)
+            sol = cg_solve(desc.masked(row_mask=mu, col_mask=mu), tmp * mu.view(-1, 1), **cg_kw)[0]   # Q_uu^-1 (:28)
+            out = desc.masked(row_mask=ml, col_mask=mu).apply(sol)     # Q_lu (.)            (:29)
+            res = (tmp - out)[self._lidx]                              # (:30)
+            return res, full - sol * mu.view(-1, 1)
+
+    def _matmul(self, rhs):
+        from ..autograd import needs_grad
         _lib.require_device(rhs)
         squeeze = rhs.dim() == 1
         v = _lib.f32c(rhs.unsqueeze(-1) if squeeze else rhs)
-        ml, mu = self._masks()
-        desc = self.base._descriptor()
-        n = desc.n
-        full = torch.zeros(n, v.shape[1], device=v.device, dtype=torch.float32)
-        full[self._lidx] = v
-        tmp = desc.masked(col_mask=ml).apply(full)                 # Q[:, l] v           (:27)
-        sol = cg_solve(desc.masked(row_mask=mu, col_mask=mu), tmp * mu.view(-1, 1))[0]   # Q_uu^-1 (:28)
-        out = desc.masked(row_mask=ml, col_mask=mu).apply(sol)     # Q_lu (.)            (:29)
-        res = (tmp - out)[self._lidx]                              # (:30)
+        hyper = self._hyper_tensors()
+        if needs_grad(rhs, *hyper):
+            res = _SchurMatmul.apply(v, self, *hyper)
+        else:
+            res = self._apply_parts(v)[0]
         return res.squeeze(-1) if squeeze else res
 
     def _solve(self, rhs, preconditioner=None, num_tridiag=0):

@@ -50,6 +50,20 @@ def lanczos_tridiag_block(desc, Q0, steps):
     return (np.array(alpha, dtype=np.float64).reshape(steps, P), np.array(beta, dtype=np.float64).reshape(steps, P))
 
 
+def _generic_device(operator):
+    op = operator
+    while op is not None:
+        for name in ("mask", "scale", "noise"):
+            t = getattr(op, name, None)
+            if torch.is_tensor(t) and t.is_cuda:
+                return t.device
+        base = getattr(op, "base", None)
+        if base is not None and hasattr(base, "laplacian"):
+            return base.laplacian.x.device
+        op = getattr(op, "operator", None) or base
+    return torch.device("cuda:0")
+
+
 def _quadrature_log(alpha, beta):
     k = len(alpha)
     # an (almost) zero beta means the Krylov space is exhausted: truncate there
@@ -64,11 +78,43 @@ def _quadrature_log(alpha, beta):
     return float(np.sum(S[0, :] ** 2 * np.log(theta)))
 
 
+def _lanczos_block_generic(operator, Z, steps):
+    """The same P independent Lanczos runs for an operator that is NOT one polynomial chain (wrappers around
+    a Schur complement): torch vector algebra around `operator.matmul` on [n, P] blocks -- every matmul
+    underneath is still HIP launches (the Schur matvec runs its inner HIP CG with P right-hand sides)."""
+    n, P = Z.shape
+    Q = [Z / Z.norm(dim=0, keepdim=True).clamp_min(1e-30)]
+    alpha = np.zeros((steps, P))
+    beta = np.zeros((steps, P))
+    for j in range(steps):
+        W = operator.matmul(Q[j])
+        a = torch.zeros(P, device=Z.device)
+        for _ in range(2):                                     # classical Gram-Schmidt against q_0..q_j, twice
+            for i, q in enumerate(Q):
+                h = (W * q).sum(0)
+                W = W - q * h
+                if i == j:
+                    a = a + h
+        b = W.norm(dim=0)
+        alpha[j], beta[j] = a.double().cpu().numpy(), b.double().cpu().numpy()
+        Q.append(W / b.clamp_min(1e-30))
+    return alpha, beta
+
+
 def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
     desc = getattr(operator, "_descriptor", lambda: None)()
     if desc is None:
-        raise NotImplementedError("SLQ log-determinant needs an operator that is one polynomial chain "
-                                  "(PrecisionMatern / Scale / Noise wrappers)")
+        n = operator.shape[0]
+        num_probes = settings.num_trace_samples.value() if num_probes is None else num_probes
+        steps = min(n, 20 if steps is None else steps)
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        dev = operator.device if hasattr(operator, "device") else None
+        Z = (torch.randint(0, 2, (n, num_probes), generator=gen).float() * 2 - 1)
+        Z = Z.to(_generic_device(operator))
+        with torch.no_grad():
+            a, b = _lanczos_block_generic(operator, Z, steps)
+        total = sum(_quadrature_log(a[:, p], b[:, p]) for p in range(num_probes))
+        return torch.tensor(n * total / num_probes, dtype=torch.float32, device=Z.device)
     n = desc.n
     num_probes = settings.num_trace_samples.value() if num_probes is None else num_probes
     steps = min(n, 20 if steps is None else steps)

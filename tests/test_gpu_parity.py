@@ -1146,3 +1146,86 @@ def test_knn_lowdim_few_queries_split_point_range(mgp, dev):
         D, I = nn.search(T(q, dev), k)
         assert nn.last_stats["candidates"] == -1
         assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), k
+
+
+def test_schur_matmul_gradients(mgp, golden, dev):
+    """Gradients through the semi-supervised precision (Schur complement with an inner HIP CG): rhs
+    gradient = S g, hyper-parameter gradients = U^T (dQ/d theta) V, against central differences; and
+    through the Scale / Noise wrappers that RiemannGP.precision() stacks on top."""
+    O = mgp.operators
+    g = golden("dumbbell_k10_loop")
+    n = g["train_x"].shape[0]
+    mask = T(g["symmetric_schur_mask"], dev).bool()
+    idx, val = T(g["edge_index"].astype(np.int64), dev), T(g["edge_value"], dev)
+    eps0, ls0 = float(g["eps"]) * 1.5, 1.3
+    torch.manual_seed(1)
+    v = torch.randn(int(mask.sum()), device=dev)
+    u = torch.randn(int(mask.sum()), device=dev)
+
+    def form(eps_t, ls_t, vv):
+        lap = O.GraphLaplacianOperator(val, idx, n, eps_t, "symmetric")
+        S = O.SchurComplementOperator(O.PrecisionMaternOperator(lap, 1, ls_t), mask)
+        with mgp.settings.cg_tolerance(1e-7), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(8000):
+            return torch.dot(u, S.matmul(vv))
+
+    eps = torch.tensor([[eps0]], device=dev, requires_grad=True)
+    ls = torch.tensor([[ls0]], device=dev, requires_grad=True)
+    vv = v.clone().requires_grad_()
+    f = form(eps, ls, vv)
+    f.backward()
+    with torch.no_grad():
+        Sg = O.SchurComplementOperator(O.PrecisionMaternOperator(O.GraphLaplacianOperator(val, idx, n, eps.detach(), "symmetric"),
+                                                                 1, ls.detach()), mask)
+        with mgp.settings.cg_tolerance(1e-7), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(8000):
+            ref_v = Sg.matmul(u)
+        assert float((vv.grad - ref_v).abs().max()) < 1e-3 * float(ref_v.abs().max())
+        for name, t, h in (("eps", eps, 2e-3 * eps0), ("ls", ls, 2e-3 * ls0)):
+            e_p = torch.tensor([[eps0 + (h if name == "eps" else 0.0)]], device=dev)
+            e_m = torch.tensor([[eps0 - (h if name == "eps" else 0.0)]], device=dev)
+            l_p = torch.tensor([[ls0 + (h if name == "ls" else 0.0)]], device=dev)
+            l_m = torch.tensor([[ls0 - (h if name == "ls" else 0.0)]], device=dev)
+            fd = float(form(e_p, l_p, v) - form(e_m, l_m, v)) / (2 * h)
+            assert abs(float(t.grad) - fd) < 3e-2 * abs(fd) + 1e-4 * abs(float(f)), (name, float(t.grad), fd)
+    # through the wrappers of RiemannGP.precision()
+    eps2 = torch.tensor([[eps0]], device=dev, requires_grad=True)
+    noise = torch.tensor(1e-3, device=dev, requires_grad=True)
+    scale = torch.tensor(0.8, device=dev, requires_grad=True)
+    lap = O.GraphLaplacianOperator(val, idx, n, eps2, "symmetric")
+    P = O.NoiseWrapperOperator(O.ScaleWrapperOperator(O.SchurComplementOperator(O.PrecisionMaternOperator(lap, 1, ls.detach()), mask),
+                                                      scale), noise)
+    with mgp.settings.cg_tolerance(1e-7), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(8000):
+        loss = torch.dot(v, P.matmul(v))
+    loss.backward()
+    assert all(torch.isfinite(t.grad).all() and float(t.grad.abs().max()) > 0 for t in (eps2, noise, scale))
+
+
+@pytest.mark.parametrize("max_cholesky", [4000, 50])
+def test_semisupervised_training_loop(mgp, golden, dev, max_cholesky):
+    """C4 flow: RiemannGP with a labelled mask -> precision() = Noise(Scale(Schur(Q))) -> the precision-form
+    loss and its gradients (through the Schur complement's inner solves) drive an optimiser; dense and
+    iterative (generic block SLQ + surrogate gradients) branches."""
+    from manifold_gp_amd.models import GaussianLikelihood, RiemannGP, ScaleKernel
+    from manifold_gp_amd.utils import manifold_informed_train
+    g = golden("dumbbell_k10_loop")
+    x, y = T(g["train_x"], dev), T(g["train_y"], dev)
+    labeled = T(g["symmetric_schur_mask"], dev).bool()
+    kern = mgp.kernels.RiemannMaternKernel(nu=1, x=x, nearest_neighbors=int(g["k"]), laplacian_normalization="symmetric",
+                                           num_modes=20).to(dev)
+    kern.initialize(graphbandwidth=float(g["eps"]) * 2.0, lengthscale=1.0)
+    model = RiemannGP(x[labeled], y[labeled], GaussianLikelihood(1e-2).to(dev), ScaleKernel(kern, 1.0).to(dev),
+                      labeled=labeled).to(dev)
+    params = [p for p in model.parameters() if p.requires_grad]
+    before = [p.detach().clone() for p in params]
+    opt = torch.optim.Adam(params, lr=2e-2)
+    losses = []
+
+    class Rec:
+        def step(self, loss):
+            losses.append(float(loss.detach()))
+    last = manifold_informed_train(model, opt, max_iter=3, tolerance=0.0, num_rand_vec=16, max_cholesky=max_cholesky,
+                                   cg_tolerance=1e-4, cg_max_iter=4000, scheduler=Rec())
+    assert len(losses) == 4 and all(np.isfinite(losses)) and np.isfinite(last)
+    moved = [float((p.detach() - b).abs().max()) for p, b in zip(params, before)]
+    assert sum(m > 1e-4 for m in moved) >= 3, moved
+    if max_cholesky >= 4000:
+        assert losses[-1] < losses[0]
