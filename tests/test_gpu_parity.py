@@ -1229,3 +1229,81 @@ def test_semisupervised_training_loop(mgp, golden, dev, max_cholesky):
     assert sum(m > 1e-4 for m in moved) >= 3, moved
     if max_cholesky >= 4000:
         assert losses[-1] < losses[0]
+
+
+@pytest.mark.parametrize("shape", ["tiny2", "tiny3", "n63", "n65", "hub", "wide_dict", "dense_small", "lds_overflow"])
+def test_tile_spmv_edge_shapes(mgp, dev, shape):
+    """Edge shapes of the tile format against the gather kernel and a dense fp64 product: two nodes,
+    sizes around the tile boundary, a hub row with thousands of entries (tile with more than 16 * 256
+    entries -> remainder loops), a tile whose dictionary exceeds 4 * 256 columns, a dense small graph, and a
+    graph whose 64-row tiles do not fit the LDS budget (32-row tiles or the gather fallback)."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.graph import KnnGraph, LaplacianData
+    rng = np.random.default_rng(abs(hash(shape)) % 1000)
+    if shape == "tiny2":
+        n, pairs = 2, np.array([[0, 1]])
+    elif shape == "tiny3":
+        n, pairs = 3, np.array([[0, 1], [1, 2]])
+    elif shape in ("n63", "n65"):
+        n = 63 if shape == "n63" else 65
+        r, c = rng.integers(0, n, 400), rng.integers(0, n, 400)
+        pairs = np.stack([np.minimum(r, c), np.maximum(r, c)], 1)
+    elif shape == "hub":
+        n = 9000
+        hub = np.stack([np.zeros(6000, np.int64), np.arange(1, 6001)], 1)          # row 0 touches 6000 nodes
+        r, c = rng.integers(0, n, 20000), rng.integers(0, n, 20000)
+        pairs = np.concatenate([hub, np.stack([np.minimum(r, c), np.maximum(r, c)], 1)])
+    elif shape == "wide_dict":
+        n = 20000
+        r = rng.integers(0, 64, 40000)                                            # first tile references ~17k columns
+        c = rng.integers(64, n, 40000)
+        pairs = np.stack([r, c], 1)
+    elif shape == "dense_small":
+        n = 200
+        r, c = np.triu_indices(n, 1)
+        pairs = np.stack([r, c], 1)
+    else:  # lds_overflow: every row of the first tiles has ~700 distinct far columns
+        n = 60000
+        r = np.repeat(np.arange(128), 700)
+        c = rng.integers(200, n, r.shape[0])
+        pairs = np.stack([r, c], 1)
+    pairs = pairs[pairs[:, 0] < pairs[:, 1]] if len(pairs) else pairs
+    pairs = np.unique(pairs, axis=0) if len(pairs) else pairs
+    idx = torch.from_numpy(np.ascontiguousarray(pairs.T.reshape(2, -1))).to(dev)
+    val = torch.from_numpy((rng.random(len(pairs)) * 0.02).astype(np.float32)).to(dev)
+    graph = KnnGraph.from_coo(idx, val, n)
+    data = LaplacianData(graph, 0.1, True)
+    lib = _lib.lib()
+    x = torch.randn(n, 1, device=dev)
+    pre = torch.rand(n, device=dev) + 0.5
+    base = torch.randn(n, 1, device=dev)
+    ys = []
+    try:
+        for mode in (0, 1):
+            lib.mgp_spmm_set_tile_mode(mode)
+            csr = data.csr()
+            nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), 1)
+            part = torch.zeros(max(nb, 1), device=dev)
+            y = torch.empty_like(x)
+            _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(x), 1, _lib.ptr(y), 1.25, 1.0, _lib.ptr(pre), _lib.ptr(pre),
+                                          _lib.ptr(base), 0.5, 2.0, _lib.ptr(x), _lib.ptr(part), _lib.stream()), "mgp_spmm_fused")
+            ys.append((y.cpu().double(), float(part.double().sum())))
+    finally:
+        lib.mgp_spmm_set_tile_mode(1)
+    # dense fp64 reference from the CSR itself
+    rowptr, col, vals = graph.rowptr.cpu().numpy(), graph.col.cpu().numpy(), data.vals.cpu().numpy().astype(np.float64)
+    xs = (pre.cpu().double() * x[:, 0].cpu().double()).numpy()
+    Sx = np.zeros(n)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    np.add.at(Sx, rows, vals * xs[col])
+    lx = data.diag.cpu().double().numpy() * xs - Sx
+    ref = 0.5 * base[:, 0].cpu().double().numpy() + 2.0 * pre.cpu().double().numpy() * (1.25 * xs + lx)
+    scale = max(np.abs(ref).max(), 1e-6)
+    for y, dsum in ys:
+        assert np.abs(y[:, 0].numpy() - ref).max() < 2e-5 * scale, shape
+        assert abs(dsum - float((x[:, 0].cpu().double().numpy() * ref).sum())) < 2e-4 * scale * max(n, 16) ** 0.5
+    if shape == "hub":
+        assert graph.tiles is not None and graph.tiles["max_entries"] > 16 * 256
+    if shape == "wide_dict":
+        assert graph.tiles is None or graph.tiles["max_cols"] > 1024 or graph.tiles["rows"] == 32
