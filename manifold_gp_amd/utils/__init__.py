@@ -1,8 +1,8 @@
 """Hot-path subset of manifold_gp.utils (manifold_gp/utils/__init__.py:3-18): NearestNeighbors,
-bump_function and the precision-form training loop `manifold_informed_train`.  Dataset loaders and
+bump_function and the training loops `manifold_informed_train` (precision form) / `vanilla_train`.  Dataset loaders and
 plotting are out of scope."""
 from .nearest_neighbors import NearestNeighbors
 from .torch_utils import bump_function
-from .train_model import manifold_informed_train
+from .train_model import manifold_informed_train, vanilla_train
 
-__all__ = ["NearestNeighbors", "bump_function", "manifold_informed_train"]
+__all__ = ["NearestNeighbors", "bump_function", "manifold_informed_train", "vanilla_train"]

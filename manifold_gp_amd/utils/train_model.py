@@ -5,8 +5,13 @@ the log-priors), same output-scale normalisation before / after the loop.  Every
 path: `precision_operator.matmul` is the differentiable fused SpMM chain (autograd.py), `inv_quad_logdet`
 is the dense Cholesky below `max_cholesky` and stochastic Lanczos + surrogate gradients above it
 (solvers.inv_quad_logdet), `_average_variance` is a multi-right-hand-side HIP CG.
-`vanilla_train` (gpytorch's ExactMarginalLogLikelihood on the spectral kernel) is a caller of gpytorch,
-not of this path, and is not provided.
+`vanilla_train` (train_model.py:10-46) maximises the exact marginal likelihood of the spectral kernel
+K = s Z Z^T + noise I, Z = sqrt(N S(lambda; kappa) / sum S) (.) Phi.  The reference gets it from gpytorch's
+ExactMarginalLogLikelihood (Woodbury on the m x m root); without gpytorch the same closed form is written
+out here: the N-sized quantities Phi^T Phi, Phi^T y, Phi^T 1 are formed once on the device, every epoch is
+m x m fp64 algebra under autograd (noise, output scale, length scale, constant mean; the eigenpairs -- and
+with them the graph bandwidth -- are held fixed exactly as in the reference, which computes them under
+no_grad in eval()).
 """
 import math
 
@@ -80,4 +85,80 @@ def manifold_informed_train(model, optimizer, max_iter=100, tolerance=1e-2, upda
 
     if hasattr(model.covar_module, "outputscale"):
         model.covar_module.outputscale = model.covar_module.outputscale.detach() * average_variance()
+    return loss.item()
+
+
+def exact_mll_lowrank(model):
+    """-(1/N) log p(y) for K = s Z Z^T + noise I (what gpytorch's ExactMarginalLogLikelihood returns, negated),
+    differentiable wrt noise / output scale / length scale / constant mean."""
+    kern = model.base_kernel
+    if getattr(kern, "eigvec", None) is None:
+        training = model.training
+        kern.eval()                      # eigenpairs of the current graph bandwidth (no_grad, as the reference)
+        model.train(training)
+    cache = getattr(model, "_vanilla_cache", None)
+    x, y = model.train_inputs[0], model.train_targets
+    insample = kern._is_train_inputs(x)
+
+    def scale():
+        # Z = A * sqrt(N S / sum S): S the spectral density, divided by (1 - eps^2 lambda)^2 for inputs that are
+        # not the graph's own points (riemann_kernel.py:134-136 / :143-145)
+        S = kern.spectral_density().double().reshape(-1)
+        if not insample:
+            eps = kern.graphbandwidth.detach().double().reshape(-1)[0].to(S.device)
+            S = S / (1.0 - eps * eps * kern.eigval.double()).square()
+        return (float(kern.eigvec.shape[0]) * S / S.sum()).sqrt()
+
+    if cache is None or cache["eigvec"] is not kern.eigvec or cache["x"] is not x:
+        with torch.no_grad():
+            A = kern.eigvec.double() if insample else kern.features(x).double() / scale()
+            yd = y.double()
+            one = torch.ones_like(yd)
+            cache = dict(eigvec=kern.eigvec, x=x, G0=A.t() @ A, by=A.t() @ yd, b1=A.t() @ one, yy=torch.dot(yd, yd),
+                         y1=yd.sum(), n=float(yd.shape[0]))
+        model._vanilla_cache = cache
+    N = cache["n"]
+    d = scale()
+    s = model.covar_module.outputscale.double().reshape(()) if hasattr(model.covar_module, "outputscale") \
+        else torch.ones((), dtype=torch.float64, device=d.device)
+    noise = model.likelihood.noise.double().reshape(())
+    c = model.mean_constant.double() if hasattr(model, "mean_constant") else torch.zeros((), dtype=torch.float64, device=d.device)
+    G = d.view(-1, 1) * cache["G0"] * d.view(1, -1)
+    m = G.shape[0]
+    C = G + (noise / s) * torch.eye(m, dtype=torch.float64, device=G.device)
+    Lc = torch.linalg.cholesky(C)
+    zty = d * (cache["by"] - c * cache["b1"])
+    rr = cache["yy"] - 2.0 * c * cache["y1"] + c * c * N
+    t = torch.cholesky_solve(zty.view(-1, 1), Lc).view(-1)
+    quad = (rr - torch.dot(zty, t)) / noise
+    logdet = (N - m) * torch.log(noise) + m * torch.log(s) + 2.0 * torch.log(torch.diagonal(Lc)).sum()
+    return (0.5 * (quad + logdet + N * math.log(2 * math.pi)) / N).float()
+
+
+def vanilla_train(model, optimizer, max_iter=100, max_cholesky=800, tolerance=1e-2, cg_tolerance=1e-2, cg_max_iter=1000,
+                  scheduler=None, verbose=False):
+    model.train()
+    model.likelihood.train()
+    epoch = 0
+    prev_loss = 1e6
+    loss = torch.zeros(())
+    while epoch <= max_iter:
+        optimizer.zero_grad()
+        loss = exact_mll_lowrank(model)
+        if verbose:
+            lr = scheduler.get_last_lr()[0] if scheduler is not None and hasattr(scheduler, "get_last_lr") \
+                else optimizer.param_groups[0]["lr"]
+            msg = ["Iteration: %d, Loss: %0.3f, Lr: %s" % (epoch, loss.item(), lr),
+                   "Noise Variance: %0.3f" % model.likelihood.noise.item()]
+            if hasattr(model.covar_module, "outputscale"):
+                msg += ["Signal Variance: %0.3f" % model.covar_module.outputscale.item()]
+            msg += ["Lengthscale: %0.3f" % model.base_kernel.lengthscale.item()]
+            print(",\t".join(msg))
+        loss.backward()
+        optimizer.step()
+        if scheduler is not None:
+            scheduler.step(loss)
+        epoch += 1
+        if abs(loss.item() - prev_loss) <= tolerance:       # prev_loss is never updated in the reference either (:16, :40)
+            break
     return loss.item()

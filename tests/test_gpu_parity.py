@@ -1307,3 +1307,53 @@ def test_tile_spmv_edge_shapes(mgp, dev, shape):
         assert graph.tiles is not None and graph.tiles["max_entries"] > 16 * 256
     if shape == "wide_dict":
         assert graph.tiles is None or graph.tiles["max_cols"] > 1024 or graph.tiles["rows"] == 32
+
+
+def test_vanilla_train_exact_mll(mgp, golden, dev):
+    """train_model.py:10-46: the exact marginal likelihood of K = s Z Z^T + noise I in its m x m Woodbury form
+    against the dense fp64 Gaussian log density on the same HIP features, its gradients against central
+    differences, and the loop driving an optimiser downhill."""
+    from manifold_gp_amd.models import GaussianLikelihood, RiemannGP, ScaleKernel
+    from manifold_gp_amd.utils import vanilla_train
+    from manifold_gp_amd.utils.train_model import exact_mll_lowrank
+    g = golden("dumbbell_k10_loop")
+    x, y = T(g["train_x"], dev), T(g["train_y"], dev)
+    kern = mgp.kernels.RiemannMaternKernel(nu=2, x=x, nearest_neighbors=int(g["k"]), laplacian_normalization="randomwalk",
+                                           num_modes=30).to(dev)
+    kern.initialize(graphbandwidth=float(g["eps"]) * 2.0, lengthscale=0.7)
+    model = RiemannGP(x, y, GaussianLikelihood(5e-2).to(dev), ScaleKernel(kern, 1.3).to(dev)).to(dev)
+    with torch.no_grad():
+        model.mean_constant.fill_(0.1)
+    model.eval()
+    model.train()
+    loss = exact_mll_lowrank(model)
+    Z = kern.features(x).double().cpu().numpy()
+    n = Z.shape[0]
+    K = 1.3 * Z @ Z.T + float(model.likelihood.noise.detach()) * np.eye(n)
+    r = y.double().cpu().numpy() - 0.1
+    sign, logdet = np.linalg.slogdet(K)
+    want = 0.5 * (r @ np.linalg.solve(K, r) + logdet + n * np.log(2 * np.pi)) / n
+    assert abs(float(loss) - want) <= 1e-4 * max(1.0, abs(want)), (float(loss), want)
+
+    params = {k: p for k, p in model.named_parameters() if p.requires_grad}
+    loss.backward()
+    checked = 0
+    for name, p in params.items():
+        if "graphbandwidth" in name or "epsilon" in name:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0     # eigenpairs are held fixed (no_grad in eval)
+            continue
+        gr = float(p.grad.reshape(-1)[0])
+        h = 1e-3
+        with torch.no_grad():
+            p.add_(h); up = float(exact_mll_lowrank(model).double())
+            p.sub_(2 * h); dn = float(exact_mll_lowrank(model).double())
+            p.add_(h)
+        fd = (up - dn) / (2 * h)
+        assert abs(gr - fd) <= 2e-2 * max(abs(fd), 1e-2), (name, gr, fd)
+        checked += 1
+    assert checked >= 4                                                   # noise, output scale, length scale, mean
+
+    opt = torch.optim.Adam([p for p in params.values()], lr=5e-2)
+    first = float(exact_mll_lowrank(model))
+    last = vanilla_train(model, opt, max_iter=20)
+    assert np.isfinite(last) and last < first
