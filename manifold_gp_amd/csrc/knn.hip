@@ -207,6 +207,10 @@ struct SelectArgs {
   int* fail_list;
   int* fail_count;
   double gamma;
+  // absolute form of the sufficiency check (keys from knn_mfma.hip); qn2 == nullptr: relative form
+  const float* qn2;          // |c_x|^2 per chunk row
+  const unsigned* r2max;     // bits of R^2
+  double alpha, beta;        // E = alpha |c_x| R + beta (|c_x| + R)^2
 };
 
 // Visit every key of a slab row: 4 x 16-byte loads per lane are issued before the first key is used.
@@ -338,7 +342,13 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   bool ok = true;
   if (want < N) {
     const double t32 = (double)__uint_as_float(T);
-    ok = cand_d[a.k - 1] < t32 / (1.0 + a.gamma) * (1.0 - 1e-12);
+    if (a.qn2) {
+      const double nx = sqrt((double)a.qn2[row] * (1.0 + 1e-6)), R = sqrt((double)__uint_as_float(*a.r2max) * (1.0 + 1e-6));
+      const double E = a.alpha * nx * R + a.beta * (nx + R) * (nx + R);
+      ok = cand_d[a.k - 1] + 2.0 * E < t32 * (1.0 - 1e-12);
+    } else {
+      ok = cand_d[a.k - 1] < t32 / (1.0 + a.gamma) * (1.0 - 1e-12);
+    }
   }
   if (ok) {
     for (int t = tid; t < a.k; t += kBlock) {
@@ -409,6 +419,12 @@ int64_t chunk_rows(int64_t N, int64_t n) {
   return qc < ncap ? qc : ncap;
 }
 
+// candidate distances on the matrix cores (knn_mfma.hip) from 32 features up; mgp_knn_set_mfma(0) forces
+// the direct-difference tiles
+int g_knn_mfma = 1;
+int64_t g_last_direct_chunks = 0;
+bool use_mfma(int d) { return g_knn_mfma && d >= 32; }
+
 int next_pow2(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -425,6 +441,7 @@ static size_t bruteforce_bytes(int64_t N, int64_t n, int d, int k) {
   b += 2 * mgp_align((size_t)qc * sizeof(int));
   b += mgp_align(64);
   b += mgp_align((size_t)kExactBatch * N * sizeof(double));
+  if (use_mfma(d)) b += mgp_knn_mfma_bytes(N, qc, d);
   return b + 1024;
 }
 
@@ -444,28 +461,50 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   int* counter = ar.take<int>(16);
   double* scratch = ar.take<double>((size_t)kExactBatch * N);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  const bool mfma = use_mfma(d);
+  MgpKnnMfma mm{};
+  double alpha = 0.0, beta = 0.0;
+  if (mfma) {
+    MGP_TRY(mgp_knn_mfma_take(ar, N, qc, d, &mm));
+    MGP_TRY(mgp_knn_mfma_prepare_points(db, N, d, mm, st));
+    mgp_knn_mfma_bound(mm.dpad, &alpha, &beta);
+  }
 
   int Kp0 = next_pow2(k + (k / 4 > 16 ? k / 4 : 16));
   if (Kp0 < 64) Kp0 = 64;
   if (Kp0 > kMaxKp) Kp0 = kMaxKp;
   // fp32 direct-difference distance: one rounding per subtraction, one per fused accumulate
   const double gamma = (double)(d + 4) * 1.1920928955078125e-07;   // (d+4) * 2^-23
-  int64_t n_wide = 0, n_exact = 0, n_chunks = 0;
+  int64_t n_wide = 0, n_exact = 0, n_chunks = 0, n_direct = 0;
 
   for (int64_t q0 = 0; q0 < n; q0 += qc) {
     const int64_t rows = (n - q0) < qc ? (n - q0) : qc;
     ++n_chunks;
     dim3 grid((unsigned)mgp_cdiv(N, kTile), (unsigned)mgp_cdiv(rows, kTile));
-    if (d % 4 == 0) hipLaunchKernelGGL(dist_tile_kernel<true>, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
-    else hipLaunchKernelGGL(dist_tile_kernel<false>, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
-    MGP_LAUNCH_CHECK();
-    SelectArgs a{slab, ld, N, db, q + q0 * d, d, k, Kp0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, gamma};
-    MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
-    hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, a);
-    MGP_LAUNCH_CHECK();
+    SelectArgs a{slab, ld, N, db, q + q0 * d, d, k, Kp0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, gamma,
+                 nullptr, nullptr, 0.0, 0.0};
     int fails = 0;
-    MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
-    MGP_HIP_TRY(hipStreamSynchronize(st));
+    // pass 0: MFMA keys + absolute check; pass 1 (no MFMA, or too many rows of the chunk failed the
+    // absolute check): exact fp32 direct-difference keys + relative check
+    for (int pass = mfma ? 0 : 1; pass < 2; ++pass) {
+      if (pass == 0) {
+        MGP_TRY(mgp_knn_mfma_prepare_queries(q + q0 * d, rows, d, mm, st));
+        MGP_TRY(mgp_knn_mfma_tiles(mm, rows, N, slab, ld, st));
+        a.qn2 = mm.qn2; a.r2max = mm.r2max; a.alpha = alpha; a.beta = beta;
+      } else {
+        if (d % 4 == 0) hipLaunchKernelGGL(dist_tile_kernel<true>, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
+        else hipLaunchKernelGGL(dist_tile_kernel<false>, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
+        MGP_LAUNCH_CHECK();
+        a.qn2 = nullptr; a.r2max = nullptr;
+      }
+      MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
+      hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, a);
+      MGP_LAUNCH_CHECK();
+      MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
+      MGP_HIP_TRY(hipStreamSynchronize(st));
+      if (pass == 0 && fails > rows / 16 + 8) { ++n_direct; continue; }
+      break;
+    }
     int Kp = Kp0;
     int* cur = list_a;
     int* nxt = list_b;
@@ -493,8 +532,17 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   }
   MGP_HIP_TRY(hipStreamSynchronize(st));
   if (stats) { stats[0] = n_wide; stats[1] = n_exact; stats[2] = n_chunks; stats[3] = Kp0; }
+  g_last_direct_chunks = n_direct;
   return MGP_OK;
 }
+
+extern "C" int mgp_knn_set_mfma(int on) {
+  g_knn_mfma = on ? 1 : 0;
+  return MGP_OK;
+}
+
+// chunks of the last slab search that were redone with direct-difference tiles (diagnostic)
+extern "C" int64_t mgp_knn_last_direct_chunks(void) { return g_last_direct_chunks; }
 
 // ---------------------------------------------------------------------------------------------------
 // Public entry: d <= 3 and N >= 4096 take the slab-free path of knn_lowd.hip; its (rare) overflow rows,

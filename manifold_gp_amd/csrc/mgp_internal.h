@@ -79,5 +79,22 @@ int mgp_knn_gather_rows(const float* src, const int32_t* rows_dev, int64_t m, in
 int mgp_knn_scatter_rows(const float* Ds, const int32_t* Is, const int32_t* rows_dev, int64_t m, int k, float* D,
                          int32_t* I, void* stream);
 
+// candidate distances on the matrix cores (knn_mfma.hip): centred bf16 h/l split of points and queries
+struct MgpKnnMfma {
+  int dpad;
+  uint16_t *Ph, *Pl, *Qh, *Ql;   // [N, dpad] / [chunk rows, dpad]
+  float *pn2, *qn2;              // |c|^2
+  float* mu;                     // [d] column means of the points
+  float* partial;
+  unsigned* r2max;               // bits of max |c_y|^2 over the points
+};
+int mgp_knn_mfma_dpad(int d);
+size_t mgp_knn_mfma_bytes(int64_t N, int64_t qc, int d);
+int mgp_knn_mfma_take(MgpArena& ar, int64_t N, int64_t qc, int d, MgpKnnMfma* m);
+int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnMfma& m, hipStream_t st);
+int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpKnnMfma& m, hipStream_t st);
+int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab, int64_t ld, hipStream_t st);
+void mgp_knn_mfma_bound(int dpad, double* alpha, double* beta);
+
 // fp64 operator apply from the fp32 matrix (true residual of the CG refinement); work64 = 4 n C doubles
 int mgp_operator_apply_f64(const mgp_operator_t* op, const double* X, int C, double* Y, double* work64, void* stream);
