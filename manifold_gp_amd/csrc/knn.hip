@@ -4,16 +4,23 @@
 // manifold_gp/utils/nearest_neighbors.py:35-37.
 //
 // Pipeline per chunk of query rows (fp32 distance slab of 1-8 GiB of HBM, see chunk_rows):
-//   1. dist_tile_kernel   fp32 direct-difference distances, 128x128 tile per workgroup,
+//   1. keys: d >= 32: dist_mfma_kernel (knn_mfma.hip, centred bf16-split GEMM form on the matrix cores);
+//      else, or for a chunk where many rows fail the absolute check:
+//      dist_tile_kernel   fp32 direct-difference distances, 128x128 tile per workgroup,
 //                         8x8 register micro-tile per lane, operands staged k-major in LDS so
 //                         a lane reads its 8 queries / 8 points with two ds_read_b128 each
-//                         (VALU FMA, not MFMA: MFMA is reserved for the eigenfeature contraction)
-//   2. select_kernel      one workgroup per query row: 3-pass radix select (11/11/10 bits) of
-//                         the K' smallest fp32 keys, K' = pow2 >= k + pad; fp64 re-evaluation of
-//                         those K' candidates in the oracle's exact operation order; bitonic
-//                         sort by (d64, index); sufficiency check
-//                            d64[k-1] < T32 / (1 + gamma)      (T32 = K'-th smallest fp32 key,
-//                                                               gamma = fp32 relative error bound)
+//   2. select_kernel      one workgroup per query row.  T = the K'-th smallest key of the row (K' = k + pad):
+//                         rows of 8192+ keys take the K'-th smallest of a 1/16 sample as an upper bound,
+//                         keep the keys under it in LDS in ONE pass over the row and radix-select
+//                         (11/11/10 bits) inside that list; short rows / overflowing lists radix-select
+//                         over the row.  fp64 re-evaluation of the K' candidates in the oracle's exact
+//                         operation order (the selection's dominant cost at large d: K' rows of d
+//                         floats per query, a strictly sequential fp64 chain per candidate); order by
+//                         (d64, index) -- by counting for K' <= 256, bitonic for retry widths;
+//                         sufficiency check
+//                            d64[k-1] < T / (1 + gamma)        direct-difference keys (gamma = fp32
+//                                                               relative error bound), or
+//                            d64[k-1] + 2 E(x) < T             MFMA keys (knn_mfma.hip, absolute bound)
 //                         which proves no unselected point can enter the top k.
 //   3. rows that fail the check are redone with K' x 4 (up to 2048), then by exact_row_kernel:
 //      fp64 distances to every point + k rounds of (d, index) arg-min.
@@ -200,7 +207,8 @@ struct SelectArgs {
   const float* q;        // queries of this chunk [rows_in_chunk, d]
   int d;
   int k;
-  int Kp;                // candidate count (pow2, <= kMaxKp)
+  int Kp;                // sort width (pow2, <= kMaxKp)
+  int cand;              // candidates re-evaluated in fp64 (<= Kp; 0: Kp)
   const int* rows;       // nullable: row list (local row ids)
   float* D;              // [rows_in_chunk, k] (chunk-local base)
   int32_t* I;
@@ -239,76 +247,145 @@ __device__ __forceinline__ void for_each_key(const uint32_t* __restrict__ keys, 
 }
 
 // ------------------------------------------------------------------ 2. select + re-rank
+constexpr int kListCap = 4096;      // LDS list of the keys under the sampled threshold
+constexpr int kSampleBlock = 64;    // sampled keys come in runs of 64 (256-byte loads)
+
+// rank-th smallest (1-based) of the keys `scan` visits: 3-pass radix select (11 / 11 / 10 bits) with an LDS
+// histogram.  Returns the key; *rank_eq = how many of the keys equal to it are among the `rank` smallest.
+// passes = 2: only the top 22 bits are resolved and the largest key of that bucket is returned -- an upper
+// bound of the rank-th smallest (*rank_eq is then meaningless).
+template <class Scan>
+__device__ uint32_t radix_kth(Scan scan, int rank, int* hist, int* sh_wave, int* sh_bin, int* sh_rank, int* rank_eq,
+                              int passes = 3) {
+  const int tid = threadIdx.x;
+  uint32_t prefix = 0, pmask = 0;
+  const int shifts[3] = {21, 10, 0};
+  const int nbits[3] = {11, 11, 10};
+  for (int ps = 0; ps < passes; ++ps) {
+    const int nb = 1 << nbits[ps];
+    for (int i = tid; i < nb; i += kBlock) hist[i] = 0;
+    __syncthreads();
+    const int sh = shifts[ps];
+    scan([&](uint32_t key, int64_t) {
+      if ((key & pmask) == prefix) atomicAdd(&hist[(key >> sh) & (nb - 1)], 1);
+    });
+    __syncthreads();
+    // 256 threads x (nb/256) bins: find the bin holding the rank-th key
+    const int per = nb / kBlock;
+    int local = 0;
+    for (int j = 0; j < per; ++j) local += hist[tid * per + j];
+    int total;
+    int excl = block_excl_scan(local, sh_wave, &total);
+    if (rank > excl && rank <= excl + local) {
+      int run = excl;
+      for (int j = 0; j < per; ++j) {
+        const int h = hist[tid * per + j];
+        if (rank <= run + h) { *sh_bin = tid * per + j; *sh_rank = rank - run; break; }
+        run += h;
+      }
+    }
+    __syncthreads();
+    prefix |= ((uint32_t)*sh_bin) << shifts[ps];
+    pmask |= ((uint32_t)(nb - 1)) << shifts[ps];
+    rank = *sh_rank;
+    __syncthreads();
+  }
+  *rank_eq = rank;
+  return passes == 3 ? prefix : (prefix | 0x3ffu);
+}
+
+// One workgroup per query row.  Rows of 8192+ keys are not radix-selected over the whole row: the K'-th
+// smallest of a 1/S sample of the row (runs of 64 keys, S = 16 up to 65536 keys) bounds the K'-th smallest
+// of the row from above, ONE pass over the row keeps the ~S K' keys under that bound in LDS, and the exact
+// K'-th smallest (the same T as a full-row select) comes from that list.  A list that overflows falls back
+// to the three full-row passes.
 __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   __shared__ int hist[2048];
   __shared__ int sh_wave[4];
-  __shared__ int sh_bin, sh_rank, sh_cnt_lt, sh_cnt_eq;
+  __shared__ int sh_bin, sh_rank, sh_cnt_lt, sh_cnt_eq, sh_cnt_list;
+  __shared__ double sh_dk;
   __shared__ int cand_idx[kMaxKp];
   __shared__ double cand_d[kMaxKp];
-  __shared__ float qrow_s[kMaxDimLds];
+  // the key list is dead before the query row is staged: same storage
+  __shared__ __attribute__((aligned(16))) uint32_t list_mem[2 * kListCap];
+  uint32_t* list_key = list_mem;
+  int* list_idx = reinterpret_cast<int*>(list_mem + kListCap);
+  float* qrow_s = reinterpret_cast<float*>(list_mem);
+  static_assert(kMaxDimLds * sizeof(float) <= sizeof(uint32_t) * 2 * kListCap, "query row staging");
 
   const int tid = threadIdx.x;
   const int row = a.rows ? a.rows[blockIdx.x] : (int)blockIdx.x;
   const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.dist + (int64_t)row * a.ld);
   const int64_t N = a.N;
   const int Kp = a.Kp;
-  const int want = (int64_t)Kp < N ? Kp : (int)N;   // number of real candidates
-
-  uint32_t prefix = 0, pmask = 0;
-  int rank = want;   // 1-based rank of the threshold key among keys matching the prefix
+  const int cand = a.cand > 0 && a.cand < Kp ? a.cand : Kp;
+  const int want = (int64_t)cand < N ? cand : (int)N;   // number of real candidates
+  int rank = want;   // how many of the keys equal to T are wanted
   uint32_t T = 0xffffffffu;
+  bool from_list = false;
+  int n_list = 0;
   if (want < N) {
-    const int shifts[3] = {21, 10, 0};
-    const int nbits[3] = {11, 11, 10};
-    for (int ps = 0; ps < 3; ++ps) {
-      const int nb = 1 << nbits[ps];
-      for (int i = tid; i < nb; i += kBlock) hist[i] = 0;
+    int S = 16;
+    while ((int64_t)S * 65536 < N) S <<= 1;
+    const int64_t n_runs = (N / kSampleBlock + S - 1) / S;            // sampled runs (all complete)
+    const int64_t n_samp = n_runs * kSampleBlock;
+    if (N >= 8192 && n_samp <= kListCap && n_samp >= 2 * want && (int64_t)S * want <= kListCap / 2) {
+      // ---- sample -> LDS, its want-th smallest bounds the row's want-th smallest
+      const int phase = row & (S - 1);
+      for (int j = tid; j < (int)n_samp; j += kBlock) {
+        int64_t run = (int64_t)(j / kSampleBlock) * S + phase;
+        if ((run + 1) * kSampleBlock > N) run -= phase;                // last group: its first run is complete
+        list_key[j] = keys[run * kSampleBlock + (j & (kSampleBlock - 1))];
+      }
+      if (tid == 0) sh_cnt_list = 0;
       __syncthreads();
-      const int sh = shifts[ps];
-      for_each_key(keys, N, tid, [&](uint32_t key, int64_t) {
-        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> sh) & (nb - 1)], 1);
+      int dummy;
+      const uint32_t tau = radix_kth([&](auto f) { for (int j = tid; j < (int)n_samp; j += kBlock) f(list_key[j], (int64_t)j); },
+                                     want, hist, sh_wave, &sh_bin, &sh_rank, &dummy, 2);
+      __syncthreads();
+      // ---- one pass over the row: keys <= tau into the list (at least `want` of them exist)
+      for_each_key(keys, N, tid, [&](uint32_t key, int64_t i) {
+        if (key <= tau) {
+          const int slot = atomicAdd(&sh_cnt_list, 1);
+          if (slot < kListCap) { list_key[slot] = key; list_idx[slot] = (int)i; }
+        }
       });
       __syncthreads();
-      // 256 threads x (nb/256) bins: find the bin holding the rank-th key
-      const int per = nb / kBlock;
-      int local = 0;
-      for (int j = 0; j < per; ++j) local += hist[tid * per + j];
-      int total;
-      int excl = block_excl_scan(local, sh_wave, &total);
-      if (rank > excl && rank <= excl + local) {
-        int run = excl;
-        for (int j = 0; j < per; ++j) {
-          const int h = hist[tid * per + j];
-          if (rank <= run + h) { sh_bin = tid * per + j; sh_rank = rank - run; break; }
-          run += h;
-        }
+      n_list = sh_cnt_list;
+      from_list = n_list <= kListCap;
+      if (from_list) {
+        T = radix_kth([&](auto f) { for (int j = tid; j < n_list; j += kBlock) f(list_key[j], (int64_t)list_idx[j]); },
+                      want, hist, sh_wave, &sh_bin, &sh_rank, &rank);
       }
-      __syncthreads();
-      prefix |= ((uint32_t)sh_bin) << shifts[ps];
-      pmask |= ((uint32_t)(nb - 1)) << shifts[ps];
-      rank = sh_rank;
-      __syncthreads();
     }
-    T = prefix;   // exact K'-th smallest key; `rank` of the keys equal to T are still wanted
+    if (!from_list) {
+      T = radix_kth([&](auto f) { for_each_key(keys, N, tid, f); }, want, hist, sh_wave, &sh_bin, &sh_rank, &rank);
+    }
+    // T: exact K'-th smallest key; `rank` of the keys equal to T are still wanted
   }
-
   // ---- collect candidates: all keys < T, plus `rank` keys == T (any of them; see header)
   if (tid == 0) { sh_cnt_lt = 0; sh_cnt_eq = 0; }
   for (int i = tid; i < Kp; i += kBlock) { cand_idx[i] = INT_MAX; cand_d[i] = INFINITY; }
   __syncthreads();
+  auto keep = [&](uint32_t key, int64_t i) {
+    if (key < T) {
+      const int slot = atomicAdd(&sh_cnt_lt, 1);
+      cand_idx[slot] = (int)i;
+    } else if (key == T) {
+      const int e = atomicAdd(&sh_cnt_eq, 1);
+      if (e < rank) cand_idx[want - 1 - e] = (int)i;
+    }
+  };
   if (want < N) {
-    for_each_key(keys, N, tid, [&](uint32_t key, int64_t i) {
-      if (key < T) {
-        const int slot = atomicAdd(&sh_cnt_lt, 1);
-        cand_idx[slot] = (int)i;
-      } else if (key == T) {
-        const int e = atomicAdd(&sh_cnt_eq, 1);
-        if (e < rank) cand_idx[want - 1 - e] = (int)i;
-      }
-    });
+    if (from_list) {
+      for (int j = tid; j < n_list; j += kBlock) keep(list_key[j], (int64_t)list_idx[j]);
+    } else {
+      for_each_key(keys, N, tid, keep);
+    }
   } else {
     for (int i = tid; i < want; i += kBlock) cand_idx[i] = i;
   }
+  __syncthreads();   // the list is dead from here on
   // query row to LDS (falls back to global reads for very wide features)
   const float* qrow = a.q + (int64_t)row * a.d;
   const bool q_lds = a.d <= kMaxDimLds;
@@ -321,39 +398,64 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
     cand_d[c] = oracle_d2(q_lds ? qrow_s : qrow, a.db + (int64_t)idx * a.d, a.d);
   }
   __syncthreads();
-
-  // ---- bitonic sort of Kp (pow2) entries by (d64, index)
-  for (int size = 2; size <= Kp; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < Kp / 2; t += kBlock) {
-        const int lo = (t / stride) * stride * 2 + (t % stride);
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const double dl = cand_d[lo], dh = cand_d[hi];
-        const int il = cand_idx[lo], ih = cand_idx[hi];
-        const bool swap = up ? cand_less(dh, ih, dl, il) : cand_less(dl, il, dh, ih);
-        if (swap) { cand_d[lo] = dh; cand_d[hi] = dl; cand_idx[lo] = ih; cand_idx[hi] = il; }
+  // ---- order by (d64, index).  Up to 256 candidates: every candidate counts the candidates ahead of it
+  // (all pairs are distinct, so the counts are the sorted positions; LDS reads are broadcasts) -- one
+  // barrier instead of the 28+ of a bitonic network; wider retry sets: bitonic sort of Kp (pow2) entries.
+  const bool by_rank = want <= kBlock;
+  int my_pos = INT_MAX;
+  double my_d = 0.0;
+  int my_i = 0;
+  if (by_rank) {
+    if (tid < want) {
+      my_d = cand_d[tid];
+      my_i = cand_idx[tid];
+      int ahead = 0;
+#pragma unroll 8
+      for (int j = 0; j < want; ++j) ahead += cand_less(cand_d[j], cand_idx[j], my_d, my_i) ? 1 : 0;
+      my_pos = ahead;
+      if (ahead == a.k - 1) sh_dk = my_d;
+    }
+    __syncthreads();
+  } else {
+    for (int size = 2; size <= Kp; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = tid; t < Kp / 2; t += kBlock) {
+          const int lo = (t / stride) * stride * 2 + (t % stride);
+          const int hi = lo + stride;
+          const bool up = ((lo & size) == 0);
+          const double dl = cand_d[lo], dh = cand_d[hi];
+          const int il = cand_idx[lo], ih = cand_idx[hi];
+          const bool swap = up ? cand_less(dh, ih, dl, il) : cand_less(dl, il, dh, ih);
+          if (swap) { cand_d[lo] = dh; cand_d[hi] = dl; cand_idx[lo] = ih; cand_idx[hi] = il; }
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
-
   // ---- sufficiency check, then write or flag
+  const double dk = by_rank ? sh_dk : cand_d[a.k - 1];
   bool ok = true;
   if (want < N) {
     const double t32 = (double)__uint_as_float(T);
     if (a.qn2) {
       const double nx = sqrt((double)a.qn2[row] * (1.0 + 1e-6)), R = sqrt((double)__uint_as_float(*a.r2max) * (1.0 + 1e-6));
       const double E = a.alpha * nx * R + a.beta * (nx + R) * (nx + R);
-      ok = cand_d[a.k - 1] + 2.0 * E < t32 * (1.0 - 1e-12);
+      ok = dk + 2.0 * E < t32 * (1.0 - 1e-12);
     } else {
-      ok = cand_d[a.k - 1] < t32 / (1.0 + a.gamma) * (1.0 - 1e-12);
+      ok = dk < t32 / (1.0 + a.gamma) * (1.0 - 1e-12);
     }
   }
   if (ok) {
-    for (int t = tid; t < a.k; t += kBlock) {
-      a.D[(int64_t)row * a.k + t] = (float)cand_d[t];
-      a.I[(int64_t)row * a.k + t] = cand_idx[t];
+    if (by_rank) {
+      if (my_pos < a.k) {
+        a.D[(int64_t)row * a.k + my_pos] = (float)my_d;
+        a.I[(int64_t)row * a.k + my_pos] = my_i;
+      }
+    } else {
+      for (int t = tid; t < a.k; t += kBlock) {
+        a.D[(int64_t)row * a.k + t] = (float)cand_d[t];
+        a.I[(int64_t)row * a.k + t] = cand_idx[t];
+      }
     }
   } else if (tid == 0) {
     const int slot = atomicAdd(a.fail_count, 1);
@@ -470,9 +572,14 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
     mgp_knn_mfma_bound(mm.dpad, &alpha, &beta);
   }
 
-  int Kp0 = next_pow2(k + (k / 4 > 16 ? k / 4 : 16));
+  // first attempt: k + pad candidates (each costs a d-float row read in the fp64 re-rank: the selection's
+  // dominant traffic at large d), sorted in the next power of two; retries use the full sort width
+  // (MFMA keys carry an absolute error: a wider pad there keeps the retry launches rare)
+  int cand0 = mfma ? k + (k / 2 > 24 ? k / 2 : 24) : k + (k / 4 > 16 ? k / 4 : 16);
+  int Kp0 = next_pow2(cand0);
   if (Kp0 < 64) Kp0 = 64;
   if (Kp0 > kMaxKp) Kp0 = kMaxKp;
+  if (cand0 > Kp0) cand0 = Kp0;
   // fp32 direct-difference distance: one rounding per subtraction, one per fused accumulate
   const double gamma = (double)(d + 4) * 1.1920928955078125e-07;   // (d+4) * 2^-23
   int64_t n_wide = 0, n_exact = 0, n_chunks = 0, n_direct = 0;
@@ -481,7 +588,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
     const int64_t rows = (n - q0) < qc ? (n - q0) : qc;
     ++n_chunks;
     dim3 grid((unsigned)mgp_cdiv(N, kTile), (unsigned)mgp_cdiv(rows, kTile));
-    SelectArgs a{slab, ld, N, db, q + q0 * d, d, k, Kp0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, gamma,
+    SelectArgs a{slab, ld, N, db, q + q0 * d, d, k, Kp0, cand0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, gamma,
                  nullptr, nullptr, 0.0, 0.0};
     int fails = 0;
     // pass 0: MFMA keys + absolute check; pass 1 (no MFMA, or too many rows of the chunk failed the
@@ -512,7 +619,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
       Kp = Kp * 4 > kMaxKp ? kMaxKp : Kp * 4;
       n_wide += fails;
       SelectArgs b = a;
-      b.Kp = Kp; b.rows = cur; b.fail_list = nxt;
+      b.Kp = Kp; b.cand = 0; b.rows = cur; b.fail_list = nxt;
       MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
       hipLaunchKernelGGL(select_kernel, dim3((unsigned)fails), dim3(kBlock), 0, st, b);
       MGP_LAUNCH_CHECK();
@@ -531,7 +638,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
     }
   }
   MGP_HIP_TRY(hipStreamSynchronize(st));
-  if (stats) { stats[0] = n_wide; stats[1] = n_exact; stats[2] = n_chunks; stats[3] = Kp0; }
+  if (stats) { stats[0] = n_wide; stats[1] = n_exact; stats[2] = n_chunks; stats[3] = cand0; }
   g_last_direct_chunks = n_direct;
   return MGP_OK;
 }

@@ -102,11 +102,18 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
                                                            const float* __restrict__ qn2, int64_t nq,
                                                            const uint16_t* __restrict__ Ph, const uint16_t* __restrict__ Pl,
                                                            const float* __restrict__ pn2, int64_t N, int dpad,
-                                                           float* __restrict__ out, int64_t ld) {
+                                                           float* __restrict__ out, int64_t ld, int ny_per_xcd) {
   __shared__ __attribute__((aligned(16))) uint16_t sm[4][kMT][kRowE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t p0 = (int64_t)blockIdx.x * kMT, q0 = (int64_t)blockIdx.y * kMT;
+  // blocks are dealt round-robin over the 8 XCDs: XCD c takes the query tiles c, c + 8, ... and walks the
+  // point tiles with its query tiles innermost, so that a point tile fetched into that XCD's L2 is used
+  // by all its query tiles at about the same time and the few query tiles stay L2-resident.
+  const int xcd = blockIdx.x % MGP_NXCD;
+  const int t = blockIdx.x / MGP_NXCD;
+  const int ty = t % ny_per_xcd, tx = t / ny_per_xcd;
+  const int64_t q0 = (int64_t)(xcd + MGP_NXCD * ty) * kMT, p0 = (int64_t)tx * kMT;
+  if (q0 >= nq) return;
   knn_f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -244,8 +251,12 @@ int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpK
 }
 
 int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab, int64_t ld, hipStream_t st) {
-  dim3 grid((unsigned)mgp_cdiv(N, kMT), (unsigned)mgp_cdiv(rows, kMT));
-  hipLaunchKernelGGL(dist_mfma_kernel, grid, dim3(kBlock), 0, st, m.Qh, m.Ql, m.qn2, rows, m.Ph, m.Pl, m.pn2, N, m.dpad, slab, ld);
+  const int64_t nx = mgp_cdiv(N, kMT), ny = mgp_cdiv(rows, kMT);
+  const int ny_per_xcd = (int)mgp_cdiv(ny, MGP_NXCD);
+  const int64_t blocks = (int64_t)MGP_NXCD * ny_per_xcd * nx;
+  if (blocks > 0x7fffffff) return MGP_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(dist_mfma_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, m.Qh, m.Ql, m.qn2, rows, m.Ph, m.Pl, m.pn2,
+                     N, m.dpad, slab, ld, ny_per_xcd);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
