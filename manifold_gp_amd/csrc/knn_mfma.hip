@@ -28,7 +28,6 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMT = 128;     // queries x points per workgroup
 constexpr int kBK = 32;      // features per LDS stage
-constexpr int kRowE = 40;    // LDS row pitch in bf16 elements (32 + 8 pad: 80 B, conflict-free ds_read_b128)
 
 typedef __bf16 knn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
@@ -61,12 +60,31 @@ __device__ __forceinline__ unsigned bf16_rne(float v) {
   return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
 }
 
+// Operand layout (H and L alike): [row tile of 128][stage of 32 features][128 rows][32 bf16], i.e. the 8 KB
+// one workgroup stages per operand and stage are contiguous (the kernel copies them global -> LDS with
+// 16-byte global_load_lds, no registers, no ds_write), and the four 16-byte pieces of a row are stored
+// XOR-swizzled by (row / 4) % 4 so that the MFMA fragment reads (16 lanes, 16 rows, the same piece) fall
+// on 16 different 16-byte bank groups.  Rows past n (up to the next multiple of 128) are zero.
+__device__ __forceinline__ int64_t tiled_index(int64_t row, int k, int nst) {
+  const int rl = (int)(row & (kMT - 1));
+  const int kl = k & (kBK - 1);
+  return (((row / kMT) * nst + k / kBK) * kMT + rl) * kBK + ((((kl >> 3) ^ ((rl >> 2) & 3)) << 3) | (kl & 7));
+}
+
 __global__ __launch_bounds__(kBlock) void split_kernel(const float* __restrict__ x, int64_t n, int d, int dpad,
                                                        const float* __restrict__ mu, uint16_t* __restrict__ H,
                                                        uint16_t* __restrict__ L, float* __restrict__ norm2,
                                                        unsigned* __restrict__ r2max) {
   __shared__ double red[kBlock / MGP_WAVE];
   const int64_t row = blockIdx.x;
+  const int nst = dpad / kBK;
+  if (row >= n) {                         // padding rows of the last tile
+    for (int j = threadIdx.x; j < dpad; j += kBlock) {
+      const int64_t o = tiled_index(row, j, nst);
+      H[o] = 0; L[o] = 0;
+    }
+    return;
+  }
   const float* xr = x + row * d;
   double s = 0.0;
   for (int j = threadIdx.x; j < dpad; j += kBlock) {
@@ -77,8 +95,9 @@ __global__ __launch_bounds__(kBlock) void split_kernel(const float* __restrict__
       l = bf16_rne(c - __uint_as_float(h << 16));
       s += (double)c * (double)c;
     }
-    H[row * dpad + j] = (uint16_t)h;
-    L[row * dpad + j] = (uint16_t)l;
+    const int64_t o = tiled_index(row, j, nst);
+    H[o] = (uint16_t)h;
+    L[o] = (uint16_t)l;
   }
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -94,8 +113,9 @@ __global__ __launch_bounds__(kBlock) void split_kernel(const float* __restrict__
 
 // ------------------------------------------------------------------ distance tiles on MFMA
 // 128 x 128 tile per workgroup, 4 waves as 2 x 2, each wave 2 x 2 accumulators of 32 x 32.  The four
-// operand tiles (query h / l, point h / l) of a 32-feature stage sit in LDS in rows of 80 bytes; the next
-// stage is fetched into registers while the current one is multiplied.  Fragment maps of
+// operand tiles (query h / l, point h / l; 8 KB each) of a 32-feature stage are copied global -> LDS by
+// global_load_lds (16 bytes per lane, LDS image = memory image) into one of two LDS buffers while the
+// other one is multiplied: one barrier per stage, no staging registers.  Fragment maps of
 // v_mfma_f32_32x32x16_bf16: lane (r = l & 31, g = l >> 5) holds A[row r][k = 8 g + 0..7] and
 // B[k = 8 g + 0..7][col r]; D[col = l & 31][row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)].
 __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Ql,
@@ -103,7 +123,9 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
                                                            const uint16_t* __restrict__ Ph, const uint16_t* __restrict__ Pl,
                                                            const float* __restrict__ pn2, int64_t N, int dpad,
                                                            float* __restrict__ out, int64_t ld, int ny_per_xcd) {
-  __shared__ __attribute__((aligned(16))) uint16_t sm[4][kMT][kRowE];
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int kTileE = kMT * kBK;                 // bf16 elements of one operand tile (8 KB)
+  __shared__ __attribute__((aligned(16))) uint16_t sm[2][4][kTileE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // blocks are dealt round-robin over the 8 XCDs: XCD c takes the query tiles c, c + 8, ... and walks the
@@ -112,7 +134,8 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
   const int xcd = blockIdx.x % MGP_NXCD;
   const int t = blockIdx.x / MGP_NXCD;
   const int ty = t % ny_per_xcd, tx = t / ny_per_xcd;
-  const int64_t q0 = (int64_t)(xcd + MGP_NXCD * ty) * kMT, p0 = (int64_t)tx * kMT;
+  const int64_t qt = xcd + MGP_NXCD * ty;
+  const int64_t q0 = qt * kMT, p0 = (int64_t)tx * kMT;
   if (q0 >= nq) return;
   knn_f32x16 acc[2][2];
 #pragma unroll
@@ -122,46 +145,44 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // staging: 16-byte piece f -> (row = f / 4, c = f % 4); 2 pieces per lane per operand tile
-  const int f0 = tid, f1 = tid + kBlock;
-  const int64_t sq0 = (q0 + (f0 >> 2) < nq ? q0 + (f0 >> 2) : nq - 1) * dpad + 8 * (f0 & 3);
-  const int64_t sq1 = (q0 + (f1 >> 2) < nq ? q0 + (f1 >> 2) : nq - 1) * dpad + 8 * (f1 & 3);
-  const int64_t sp0 = (p0 + (f0 >> 2) < N ? p0 + (f0 >> 2) : N - 1) * dpad + 8 * (f0 & 3);
-  const int64_t sp1 = (p0 + (f1 >> 2) < N ? p0 + (f1 >> 2) : N - 1) * dpad + 8 * (f1 & 3);
-  uint4 qh0, qh1, ql0, ql1, ph0, ph1, pl0, pl1;
-#define MGP_KNN_FETCH(k0)                                            \
-  do {                                                               \
-    qh0 = *reinterpret_cast<const uint4*>(Qh + sq0 + (k0));           \
-    qh1 = *reinterpret_cast<const uint4*>(Qh + sq1 + (k0));           \
-    ql0 = *reinterpret_cast<const uint4*>(Ql + sq0 + (k0));           \
-    ql1 = *reinterpret_cast<const uint4*>(Ql + sq1 + (k0));           \
-    ph0 = *reinterpret_cast<const uint4*>(Ph + sp0 + (k0));           \
-    ph1 = *reinterpret_cast<const uint4*>(Ph + sp1 + (k0));           \
-    pl0 = *reinterpret_cast<const uint4*>(Pl + sp0 + (k0));           \
-    pl1 = *reinterpret_cast<const uint4*>(Pl + sp1 + (k0));           \
-  } while (0)
-  MGP_KNN_FETCH(0);
-  const int r = lane & 31, g8 = (lane >> 5) * 8;
-  for (int k0 = 0; k0 < dpad; k0 += kBK) {
-    *reinterpret_cast<uint4*>(&sm[0][f0 >> 2][8 * (f0 & 3)]) = qh0;
-    *reinterpret_cast<uint4*>(&sm[0][f1 >> 2][8 * (f1 & 3)]) = qh1;
-    *reinterpret_cast<uint4*>(&sm[1][f0 >> 2][8 * (f0 & 3)]) = ql0;
-    *reinterpret_cast<uint4*>(&sm[1][f1 >> 2][8 * (f1 & 3)]) = ql1;
-    *reinterpret_cast<uint4*>(&sm[2][f0 >> 2][8 * (f0 & 3)]) = ph0;
-    *reinterpret_cast<uint4*>(&sm[2][f1 >> 2][8 * (f1 & 3)]) = ph1;
-    *reinterpret_cast<uint4*>(&sm[3][f0 >> 2][8 * (f0 & 3)]) = pl0;
-    *reinterpret_cast<uint4*>(&sm[3][f1 >> 2][8 * (f1 & 3)]) = pl1;
-    __syncthreads();
-    if (k0 + kBK < dpad) MGP_KNN_FETCH(k0 + kBK);
+  const int nst = dpad / kBK;
+  const uint16_t* gq_h = Qh + qt * nst * kTileE;
+  const uint16_t* gq_l = Ql + qt * nst * kTileE;
+  const uint16_t* gp_h = Ph + (int64_t)tx * nst * kTileE;
+  const uint16_t* gp_l = Pl + (int64_t)tx * nst * kTileE;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  // one stage: 8 copies of 4 KB (256 lanes x 16 bytes); LDS destination = wave-uniform base + lane * 16
+  auto issue = [&](int st, int buf) {
+    const int64_t so = (int64_t)st * kTileE;
 #pragma unroll
-    for (int kk = 0; kk < kBK; kk += 16) {
+    for (int h = 0; h < 2; ++h) {
+      const int eo = h * (kTileE / 2) + wave * 512;          // this wave's 1 KB slice (elements)
+      __builtin_amdgcn_global_load_lds((gptr_t)(gq_h + so + eo + lane * 8), (lptr_t)&sm[buf][0][eo], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gq_l + so + eo + lane * 8), (lptr_t)&sm[buf][1][eo], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gp_h + so + eo + lane * 8), (lptr_t)&sm[buf][2][eo], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(gp_l + so + eo + lane * 8), (lptr_t)&sm[buf][3][eo], 16, 0, 0);
+    }
+  };
+  const int r = lane & 31, g = lane >> 5;
+  // fragment (row, piece c) of a tile: row * 32 + ((c ^ ((row >> 2) & 3)) * 8); row = 32-aligned base + r
+  const int sw = (r >> 2) & 3;
+  issue(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this stage's copies have landed
+    __syncthreads();                          // ... for every wave; the other buffer is free again
+    if (st + 1 < nst) issue(st + 1, (st + 1) & 1);
+    const int buf = st & 1;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int pc = ((2 * kk + g) ^ sw) * 8;
       knn_bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[0][wm * 64 + i * 32 + r][kk + g8]);
-        al[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[1][wm * 64 + i * 32 + r][kk + g8]);
-        bh[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[2][wn * 64 + i * 32 + r][kk + g8]);
-        bl[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[3][wn * 64 + i * 32 + r][kk + g8]);
+        ah[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][0][(wm * 64 + i * 32 + r) * kBK + pc]);
+        al[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][1][(wm * 64 + i * 32 + r) * kBK + pc]);
+        bh[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][2][(wn * 64 + i * 32 + r) * kBK + pc]);
+        bl[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][3][(wn * 64 + i * 32 + r) * kBK + pc]);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -172,8 +193,8 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    __syncthreads();
   }
+  __syncthreads();
   // key = max(|c_x|^2 + |c_y|^2 - 2 S, +0): 32 consecutive points per half wave and register.  The
   // query norms go through LDS (a global load per element would be 64 dependent round trips).
   float* qn_s = reinterpret_cast<float*>(&sm[0][0][0]);
@@ -192,9 +213,8 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
         if (q0 + rl < nq && pc < N) out[(q0 + rl) * ld + pc] = v > 0.f ? v : 0.f;
       }
   }
+#endif
 }
-
-#undef MGP_KNN_FETCH
 
 constexpr int kMaxPartialBlocks = 256;
 
@@ -205,8 +225,8 @@ int mgp_knn_mfma_dpad(int d) { return (int)(mgp_cdiv(d, kBK) * kBK); }
 size_t mgp_knn_mfma_bytes(int64_t N, int64_t qc, int d) {
   const int dpad = mgp_knn_mfma_dpad(d);
   size_t b = 0;
-  b += 2 * mgp_align((size_t)N * dpad * sizeof(uint16_t));
-  b += 2 * mgp_align((size_t)qc * dpad * sizeof(uint16_t));
+  b += 2 * mgp_align((size_t)(mgp_cdiv(N, kMT) * kMT) * dpad * sizeof(uint16_t));
+  b += 2 * mgp_align((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad * sizeof(uint16_t));
   b += mgp_align((size_t)N * sizeof(float)) + mgp_align((size_t)qc * sizeof(float));
   b += mgp_align((size_t)d * sizeof(float)) + mgp_align((size_t)kMaxPartialBlocks * d * sizeof(float)) + mgp_align(64);
   return b;
@@ -215,10 +235,10 @@ size_t mgp_knn_mfma_bytes(int64_t N, int64_t qc, int d) {
 int mgp_knn_mfma_take(MgpArena& ar, int64_t N, int64_t qc, int d, MgpKnnMfma* m) {
   const int dpad = mgp_knn_mfma_dpad(d);
   m->dpad = dpad;
-  m->Ph = ar.take<uint16_t>((size_t)N * dpad);
-  m->Pl = ar.take<uint16_t>((size_t)N * dpad);
-  m->Qh = ar.take<uint16_t>((size_t)qc * dpad);
-  m->Ql = ar.take<uint16_t>((size_t)qc * dpad);
+  m->Ph = ar.take<uint16_t>((size_t)(mgp_cdiv(N, kMT) * kMT) * dpad);
+  m->Pl = ar.take<uint16_t>((size_t)(mgp_cdiv(N, kMT) * kMT) * dpad);
+  m->Qh = ar.take<uint16_t>((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad);
+  m->Ql = ar.take<uint16_t>((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad);
   m->pn2 = ar.take<float>(N);
   m->qn2 = ar.take<float>(qc);
   m->mu = ar.take<float>(d);
@@ -238,13 +258,13 @@ int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnM
   hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)mgp_cdiv(d, kBlock)), dim3(kBlock), 0, st, m.partial, nblk, d, N, m.mu,
                      m.r2max);
   MGP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)N), dim3(kBlock), 0, st, db, N, d, m.dpad, m.mu, m.Ph, m.Pl, m.pn2, m.r2max);
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(N, kMT) * kMT)), dim3(kBlock), 0, st, db, N, d, m.dpad, m.mu, m.Ph, m.Pl, m.pn2, m.r2max);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
 
 int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpKnnMfma& m, hipStream_t st) {
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, q, rows, d, m.dpad, m.mu, m.Qh, m.Ql, m.qn2,
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(rows, kMT) * kMT)), dim3(kBlock), 0, st, q, rows, d, m.dpad, m.mu, m.Qh, m.Ql, m.qn2,
                      (unsigned*)nullptr);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
