@@ -5,7 +5,7 @@
 // unselected point can enter the top k.  So the O(N^2 d) part does not have to be the exact fp32
 // direct-difference form (2 VALU instructions per pair-feature, 86 TF): here it is the GEMM form
 //     key(x, y) = max(|c_x|^2 + |c_y|^2 - 2 c_x . c_y, 0),      c = x - mean(db)   (centred),
-// with the dot product on v_mfma_f32_32x32x16_bf16 through a two-term bf16 split c = h + l (+ eps):
+// with the dot product on v_mfma_f32_16x16x32_bf16 through a two-term bf16 split c = h + l (+ eps):
 // c_x . c_y ~ h_x.h_y + h_x.l_y + l_x.h_y (3 MFMAs, fp32 accumulate, products exact in fp32).
 //
 // Error bound used by the sufficiency check (select_kernel, absolute form), per query row x with
@@ -30,7 +30,7 @@ constexpr int kMT = 128;     // queries x points per workgroup
 constexpr int kBK = 32;      // features per LDS stage
 
 typedef __bf16 knn_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float knn_f32x16 __attribute__((ext_vector_type(16)));
+typedef float knn_f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ column means (deterministic two-pass)
 __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(const float* __restrict__ x, int64_t n, int d,
@@ -112,12 +112,13 @@ __global__ __launch_bounds__(kBlock) void split_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ distance tiles on MFMA
-// 128 x 128 tile per workgroup, 4 waves as 2 x 2, each wave 2 x 2 accumulators of 32 x 32.  The four
+// 128 x 128 tile per workgroup, 4 waves as 2 x 2, each wave 4 x 4 accumulators of 16 x 16 (K = 32 per
+// instruction = one stage; measured 7 % faster here than 2 x 2 tiles of v_mfma_f32_32x32x16_bf16).  The four
 // operand tiles (query h / l, point h / l; 8 KB each) of a 32-feature stage are copied global -> LDS by
 // global_load_lds (16 bytes per lane, LDS image = memory image) into one of two LDS buffers while the
 // other one is multiplied: one barrier per stage, no staging registers.  Fragment maps of
-// v_mfma_f32_32x32x16_bf16: lane (r = l & 31, g = l >> 5) holds A[row r][k = 8 g + 0..7] and
-// B[k = 8 g + 0..7][col r]; D[col = l & 31][row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)].
+// v_mfma_f32_16x16x32_bf16: lane (r = l & 15, g = l >> 4) holds A[row r][k = 8 g + 0..7] and
+// B[k = 8 g + 0..7][col r]; D[col = l & 15][row = 4 (l >> 4) + reg].
 __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Ql,
                                                            const float* __restrict__ qn2, int64_t nq,
                                                            const uint16_t* __restrict__ Ph, const uint16_t* __restrict__ Pl,
@@ -137,13 +138,11 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
   const int64_t qt = xcd + MGP_NXCD * ty;
   const int64_t q0 = qt * kMT, p0 = (int64_t)tx * kMT;
   if (q0 >= nq) return;
-  knn_f32x16 acc[2][2];
+  knn_f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int j = 0; j < 4; ++j) acc[i][j] = knn_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nst = dpad / kBK;
   const uint16_t* gq_h = Qh + qt * nst * kTileE;
@@ -164,53 +163,49 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
       __builtin_amdgcn_global_load_lds((gptr_t)(gp_l + so + eo + lane * 8), (lptr_t)&sm[buf][3][eo], 16, 0, 0);
     }
   };
-  const int r = lane & 31, g = lane >> 5;
-  // fragment (row, piece c) of a tile: row * 32 + ((c ^ ((row >> 2) & 3)) * 8); row = 32-aligned base + r
-  const int sw = (r >> 2) & 3;
+  const int r = lane & 15, g = lane >> 4;
+  // fragment (row, piece g) of a tile: row * 32 + ((g ^ ((row >> 2) & 3)) * 8); row = 16-aligned base + r
+  const int pc = (g ^ ((r >> 2) & 3)) * 8;
   issue(0, 0);
   for (int st = 0; st < nst; ++st) {
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this stage's copies have landed
     __syncthreads();                          // ... for every wave; the other buffer is free again
     if (st + 1 < nst) issue(st + 1, (st + 1) & 1);
     const int buf = st & 1;
+    knn_bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int pc = ((2 * kk + g) ^ sw) * 8;
-      knn_bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        ah[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][0][(wm * 64 + i * 32 + r) * kBK + pc]);
-        al[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][1][(wm * 64 + i * 32 + r) * kBK + pc]);
-        bh[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][2][(wn * 64 + i * 32 + r) * kBK + pc]);
-        bl[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][3][(wn * 64 + i * 32 + r) * kBK + pc]);
-      }
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
+    for (int i = 0; i < 4; ++i) {
+      ah[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][0][(wm * 64 + i * 16 + r) * kBK + pc]);
+      al[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][1][(wm * 64 + i * 16 + r) * kBK + pc]);
+      bh[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][2][(wn * 64 + i * 16 + r) * kBK + pc]);
+      bl[i] = *reinterpret_cast<const knn_bf16x8*>(&sm[buf][3][(wn * 64 + i * 16 + r) * kBK + pc]);
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
   }
   __syncthreads();
-  // key = max(|c_x|^2 + |c_y|^2 - 2 S, +0): 32 consecutive points per half wave and register.  The
+  // key = max(|c_x|^2 + |c_y|^2 - 2 S, +0): 16 consecutive points per 16 lanes and register.  The
   // query norms go through LDS (a global load per element would be 64 dependent round trips).
   float* qn_s = reinterpret_cast<float*>(&sm[0][0][0]);
   if (tid < kMT) qn_s[tid] = qn2[q0 + tid < nq ? q0 + tid : nq - 1];
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t pc = p0 + wn * 64 + j * 32 + r;
-    const float pn = pn2[pc < N ? pc : N - 1];
+  for (int j = 0; j < 4; ++j) {
+    const int64_t pcol = p0 + wn * 64 + j * 16 + r;
+    const float pn = pn2[pcol < N ? pcol : N - 1];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int rl = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      for (int e = 0; e < 4; ++e) {
+        const int rl = wm * 64 + i * 16 + g * 4 + e;
         const float v = (qn_s[rl] + pn) - 2.f * acc[i][j][e];
-        if (q0 + rl < nq && pc < N) out[(q0 + rl) * ld + pc] = v > 0.f ? v : 0.f;
+        if (q0 + rl < nq && pcol < N) out[(q0 + rl) * ld + pcol] = v > 0.f ? v : 0.f;
       }
   }
 #endif
