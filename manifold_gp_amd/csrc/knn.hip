@@ -304,8 +304,11 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   __shared__ int sh_wave[4];
   __shared__ int sh_bin, sh_rank, sh_cnt_lt, sh_cnt_eq, sh_cnt_list;
   __shared__ double sh_dk;
-  __shared__ int cand_idx[kMaxKp];
-  __shared__ double cand_d[kMaxKp];
+  // candidate arrays sized by the launch (Kp x 12 bytes): the first attempt's Kp <= 256 leaves room for three
+  // workgroups per CU (fp64-chain-bound re-rank of one overlaps the memory-bound scans of the others)
+  extern __shared__ __attribute__((aligned(16))) unsigned char cand_mem[];
+  double* cand_d = reinterpret_cast<double*>(cand_mem);
+  int* cand_idx = reinterpret_cast<int*>(cand_mem + (size_t)a.Kp * sizeof(double));
   // the key list is dead before the query row is staged: same storage
   __shared__ __attribute__((aligned(16))) uint32_t list_mem[2 * kListCap];
   uint32_t* list_key = list_mem;
@@ -605,7 +608,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
         a.qn2 = nullptr; a.r2max = nullptr;
       }
       MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
-      hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, a);
+      hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(kBlock), (size_t)a.Kp * 12, st, a);
       MGP_LAUNCH_CHECK();
       MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
       MGP_HIP_TRY(hipStreamSynchronize(st));
@@ -621,7 +624,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
       SelectArgs b = a;
       b.Kp = Kp; b.cand = 0; b.rows = cur; b.fail_list = nxt;
       MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
-      hipLaunchKernelGGL(select_kernel, dim3((unsigned)fails), dim3(kBlock), 0, st, b);
+      hipLaunchKernelGGL(select_kernel, dim3((unsigned)fails), dim3(kBlock), (size_t)b.Kp * 12, st, b);
       MGP_LAUNCH_CHECK();
       MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
       MGP_HIP_TRY(hipStreamSynchronize(st));

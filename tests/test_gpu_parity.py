@@ -1357,3 +1357,47 @@ def test_vanilla_train_exact_mll(mgp, golden, dev):
     first = float(exact_mll_lowrank(model))
     last = vanilla_train(model, opt, max_iter=20)
     assert np.isfinite(last) and last < first
+
+
+def test_knn_matrix_core_keys_paths(mgp, dev):
+    """d >= 32: candidate keys from the matrix cores (centred bf16-split GEMM form) + absolute-bound check.
+    Whatever the keys' accuracy, the result is the oracle's bit for bit: ragged shapes (d, N, n off the tile
+    sizes), data far from the origin, queries far from the points, data whose spread is tiny against its
+    norm (rows fail the absolute check -> wider sets / direct-difference redo), both key paths identical."""
+    from oracle import knn as oknn
+    from manifold_gp_amd import _lib
+    rng = np.random.default_rng(11)
+
+    def check(x, q, k, expect_clean=None):
+        Dr, Ir = oknn.knn_search(x, q, k)
+        nn = mgp.utils.NearestNeighbors(T(x, dev))
+        D, I = nn.search(T(q, dev), k)
+        st = dict(nn.last_stats)
+        assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), st
+        _lib.lib().mgp_knn_set_mfma(0)
+        try:
+            D0, I0 = nn.search(T(q, dev), k)
+        finally:
+            _lib.lib().mgp_knn_set_mfma(1)
+        assert torch.equal(I, I0) and torch.equal(D, D0)
+        if expect_clean is True:
+            assert st["chunks_redone_direct"] == 0 and st["rows_redone_exact"] == 0, st
+        if expect_clean is False:
+            assert st["chunks_redone_direct"] + st["rows_redone_wide"] > 0, st
+        return st
+
+    # smooth low-dimensional structure in a high-dimensional ambient space (the RMNIST situation)
+    t = rng.uniform(0, 1, size=(1500, 3))
+    W = rng.normal(size=(3, 100)).astype(np.float64)
+    x = (np.sin(t @ W) + 0.01 * rng.normal(size=(1500, 100))).astype(np.float32)
+    check(x, x[:333], 20, expect_clean=True)                       # d = 100 -> 4 stages, N, n ragged
+    check(x + np.float32(1000.0), x[:130] + np.float32(1000.0), 20)   # far from the origin: centring
+    check(x[:, :33].copy(), x[:77, :33].copy(), 9)                 # d = 33: one full stage + 1 feature
+    check(x, (x[:50] * 3 + 5).astype(np.float32), 12)              # queries far from every point
+    # tight clusters on a sphere of radius ~30: |c|^2 ~ 900 against neighbour distances ~ 1e-2
+    base = rng.normal(size=(30, 256)).astype(np.float32) * 2
+    xc = (base[rng.integers(0, 30, 3000)] + 3e-3 * rng.normal(size=(3000, 256))).astype(np.float32)
+    check(xc, xc[:400], 40, expect_clean=False)
+    # exact duplicates + k close to the candidate width
+    xd = np.concatenate([x[:600], x[:200]])
+    check(xd, xd[:100], 64)
