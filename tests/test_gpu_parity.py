@@ -1333,7 +1333,7 @@ def test_vanilla_train_exact_mll(mgp, golden, dev):
     r = y.double().cpu().numpy() - 0.1
     sign, logdet = np.linalg.slogdet(K)
     want = 0.5 * (r @ np.linalg.solve(K, r) + logdet + n * np.log(2 * np.pi)) / n
-    assert abs(float(loss) - want) <= 1e-4 * max(1.0, abs(want)), (float(loss), want)
+    assert abs(loss.item() - want) <= 1e-4 * max(1.0, abs(want)), (loss.item(), want)
 
     params = {k: p for k, p in model.named_parameters() if p.requires_grad}
     loss.backward()
