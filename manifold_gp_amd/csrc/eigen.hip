@@ -24,6 +24,9 @@
 #include <string.h>
 #include <algorithm>
 #include <vector>
+#include <thread>
+#include <chrono>
+#include <cstdio>
 #include "mgp_common.h"
 #include "mgp_internal.h"
 
@@ -290,6 +293,59 @@ void tql2(int n, int ld, double* V, double* d, double* e) {
   }
 }
 
+// fn(i) for i in [0, n) on up to 8 host threads (contiguous ranges; every output row has one owner)
+template <class F>
+void parallel_rows(int n, F fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<unsigned>(hw ? hw : 1u, 8u);
+  if (nt > n / 16) nt = n / 16;
+  if (nt <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (int t = 0; t < nt; ++t) {
+    const int i0 = (int)((int64_t)n * t / nt), i1 = (int)((int64_t)n * (t + 1) / nt);
+    th.emplace_back([=]() { for (int i = i0; i < i1; ++i) fn(i); });
+  }
+  for (auto& x : th) x.join();
+}
+
+// Gn (b x b, unit diagonal, symmetric positive definite) = C C^T; T = D C^-T (b x b) so that
+// T^T (D^-1 Gn D^-1) T = I.  False when a pivot falls under 1e-10 (relative to the unit diagonal): the caller
+// then needs the rank-revealing path.
+bool cholesky_whiten(int b, const std::vector<double>& Gn, const std::vector<double>& dg, std::vector<double>& T) {
+  std::vector<double> C((size_t)b * b, 0.0);
+  for (int j = 0; j < b; ++j) {
+    double s = Gn[(size_t)j * b + j];
+    for (int k = 0; k < j; ++k) s -= C[(size_t)j * b + k] * C[(size_t)j * b + k];
+    if (!(s > 1e-10)) return false;
+    const double cjj = sqrt(s);
+    C[(size_t)j * b + j] = cjj;
+    for (int i = j + 1; i < b; ++i) {
+      double v = Gn[(size_t)i * b + j];
+      const double* ci = &C[(size_t)i * b];
+      const double* cj = &C[(size_t)j * b];
+      for (int k = 0; k < j; ++k) v -= ci[k] * cj[k];
+      C[(size_t)i * b + j] = v / cjj;
+    }
+  }
+  // Ci = C^-1 (lower), column by column: C Ci = I
+  std::vector<double> Ci((size_t)b * b, 0.0);
+  for (int j = 0; j < b; ++j) {
+    Ci[(size_t)j * b + j] = 1.0 / C[(size_t)j * b + j];
+    for (int i = j + 1; i < b; ++i) {
+      double v = 0.0;
+      const double* ci = &C[(size_t)i * b];
+      for (int k = j; k < i; ++k) v -= ci[k] * Ci[(size_t)k * b + j];
+      Ci[(size_t)i * b + j] = v / ci[i];
+    }
+  }
+  // T = D C^-T: T[i][j] = dg[i] * Ci[j][i]
+  T.assign((size_t)b * b, 0.0);
+  for (int i = 0; i < b; ++i)
+    for (int j = i; j < b; ++j) T[(size_t)i * b + j] = dg[i] * Ci[(size_t)j * b + i];
+  return true;
+}
+
 void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& evals, std::vector<double>& V) {
   // (name kept from the Jacobi days: every caller wants "eigh of a small symmetric matrix")
   // The work matrix has a padded leading dimension: tred2 / tql2 walk columns, and with ld = n a
@@ -486,6 +542,7 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
     MGP_HIP_TRY(hipMemcpyAsync(G.data(), w.G, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, st));
     MGP_HIP_TRY(hipMemcpyAsync(H.data(), w.H, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, st));
     MGP_HIP_TRY(hipStreamSynchronize(st));
+    auto tp0 = std::chrono::steady_clock::now();
     std::vector<double> dg(b);
     for (int i = 0; i < b; ++i) {
       const double g = G[(size_t)i * b + i];
@@ -495,38 +552,64 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
     std::vector<double> Gn((size_t)b * b);
     for (int i = 0; i < b; ++i)
       for (int j = 0; j < b; ++j) Gn[(size_t)i * b + j] = 0.5 * (G[(size_t)i * b + j] + G[(size_t)j * b + i]) * dg[i] * dg[j];
-    jacobi_eigh(b, Gn, lam, U);
-    const double lmax = lam[b - 1];
-    int k0 = 0;
-    while (k0 < b && lam[k0] <= 1e-10 * lmax) ++k0;
-    kept = b - k0;
-    // T = D U[:, k0:] Lambda^-1/2   (b x kept)
-    std::vector<double> T((size_t)b * kept);
-    for (int i = 0; i < b; ++i)
-      for (int j = 0; j < kept; ++j) T[(size_t)i * kept + j] = dg[i] * U[(size_t)i * b + k0 + j] / sqrt(lam[k0 + j]);
-    // Hp = T^T Hs T
+    // whitening T (b x kept) with T^T G T = I: Cholesky Gn = C C^T, T = D C^-T (0.2 ms); a block that has
+    // (nearly) dependent columns -- pivot ratio under 1e-5, i.e. cond(Gn) ~ 1e10 -- takes the rank-revealing
+    // eigendecomposition instead (3 ms) and drops the dependent directions
+    std::vector<double> T;
+    if (cholesky_whiten(b, Gn, dg, T)) {
+      kept = b;
+    } else {
+      jacobi_eigh(b, Gn, lam, U);
+      const double lmax = lam[b - 1];
+      int k0 = 0;
+      while (k0 < b && lam[k0] <= 1e-10 * lmax) ++k0;
+      kept = b - k0;
+      // T = D U[:, k0:] Lambda^-1/2   (b x kept)
+      T.assign((size_t)b * kept, 0.0);
+      for (int i = 0; i < b; ++i)
+        for (int j = 0; j < kept; ++j) T[(size_t)i * kept + j] = dg[i] * U[(size_t)i * b + k0 + j] / sqrt(lam[k0 + j]);
+    }
+    auto tp1 = std::chrono::steady_clock::now();
+    // Hp = T^T Hs T   (rows of the outputs are independent: split over host threads, fixed order inside)
     std::vector<double> HT((size_t)b * kept, 0.0), Hp((size_t)kept * kept, 0.0);
-    for (int i = 0; i < b; ++i)
+    parallel_rows(b, [&](int i) {
+      double* o = &HT[(size_t)i * kept];
       for (int l = 0; l < b; ++l) {
         const double h = 0.5 * (H[(size_t)i * b + l] + H[(size_t)l * b + i]);
         if (h == 0.0) continue;
-        for (int j = 0; j < kept; ++j) HT[(size_t)i * kept + j] += h * T[(size_t)l * kept + j];
+        const double* t = &T[(size_t)l * kept];
+        for (int j = 0; j < kept; ++j) o[j] += h * t[j];
       }
-    for (int i = 0; i < b; ++i)
-      for (int j = 0; j < kept; ++j) {
+    });
+    parallel_rows(kept, [&](int j) {
+      double* o = &Hp[(size_t)j * kept];
+      for (int i = 0; i < b; ++i) {
         const double t = T[(size_t)i * kept + j];
-        for (int l = 0; l < kept; ++l) Hp[(size_t)j * kept + l] += t * HT[(size_t)i * kept + l];
+        const double* h = &HT[(size_t)i * kept];
+        for (int l = 0; l < kept; ++l) o[l] += t * h[l];
       }
+    });
+    auto tp2 = std::chrono::steady_clock::now();
     jacobi_eigh(kept, Hp, th, S);
+    auto tp3 = std::chrono::steady_clock::now();
     // W = T S (b x kept); upload W^T rows = Ritz directions, zero-padded to b
     std::fill(wt.begin(), wt.end(), 0.f);
-    for (int i = 0; i < b; ++i)
-      for (int j = 0; j < kept; ++j) {
-        double s = 0.0;
-        for (int l = 0; l < kept; ++l) s += T[(size_t)i * kept + l] * S[(size_t)l * kept + j];
-        wt[(size_t)j * b + i] = (float)s;
+    parallel_rows(b, [&](int i) {
+      std::vector<double> acc(kept, 0.0);
+      for (int l = 0; l < kept; ++l) {
+        const double t = T[(size_t)i * kept + l];
+        const double* sr = &S[(size_t)l * kept];
+        for (int j = 0; j < kept; ++j) acc[j] += t * sr[j];
       }
+      for (int j = 0; j < kept; ++j) wt[(size_t)j * b + i] = (float)acc[j];
+    });
     for (int j = 0; j < b; ++j) thf[j] = j < kept ? (float)th[j] : 0.f;
+    auto tp4 = std::chrono::steady_clock::now();
+    if (getenv("MGP_EIG_TIMING")) {
+      auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      fprintf(stderr, "[eig] round %d: whiten %.2f  HT/Hp %.2f  eigh(Hp) %.2f  W %.2f ms\n", outer, ms(tp0, tp1), ms(tp1, tp2),
+              ms(tp2, tp3), ms(tp3, tp4));
+    }
     MGP_HIP_TRY(hipMemcpyAsync(w.wt, wt.data(), (size_t)b * b * sizeof(float), hipMemcpyHostToDevice, st));
     MGP_HIP_TRY(hipMemcpyAsync(w.theta, thf.data(), b * sizeof(float), hipMemcpyHostToDevice, st));
     // ---- rotate on the MFMA: Vn = V W, LVn = LV W   (K = Z1 Z2^T with Z2 = W^T)

@@ -1,0 +1,15 @@
+#!/usr/bin/env python
+"""Warm timing of the eigensolve (100 smallest eigenpairs of the C3 graph Laplacian)."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import bench
+from manifold_gp_amd.solvers import lanczos_smallest
+class A: workload, nodes, gpus, s5_order = "c3", 0, 1, "morton"
+wl = bench.build_workload(A(), torch.device("cuda:0"), 0, 1)
+data = wl["lap"].data
+m = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ev, V, res = lanczos_smallest(data, m, tol=1e-5)
+    torch.cuda.synchronize()
+    print("eigensolve ms %.1f info %s max resid %.2e" % ((time.perf_counter() - t0) * 1e3, lanczos_smallest.last_info, max(res)), flush=True)
