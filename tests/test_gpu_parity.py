@@ -1401,3 +1401,78 @@ def test_knn_matrix_core_keys_paths(mgp, dev):
     # exact duplicates + k close to the candidate width
     xd = np.concatenate([x[:600], x[:200]])
     check(xd, xd[:100], 64)
+
+
+@pytest.mark.parametrize("shape", ["golden", "n65", "hub", "dense_small", "ordered"])
+def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
+    """C > 16: the multi-column SpMM against a dense fp64 reference with every epilogue operand in play (pre / post
+    scalings, base term, weighted dot partials), with and without tile dictionaries on the CSR; ragged row
+    counts, a hub row, a dense block, a graph whose tiles follow a locality order."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.graph import KnnGraph, LaplacianData
+    rng = np.random.default_rng(len(shape))
+    if shape == "golden":
+        g = golden("dumbbell_k10_loop")
+        idx, val, n = T(g["edge_index"].astype(np.int64), dev), T(g["edge_value"], dev), g["train_x"].shape[0]
+        graph = KnnGraph.from_coo(idx, val, n)
+    elif shape == "ordered":
+        # random node order: build_tiles_auto picks tiles over a locality (BFS) order
+        t = rng.random(6000)
+        order = rng.permutation(6000)
+        x = np.stack([np.cos(6.28 * t), np.sin(6.28 * t)], 1)[order].astype(np.float32)
+        nn = mgp.utils.NearestNeighbors(T(x, dev))
+        nn.graph(12)
+        graph, n = nn.knn_graph, 6000
+    else:
+        if shape == "n65":
+            n = 65
+            r, c = rng.integers(0, n, 400), rng.integers(0, n, 400)
+        elif shape == "hub":
+            n = 9000
+            r = np.concatenate([np.zeros(1500, np.int64), rng.integers(0, n, 20000)])
+            c = np.concatenate([np.arange(1, 1501), rng.integers(0, n, 20000)])
+        else:
+            n = 200
+            r, c = np.triu_indices(n, 1)
+        pairs = np.stack([np.minimum(r, c), np.maximum(r, c)], 1)
+        pairs = np.unique(pairs[pairs[:, 0] < pairs[:, 1]], axis=0)
+        idx = torch.from_numpy(np.ascontiguousarray(pairs.T)).to(dev)
+        val = torch.from_numpy((rng.random(len(pairs)) * 0.02).astype(np.float32)).to(dev)
+        graph = KnnGraph.from_coo(idx, val, n)
+    data = LaplacianData(graph, 0.1, True)
+    if shape == "ordered":
+        assert graph.tiles is not None and graph.tiles.get("rowid") is not None
+    lib = _lib.lib()
+    rowptr, col = graph.rowptr.cpu().numpy(), graph.col.cpu().numpy()
+    vals = data.vals.cpu().numpy().astype(np.float64)
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    for C in (20, 100, 152, 256):
+        X = torch.randn(n, C, device=dev)
+        pre = torch.rand(n, device=dev) + 0.5
+        base = torch.randn(n, C, device=dev)
+        W = torch.randn(n, C, device=dev)
+        outs = []
+        try:
+            for mode in (0, 1):
+                lib.mgp_spmm_set_tile_mode(mode)
+                csr = data.csr()
+                nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), C)
+                part = torch.full((max(nb, 1), C), float("nan"), device=dev)
+                Y = torch.empty_like(X)
+                _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y), 1.25, 1.0, _lib.ptr(pre),
+                                              _lib.ptr(pre), _lib.ptr(base), 0.5, 2.0, _lib.ptr(W), _lib.ptr(part),
+                                              _lib.stream()), "mgp_spmm_fused")
+                outs.append((Y.cpu().double().numpy(), part.double().sum(0).cpu().numpy(), nb))
+        finally:
+            lib.mgp_spmm_set_tile_mode(1)
+        Xs = (pre.cpu().double().view(-1, 1) * X.cpu().double()).numpy()
+        SX = np.zeros((n, C))
+        np.add.at(SX, rows, vals[:, None] * Xs[col])
+        LX = data.diag.cpu().double().numpy()[:, None] * Xs - SX
+        ref = 0.5 * base.cpu().double().numpy() + 2.0 * pre.cpu().double().numpy()[:, None] * (1.25 * Xs + LX)
+        dref = (W.cpu().double().numpy() * ref).sum(0)
+        scale = max(np.abs(ref).max(), 1e-6)
+        for Y, d, nb in outs:
+            assert np.abs(Y - ref).max() < 2e-5 * scale, (shape, C)
+            assert np.abs(d - dref).max() < 2e-4 * scale * max(n, 16) ** 0.5, (shape, C)
