@@ -156,6 +156,14 @@ __global__ __launch_bounds__(kBlock) void residual_kernel(const float* __restric
   }
 }
 
+// dst[r, dc0 + j] = src[r, sc0 + j], j < m  (column sub-blocks between row-major blocks of different widths)
+__global__ void move_cols_kernel(const float* __restrict__ src, int64_t n, int sld, int sc0, int m, float* __restrict__ dst,
+                                 int dld, int dc0) {
+  const int64_t total = n * m;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    dst[(i / m) * dld + dc0 + (i % m)] = src[(i / m) * sld + sc0 + (i % m)];
+}
+
 __global__ void copy_cols_kernel(const float* __restrict__ V, int64_t n, int ld, int m, float* __restrict__ out) {
   const int64_t total = n * m;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
@@ -502,40 +510,53 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
   hipLaunchKernelGGL(random_cols_kernel, dim3(rgrid), dim3(kBlock), 0, st, w.buf[0], n, b, 0, b, seed);
   MGP_LAUNCH_CHECK();
 
-  int iV = 0;                      // buffer holding the current block
+  // Buffers: bV / bLV hold the current block V and L V (full width b); three more serve the filter.
+  // Soft locking: the leading run of converged Ritz vectors (a multiple of 4 columns) is no longer filtered --
+  // the Chebyshev recurrence and the L apply run on the remaining `ba` columns, compacted to an [n, ba]
+  // block -- but stays in the Rayleigh-Ritz basis, so it keeps being refined and the block stays orthogonal.
+  int bV = 0, bLV = 1, c0 = 2, c1 = 3, c2 = 4;
+  int nlock = 0;
   double a = ub / 4.0, a0 = 0.0;
   int deg = (p && p->degree > 0) ? p->degree : 10;
   std::vector<double> G((size_t)b * b), H((size_t)b * b), th, S, lam, U;
   std::vector<float> wt((size_t)b * b), thf(b);
   std::vector<double> rp((size_t)w.rchunks * b), res(b, 1e300);
   int outer = 0, nspmm = 0, nconv = 0, kept = b;
+  auto move_cols = [&](const float* src, int sld, int sc0, int mcols, float* dst, int dld, int dc0) {
+    const int grid = (int)std::min<int64_t>(4096, mgp_cdiv(n * mcols, kBlock));
+    hipLaunchKernelGGL(move_cols_kernel, dim3(grid), dim3(kBlock), 0, st, src, n, sld, sc0, mcols, dst, dld, dc0);
+  };
   for (outer = 0; outer < max_outer; ++outer) {
-    // ---- scaled Chebyshev filter of degree `deg` damping [a, ub], normalised at a0
+    // ---- scaled Chebyshev filter of degree `deg` damping [a, ub], normalised at a0, on the active columns
+    const int ba = b - nlock;
     const double e = (ub - a) / 2.0, c = (ub + a) / 2.0;
     double sig = e / (a0 - c);
     const double tau = 2.0 / sig;
-    int iX = iV, iY = (iV + 1) % 5, iN = (iV + 2) % 5;
+    int iX = c0, iY = c1, iN = c2;
+    move_cols(w.buf[bV], b, nlock, ba, w.buf[iX], ba, 0);
+    MGP_LAUNCH_CHECK();
     // Y = (sig/e) (L X - c X)
-    MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iX], b, w.buf[iY], (float)(-c * sig / e), (float)(sig / e), nullptr, nullptr,
+    MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iX], ba, w.buf[iY], (float)(-c * sig / e), (float)(sig / e), nullptr, nullptr,
                               nullptr, 0.f, 1.f, nullptr, nullptr, nullptr, nullptr, stream));
     ++nspmm;
     for (int i = 2; i <= deg; ++i) {
       const double sn = 1.0 / (tau - sig);
       // Ynew = (2 sn / e) (L Y - c Y) - (sig sn) X
-      MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iY], b, w.buf[iN], (float)(-c * 2.0 * sn / e), (float)(2.0 * sn / e),
+      MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iY], ba, w.buf[iN], (float)(-c * 2.0 * sn / e), (float)(2.0 * sn / e),
                                 nullptr, nullptr, w.buf[iX], (float)(-sig * sn), 1.f, nullptr, nullptr, nullptr,
                                 nullptr, stream));
       ++nspmm;
       const int t = iX; iX = iY; iY = iN; iN = t;
       sig = sn;
     }
-    const int iF = iY;                                   // filtered block
-    int free_[4], nf = 0;
-    for (int i = 0; i < 5; ++i) if (i != iF) free_[nf++] = i;
-    const int iLV = free_[0], iVn = free_[1], iLVn = free_[2];
-    MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iF], b, w.buf[iLV], 0.f, 1.f, nullptr, nullptr, nullptr, 0.f, 1.f, nullptr,
+    // filtered active block in iY; L (filtered) into iN; both back into the active columns of V / L V
+    MGP_TRY(mgp_spmm_fused_ex(L, w.buf[iY], ba, w.buf[iN], 0.f, 1.f, nullptr, nullptr, nullptr, 0.f, 1.f, nullptr,
                               nullptr, nullptr, nullptr, stream));
     ++nspmm;
+    move_cols(w.buf[iY], ba, 0, ba, w.buf[bV], b, nlock);
+    move_cols(w.buf[iN], ba, 0, ba, w.buf[bLV], b, nlock);
+    MGP_LAUNCH_CHECK();
+    const int iF = bV, iLV = bLV, iVn = c0, iLVn = c1;
     // ---- Rayleigh-Ritz: G = V^T V, H = V^T L V (fp64), generalized eigenproblem on the host
     MGP_TRY(launch_gram(w.buf[iF], w.buf[iF], n, b, w, w.G, st));
     MGP_TRY(launch_gram(w.buf[iF], w.buf[iLV], n, b, w, w.H, st));
@@ -625,16 +646,29 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
       for (int cch = 0; cch < w.rchunks; ++cch) s += rp[(size_t)cch * b + j];
       res[j] = sqrt(s);
     }
-    if (kept < b) {   // refill dropped directions with fresh random vectors
+    if (kept < b) {   // refill dropped directions with fresh random vectors (their L V column is rebuilt by
+                      // the next round's filter: dropped directions sit at the end, locked ones at the start)
       hipLaunchKernelGGL(random_cols_kernel, dim3(rgrid), dim3(kBlock), 0, st, w.buf[iVn], n, b, kept, b,
                          seed + 7919ULL * (outer + 1));
       MGP_LAUNCH_CHECK();
     }
-    iV = iVn;
+    { const int ov = bV, olv = bLV; bV = iVn; bLV = iLVn; c0 = ov; c1 = olv; }
     nconv = 0;
+    nlock = 0;
     if (kept >= m) {
       for (int j = 0; j < m; ++j) nconv += (res[j] <= tol * ub) ? 1 : 0;
+      if (getenv("MGP_EIG_TIMING")) {
+        int lead = 0;
+        while (lead < m && res[lead] <= tol * ub) ++lead;
+        fprintf(stderr, "[eig] round %d: deg %d, converged %d of %d (leading run %d)\n", outer, deg, nconv, m, lead);
+      }
       if (nconv == m) { ++outer; break; }
+      {
+        int lead = 0;
+        while (lead < m && res[lead] <= tol * ub) ++lead;
+        nlock = lead / 4 * 4;
+        if (b - nlock < 8) nlock = 0;
+      }
       a = th[kept - 1];
       a0 = std::min(th[0], 0.0);
       const double gap = std::max(a - th[m - 1], 1e-12 * ub);
@@ -644,7 +678,7 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
     }
   }
   const int cgrid = (int)std::min<int64_t>(4096, mgp_cdiv(n * m, kBlock));
-  hipLaunchKernelGGL(copy_cols_kernel, dim3(cgrid), dim3(kBlock), 0, st, w.buf[iV], n, b, m, evecs);
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(cgrid), dim3(kBlock), 0, st, w.buf[bV], n, b, m, evecs);
   MGP_LAUNCH_CHECK();
   MGP_HIP_TRY(hipStreamSynchronize(st));
   for (int j = 0; j < m; ++j) {
