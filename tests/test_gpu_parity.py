@@ -1345,8 +1345,8 @@ def test_vanilla_train_exact_mll(mgp, golden, dev):
         gr = float(p.grad.reshape(-1)[0])
         h = 1e-3
         with torch.no_grad():
-            p.add_(h); up = float(exact_mll_lowrank(model).double())
-            p.sub_(2 * h); dn = float(exact_mll_lowrank(model).double())
+            p.add_(h); up = exact_mll_lowrank(model).item()
+            p.sub_(2 * h); dn = exact_mll_lowrank(model).item()
             p.add_(h)
         fd = (up - dn) / (2 * h)
         assert abs(gr - fd) <= 2e-2 * max(abs(fd), 1e-2), (name, gr, fd)
@@ -1354,7 +1354,7 @@ def test_vanilla_train_exact_mll(mgp, golden, dev):
     assert checked >= 4                                                   # noise, output scale, length scale, mean
 
     opt = torch.optim.Adam([p for p in params.values()], lr=5e-2)
-    first = float(exact_mll_lowrank(model))
+    first = exact_mll_lowrank(model).item()
     last = vanilla_train(model, opt, max_iter=20)
     assert np.isfinite(last) and last < first
 
@@ -1476,3 +1476,41 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
         for Y, d, nb in outs:
             assert np.abs(Y - ref).max() < 2e-5 * scale, (shape, C)
             assert np.abs(d - dref).max() < 2e-4 * scale * max(n, 16) ** 0.5, (shape, C)
+
+
+@pytest.mark.parametrize("kind", ["gauss", "cube", "huge", "tiny", "mixed", "spike"])
+def test_knn_matrix_core_keys_equal_direct_keys(mgp, dev, kind):
+    """The two key paths of the slab pipeline (bf16-split MFMA + absolute bound; fp32 direct differences +
+    relative bound) must return the same lists on any data: concentrated distances (every row fails the
+    absolute check), wide dynamic range, values near the bf16 / fp32 underflow, one dominant feature."""
+    from manifold_gp_amd import _lib
+    rng = np.random.default_rng(17)
+    n, d, k = 12000, 96, 30
+    if kind == "gauss":
+        x = rng.normal(size=(n, d))
+    elif kind == "cube":
+        x = rng.random(size=(n, d))
+    elif kind == "huge":
+        x = rng.normal(size=(n, d)) * 3e4 + 1e6
+    elif kind == "tiny":
+        x = rng.normal(size=(n, d)) * 1e-18
+    elif kind == "mixed":
+        x = rng.normal(size=(n, d)) * np.logspace(-6, 4, d)
+    else:
+        x = rng.normal(size=(n, d)) * 1e-3
+        x[:, 5] += rng.integers(0, 3, n) * 1e3
+    x = x.astype(np.float32)
+    nn = mgp.utils.NearestNeighbors(T(x, dev))
+    q = T(x[:3000], dev)
+    D1, I1 = nn.search(q, k)
+    s1 = dict(nn.last_stats)
+    _lib.lib().mgp_knn_set_mfma(0)
+    try:
+        D0, I0 = nn.search(q, k)
+    finally:
+        _lib.lib().mgp_knn_set_mfma(1)
+    assert torch.equal(I1, I0) and torch.equal(D1, D0), (kind, s1)
+    assert bool((I1[:, 0] == torch.arange(3000, device=dev)).all())           # self is the first neighbour
+    from oracle import knn as oknn
+    Dr, Ir = oknn.knn_search(x, x[:64], k)
+    assert np.array_equal(I1[:64].cpu().numpy(), Ir) and np.array_equal(D1[:64].cpu().numpy(), Dr), kind
