@@ -919,6 +919,15 @@ def test_riemann_gp_posterior_and_hybrid(mgp, golden, dev, norm):
                                cov_o + np.outer(w, w) * b.covariance_matrix.cpu().numpy(), rtol=0, atol=3e-4)
     np.testing.assert_allclose(model.posterior_stddev.cpu().numpy(),
                                np.sqrt(np.clip(np.diag(cov_o), 0, None)) + w * b.stddev.cpu().numpy(), rtol=0, atol=2e-3)
+    # test_model (utils/test_model.py:10-29): RMSE / NLL of the noisy hybrid posterior vs the oracle's metrics
+    from manifold_gp_amd.utils import test_model as run_test_model
+    from oracle.solvers import rmse_nll
+    yt = T((rng.normal(size=40) * 0.3).astype(np.float32), dev)
+    rmse, nll = run_test_model(model, xt, yt, noisy_test=True, base_model=base)
+    cov_h = cov_o + noise * np.eye(40) + np.outer(w, w) * (b.covariance_matrix.cpu().numpy() + noise * np.eye(40))
+    rmse_o, nll_o = rmse_nll(yt.cpu().numpy().astype(np.float64) - (mean_o + w * b.mean.cpu().numpy()), cov_h)
+    assert abs(float(rmse) - rmse_o) <= 1e-4 * max(1.0, rmse_o)
+    assert abs(float(nll) - nll_o) <= 2e-3 * max(1.0, abs(nll_o)), (float(nll), nll_o)
     # precision(): Schur (if labelled) -> Scale -> Noise (riemann_gp.py:32-39)
     Qn = model.precision()
     assert isinstance(Qn, O.NoiseWrapperOperator) and isinstance(model.precision(noise=False), O.ScaleWrapperOperator)

@@ -154,6 +154,7 @@ def test_operator_exports_match_reference_names():
     assert importlib.import_module("manifold_gp.models").RiemannGP is mgp.models.RiemannGP
     assert callable(importlib.import_module("manifold_gp.utils").manifold_informed_train)
     assert callable(importlib.import_module("manifold_gp.utils").vanilla_train)
+    assert callable(importlib.import_module("manifold_gp.utils").test_model)
     # RiemannGP surface of manifold_gp/models/riemann_gp.py:10-75
     for name in ("precision", "modulation", "posterior", "posterior_mean", "posterior_covar", "posterior_stddev",
                  "base_kernel", "eval"):
