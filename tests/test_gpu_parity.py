@@ -346,6 +346,32 @@ def test_eigensolver_disconnected_components(mgp, dev):
     np.testing.assert_allclose(evals.cpu().numpy(), w, rtol=0, atol=2e-6 * np.abs(np.diag(A)).max())
 
 
+def test_eigensolver_on_unordered_nodes_uses_the_locality_order(mgp, dev):
+    """Nodes handed over in random order: the graph carries tiles over a locality order and the eigensolver
+    runs on the matrix relabelled by it (solvers.lanczos_smallest).  Eigenvalues against dense eigh and the
+    residuals of the returned vectors IN THE CALLER'S NODE ORDER (a wrong un-permutation cannot pass)."""
+    from manifold_gp_amd.solvers import lanczos_smallest
+    rng = np.random.default_rng(4)
+    n = 3000
+    t = rng.random(n)
+    x = (np.stack([np.cos(6.28318 * t), np.sin(6.28318 * t), 0.3 * np.cos(3 * 6.28318 * t)], 1)
+         + 0.01 * rng.normal(size=(n, 3))).astype(np.float32)
+    x = x[rng.permutation(n)]
+    knn = mgp.utils.NearestNeighbors(T(x, dev))
+    idx, val = knn.graph(10)
+    assert knn.knn_graph.tiles is not None and knn.knn_graph.tiles.get("rowid") is not None
+    op = mgp.operators.GraphLaplacianOperator(val, idx, n, torch.tensor([[0.05]], device=dev), "symmetric",
+                                              graph=knn.knn_graph)
+    evals, evecs, resid = lanczos_smallest(op.data, 12, tol=1e-6)
+    A = op.to_dense().double().cpu().numpy()
+    w = np.linalg.eigvalsh(0.5 * (A + A.T))[:12]
+    scale = np.abs(np.diag(A)).max()
+    np.testing.assert_allclose(evals.cpu().numpy(), w, rtol=0, atol=5e-6 * scale)
+    R = op.matmul(evecs) - evecs * evals.view(1, -1)
+    assert float(R.norm(dim=0).max()) <= 2e-5 * scale, float(R.norm(dim=0).max())
+    assert float((evecs.t() @ evecs - torch.eye(12, device=dev)).abs().max()) < 5e-5
+
+
 def test_lanczos_tridiag_matches_operator(mgp, golden, dev):
     """Full-reorth Lanczos: Q^T A Q = T and Q^T Q = I."""
     import ctypes
