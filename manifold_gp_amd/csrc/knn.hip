@@ -447,6 +447,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
     } else {
       ok = dk < t32 / (1.0 + a.gamma) * (1.0 - 1e-12);
     }
+    if (!(t32 < (double)INFINITY)) ok = false;    // overflowed fp32 keys order nothing: exact path
   }
   if (ok) {
     if (by_rank) {

@@ -1549,3 +1549,16 @@ def test_knn_matrix_core_keys_equal_direct_keys(mgp, dev, kind):
     from oracle import knn as oknn
     Dr, Ir = oknn.knn_search(x, x[:64], k)
     assert np.array_equal(I1[:64].cpu().numpy(), Ir) and np.array_equal(D1[:64].cpu().numpy(), Dr), kind
+
+
+def test_knn_fp32_overflowing_distances_take_the_exact_path(mgp, dev):
+    """Coordinates around 1e19..1e20: squared fp32 distances overflow to inf and order nothing; the exact fp64
+    scan must take over (the oracle works in fp64)."""
+    from oracle import knn as oknn
+    rng = np.random.default_rng(23)
+    x = (rng.normal(size=(700, 40)) * 3e19).astype(np.float32)
+    Dr, Ir = oknn.knn_search(x, x[:90], 7)
+    nn = mgp.utils.NearestNeighbors(T(x, dev))
+    D, I = nn.search(T(x[:90], dev), 7)
+    assert np.array_equal(I.cpu().numpy(), Ir)
+    assert np.array_equal(D.cpu().numpy(), Dr)             # (float) of the fp64 distance: inf where it overflows
