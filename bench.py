@@ -239,15 +239,19 @@ def _main(quiet):
         out = plan.solve(y, copy=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    iters = 0
+    iters = applies = 0
     for _ in range(args.steps):
         out = plan.solve(y, copy=False)      # solution stays in the plan's device buffer
         iters += plan.iters
+        applies += plan.applies
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     its = iters / args.steps
     B = spmm_bytes(g.n, g.M)
-    spmvs_per_solve = (its + 1) * wl["nu"]
+    # SpMVs that actually ran: nu per operator apply; the plan reports its applies (a solve of k iterations
+    # runs k of them once its graph ends in the decision-only launch, k + 1 before).  With refinement rounds the
+    # fp32 applies of every round are iterations + 1.
+    spmvs_per_solve = (applies / args.steps if refine == 0 else its + 1) * wl["nu"]
     value = B * spmvs_per_solve * args.steps / dt / 1e9
     resid = max(plan.resid)
     # residual re-check with one explicit operator apply

@@ -278,6 +278,11 @@ int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, floa
                       int32_t* status); /* status 1 converged, 2 max_iter, 3 breakdown (NaN) */
 float* mgp_cg_plan_x(void* plan);    /* device pointer of the plan's own solution buffer [n,C]; pass
                                          X = NULL to mgp_cg_plan_solve to skip the copy into X */
+/* operator applies the last solve actually ran (refinement off).  A plan's first graph is captured for the
+ * step count its previous solves needed; for C = 1 its last step -- the one that would only notice
+ * ||r|| <= tol after running one more apply for nothing -- is a single-workgroup decision launch, so a
+ * solve that takes k iterations runs k applies, not k + 1.  Same iterates, residuals and flags. */
+int mgp_cg_plan_last_applies(void* plan);
 int mgp_cg_plan_destroy(void* plan);
 int mgp_cg_solve(const mgp_operator_t* op, const float* B, int C, float* X, const float* minv,
                  const mgp_cg_params_t* params, int32_t* iters, float* resid, void* work,

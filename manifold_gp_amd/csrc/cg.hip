@@ -450,6 +450,49 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   }
 }
 
+// ---- Stopping decision alone (C == 1).  The update kernel of step k+1 is where ||r_k|| <= tol is noticed, after
+// apply k+1 has already run for nothing: at 3 iterations per solve that is 2 of 8 SpMVs + a launch, ~14 us of
+// ~76.  The first graph of a plan is captured for the step count the previous solves needed, so its last
+// (apply, update) pair -- the one that only detects -- is replaced by this single-workgroup launch: the same
+// partial sums in the same order, the same rule, the same flags as cg_update_c1_kernel would write at
+// it + 1.  Not converged: it writes nothing and the continuation graph carries on as before.
+__global__ __launch_bounds__(kBlock) void cg_decide_c1_kernel(CgArgs a) {
+  __shared__ float sh_w[kBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const CgScalars sc = *reinterpret_cast<const CgScalars*>(a.gamma_old);
+  if (sc.done) return;
+  const int it = sc.it + 1;                 // the step whose update would take this decision
+  const int prev = (it & 1) ^ 1;            // slot the last update wrote
+  float t = 0.f;
+#pragma unroll
+  for (int q = 0; q < kC1GammaSlots; ++q) {
+    const int b = tid + q * kBlock;
+    const float v = a.pd_rr[(int64_t)prev * a.nbv + (b < a.nbv ? b : a.nbv - 1)];
+    t += (b < a.nbv) ? v : 0.f;
+  }
+  t = mgp_wave_sum(t);
+  if (lane == 0) sh_w[wave] = t;
+  __syncthreads();
+  if (tid != 0) return;
+  const float rr2 = (sh_w[0] + sh_w[1]) + (sh_w[2] + sh_w[3]);
+  const float bb = sc.bb;                   // it >= 2 here: written by the first update
+  const float rel = (bb > 0.f) ? sqrtf(rr2 / bb) : 0.f;
+  int done = 0, status = 0;
+  if (a.stop_mode == 0) {
+    if (it > a.min_iter && rel < a.tol) { done = 1; status = 1; }
+  } else if (rel <= a.tol) { done = 1; status = 1; }
+  if (!isfinite(rel)) { done = 1; status = 3; }
+  if (!done && it > a.max_iter) { done = 1; status = 2; }
+  if (!done) return;
+  a.resid[0] = rel;
+  a.state[2] = status; a.state[1] = 1;
+  a.host_resid[0] = rel;
+  a.host_state[0] = it; a.host_state[2] = status;
+  a.host_state[3] = 1;                      // decided without running apply `it`
+  __threadfence_system();
+  a.host_state[1] = 1;
+}
+
 // ---- Fused CG step (C == 1, tile SpMV, single-chain operator with nu >= 2, no preconditioner).
 // update_k and the FIRST SpMV of apply_{k+1} in one launch: one launch floor (~2.7 us) and the update
 // kernel's own load chain less per step.  A workgroup owns the same 64-row tiles as spmv_tile_kernel.
@@ -925,7 +968,15 @@ void capture_first(CgPlan* pl, int len) {
                        (const float*)pl->args.x);   // placeholder rhs, patched before every launch
     int rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
     if (rc == MGP_OK) rc = enqueue_head(pl, pl->cap_stream);
-    for (int i = 0; i < len && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
+    // `len` = steps until the stopping rule fires: the last of them only detects (see cg_decide_c1_kernel)
+    const bool decide = len >= 2 && !pl->fused && !pl->is_dist && pl->C == 1 &&
+                        pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock;
+    const int bodies = decide ? len - 1 : len;
+    for (int i = 0; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
+    if (decide && rc == MGP_OK) {
+      hipLaunchKernelGGL(cg_decide_c1_kernel, dim3(1), dim3(kBlock), 0, pl->cap_stream, pl->args);
+      rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
+    }
     hipGraph_t graph = nullptr;
     const hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
     ok = (rc == MGP_OK && e2 == hipSuccess && graph != nullptr);
@@ -1119,6 +1170,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   hipStream_t st = pl->stream;
   const size_t nc = (size_t)pl->args.n * pl->C;
   pl->host_state[1] = 0;
+  pl->host_state[3] = 0;
   bool first = true;
   if (pl->solves++ >= 1 && !pl->graphs_tried) capture_graphs(pl);
   if (pl->has_first && !patch_first_rhs(pl, rhs)) pl->has_first = false;
@@ -1234,6 +1286,14 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
   if (status) *status = last_status;
   if (resid) memcpy(resid, pl->host_true_rel, (size_t)pl->C * sizeof(float));   // TRUE relative residuals
   return MGP_OK;
+}
+
+// operator applies the last (non-refined) solve actually ran: its step count, minus the detecting step when the
+// stopping decision came from the decision-only launch at the end of the first graph
+extern "C" int mgp_cg_plan_last_applies(void* plan) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  if (!pl) return MGP_ERR_ARG;
+  return pl->host_state[0] - (pl->host_state[3] ? 1 : 0);
 }
 
 // device pointer of the plan's solution buffer [n, C] (valid until the plan is destroyed)

@@ -41,6 +41,7 @@ class CgPlan:
                                        ptr(self.work), self.work.numel(), stream(), ctypes.byref(self.handle)),
               "mgp_cg_plan_create")
         self.iters = 0
+        self.applies = 0
         self.status = 0
         self.resid = None
 
@@ -65,6 +66,7 @@ class CgPlan:
         if X is None:
             X = self.solution_view()
         self.iters, self.status = iters.value, status.value
+        self.applies = int(lib().mgp_cg_plan_last_applies(self.handle))    # operator applies that actually ran
         self.resid = list(resid)
         return X
 
