@@ -163,7 +163,7 @@ def cpu_baseline(wl, gpu_iters):
     xs, its = torch_cg(prec.posterior_system, y, 1e-6, 1000)
     t_cg = time.perf_counter() - t0
     B = spmm_bytes(g.n, g.M)
-    spmvs = (its + 1) * wl["nu"]
+    spmvs = its * wl["nu"]                            # torch_cg: one operator apply per iteration, x0 = 0
     return dict(value=round(B * spmvs / t_cg / 1e9, 3), unit="GB/s", cores=cores, kind="port",
                 sample="full C3 workload: 1 CG solve (%d iterations, %d SpMV) + 20 SpMV repeats on %d threads"
                        % (its, spmvs, torch.get_num_threads()),
