@@ -407,11 +407,13 @@ struct EigWork {
 };
 
 int block_size_for(int m, const mgp_lanczos_params_t* p) {
-  int b = (p && p->max_basis > 0) ? p->max_basis : m + std::max(m / 2, 32);   // measured: 100 -> 152 halves the SpMM count of 125
+  // measured at N = 60k, m = 100 (soft locking on, 4 ms of host work per round): 125 columns 29 rounds,
+  // 152: 13 rounds / 164 ms, 192: 8 rounds / 138 ms, 208: 7 / 136 ms, 256: 6 / 183 ms -- about 2 m
+  int b = (p && p->max_basis > 0) ? p->max_basis : m + std::max(m * 9 / 10, 32);
   if (b < m + 2) b = m + 2;
-  // a multiple of 4 unless the caller fixed the size: block rows are then 16-byte aligned, which the SpMM
-  // and the MFMA rotation kernel exploit (C = 128 runs faster than C = 125)
-  if (!(p && p->max_basis > 0)) b = (b + 3) / 4 * 4;
+  // a multiple of 16 unless the caller fixed the size: block rows are then 64-byte aligned (whole or half cache
+  // lines per gathered row; 200 columns measured slower than both 192 and 208)
+  if (!(p && p->max_basis > 0)) b = (b + 15) / 16 * 16;
   return b;
 }
 
