@@ -1,0 +1,21 @@
+#!/usr/bin/env bash
+# MFMA utilisation counters of the k-NN key kernel (tools/time_knn.py), one counter group per pass.
+set -eo pipefail
+out="gpurun_out/pmc_knn"; mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+i=0
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+  i=$((i+1))
+  timeout -k 10 250 rocprofv3 --pmc $grp --output-format csv -d "$out/p$i" -- python3 tools/time_knn.py 200 > "$out/p$i.log" 2>&1 || echo "pass $i failed"
+done
+python3 - <<'PY'
+import csv, glob, collections
+for d in sorted(glob.glob("gpurun_out/pmc_knn/p*/")):
+    for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "dist_mfma_kernel" in r["Kernel_Name"]:
+                acc[(r["Counter_Name"], r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
+        for k, v in sorted(acc.items()):
+            print(k[0], "grid", k[1], "launches", len(v), "mean", sum(v) / len(v))
+PY
