@@ -136,25 +136,15 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   const int tid = threadIdx.x, cc = tid % a.TC, sl = tid / a.TC;
   const int C = a.C;
   // Every first touch of a line in a kernel is served from beyond L2 (~0.7 us), so the prologue is ONE
-  // round trip: iteration counter + done flag, the dot partials of BOTH parities, gamma_old / alpha_old
-  // of both parities and this thread's first vector element are all requested before the first wait;
-  // the parity (a function of the iteration counter) only selects among values already in registers.
+  // round trip: iteration counter + done flag, the dot partials of BOTH parities and gamma_old / alpha_old
+  // of both parities are all requested before the first wait; the parity (a function of the iteration
+  // counter) only selects among values already in registers.
   const int st_it = a.state[0], st_done = a.state[1];
 
   const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
   int64_t r1 = r0 + a.rows_per_block;
   if (r1 > a.n) r1 = a.n;
   const int64_t rf = r0 + sl;
-  const bool have = cc < C && rf < r1;
-  float f_u = 0.f, f_p = 0.f, f_s = 0.f, f_w = 0.f, f_x = 0.f, f_r = 0.f, f_m = 1.f, f_pre = 1.f;
-  {
-    const int64_t rs = have ? rf : 0;          // clamped: unconditional loads, no exec-masked waits
-    const int64_t i = rs * C + (cc < C ? cc : 0);
-    f_u = a.u[i]; f_p = a.p[i]; f_s = a.s[i]; f_w = a.w[i]; f_x = a.x[i]; f_r = a.r[i];
-    if (a.minv) f_m = a.minv[rs];
-    if (a.us) f_pre = a.pre[rs];
-  }
-
   // ---- every workgroup reduces the partials in the same fixed order: thread (sl, cc) sums
   // partials sl, sl+TS, ... of column cc with independent loads, LDS combines the TS slices
   float g2[2] = {0.f, 0.f}, rr2[2] = {0.f, 0.f}, d = 0.f;
@@ -271,26 +261,40 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   float ng = 0.f, nrr = 0.f;
   if (cc < C) {
     const float alpha = sh_alpha[cc], beta = sh_beta[cc];
-    for (int64_t r = rf; r < r1; r += a.TS) {
-      const int64_t i = r * C + cc;
-      float un, po, so, wo, xo, ro, mo = 1.f;
-      if (r == rf) { un = f_u; po = f_p; so = f_s; wo = f_w; xo = f_x; ro = f_r; mo = f_m; }
-      else {
-        un = a.u[i]; po = a.p[i]; so = a.s[i]; wo = a.w[i]; xo = a.x[i]; ro = a.r[i];
-        if (a.minv) mo = a.minv[r];
+    // eight row passes per batch, all their loads (clamped rows, masked afterwards) in flight before the
+    // first use: with one pass at a time a workgroup's 30 passes were 30 dependent round trips (27 us per
+    // launch at 60k x 12); the per-element arithmetic and the order of the two running sums are unchanged
+    constexpr int U = 8;
+    for (int64_t rb = rf; rb < r1; rb += (int64_t)U * a.TS) {
+      float un[U], po[U], so[U], wo[U], xo[U], ro[U], mo[U], pr[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int64_t r = rb + (int64_t)k * a.TS;
+        const int64_t rc = r < r1 ? r : rf;
+        const int64_t i = rc * C + cc;
+        un[k] = a.u[i]; po[k] = a.p[i]; so[k] = a.s[i]; wo[k] = a.w[i]; xo[k] = a.x[i]; ro[k] = a.r[i];
+        mo[k] = a.minv ? a.minv[rc] : 1.f;
+        pr[k] = a.us ? a.pre[rc] : 1.f;
       }
-      const float p = fmaf(beta, po, un);
-      const float s = fmaf(beta, so, wo);
-      a.p[i] = p;
-      a.s[i] = s;
-      a.x[i] = fmaf(alpha, p, xo);
-      const float rn = fmaf(-alpha, s, ro);
-      a.r[i] = rn;
-      float u2 = rn;
-      if (a.minv) { u2 = mo * rn; a.u[i] = u2; }
-      if (a.us) a.us[i] = (r == rf ? f_pre : a.pre[r]) * u2;
-      ng = fmaf(rn, u2, ng);
-      nrr = fmaf(rn, rn, nrr);
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int64_t r = rb + (int64_t)k * a.TS;
+        if (r < r1) {
+          const int64_t i = r * C + cc;
+          const float p = fmaf(beta, po[k], un[k]);
+          const float s = fmaf(beta, so[k], wo[k]);
+          a.p[i] = p;
+          a.s[i] = s;
+          a.x[i] = fmaf(alpha, p, xo[k]);
+          const float rn = fmaf(-alpha, s, ro[k]);
+          a.r[i] = rn;
+          float u2 = rn;
+          if (a.minv) { u2 = mo[k] * rn; a.u[i] = u2; }
+          if (a.us) a.us[i] = pr[k] * u2;
+          ng = fmaf(rn, u2, ng);
+          nrr = fmaf(rn, rn, nrr);
+        }
+      }
     }
   }
   __syncthreads();

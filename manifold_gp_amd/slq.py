@@ -106,6 +106,7 @@ def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
     if desc is None:
         n = operator.shape[0]
         num_probes = settings.num_trace_samples.value() if num_probes is None else num_probes
+        num_probes = -(-num_probes // 4) * 4     # 4 / 8 / 12 / 16 columns: the 16-byte-row SpMM kernel (30 vs 43 us)
         steps = min(n, 20 if steps is None else steps)
         gen = torch.Generator(device="cpu").manual_seed(seed)
         dev = operator.device if hasattr(operator, "device") else None
