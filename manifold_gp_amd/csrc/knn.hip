@@ -529,7 +529,8 @@ int64_t chunk_rows(int64_t N, int64_t n) {
 // the direct-difference tiles
 int g_knn_mfma = 1;
 int64_t g_last_direct_chunks = 0;
-bool use_mfma(int d) { return g_knn_mfma && d >= 32; }
+// (the centring + split of the points is a fixed ~1 ms at 60k x 784: it pays from ~1000 queries on)
+bool use_mfma(int d, int64_t n) { return g_knn_mfma && d >= 32 && n >= 1024; }
 
 int next_pow2(int v) {
   int p = 1;
@@ -547,7 +548,7 @@ static size_t bruteforce_bytes(int64_t N, int64_t n, int d, int k) {
   b += 2 * mgp_align((size_t)qc * sizeof(int));
   b += mgp_align(64);
   b += mgp_align((size_t)kExactBatch * N * sizeof(double));
-  if (use_mfma(d)) b += mgp_knn_mfma_bytes(N, qc, d);
+  if (use_mfma(d, n)) b += mgp_knn_mfma_bytes(N, qc, d);
   return b + 1024;
 }
 
@@ -567,7 +568,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   int* counter = ar.take<int>(16);
   double* scratch = ar.take<double>((size_t)kExactBatch * N);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
-  const bool mfma = use_mfma(d);
+  const bool mfma = use_mfma(d, n);
   MgpKnnMfma mm{};
   double alpha = 0.0, beta = 0.0;
   if (mfma) {

@@ -1425,17 +1425,19 @@ def test_knn_matrix_core_keys_paths(mgp, dev):
     t = rng.uniform(0, 1, size=(1500, 3))
     W = rng.normal(size=(3, 100)).astype(np.float64)
     x = (np.sin(t @ W) + 0.01 * rng.normal(size=(1500, 100))).astype(np.float32)
-    check(x, x[:333], 20, expect_clean=True)                       # d = 100 -> 4 stages, N, n ragged
-    check(x + np.float32(1000.0), x[:130] + np.float32(1000.0), 20)   # far from the origin: centring
-    check(x[:, :33].copy(), x[:77, :33].copy(), 9)                 # d = 33: one full stage + 1 feature
-    check(x, (x[:50] * 3 + 5).astype(np.float32), 12)              # queries far from every point
+    check(x, x[:1333], 20, expect_clean=True)                      # d = 100 -> 4 stages, N, n ragged
+    check(x + np.float32(1000.0), x[:1130] + np.float32(1000.0), 20)  # far from the origin: centring
+    check(x[:, :33].copy(), x[:1077, :33].copy(), 9)               # d = 33: one full stage + 1 feature
+    check(x, (x[:1050] * 3 + 5).astype(np.float32), 12)            # queries far from every point
     # tight clusters on a sphere of radius ~30: |c|^2 ~ 900 against neighbour distances ~ 1e-2
     base = rng.normal(size=(30, 256)).astype(np.float32) * 2
     xc = (base[rng.integers(0, 30, 3000)] + 3e-3 * rng.normal(size=(3000, 256))).astype(np.float32)
-    check(xc, xc[:400], 40, expect_clean=False)
+    check(xc, xc[:1400], 40, expect_clean=False)
     # exact duplicates + k close to the candidate width
-    xd = np.concatenate([x[:600], x[:200]])
-    check(xd, xd[:100], 64)
+    xd = np.concatenate([x[:1200], x[:200]])
+    check(xd, xd[:1100], 64)
+    # under 1024 queries the split of the points would cost more than it saves: direct keys, same lists
+    check(x, x[:200], 20)
 
 
 @pytest.mark.parametrize("shape", ["golden", "n65", "hub", "dense_small", "ordered"])
