@@ -58,7 +58,7 @@ size_t mgp_knn_workspace_bytes(int64_t N, int64_t n, int d, int k);
 int mgp_knn_search(const float* db, int64_t N, int d, const float* q, int64_t n, int k,
                    float* D, int32_t* I, void* work, size_t work_bytes, int64_t* stats,
                    void* stream);
-/* d >= 32: the candidate keys of the slab pipeline come from the matrix cores (centred bf16 two-term
+/* d >= 32 and >= 1024 queries: the candidate keys of the slab pipeline come from the matrix cores (centred bf16 two-term
  * split, GEMM form, knn_mfma.hip) with an absolute error bound in the sufficiency check; a chunk in which
  * many rows fail that check is redone with the direct-difference tiles.  0 forces the direct tiles
  * (default 1).  mgp_knn_last_direct_chunks: chunks of the last slab search that were redone. */
