@@ -361,6 +361,15 @@ int mgp_kernel_diag(const float* Z1, const float* Z2, int64_t n, int m, float sc
 size_t mgp_lowrank_workspace_bytes(int m, int C);
 int mgp_lowrank_apply(const float* Z, int64_t n, int m, const float* X, int C, float alpha,
                       float beta, float* Y, void* work, size_t work_bytes, void* stream);
+/* Woodbury solve of (s Z Z^T + noise I) x = v, the way gpytorch evaluates the reference's spectral kernel
+ * (LowRankRootAddedDiagLinearOperator), in two device steps around an m x m fp64 system:
+ *   mgp_gram_f64          G = A^T A for a tall block A [n,b] (b <= 512), fp64 accumulation -> device double [b,b];
+ *                         with A = [Z | v] one pass gives Z^T Z, Z^T v (and v^T v)
+ *   mgp_lowrank_residual  out = scale * (V - Z T), T device double [m,C] (m C <= 6144), row sums in fp64 */
+size_t mgp_gram_workspace_bytes(int64_t n, int b);
+int mgp_gram_f64(const float* A, int64_t n, int b, double* G, void* work, size_t work_bytes, void* stream);
+int mgp_lowrank_residual(const float* Z, int64_t n, int m, const double* T, const float* V, int C, double scale,
+                         float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Multi-GPU (one process per GPU, RCCL over xGMI): row-partitioned operator apply and CG.

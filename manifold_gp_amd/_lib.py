@@ -7,7 +7,7 @@ on a HIP device.
 import ctypes
 import os
 import threading
-from ctypes import (POINTER, Structure, byref, c_float, c_int, c_int32, c_int64, c_size_t,
+from ctypes import (POINTER, Structure, byref, c_double, c_float, c_int, c_int32, c_int64, c_size_t,
                     c_uint64, c_void_p)
 
 import torch
@@ -137,6 +137,9 @@ SIGNATURES = {
     "mgp_kernel_diag": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _P]),
     "mgp_lowrank_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mgp_lowrank_apply": (c_int, [_P, c_int64, c_int, _P, c_int, c_float, c_float, _P, _P, c_size_t, _P]),
+    "mgp_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "mgp_gram_f64": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _P]),
+    "mgp_lowrank_residual": (c_int, [_P, c_int64, c_int, _P, _P, c_int, c_double, _P, _P]),
 }
 
 

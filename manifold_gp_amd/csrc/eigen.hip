@@ -451,6 +451,27 @@ int launch_gram(const float* A, const float* B, int64_t n, int b, EigWork& w, do
 int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale, float* K,
                         int64_t ldk, void* stream);
 
+// G = A^T A (b x b, fp64 accumulation of the fp32 entries' exact products) for a tall block A [n, b]:
+// the Gram kernel of the eigensolver behind the C-ABI.  rocBLAS' dgemm takes 53 ms for this shape at
+// n = 1M, b = 50 (one long K loop per output tile); here the rows are split over up to 512 chunks.
+extern "C" size_t mgp_gram_workspace_bytes(int64_t n, int b) {
+  if (n <= 0 || b <= 0 || b > 512) return 0;
+  int chunks; int64_t rpc;
+  chunking(n, &chunks, &rpc, 512, 512);
+  return mgp_align((size_t)chunks * b * b * sizeof(double)) + 256;
+}
+
+extern "C" int mgp_gram_f64(const float* A, int64_t n, int b, double* G, void* work, size_t work_bytes, void* stream) {
+  if (!A || !G || !work || n <= 0 || b <= 0 || b > 512) return MGP_ERR_ARG;
+  if (work_bytes < mgp_gram_workspace_bytes(n, b)) return MGP_ERR_WORKSPACE;
+  EigWork w{};
+  chunking(n, &w.chunks, &w.rows_per_chunk, 512, 512);
+  MgpArena ar(work, work_bytes);
+  w.gpart = ar.take<double>((size_t)w.chunks * b * b);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  return launch_gram(A, A, n, b, w, G, mgp_stream(stream));
+}
+
 // host-only: the small dense symmetric eigensolver used inside the block eigensolver (exported so that
 // the CPU test suite can pin it against LAPACK).  A [n x n] row-major; evals [n]; V [n x n] columns.
 extern "C" int mgp_host_symeig(int n, const double* A, double* evals, double* V) {

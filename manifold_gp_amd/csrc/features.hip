@@ -406,6 +406,38 @@ extern "C" int mgp_kernel_diag(const float* Z1, const float* Z2, int64_t n, int 
   return MGP_OK;
 }
 
+// out = scale * (V - Z T): the last step of the Woodbury solve (K + noise I)^-1 v with K = s Z Z^T, T = the
+// m x C solution of the m x m system in fp64.  The row sums run in fp64 (v - Z t cancels when the fit is good).
+namespace {
+__global__ __launch_bounds__(256) void lowrank_residual_kernel(const float* __restrict__ Z, int64_t n, int m,
+                                                               const double* __restrict__ T, const float* __restrict__ V, int C,
+                                                               double scale, float* __restrict__ out) {
+  extern __shared__ double t_s[];                      // [m * C]
+  for (int i = threadIdx.x; i < m * C; i += 256) t_s[i] = T[i];
+  __syncthreads();
+  const int64_t total = n * C;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / C;
+    const int c = (int)(e % C);
+    const float* zr = Z + r * m;
+    double acc = 0.0;
+    for (int j = 0; j < m; ++j) acc = fma((double)zr[j], t_s[j * C + c], acc);
+    out[e] = (float)(scale * ((double)V[e] - acc));
+  }
+}
+}  // namespace
+
+extern "C" int mgp_lowrank_residual(const float* Z, int64_t n, int m, const double* T, const float* V, int C, double scale,
+                                    float* out, void* stream) {
+  if (!Z || !T || !V || !out || n <= 0 || m <= 0 || C <= 0) return MGP_ERR_ARG;
+  const size_t lds = (size_t)m * C * sizeof(double);
+  if (lds > 48 * 1024) return MGP_ERR_UNSUPPORTED;
+  const int grid = (int)std::min<int64_t>(8192, mgp_cdiv(n * C, 256));
+  hipLaunchKernelGGL(lowrank_residual_kernel, dim3(grid), dim3(256), lds, mgp_stream(stream), Z, n, m, T, V, C, scale, out);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
 extern "C" size_t mgp_lowrank_workspace_bytes(int m, int C) {
   if (m <= 0 || C <= 0) return 0;
   return mgp_align((size_t)513 * m * C * sizeof(float)) + 256;

@@ -121,19 +121,16 @@ class RiemannGP(torch.nn.Module):
             x, y = self.train_inputs[0], self.train_targets
             s, n = self._scale_noise()
             Z = self.base_kernel.features(x)
-            Zd = Z.double()
-            G = Zd.t() @ Zd                                            # m x m Gram (library GEMM, fp64)
-            m = G.shape[0]
-            C = G + (n / s) * torch.eye(m, dtype=torch.float64, device=G.device)
-            Lc = torch.linalg.cholesky(C)
             c = float(self.mean_constant.detach())
-            v = (y.double() - c)
-            t = torch.cholesky_solve((Zd.t() @ v).unsqueeze(-1), Lc).squeeze(-1)
-            alpha = (v - Zd @ t) / n                                  # (K + n I)^-1 (y - c)
-            w = s * (Zd.t() @ alpha)                                  # mean(x*) = c + Z* w
+            from ..solvers import woodbury
+            wd = woodbury(Z, y - c, s, n)                              # (K + n I)^-1 (y - c) on the m x m root
+            G, Lc, alpha = wd["G"], wd["Lc"], wd["alpha"]
+            m = G.shape[0]
+            # mean(x*) = c + Z* w,  w = s Z^T alpha = s (Z^T v - G t) / n = t   [(G + (n/s) I) t = Z^T v]
+            w = wd["t"].squeeze(-1)
             # cov(x*) = s Z* M Z*^T with M = I - (s/n)(G - G C^-1 G)
             M = torch.eye(m, dtype=torch.float64, device=G.device) - (s / n) * (G - G @ torch.cholesky_solve(G, Lc))
-            self._cache = dict(Z=Z, w=w.float(), M=(0.5 * (M + M.t())).float(), s=s, n=n, c=c, alpha=alpha.float())
+            self._cache = dict(Z=Z, w=w.float(), M=(0.5 * (M + M.t())).float(), s=s, n=n, c=c, alpha=alpha)
         return self._cache
 
     def __call__(self, x):

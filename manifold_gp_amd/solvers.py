@@ -302,19 +302,52 @@ def lowrank_cg(Z, y, outputscale, noise, tol=1e-6, max_iter=500):
     return x, it
 
 
-def lowrank_solve(Z, y, outputscale, noise):
-    """(outputscale Z Z^T + noise I)^-1 y by Woodbury on the m x m root (fp64 Gram + Cholesky through
-    torch: library GEMM / POTRF on a 100 x 100 matrix, not a hot op) -- the direct form of lowrank_cg and
-    what gpytorch does for a LowRankRootAddedDiagLinearOperator."""
+def gram_f64(A):
+    """A^T A for a tall fp32 block A [n, b <= 512], fp64 accumulation on the device (mgp_gram_f64) -> f64 [b, b]."""
+    _lib.require_device(A)
+    A = _lib.f32c(A)
+    n, b = A.shape
+    G = torch.empty(b, b, dtype=torch.float64, device=A.device)
+    wb = lib().mgp_gram_workspace_bytes(n, b)
+    work = _lib.workspace(wb, "gram", A.device)
+    check(lib().mgp_gram_f64(ptr(A), n, b, ptr(G), ptr(work), work.numel(), stream()), "mgp_gram_f64")
+    return G
+
+
+def woodbury(Z, y, outputscale, noise):
+    """The pieces of (outputscale Z Z^T + noise I)^-1 y on the m x m root, the way gpytorch evaluates a
+    LowRankRootAddedDiagLinearOperator: G = Z^T Z and Z^T y from ONE fp64-accumulating HIP
+    Gram pass over [Z | y] (mgp_gram_f64; rocBLAS' dgemm takes 53 ms for the 1M x 50 shape, 3 ms at 60k x 100),
+    the m x m system in fp64 through torch (POTRF on a 100 x 100 matrix), the solution rows summed in fp64
+    (mgp_lowrank_residual).  Returns dict(G [m,m] f64, Lc, ZTy [m,C] f64, t [m,C] f64, alpha [n,C] f32)."""
     _lib.require_device(Z, y)
-    Zd = Z.double()
-    G = Zd.t() @ Zd
-    m = G.shape[0]
-    C = G + (noise / outputscale) * torch.eye(m, dtype=torch.float64, device=G.device)
-    Lc = torch.linalg.cholesky(C)
-    v = y.double()
-    t = torch.cholesky_solve((Zd.t() @ v).reshape(m, -1), Lc).reshape((m,) + tuple(v.shape[1:]))
-    return ((v - Zd @ t) / noise).float()
+    Z = _lib.f32c(Z)
+    n, m = Z.shape
+    Y = _lib.f32c(y.reshape(n, -1))
+    C = Y.shape[1]
+    eye = torch.eye(m, dtype=torch.float64, device=Z.device)
+    if m + C <= 512 and m * C <= 6144:
+        Gb = gram_f64(torch.cat([Z, Y], 1))
+        G = 0.5 * (Gb[:m, :m] + Gb[:m, :m].t())
+        ZTy = Gb[:m, m:].contiguous()
+        Lc = torch.linalg.cholesky(G + (noise / outputscale) * eye)
+        t = torch.cholesky_solve(ZTy, Lc).contiguous()
+        alpha = torch.empty_like(Y)
+        check(lib().mgp_lowrank_residual(ptr(Z), n, m, ptr(t), ptr(Y), C, 1.0 / float(noise), ptr(alpha), stream()),
+              "mgp_lowrank_residual")
+    else:                                   # very wide right-hand sides: library GEMMs in fp64
+        Zd = Z.double()
+        G = Zd.t() @ Zd
+        ZTy = Zd.t() @ Y.double()
+        Lc = torch.linalg.cholesky(G + (noise / outputscale) * eye)
+        t = torch.cholesky_solve(ZTy, Lc)
+        alpha = ((Y.double() - Zd @ t) / noise).float()
+    return dict(G=G, Lc=Lc, ZTy=ZTy, t=t, alpha=alpha.reshape(y.shape))
+
+
+def lowrank_solve(Z, y, outputscale, noise):
+    """(outputscale Z Z^T + noise I)^-1 y by Woodbury on the m x m root -- the direct form of lowrank_cg."""
+    return woodbury(Z, y, outputscale, noise)["alpha"]
 
 
 def kernel_block(Z1, Z2, scale=1.0):

@@ -111,11 +111,18 @@ def exact_mll_lowrank(model):
 
     if cache is None or cache["eigvec"] is not kern.eigvec or cache["x"] is not x:
         with torch.no_grad():
-            A = kern.eigvec.double() if insample else kern.features(x).double() / scale()
+            A = kern.eigvec if insample else (kern.features(x).double() / scale()).float()
             yd = y.double()
-            one = torch.ones_like(yd)
-            cache = dict(eigvec=kern.eigvec, x=x, G0=A.t() @ A, by=A.t() @ yd, b1=A.t() @ one, yy=torch.dot(yd, yd),
-                         y1=yd.sum(), n=float(yd.shape[0]))
+            m = A.shape[1]
+            if m + 2 <= 512:
+                # one fp64-accumulating HIP Gram pass over [A | y | 1]: A^T A, A^T y, A^T 1 (mgp_gram_f64)
+                from ..solvers import gram_f64
+                Gb = gram_f64(torch.cat([A.float(), y.float().view(-1, 1), torch.ones_like(y).float().view(-1, 1)], 1))
+                G0, by, b1 = 0.5 * (Gb[:m, :m] + Gb[:m, :m].t()), Gb[:m, m].clone(), Gb[:m, m + 1].clone()
+            else:
+                Ad = A.double()
+                G0, by, b1 = Ad.t() @ Ad, Ad.t() @ yd, Ad.t() @ torch.ones_like(yd)
+            cache = dict(eigvec=kern.eigvec, x=x, G0=G0, by=by, b1=b1, yy=torch.dot(yd, yd), y1=yd.sum(), n=float(yd.shape[0]))
         model._vanilla_cache = cache
     N = cache["n"]
     d = scale()
