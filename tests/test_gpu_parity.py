@@ -438,6 +438,23 @@ def test_spectral_posterior_vs_woodbury_fp64(mgp, golden, dev):
     assert np.abs(alpha.cpu().numpy() - ref_alpha).max() < 1e-4 * np.abs(ref_alpha).max()
     alpha_w = lowrank_solve(Z, y, s, noise)                       # direct (Woodbury) form of the same solve
     assert np.abs(alpha_w.cpu().numpy() - ref_alpha).max() < 1e-5 * np.abs(ref_alpha).max()
+    # several right-hand sides at once (HIP Gram over [Z | Y] + fp64 residual rows), a column count past the
+    # kernels' limits (library fp64 GEMMs), and the Gram itself against numpy in fp64
+    from manifold_gp_amd.solvers import gram_f64, woodbury
+    rng = np.random.default_rng(5)
+    Y = T(rng.normal(size=(Z.shape[0], 7)).astype(np.float32), dev)
+    Zn = Z.double().cpu().numpy()
+    K = s * Zn @ Zn.T + noise * np.eye(Zn.shape[0])
+    ref = np.linalg.solve(K, Y.double().cpu().numpy())
+    out = lowrank_solve(Z, Y, s, noise)
+    assert out.shape == Y.shape and np.abs(out.cpu().numpy() - ref).max() < 1e-5 * np.abs(ref).max()
+    Yw = T(rng.normal(size=(Z.shape[0], 130)).astype(np.float32), dev)          # 50 x 130 > 6144: wide fallback
+    refw = np.linalg.solve(K, Yw.double().cpu().numpy())
+    assert np.abs(lowrank_solve(Z, Yw, s, noise).cpu().numpy() - refw).max() < 1e-5 * np.abs(refw).max()
+    G = gram_f64(Z).cpu().numpy()
+    assert np.abs(G - Zn.T @ Zn).max() < 1e-12 * np.abs(G).max()
+    wd = woodbury(Z, y, s, noise)
+    assert np.abs(wd["ZTy"][:, 0].cpu().numpy() - Zn.T @ g["train_y"].astype(np.float64)).max() < 1e-10 * np.abs(G).max()
 
 
 # ----------------------------------------------------------------------------- full-size properties
