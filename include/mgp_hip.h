@@ -301,8 +301,8 @@ int mgp_operator_jacobi(const mgp_operator_t* op, float* minv, void* stream);
  *   evals [m] ascending (host), evecs [n,m] row-major (device, orthonormal), resid [m] (host)
  *   = ||L v - lambda v||_2.  Synchronises `stream`. */
 typedef struct {
-  int32_t max_basis;   /* block size b (0 = default m + max(0.9 m, 32), rounded to a multiple of 16) */
-  int32_t degree;      /* Chebyshev filter degree (0 = adaptive 8..80) */
+  int32_t max_basis;   /* block size b (0 = default: next multiple of 64 above m + max(m/8, 12)) */
+  int32_t degree;      /* Chebyshev filter degree (0 = adaptive 8..200) */
   int32_t max_restarts;/* outer filter + Rayleigh-Ritz rounds (0 = 40) */
   float tol;           /* residual tolerance relative to lambda_max */
   uint64_t seed;

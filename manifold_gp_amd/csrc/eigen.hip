@@ -407,13 +407,17 @@ struct EigWork {
 };
 
 int block_size_for(int m, const mgp_lanczos_params_t* p) {
-  // measured at N = 60k, m = 100 (soft locking on, 4 ms of host work per round): 125 columns 29 rounds,
-  // 152: 13 rounds / 164 ms, 192: 8 rounds / 138 ms, 208: 7 / 136 ms, 256: 6 / 183 ms -- about 2 m
-  int b = (p && p->max_basis > 0) ? p->max_basis : m + std::max(m * 9 / 10, 32);
+  // The SpMM's cost steps with every 64 columns (one more accumulator per lane), the host side grows with b^3 and,
+  // with filter degrees up to 200, a handful of guard vectors is enough: the next multiple of 64 above
+  // m + max(m / 8, 12).  Measured at N = 60k, m = 100 (degree cap 200): 112 columns 47 ms, 128: 49 ms, 136: 67 ms,
+  // 160: 65 ms, 192: 94 ms; N = 1M, m = 50: 64 columns 0.69 s, 96: 0.82 s, 128: 0.94 s.  (With the degree capped
+  // at 80 the same sweep preferred ~2 m columns and took 138 ms / 0.84 s.)
+  int b = (p && p->max_basis > 0) ? p->max_basis : m + std::max(m / 8, 12);
   if (b < m + 2) b = m + 2;
-  // a multiple of 16 unless the caller fixed the size: block rows are then 64-byte aligned (whole or half cache
-  // lines per gathered row; 200 columns measured slower than both 192 and 208)
-  if (!(p && p->max_basis > 0)) b = (b + 15) / 16 * 16;
+  if (!(p && p->max_basis > 0)) {
+    b = (b + 63) / 64 * 64;
+    if (b > 256 && m + 2 <= 256) b = 256;
+  }
   return b;
 }
 
@@ -696,7 +700,9 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
       a0 = std::min(th[0], 0.0);
       const double gap = std::max(a - th[m - 1], 1e-12 * ub);
       int dnew = (int)ceil(3.0 / (2.0 * sqrt(gap / (ub - a))));
-      deg = std::min(std::max(dnew, 8), 80);
+      // degree cap 200 (80 until late in round 1: 8 rounds / 497 applies at m = 100 where 200 needs 4 / 343; the
+      // scaled three-term recurrence is normalised at a0, so the block does not overflow at these degrees)
+      deg = std::min(std::max(dnew, 8), 200);
       if (p && p->degree > 0) deg = p->degree;
     }
   }
