@@ -150,15 +150,18 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   float g2[2] = {0.f, 0.f}, rr2[2] = {0.f, 0.f}, d = 0.f;
   float go2[2] = {0.f, 0.f}, ao2[2] = {0.f, 0.f}, bb_old = 0.f;
   if (cc < C) {
-    // batches of 4 / 8 loads on clamped indices, masked afterwards: all in flight together
-    for (int b0 = sl; b0 < a.nbv; b0 += 4 * a.TS) {
-      float gv[2][4], rv[2][4];
+    // batches of 8 / 32 loads on clamped indices, masked afterwards: all in flight together (one round trip per
+    // batch: with 256 workgroups and TS = 16 slices the gamma / rr partials are two batches, the ~940 delta
+    // partials of a 12-column SpMM two as well)
+    constexpr int UG = 8, UD = 32;
+    for (int b0 = sl; b0 < a.nbv; b0 += UG * a.TS) {
+      float gv[2][UG], rv[2][UG];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float* pg = a.pd_gamma + (int64_t)h * a.nbv * C;
         const float* pr = a.pd_rr + (int64_t)h * a.nbv * C;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < UG; ++q) {
           const int b = b0 + q * a.TS;
           const int bc = b < a.nbv ? b : a.nbv - 1;
           gv[h][q] = pg[(int64_t)bc * C + cc];
@@ -168,23 +171,23 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < UG; ++q) {
           const bool on = b0 + q * a.TS < a.nbv;
           g2[h] += on ? gv[h][q] : 0.f;
           rr2[h] += on ? rv[h][q] : 0.f;
         }
       }
     }
-    for (int b0 = sl; b0 < a.nbs; b0 += 8 * a.TS) {
-      float dv[8];
+    for (int b0 = sl; b0 < a.nbs; b0 += UD * a.TS) {
+      float dv[UD];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
+      for (int q = 0; q < UD; ++q) {
         const int b = b0 + q * a.TS;
         const int bc = b < a.nbs ? b : a.nbs - 1;
         dv[q] = a.pd_delta[(int64_t)bc * C + cc];
       }
 #pragma unroll
-      for (int q = 0; q < 8; ++q) d += (b0 + q * a.TS < a.nbs) ? dv[q] : 0.f;
+      for (int q = 0; q < UD; ++q) d += (b0 + q * a.TS < a.nbs) ? dv[q] : 0.f;
     }
   }
   if (tid < C) {
@@ -1083,8 +1086,8 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   pl->op_work = ar.take<char>(pl->op_work_bytes);
   // contiguous row ranges per workgroup, at most kMaxGridVec workgroups.  C > 1: every workgroup of the
   // update kernel re-reduces ALL dot partials of ALL columns (nbv x (2 nbv + nbs) x C loads per launch),
-  // so the grid is kept small -- 128 workgroups still cover N C >> 32k elements
-  const int max_grid_vec = (C == 1) ? kMaxGridVec : 128;
+  // so the grid is kept to one workgroup per CU (their loads go out in batches of 8 / 32 per lane)
+  const int max_grid_vec = (C == 1) ? kMaxGridVec : 256;
   int64_t rpb = a.TS;
   int64_t nbv = mgp_cdiv(n, rpb);
   if (nbv > max_grid_vec) { rpb = mgp_cdiv(mgp_cdiv(n, max_grid_vec), a.TS) * a.TS; nbv = mgp_cdiv(n, rpb); }
