@@ -42,14 +42,21 @@ class CgPlan:
               "mgp_cg_plan_create")
         self.iters = 0
         self.applies = 0
+        self._xview = None
+        self._iters, self._status = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._iters_ref, self._status_ref = ctypes.byref(self._iters), ctypes.byref(self._status)
+        self._resid = (ctypes.c_float * self.C)()
+        self._solve_fn, self._applies_fn = lib().mgp_cg_plan_solve, lib().mgp_cg_plan_last_applies
         self.status = 0
         self.resid = None
 
     def solution_view(self):
         """The plan's own solution buffer as a tensor view (no copy; overwritten by the next solve)."""
-        off = int(lib().mgp_cg_plan_x(self.handle)) - self.work.data_ptr()
-        nb = self.desc.n * self.C * 4
-        return self.work[off:off + nb].view(torch.float32).view(self.desc.n, self.C)
+        if self._xview is None:                 # the buffer never moves: one view for the life of the plan
+            off = int(lib().mgp_cg_plan_x(self.handle)) - self.work.data_ptr()
+            nb = self.desc.n * self.C * 4
+            self._xview = self.work[off:off + nb].view(torch.float32).view(self.desc.n, self.C)
+        return self._xview
 
     def solve(self, B, out=None, copy=True):
         _lib.require_device(B)
@@ -59,15 +66,16 @@ class CgPlan:
             X = torch.empty_like(B) if out is None else out
         else:
             X = None
-        iters, status = ctypes.c_int32(0), ctypes.c_int32(0)
-        resid = (ctypes.c_float * self.C)()
-        check(lib().mgp_cg_plan_solve(self.handle, ptr(B), ptr(X), ctypes.byref(iters), resid,
-                                      ctypes.byref(status)), "mgp_cg_plan_solve")
+        # (the ctypes out-parameters live in the plan: a solve is ~65 us, per-call allocations are visible)
+        rc = self._solve_fn(self.handle, B.data_ptr(), X.data_ptr() if X is not None else None, self._iters_ref,
+                            self._resid, self._status_ref)
+        if rc != 0:
+            check(rc, "mgp_cg_plan_solve")
         if X is None:
             X = self.solution_view()
-        self.iters, self.status = iters.value, status.value
-        self.applies = int(lib().mgp_cg_plan_last_applies(self.handle))    # operator applies that actually ran
-        self.resid = list(resid)
+        self.iters, self.status = self._iters.value, self._status.value
+        self.applies = self._applies_fn(self.handle)                       # operator applies that actually ran
+        self.resid = list(self._resid)
         return X
 
     def close(self):
