@@ -10,10 +10,11 @@
 //                         8x8 register micro-tile per lane, operands staged k-major in LDS so
 //                         a lane reads its 8 queries / 8 points with two ds_read_b128 each
 //   2. select_kernel      one workgroup per query row.  T = the K'-th smallest key of the row (K' = k + pad):
-//                         rows of 8192+ keys take the K'-th smallest of a 1/16 sample as an upper bound,
-//                         keep the keys under it in LDS in ONE pass over the row and radix-select
-//                         (11/11/10 bits) inside that list; short rows / overflowing lists radix-select
-//                         over the row.  fp64 re-evaluation of the K' candidates in the oracle's exact
+//                         rows of 8192+ keys take the K'-th smallest of a 1/S sample (S = 16 up to ~61k keys)
+//                         as an upper bound, keep the keys under it in LDS in ONE pass over the row and
+//                         radix-select (11/11/10 bits) inside that list; long rows (expected list > LDS) and
+//                         overflowing lists radix-select over the row with the bound as a filter, short rows
+//                         without it.  fp64 re-evaluation of the K' candidates in the oracle's exact
 //                         operation order (the selection's dominant cost at large d: K' rows of d
 //                         floats per query, a strictly sequential fp64 chain per candidate); order by
 //                         (d64, index) -- by counting for K' <= 256, bitonic for retry widths;
@@ -247,7 +248,8 @@ __device__ __forceinline__ void for_each_key(const uint32_t* __restrict__ keys, 
 }
 
 // ------------------------------------------------------------------ 2. select + re-rank
-constexpr int kListCap = 4096;      // LDS list of the keys under the sampled threshold
+constexpr int kListCap = 3840;      // LDS list of the keys under the sampled threshold (with the 24 KB of candidate
+                                    // arrays of the widest retry the kernel stays under 64 KB of LDS)
 constexpr int kSampleBlock = 64;    // sampled keys come in runs of 64 (256-byte loads)
 
 // rank-th smallest (1-based) of the keys `scan` visits: 3-pass radix select (11 / 11 / 10 bits) with an LDS
@@ -295,7 +297,7 @@ __device__ uint32_t radix_kth(Scan scan, int rank, int* hist, int* sh_wave, int*
 }
 
 // One workgroup per query row.  Rows of 8192+ keys are not radix-selected over the whole row: the K'-th
-// smallest of a 1/S sample of the row (runs of 64 keys, S = 16 up to 65536 keys) bounds the K'-th smallest
+// smallest of a 1/S sample of the row (runs of 64 keys, S = 16 up to ~61k keys) bounds the K'-th smallest
 // of the row from above, ONE pass over the row keeps the ~S K' keys under that bound in LDS, and the exact
 // K'-th smallest (the same T as a full-row select) comes from that list.  A list that overflows falls back
 // to the three full-row passes.
@@ -328,11 +330,13 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   bool from_list = false;
   int n_list = 0;
   if (want < N) {
+    // sampling stride: the smallest power of two from 16 up whose sample (runs of 64 keys) fits the LDS list
     int S = 16;
-    while ((int64_t)S * 65536 < N) S <<= 1;
+    while (((N / kSampleBlock + S - 1) / S) * kSampleBlock > kListCap) S <<= 1;
     const int64_t n_runs = (N / kSampleBlock + S - 1) / S;            // sampled runs (all complete)
     const int64_t n_samp = n_runs * kSampleBlock;
-    if (N >= 8192 && n_samp <= kListCap && n_samp >= 2 * want && (int64_t)S * want <= kListCap / 2) {
+    uint32_t tau = 0xffffffffu;                                       // upper bound of the want-th smallest key
+    if (N >= 8192 && n_samp >= 2 * want) {
       // ---- sample -> LDS, its want-th smallest bounds the row's want-th smallest
       const int phase = row & (S - 1);
       for (int j = tid; j < (int)n_samp; j += kBlock) {
@@ -343,26 +347,31 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
       if (tid == 0) sh_cnt_list = 0;
       __syncthreads();
       int dummy;
-      const uint32_t tau = radix_kth([&](auto f) { for (int j = tid; j < (int)n_samp; j += kBlock) f(list_key[j], (int64_t)j); },
-                                     want, hist, sh_wave, &sh_bin, &sh_rank, &dummy, 2);
+      tau = radix_kth([&](auto f) { for (int j = tid; j < (int)n_samp; j += kBlock) f(list_key[j], (int64_t)j); },
+                      want, hist, sh_wave, &sh_bin, &sh_rank, &dummy, 2);
       __syncthreads();
-      // ---- one pass over the row: keys <= tau into the list (at least `want` of them exist)
-      for_each_key(keys, N, tid, [&](uint32_t key, int64_t i) {
-        if (key <= tau) {
-          const int slot = atomicAdd(&sh_cnt_list, 1);
-          if (slot < kListCap) { list_key[slot] = key; list_idx[slot] = (int)i; }
+      if ((int64_t)S * want <= kListCap / 2) {
+        // ---- one pass over the row: keys <= tau into the list (at least `want` of them exist, ~S want expected)
+        for_each_key(keys, N, tid, [&](uint32_t key, int64_t i) {
+          if (key <= tau) {
+            const int slot = atomicAdd(&sh_cnt_list, 1);
+            if (slot < kListCap) { list_key[slot] = key; list_idx[slot] = (int)i; }
+          }
+        });
+        __syncthreads();
+        n_list = sh_cnt_list;
+        from_list = n_list <= kListCap;
+        if (from_list) {
+          T = radix_kth([&](auto f) { for (int j = tid; j < n_list; j += kBlock) f(list_key[j], (int64_t)list_idx[j]); },
+                        want, hist, sh_wave, &sh_bin, &sh_rank, &rank);
         }
-      });
-      __syncthreads();
-      n_list = sh_cnt_list;
-      from_list = n_list <= kListCap;
-      if (from_list) {
-        T = radix_kth([&](auto f) { for (int j = tid; j < n_list; j += kBlock) f(list_key[j], (int64_t)list_idx[j]); },
-                      want, hist, sh_wave, &sh_bin, &sh_rank, &rank);
       }
     }
     if (!from_list) {
-      T = radix_kth([&](auto f) { for_each_key(keys, N, tid, f); }, want, hist, sh_wave, &sh_bin, &sh_rank, &rank);
+      // radix select over the row; keys above the sampled bound cannot be among the `want` smallest and skip
+      // the histogram (its LDS atomics are what a full-row pass costs): long rows and overflowing lists land here
+      T = radix_kth([&](auto f) { for_each_key(keys, N, tid, [&](uint32_t key, int64_t i) { if (key <= tau) f(key, i); }); },
+                    want, hist, sh_wave, &sh_bin, &sh_rank, &rank);
     }
     // T: exact K'-th smallest key; `rank` of the keys equal to T are still wanted
   }

@@ -1581,3 +1581,33 @@ def test_knn_fp32_overflowing_distances_take_the_exact_path(mgp, dev):
     D, I = nn.search(T(x[:90], dev), 7)
     assert np.array_equal(I.cpu().numpy(), Ir)
     assert np.array_equal(D.cpu().numpy(), Dr)             # (float) of the fp64 distance: inf where it overflows
+
+
+def test_knn_select_paths_long_rows_and_widest_retry(mgp, dev):
+    """select_kernel beyond the bench shape: rows longer than the LDS list's sampling range (stride 32 at 70k
+    keys: list path; stride 128 at 300k keys: sample bound + filtered radix passes), and spheres of 1500
+    equidistant points that fail the sufficiency check until the widest retry set (2048 candidates)."""
+    from oracle import knn as oknn
+    rng = np.random.default_rng(31)
+    for n, nq in ((70000, 400), (300000, 200)):
+        x = rng.normal(size=(n, 4)).astype(np.float32)
+        q = x[rng.choice(n, nq, replace=False)] + np.float32(0.01)
+        Dr, Ir = oknn.knn_search(x, q, 10)
+        nn = mgp.utils.NearestNeighbors(T(x, dev))
+        D, I = nn.search(T(q, dev), 10)
+        assert nn.last_stats["candidates"] > 0                      # slab pipeline, not the low-d path
+        assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), n
+    # 1500 points on a unit sphere around each of 3 centres (fp32 rounding: distances equal to ~1e-7): for a centre
+    # as the query the fp32 keys order nothing until the candidate set holds the whole sphere (64 -> 256 -> 1024 -> 2048)
+    d = 8
+    centers = (rng.normal(size=(3, d)) * 10).astype(np.float32)
+    dirs = rng.normal(size=(4500, d))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    x = np.concatenate([(centers[np.repeat(np.arange(3), 1500)] + dirs).astype(np.float32), centers])
+    q = np.concatenate([centers, x[:20]])
+    Dr, Ir = oknn.knn_search(x, q, 10)
+    nn = mgp.utils.NearestNeighbors(T(x, dev))
+    D, I = nn.search(T(q, dev), 10)
+    st = nn.last_stats
+    assert st["rows_redone_wide"] >= 3, st
+    assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), st
