@@ -44,14 +44,19 @@ __global__ __launch_bounds__(kBlock) void colsum_partial_kernel(const float* __r
   }
 }
 
+// 64 columns per workgroup, 4 groups of partial rows each (fixed combination order: deterministic)
 __global__ __launch_bounds__(kBlock) void colmean_kernel(const float* __restrict__ partial, int nblk, int d, int64_t n,
                                                          float* __restrict__ mu, unsigned* __restrict__ r2max) {
-  const int j = blockIdx.x * kBlock + threadIdx.x;
-  if (j == 0) *r2max = 0u;
-  if (j >= d) return;
+  __shared__ double sh[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *r2max = 0u;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(int64_t)b * d + j];
-  mu[j] = (float)(s / (double)n);
+  if (j < d)
+    for (int b = g; b < nblk; b += 4) s += (double)partial[(int64_t)b * d + j];
+  sh[g][c] = s;
+  __syncthreads();
+  if (g == 0 && j < d) mu[j] = (float)(((sh[0][c] + sh[1][c]) + (sh[2][c] + sh[3][c])) / (double)n);
 }
 
 // ------------------------------------------------------------------ centre + two-term bf16 split + norms
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
 #endif
 }
 
-constexpr int kMaxPartialBlocks = 256;
+constexpr int kMaxPartialBlocks = 1024;
 
 }  // namespace
 
@@ -244,13 +249,13 @@ int mgp_knn_mfma_take(MgpArena& ar, int64_t N, int64_t qc, int d, MgpKnnMfma* m)
 
 // mean of the points, their split and norms, R^2 = max |c_y|^2
 int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnMfma& m, hipStream_t st) {
-  int nblk = (int)mgp_cdiv(N, 256);
+  int nblk = (int)mgp_cdiv(N, 64);
   if (nblk > kMaxPartialBlocks) nblk = kMaxPartialBlocks;
   const int64_t rpb = mgp_cdiv(N, nblk);
   nblk = (int)mgp_cdiv(N, rpb);
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(kBlock), 0, st, db, N, d, rpb, m.partial);
   MGP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)mgp_cdiv(d, kBlock)), dim3(kBlock), 0, st, m.partial, nblk, d, N, m.mu,
+  hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)mgp_cdiv(d, 64)), dim3(kBlock), 0, st, m.partial, nblk, d, N, m.mu,
                      m.r2max);
   MGP_LAUNCH_CHECK();
   hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(N, kMT) * kMT)), dim3(kBlock), 0, st, db, N, d, m.dpad, m.mu, m.Ph, m.Pl, m.pn2, m.r2max);
