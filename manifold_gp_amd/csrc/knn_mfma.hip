@@ -76,15 +76,16 @@ __device__ __forceinline__ int64_t tiled_index(int64_t row, int k, int nst) {
   return (((row / kMT) * nst + k / kBK) * kMT + rl) * kBK + ((((kl >> 3) ^ ((rl >> 2) & 3)) << 3) | (kl & 7));
 }
 
+// One wave per row, 4 consecutive rows (same tile) per workgroup: the 4 x 64 bytes they write per stage are
+// contiguous -- whole 128-byte lines (one row per workgroup wrote half lines: 0.69 ms for 60k x 784).
 __global__ __launch_bounds__(kBlock) void split_kernel(const float* __restrict__ x, int64_t n, int d, int dpad,
                                                        const float* __restrict__ mu, uint16_t* __restrict__ H,
-                                                       uint16_t* __restrict__ L, float* __restrict__ norm2,
-                                                       unsigned* __restrict__ r2max) {
-  __shared__ double red[kBlock / MGP_WAVE];
-  const int64_t row = blockIdx.x;
+                                                       uint16_t* __restrict__ L, float* __restrict__ norm2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nst = dpad / kBK;
   if (row >= n) {                         // padding rows of the last tile
-    for (int j = threadIdx.x; j < dpad; j += kBlock) {
+    for (int j = lane; j < dpad; j += 64) {
       const int64_t o = tiled_index(row, j, nst);
       H[o] = 0; L[o] = 0;
     }
@@ -92,27 +93,45 @@ __global__ __launch_bounds__(kBlock) void split_kernel(const float* __restrict__
   }
   const float* xr = x + row * d;
   double s = 0.0;
-  for (int j = threadIdx.x; j < dpad; j += kBlock) {
-    unsigned h = 0, l = 0;
-    if (j < d) {
-      const float c = xr[j] - mu[j];
-      h = bf16_rne(c);
-      l = bf16_rne(c - __uint_as_float(h << 16));
-      s += (double)c * (double)c;
+  // a lane converts one 16-byte piece (8 features) at a time: two 16-byte stores instead of sixteen 2-byte ones
+  const int rl = (int)(row & (kMT - 1));
+  const int64_t tile_base = (row / kMT) * nst * (int64_t)(kMT * kBK) + (int64_t)rl * kBK;
+  for (int p = lane; p < dpad / 8; p += 64) {
+    unsigned hh[8], ll[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int j = 8 * p + e;
+      unsigned h = 0, l = 0;
+      if (j < d) {
+        const float c = xr[j] - mu[j];
+        h = bf16_rne(c);
+        l = bf16_rne(c - __uint_as_float(h << 16));
+        s += (double)c * (double)c;
+      }
+      hh[e] = h; ll[e] = l;
     }
-    const int64_t o = tiled_index(row, j, nst);
-    H[o] = (uint16_t)h;
-    L[o] = (uint16_t)l;
+    const int64_t o = tile_base + (int64_t)(p >> 2) * (kMT * kBK) + (((p & 3) ^ ((rl >> 2) & 3)) << 3);
+    *reinterpret_cast<uint4*>(H + o) = make_uint4(hh[0] | (hh[1] << 16), hh[2] | (hh[3] << 16), hh[4] | (hh[5] << 16), hh[6] | (hh[7] << 16));
+    *reinterpret_cast<uint4*>(L + o) = make_uint4(ll[0] | (ll[1] << 16), ll[2] | (ll[3] << 16), ll[4] | (ll[5] << 16), ll[6] | (ll[7] << 16));
   }
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  if (lane == 0) {
+    const float nf = (float)s;
+    norm2[row] = nf;
+  }
+}
+
+// R^2 = max_y |c_y|^2 (one workgroup; 60k same-address atomics from the split kernel cost 0.6 ms)
+__global__ __launch_bounds__(1024) void r2max_kernel(const float* __restrict__ norm2, int64_t n, unsigned* __restrict__ r2max) {
+  __shared__ float sh[16];
+  float m = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, norm2[i]);
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int w = 0; w < kBlock / MGP_WAVE; ++w) t += red[w];
-    const float nf = (float)t;
-    norm2[row] = nf;
-    if (r2max) atomicMax(r2max, __float_as_uint(nf));   // non-negative floats order as their bit patterns
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, sh[w]);
+    *r2max = __float_as_uint(m);          // non-negative floats order as their bit patterns
   }
 }
 
@@ -258,14 +277,15 @@ int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnM
   hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)mgp_cdiv(d, 64)), dim3(kBlock), 0, st, m.partial, nblk, d, N, m.mu,
                      m.r2max);
   MGP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(N, kMT) * kMT)), dim3(kBlock), 0, st, db, N, d, m.dpad, m.mu, m.Ph, m.Pl, m.pn2, m.r2max);
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(N, kMT) * kMT / 4)), dim3(kBlock), 0, st, db, N, d, m.dpad, m.mu, m.Ph, m.Pl, m.pn2);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(r2max_kernel, dim3(1), dim3(1024), 0, st, m.pn2, N, m.r2max);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
 
 int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpKnnMfma& m, hipStream_t st) {
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(rows, kMT) * kMT)), dim3(kBlock), 0, st, q, rows, d, m.dpad, m.mu, m.Qh, m.Ql, m.qn2,
-                     (unsigned*)nullptr);
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(rows, kMT) * kMT / 4)), dim3(kBlock), 0, st, q, rows, d, m.dpad, m.mu, m.Qh, m.Ql, m.qn2);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
