@@ -210,8 +210,8 @@ def inv_quad_logdet(operator, inv_quad_rhs=None, logdet=False, reduce_inv_quad=T
                 # probes rounded up to a multiple of 4: the 4 / 8 / 12 / 16-column SpMM kernel (16-byte rows,
                 # DPP reductions) is ~2x faster per launch than the generic one, and more probes only help
                 P = -(-settings.num_trace_samples.value() // 4) * 4
-                gen = torch.Generator(device="cpu").manual_seed(4321)
-                Z = (torch.randint(0, 2, (n, P), generator=gen).float() * 2 - 1).to(logdet_term.device)
+                from .slq import rademacher_probes
+                Z = rademacher_probes(n, P, 4321, logdet_term.device)
                 with torch.no_grad():
                     S = operator.solve(Z)
                 sur = (S * operator.matmul(Z)).sum() / P
