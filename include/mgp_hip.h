@@ -49,8 +49,8 @@ int mgp_device_info(int* cu_count, int* wave_size, size_t* hbm_bytes); /* hipGet
  * an fp64 re-rank orders it, a per-row bound check proves the set sufficient, rows that fail
  * are redone with a wider set and finally by an exact fp64 scan.  For d <= 3 and N >= 4096 no
  * N x n distance slab is formed: points are Morton-sorted, a window around the query gives a provable
- * upper bound on its k-th neighbour distance, one fused streaming pass keeps the points under that
- * bound and the fp64 re-rank orders them (knn_lowd.hip); rows whose candidate list overflows go
+ * upper bound on its k-th neighbour distance, one fused pass over the chunks of points whose bounding box
+ * meets the workgroup's search box keeps the points under that bound and the fp64 re-rank orders them (knn_lowd.hip); rows whose candidate list overflows go
  * through the slab pipeline.  Same results bit for bit.  Synchronises `stream`.
  * stats (nullable, host int64[4]): rows redone wide, rows redone exact, chunks, candidates K'
  * (-1 when the low-dimensional path ran; [0] then counts its overflow rows). */
