@@ -671,9 +671,9 @@ extern "C" int64_t mgp_knn_last_direct_chunks(void) { return g_last_direct_chunk
 namespace {
 
 int64_t fallback_rows(int64_t n) {          // rows the low-d path may hand back per round
-  int64_t r = n / 8;
-  if (r < 4096) r = 4096;
-  return r < n ? r : n;
+  // after the low-d path's own retry with tightened bounds a handful of rows is left (4 of 1M on the random
+  // swiss roll): a small slab (512 rows x N keys) keeps the workspace -- and its first allocation -- small
+  return n < 512 ? n : 512;
 }
 
 }  // namespace

@@ -1611,3 +1611,20 @@ def test_knn_select_paths_long_rows_and_widest_retry(mgp, dev):
     st = nn.last_stats
     assert st["rows_redone_wide"] >= 3, st
     assert np.array_equal(I.cpu().numpy(), Ir) and np.array_equal(D.cpu().numpy(), Dr), st
+
+
+def test_knn_lowdim_large_random_order_surface(mgp, dev):
+    """300k points of a 2-D surface in R^3 handed over in random order, k = 64: chunk-box pruning with curve-ordered
+    query blocks, and the retry of overflowing queries with bounds tightened from their stored candidates (windows
+    that straddle a jump of the curve give loose first bounds).  A random subset of rows against the fp64 oracle."""
+    from oracle import knn as oknn
+    from tools import synth
+    x_np, _ = synth.swiss_roll(300000, order="random")
+    nn = mgp.utils.NearestNeighbors(T(x_np, dev))
+    D, I = nn.search(T(x_np, dev), 64)
+    st = nn.last_stats
+    assert st["candidates"] == -1 and st["rows_redone_wide"] <= 64, st       # low-d path; the retry leaves (almost) nothing
+    rows = np.random.default_rng(2).choice(x_np.shape[0], 400, replace=False)
+    Dr, Ir = oknn.knn_search(x_np, x_np[rows], 64)
+    assert np.array_equal(I[rows].cpu().numpy(), Ir) and np.array_equal(D[rows].cpu().numpy(), Dr)
+    assert bool((I[:, 0] == torch.arange(x_np.shape[0], device=dev)).all())
