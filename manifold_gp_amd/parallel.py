@@ -243,6 +243,9 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
     desc = base.with_(data=data, pre=pre, post=pre)
     plan = DistCgPlan(desc, part, rank, comm, C=1, tol=args.tol, max_iter=2000, stop_mode=1)
     y = part.pad(wl["y"].view(-1, 1)).contiguous()
+    import gc
+    gc.collect()
+    gc.disable()          # a generation-2 collection (tens of ms) otherwise lands inside a long timed loop
     for _ in range(args.warmup):
         out = plan.solve(y)
     torch.cuda.synchronize()
@@ -259,6 +262,7 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     tmax = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
