@@ -27,7 +27,7 @@ class Rec:
     def step(self, loss):
         torch.cuda.synchronize(); times.append(time.perf_counter()); losses.append(float(loss.detach())); print("epoch", len(times), losses[-1], flush=True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-manifold_informed_train(model, opt, max_iter=2, tolerance=0.0, num_rand_vec=32, max_cholesky=800, cg_tolerance=1e-2,
+manifold_informed_train(model, opt, max_iter=2, tolerance=0.0, num_rand_vec=32, max_cholesky=800, cg_tolerance=float(sys.argv[2]) if len(sys.argv) > 2 else 1e-2,
                         cg_max_iter=1000, scheduler=Rec())
 torch.cuda.synchronize(); t_total = time.perf_counter() - t0
 ep = [round((b - a) * 1e3, 1) for a, b in zip([t0] + times[:-1], times)]
