@@ -65,6 +65,19 @@ class SchurComplementOperator(LinearOperator):
     def _hyper_tensors(self):
         return getattr(self.base, "_hyper_tensors", lambda: [])()
 
+    def _masked_blocks(self, desc, ml, mu):
+        """The three masked descriptors of one matvec, kept while the base operator's values do not change: the
+        mask is folded into NEW pre / post vectors, and the CG plan cache keys on their addresses -- rebuilt per
+        call, every inner solve of a Lanczos / CG loop created (and evicted) a plan (0.5 ms each way)."""
+        key = (id(desc.data), desc.nu, desc.kappa, desc.scale, desc.form, desc.noise,
+               desc.pre.data_ptr() if desc.pre is not None else 0, desc.post.data_ptr() if desc.post is not None else 0)
+        if getattr(self, "_blocks_key", None) != key:
+            self._blocks = (desc.masked(col_mask=ml), desc.masked(row_mask=mu, col_mask=mu),
+                            desc.masked(row_mask=ml, col_mask=mu))
+            self._blocks_key = key
+            self._blocks_owner = desc          # keeps desc.data / pre / post alive: their ids and addresses cannot be recycled
+        return self._blocks
+
     def _apply_parts(self, v, **cg_kw):
         """(S v [k, C], V [n, C]) with V = [v on the labelled nodes; -Q_uu^-1 Q_ul v on the others]."""
         from ..solvers import cg_solve
@@ -74,9 +87,10 @@ class SchurComplementOperator(LinearOperator):
             n = desc.n
             full = torch.zeros(n, v.shape[1], device=v.device, dtype=torch.float32)
             full[self._lidx] = v
-            tmp = desc.masked(col_mask=ml).apply(full)                 # Q[:, l] v           (:27)
-            sol = cg_solve(desc.masked(row_mask=mu, col_mask=mu), tmp * mu.view(-1, 1), **cg_kw)[0]   # Q_uu^-1 (:28)
-            out = desc.masked(row_mask=ml, col_mask=mu).apply(sol)     # Q_lu (.)            (:29)
+            d_l, d_uu, d_lu = self._masked_blocks(desc, ml, mu)
+            tmp = d_l.apply(full)                                      # Q[:, l] v           (:27)
+            sol = cg_solve(d_uu, tmp * mu.view(-1, 1), **cg_kw)[0]     # Q_uu^-1 (:28)
+            out = d_lu.apply(sol)                                      # Q_lu (.)            (:29)
             res = (tmp - out)[self._lidx]                              # (:30)
             return res, full - sol * mu.view(-1, 1)
 
