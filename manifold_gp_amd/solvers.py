@@ -135,11 +135,12 @@ def cg_solve(desc, rhs, **kw):
     return (X.squeeze(-1) if squeeze else X), its, res
 
 
-def generic_cg(operator, rhs, tol=None, max_iter=None, x0=None):
+def generic_cg(operator, rhs, tol=None, max_iter=None, x0=None, precond=None):
     """linear_cg's recurrence in torch ops for operators that are not one polynomial chain (e.g.
     wrappers around a Schur complement).  Every `_matmul` underneath is still a HIP launch.
-    x0: optional initial guess.  With one the stopping rule (mean relative residual < tol) is tested from the
-    start -- linear_cg's minimum of 10 iterations belongs to its cold start from zero."""
+    x0: optional initial guess; precond: optional callable v -> M v with M ~ A^-1 (preconditioned CG).  With either
+    the stopping rule (mean relative residual < tol) is tested from the start -- linear_cg's minimum of 10
+    iterations belongs to its cold, unpreconditioned start from zero."""
     _lib.require_device(rhs)
     tol = settings.cg_tolerance.value() if tol is None else tol
     max_iter = settings.max_cg_iterations.value() if max_iter is None else max_iter
@@ -147,29 +148,30 @@ def generic_cg(operator, rhs, tol=None, max_iter=None, x0=None):
     B = _lib.f32c(rhs.unsqueeze(-1) if squeeze else rhs)
     bn = B.norm(dim=0, keepdim=True).clamp_min(1e-10)
     Bn = B / bn
-    min_iter = 10
+    min_iter = 10 if (x0 is None and precond is None) else 0
     if x0 is None:
         x = torch.zeros_like(Bn)
         r = Bn.clone()
     else:
         x = _lib.f32c(x0.unsqueeze(-1) if squeeze else x0) / bn
         r = Bn - operator._matmul(x)
-        min_iter = 0
-        if r.norm(dim=0).mean().item() < tol:
-            x = x * bn
-            return x.squeeze(-1) if squeeze else x
-    p = r.clone()
-    rz = (r * r).sum(0, keepdim=True)
+    if min_iter == 0 and r.norm(dim=0).mean().item() < tol:
+        x = x * bn
+        return x.squeeze(-1) if squeeze else x
+    z = precond(r) if precond is not None else r
+    p = z.clone()
+    rz = (r * z).sum(0, keepdim=True)
     for it in range(1, max_iter + 1):
         q = operator._matmul(p)
         pq = (p * q).sum(0, keepdim=True)
         alpha = rz / pq.where(pq.abs() > 1e-30, torch.full_like(pq, 1e-30))
         x = x + alpha * p
         r = r - alpha * q
-        rz_new = (r * r).sum(0, keepdim=True)
-        if it >= min_iter and rz_new.sqrt().mean().item() < tol:
+        if it >= min_iter and r.norm(dim=0).mean().item() < tol:
             break
-        p = r + (rz_new / rz.clamp_min(1e-30)) * p
+        z = precond(r) if precond is not None else r
+        rz_new = (r * z).sum(0, keepdim=True)
+        p = z + (rz_new / rz.where(rz.abs() > 1e-30, torch.full_like(rz, 1e-30))) * p
         rz = rz_new
     x = x * bn
     return x.squeeze(-1) if squeeze else x
