@@ -82,7 +82,7 @@ def rademacher_probes(n, num_probes, seed, device):
     return Z
 
 
-def _quadrature_log(alpha, beta):
+def _quadrature_log(alpha, beta, fun=None):
     k = len(alpha)
     # an (almost) zero beta means the Krylov space is exhausted: truncate there
     cut = k
@@ -92,13 +92,14 @@ def _quadrature_log(alpha, beta):
             break
     T = np.diag(alpha[:cut]) + np.diag(beta[:cut - 1], 1) + np.diag(beta[:cut - 1], -1)
     theta, S = np.linalg.eigh(T)
+    theta = fun(theta) if fun is not None else theta
     theta = np.maximum(theta, 1e-30)
     return float(np.sum(S[0, :] ** 2 * np.log(theta)))
 
 
-def _quadrature_log_sum(a, b):
-    """sum over the probes (columns of a / b [steps, P]) of e_1^T log(T_p) e_1: one batched eigh for the probes
-    whose Krylov space is not exhausted, the scalar routine for the (rare) others."""
+def _quadrature_log_sum(a, b, fun=None):
+    """sum over the probes (columns of a / b [steps, P]) of e_1^T log(fun(T_p)) e_1 (fun = identity by default): one
+    batched eigh for the probes whose Krylov space is not exhausted, the scalar routine for the (rare) others."""
     k, P = a.shape
     ok = np.isfinite(b[:k - 1]).all(0) & (np.abs(b[:k - 1]) >= 1e-6 * np.maximum(np.abs(a[:k - 1]), 1e-30)).all(0) if k > 1 \
         else np.ones(P, bool)
@@ -112,9 +113,10 @@ def _quadrature_log_sum(a, b):
             T[:, r[:-1], r[1:]] = b[:k - 1, idx].T
             T[:, r[1:], r[:-1]] = b[:k - 1, idx].T
         theta, S = np.linalg.eigh(T)
+        theta = fun(theta) if fun is not None else theta
         total += float(np.sum(S[:, 0, :] ** 2 * np.log(np.maximum(theta, 1e-30))))
     for p in np.nonzero(~ok)[0]:
-        total += _quadrature_log(a[:, p], b[:, p])
+        total += _quadrature_log(a[:, p], b[:, p], fun)
     return total
 
 
@@ -151,9 +153,18 @@ def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
         gen = torch.Generator(device="cpu").manual_seed(seed)
         dev = operator.device if hasattr(operator, "device") else None
         Z = rademacher_probes(n, num_probes, seed, _generic_device(operator))
+        # A noise wrapper is the polynomial p(Q) = Q - s Q^2 + s^2 Q^3 of what it wraps: log det p(Q) = tr log p(Q) is
+        # a spectral function of Q itself, so the Lanczos runs go over Q (ONE nested solve per step for a Schur
+        # complement underneath, not three) and the quadrature evaluates log p at the Ritz values.
+        from .operators.noise_wrapper_operator import NoiseWrapperOperator
+        fun, target = None, operator
+        if isinstance(operator, NoiseWrapperOperator):
+            sn = float(operator.noise.reshape(-1)[0].item()) if torch.is_tensor(operator.noise) else float(operator.noise)
+            target = operator.operator
+            fun = lambda th: th - sn * th * th + sn * sn * th * th * th     # noqa: E731
         with torch.no_grad():
-            a, b = _lanczos_block_generic(operator, Z, steps)
-        total = _quadrature_log_sum(a, b)
+            a, b = _lanczos_block_generic(target, Z, steps)
+        total = _quadrature_log_sum(a, b, fun)
         return torch.tensor(n * total / num_probes, dtype=torch.float32, device=Z.device)
     n = desc.n
     num_probes = settings.num_trace_samples.value() if num_probes is None else num_probes
