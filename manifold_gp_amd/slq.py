@@ -172,6 +172,13 @@ def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
     gen = torch.Generator(device="cpu").manual_seed(seed)
     dev = desc.data.graph.device
     total = 0.0
+    # forms 1 / 2 are polynomials of the form-0 chain Q2 (Q2 - s Q2^2 + s^2 Q2^3, I + s Q2): Lanczos over Q2 -- a third
+    # of the SpMVs per step for the noise wrapper -- and log p at the Ritz values
+    fun = None
+    if desc.form in (1, 2):
+        sn = float(desc.noise)
+        fun = (lambda th: th - sn * th * th + sn * sn * th * th * th) if desc.form == 1 else (lambda th: 1.0 + sn * th)
+        desc = desc.with_(form=0)
     if steps + 1 <= 48:
         # all probes as columns of one block (batches of <= 16, a multiple of 4 columns so that the SpMM
         # takes its 16-byte-row kernel): the runs are independent, the launch count drops by the batch size
@@ -179,10 +186,10 @@ def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
         Z = rademacher_probes(n, num_probes, seed, dev)
         for c0 in range(0, num_probes, 16):
             a, b = lanczos_tridiag_block(desc, Z[:, c0:c0 + 16].contiguous(), steps)
-            total += _quadrature_log_sum(a, b)
+            total += _quadrature_log_sum(a, b, fun)
     else:
         for _ in range(num_probes):
             z = (torch.randint(0, 2, (n,), generator=gen).float() * 2 - 1).to(dev)
             a, b = lanczos_tridiag(desc, z, steps)
-            total += _quadrature_log(a, b)
+            total += _quadrature_log(a, b, fun)
     return torch.tensor(n * total / num_probes, dtype=torch.float32, device=dev)
