@@ -597,6 +597,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   // fp32 direct-difference distance: one rounding per subtraction, one per fused accumulate
   const double gamma = (double)(d + 4) * 1.1920928955078125e-07;   // (d+4) * 2^-23
   int64_t n_wide = 0, n_exact = 0, n_chunks = 0, n_direct = 0;
+  int streak_direct = 0;
 
   for (int64_t q0 = 0; q0 < n; q0 += qc) {
     const int64_t rows = (n - q0) < qc ? (n - q0) : qc;
@@ -607,7 +608,8 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
     int fails = 0;
     // pass 0: MFMA keys + absolute check; pass 1 (no MFMA, or too many rows of the chunk failed the
     // absolute check): exact fp32 direct-difference keys + relative check
-    for (int pass = mfma ? 0 : 1; pass < 2; ++pass) {
+    // (two chunks in a row redone: this data does not suit the absolute bound, stop paying for MFMA passes)
+    for (int pass = (mfma && streak_direct < 2) ? 0 : 1; pass < 2; ++pass) {
       if (pass == 0) {
         MGP_TRY(mgp_knn_mfma_prepare_queries(q + q0 * d, rows, d, mm, st));
         MGP_TRY(mgp_knn_mfma_tiles(mm, rows, N, slab, ld, st));
@@ -623,7 +625,8 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
       MGP_LAUNCH_CHECK();
       MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
       MGP_HIP_TRY(hipStreamSynchronize(st));
-      if (pass == 0 && fails > rows / 16 + 8) { ++n_direct; continue; }
+      if (pass == 0 && fails > rows / 16 + 8) { ++n_direct; ++streak_direct; continue; }
+      if (pass == 0) streak_direct = 0;
       break;
     }
     int Kp = Kp0;
