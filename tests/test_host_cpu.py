@@ -231,3 +231,25 @@ def test_struct_fields_mirror_header_and_integration_stub():
     doc = open(os.path.join(root, "INTEGRATION.md")).read()
     stub = re.search(r"class mgp_csr_t\(ctypes\.Structure\):(.*?)\n\n", doc, re.S).group(1)
     assert re.findall(r'\("(\w+)",', stub) == [f[0] for f in _lib.CsrT._fields_]
+
+
+def test_slq_quadrature_batched_equals_scalar_and_spectral_function():
+    """slq._quadrature_log_sum: one batched eigh over the probes == the per-probe routine (including a probe whose
+    Krylov space is exhausted), and with a spectral function it integrates log f(theta): for a diagonal-dominant
+    tridiagonal built from a known matrix the quadrature of e_1^T log(p(T)) e_1 matches numpy's logm route."""
+    import numpy as np
+    from manifold_gp_amd.slq import _quadrature_log, _quadrature_log_sum
+    rng = np.random.default_rng(0)
+    k, P = 20, 12
+    a = rng.random((k, P)) + 2.0
+    b = rng.random((k, P)) * 0.5
+    b[5, 3] = 0.0                                   # exhausted Krylov space: truncated at step 6
+    ref = sum(_quadrature_log(a[:, p], b[:, p]) for p in range(P))
+    assert abs(_quadrature_log_sum(a, b) - ref) <= 1e-12 * abs(ref)
+    s = 0.05
+    fun = lambda th: th - s * th * th + s * s * th ** 3          # noqa: E731
+    got = _quadrature_log_sum(a[:, :1], b[:, :1], fun)
+    T = np.diag(a[:, 0]) + np.diag(b[:k - 1, 0], 1) + np.diag(b[:k - 1, 0], -1)
+    w, V = np.linalg.eigh(T)
+    want = float(np.sum(V[0] ** 2 * np.log(fun(w))))
+    assert abs(got - want) <= 1e-12 * max(1.0, abs(want))
