@@ -708,6 +708,37 @@ def test_schur_solve_by_block_elimination(mgp, golden, dev):
     assert np.abs(x.cpu().numpy() - ref).max() < 1e-4 * np.abs(ref).max()
 
 
+def test_noise_wrapped_schur_solve_and_logdet(mgp, golden, dev):
+    """The semi-supervised model's operator, NoiseWrapper(ScaleWrapper(Schur)): its solve (CG preconditioned by
+    Q^-1 + s I, applied with one non-nested CG on the full precision) against the dense solve, several right-hand
+    sides; its stochastic log-determinant (Lanczos over the wrapped operator, log p at the Ritz values) against the
+    dense log-determinant."""
+    from manifold_gp_amd.slq import slq_logdet
+    O = mgp.operators
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = O.PrecisionMaternOperator(lap, 1, torch.tensor([[float(g["kappa"])]], device=dev))
+    mask = g["symmetric_schur_mask"]
+    sc, noise = 0.6, 2e-2
+    A = O.NoiseWrapperOperator(O.ScaleWrapperOperator(O.SchurComplementOperator(Q, T(mask, dev)), torch.tensor(sc, device=dev)),
+                               torch.tensor(noise, device=dev))
+    assert A._descriptor() is None                                    # not one polynomial chain: the generic path
+    Qd = Q.to_dense().double().cpu().numpy()
+    Sd = Qd[np.ix_(mask, mask)] - Qd[np.ix_(mask, ~mask)] @ np.linalg.solve(Qd[np.ix_(~mask, ~mask)], Qd[np.ix_(~mask, mask)])
+    Q2 = sc * Sd
+    Ad = Q2 - noise * Q2 @ Q2 + noise * noise * Q2 @ Q2 @ Q2
+    rng = np.random.default_rng(9)
+    B = rng.normal(size=(int(mask.sum()), 4)).astype(np.float32)
+    with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(6000):
+        X = A.solve(T(B, dev))
+    ref = np.linalg.solve(Ad, B.astype(np.float64))
+    assert np.abs(X.cpu().numpy() - ref).max() < 2e-4 * np.abs(ref).max()
+    with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(6000):
+        ld = float(slq_logdet(A, num_probes=48, steps=40))
+    sign, want = np.linalg.slogdet(Ad)
+    assert sign > 0 and abs(ld - want) < 0.03 * abs(want) + 0.02 * Ad.shape[0], (ld, want)
+
+
 # ----------------------------------------------------------------------------- remaining section-8(a) rows
 @pytest.mark.parametrize("norm", NORMS)
 def test_operator_out_of_sample_vs_oracle(mgp, golden, dev, norm):
