@@ -95,6 +95,13 @@ def main():
             out[p + "mmT"] = torch.mm(L.T, probes).numpy()
             r, c = idx[0, :64], idx[1, :64]
             out[p + "offdiag64"] = L[r, c].numpy()
+            # per-edge views of the dense matrices the reference's twin returns (test/_dense_operators.py:7-24):
+            # W (graph_laplacian_operator.py:54-56), A (:73-75) and every off-diagonal entry of L, both triangles
+            ra, ca = idx[0].long(), idx[1].long()
+            out[p + "adjacency_unnorm_edges"] = adj_un[ra, ca].numpy()
+            out[p + "adjacency_edges"] = adj[ra, ca].numpy()
+            out[p + "offdiag"] = L[ra, ca].numpy()
+            out[p + "offdiagT"] = L[ca, ra].numpy()
             for nu in nu_list:
                 Q = dense.matern_precision(L, nu, ls, deg if norm == "randomwalk" else None)
                 out[p + f"Q{nu}_mv"] = torch.mv(Q, train_y).numpy()
@@ -180,6 +187,60 @@ def main():
             out[p + "oos_gram"] = (Zext @ Z[:64].T).numpy()           # rotation-invariant
             out[p + "oos_bump"] = b.numpy()
             out[p + "oos_features_abs_col1"] = Zext[:, 1].abs().numpy()
+            # ---- the same imported reference functions on .double() inputs: goldens whose own round-off is
+            # negligible, so the HIP path is held to ITS fp32 round-off and not to that of an fp32 eigh
+            torch.set_default_dtype(torch.float64)
+            gb64, ls64 = gb.double(), ls.double()
+            L64, adj_un64, deg_un64, adj64, deg64 = dense.graph_laplacian(idx, val.double(), gb64, n, normalization=norm,
+                                                                          self_loops=self_loops)
+            out[p + "degree_unnorm_f64"] = deg_un64.numpy()
+            out[p + "degree_f64"] = deg64.numpy()
+            out[p + "diag_f64"] = L64.diag().numpy()
+            out[p + "adjacency_unnorm_edges_f64"] = adj_un64[ra, ca].numpy()
+            out[p + "adjacency_edges_f64"] = adj64[ra, ca].numpy()
+            out[p + "offdiag_f64"] = L64[ra, ca].numpy()
+            y64, P64 = train_y.double(), probes.double()
+            out[p + "mv_f64"] = torch.mv(L64, y64).numpy()
+            out[p + "mvT_f64"] = torch.mv(L64.T, y64).numpy()
+            for nu_ in nu_list:
+                Q64 = dense.matern_precision(L64, nu_, ls64, deg64 if norm == "randomwalk" else None)
+                out[p + f"Q{nu_}_mv_f64"] = torch.mv(Q64, y64).numpy()
+                out[p + f"Q{nu_}_mm_f64"] = torch.mm(Q64, P64).numpy()
+                if nu_ == nu_list[0]:
+                    out[p + "Qscaled_mv_f64"] = torch.mv(dense.matern_scaled_precision(Q64, torch.tensor(0.7)), y64).numpy()
+                    out[p + "Qnoisy_mv_f64"] = torch.mv(dense.matern_noisy_precision(Q64, torch.tensor(1e-2)), y64).numpy()
+                    out[p + "schur_mv_f64"] = (dense.matern_labeled_precision(Q64, mask) @ y64[mask]).numpy()
+                    out[p + "solve_f64"] = torch.linalg.solve(Q64, y64).numpy()
+            if norm == "symmetric":
+                Lsym64, deg_sym64, deg_un_sym64 = L64, deg64, deg_un64
+            ev64, U64 = torch.linalg.eigh(Lsym64)
+            ev64, U64 = ev64[:modes + 8].clone(), U64[:, :modes + 8].clone()
+            out[p + "evals_raw_f64"] = ev64.numpy().copy()            # modes + 8: the gap behind the kept block
+            ev64, U64 = ev64[:modes].clone(), U64[:, :modes].clone()
+            ev64[0] = 0.0
+            U64 = U64 * deg_sym64.pow(-0.5).view(-1, 1)
+            U64 = torch.nn.functional.normalize(U64, p=2, dim=0)
+            sd64 = (2 * nu / ls64.square() + ev64).pow(-nu)
+            sd64 = sd64 / sd64.sum()
+            Z64 = (sd64 * n).sqrt() * U64
+            out[p + "features_gram_64_f64"] = (Z64[:64] @ Z64[:64].T).numpy()
+            out[p + "features_diag_f64"] = (Z64 * Z64).sum(-1).numpy()
+            aeu = torch.sparse_coo_tensor(torch.stack([rows, cols]), ev.double().reshape(-1).div(-4 * gb64.square()).exp().squeeze(),
+                                          (T, n)).to_dense()
+            deu = aeu.sum(dim=1)
+            ae = torch.mm(deu.pow(-1).diag(), torch.mm(aeu, deg_un_sym64.pow(-1).diag()))
+            de = ae.sum(dim=1)
+            if norm == "symmetric":
+                ext64 = torch.mm(de.pow(-0.5).diag(), torch.mm(ae, deg_sym64.pow(-0.5).diag()))
+            else:
+                ext64 = torch.mm(de.pow(-1.0).diag(), ae)
+            sd2 = (2 * nu / ls64.square() + ev64).pow(-nu)
+            sd2 = sd2 / (1 - ev64 * gb64.square()).square()
+            sd2 = sd2 / sd2.sum() * n
+            Zext64 = sd2.sqrt() * torch.mm(ext64, U64)
+            out[p + "oos_gram_f64"] = (Zext64 @ Z64[:64].T).numpy()
+            out[p + "oos_bump_f64"] = tu.bump_function(ev.double()[:, 0].sqrt(), torch.tensor(bump[0] * eps), bump[1]).numpy()
+            torch.set_default_dtype(torch.float32)
         np.savez_compressed(os.path.join(HERE, f"dumbbell_{tag}.npz"), **out)
 
     # ---- bump function known answers (torch_utils.py:38-41) ----

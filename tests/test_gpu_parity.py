@@ -129,8 +129,28 @@ def test_laplacian_pieces_and_matmul(mgp, golden, dev, case, norm):
     np.testing.assert_allclose(op.degree_mat.cpu().numpy(), g[p + "degree"], rtol=5e-6)
     np.testing.assert_allclose(op.laplacian_diag.cpu().numpy(), g[p + "diag"], rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(op.diagonal().cpu().numpy(), g[p + "diag"], rtol=1e-5, atol=2e-5)
+    # adjacency_unnorm_mat (W, :54-56), adjacency_mat (A, :73-75) and the FULL laplacian_triu (S, :104-106) per edge
+    # against the entries of the reference's dense matrices (test/_dense_operators.py:7-24), fp32 golden
+    W, A, S = op.adjacency_unnorm_mat.cpu().numpy(), op.adjacency_mat.cpu().numpy(), op.laplacian_triu.cpu().numpy()
+    assert W.shape == A.shape == S.shape == (g["edge_index"].shape[1],)
+    np.testing.assert_allclose(W, g[p + "adjacency_unnorm_edges"], rtol=2e-6)
+    np.testing.assert_allclose(A, g[p + "adjacency_edges"], rtol=5e-6)
+    r, c = g["edge_index"][0].astype(np.int64), g["edge_index"][1].astype(np.int64)
     if norm == "symmetric":
-        np.testing.assert_allclose(-op.laplacian_triu[:64].cpu().numpy(), g[p + "offdiag64"], rtol=2e-5)
+        np.testing.assert_allclose(-S[:64], g[p + "offdiag64"], rtol=2e-5)
+        np.testing.assert_allclose(-S, g[p + "offdiag"], rtol=1e-5)
+        np.testing.assert_allclose(-S, g[p + "offdiagT"], rtol=1e-5)
+    else:       # laplacian_triu is S of L_sym for either normalisation; L_rw[r, c] = -S sqrt(D_c / D_r)
+        ds = np.sqrt(g[p + "degree_f64"])
+        np.testing.assert_allclose(-S * ds[c] / ds[r], g[p + "offdiag"], rtol=1e-5)
+        np.testing.assert_allclose(-S * ds[r] / ds[c], g[p + "offdiagT"], rtol=1e-5)
+    # ... and against the float64 run of the same reference functions: the HIP values carry a few fp32 ulps
+    np.testing.assert_allclose(op.degree_unnorm_mat.cpu().numpy(), g[p + "degree_unnorm_f64"], rtol=1e-6)
+    np.testing.assert_allclose(op.degree_mat.cpu().numpy(), g[p + "degree_f64"], rtol=2e-6)
+    np.testing.assert_allclose(W, g[p + "adjacency_unnorm_edges_f64"], rtol=1e-6)
+    np.testing.assert_allclose(A, g[p + "adjacency_edges_f64"], rtol=3e-6)
+    s64 = -g[p + "offdiag_f64"] if norm == "symmetric" else -g[p + "offdiag_f64"] * ds[r] / ds[c]
+    np.testing.assert_allclose(S, s64, rtol=5e-6)
     y, P = T(g["train_y"], dev), T(g["probes"], dev)
     dmax = float(np.abs(g[p + "diag"]).max())
     tol_y = 2e-6 * dmax * float(np.abs(g["train_y"]).max())      # ~16 ulp of |L||v|
@@ -207,6 +227,25 @@ def test_precision_and_wrappers(mgp, golden, dev, case, norm):
     with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(4000):
         out = O.SchurComplementOperator(Q, T(mask, dev)).matmul(T(g["train_y"][mask], dev))
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=2e-3 * np.abs(ref).max())
+    # ---- the same products against the FLOAT64 run of the reference's dense operators: the tolerances above are
+    # those of the fp32 goldens' own round-off (up to 3e-5 here); these hold the HIP path to a few fp32 ulps of
+    # |Q| |v|
+    def rel(a, key):
+        r64 = g[p + key]
+        return float(np.abs(a.cpu().numpy().astype(np.float64) - r64).max() / np.abs(r64).max())
+    errs = {}
+    for nu in nus:
+        Qn = O.PrecisionMaternOperator(lap, nu, kappa)
+        errs["Q%d_mv" % nu] = rel(Qn.matmul(y), "Q%d_mv_f64" % nu)
+        errs["Q%d_mm" % nu] = rel(Qn.matmul(P), "Q%d_mm_f64" % nu)
+    errs["Qscaled"] = rel(O.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev), inverse_scale=True).matmul(y), "Qscaled_mv_f64")
+    errs["Qnoisy"] = rel(O.NoiseWrapperOperator(Q, torch.tensor(1e-2, device=dev)).matmul(y), "Qnoisy_mv_f64")
+    errs["schur"] = rel(out, "schur_mv_f64")
+    lv = float(np.abs(g[p + "diag"]).max()) * float(np.abs(g["train_y"]).max())          # |L| |v|: L v itself cancels
+    errs["mv"] = rel(lap.matmul(y), "mv_f64") * float(np.abs(g[p + "mv_f64"]).max()) / lv
+    print("precision parity vs f64 golden", case, norm, {k: "%.2e" % v for k, v in errs.items()})
+    assert all(v < 1e-5 for k, v in errs.items() if k != "schur"), errs
+    assert errs["schur"] < 1e-4, errs                      # inner CG at 1e-6
 
 
 @pytest.mark.parametrize("norm", NORMS)
@@ -312,6 +351,29 @@ def test_kernel_eval_features_oos(mgp, golden, dev, case, norm):
     # lazy kernel block == dense MFMA block
     K = kern(xt, x).to_dense().cpu().numpy()
     np.testing.assert_allclose(K, Zt @ Z.cpu().numpy().T, rtol=0, atol=1e-4 * np.abs(K).max() + 1e-6)
+    # ---- the same quantities against the FLOAT64 goldens (the reference's functions on .double() inputs, whose own
+    # round-off is negligible; the fp32 goldens above carry the ~1e-3 error of an fp32 dense eigh).  Default
+    # eigensolver tolerance (residual <= 1e-5 |L|): well inside the north-star 1e-4; residual <= 1e-7 |L|: fp32
+    # round-off of the HIP path itself.  Measured (tools/probe_parity.py): 4.6e-5 / 1.4e-6 (Gram), 4.2e-5 / 9e-7 (OOS).
+    r64, o64, d64 = g[p + "features_gram_64_f64"], g[p + "oos_gram_f64"], g[p + "features_diag_f64"]
+    ev64 = g[p + "evals_raw_f64"][:m]
+    b64 = g[p + "oos_bump_f64"]
+
+    def errors(k):
+        Zk = k.features(x)
+        gk = (Zk[:64].double() @ Zk[:64].double().t()).cpu().numpy()
+        Ztk = k.features(xt).double().cpu().numpy()
+        extk = (Ztk / np.where(sel, b64, 1)[:, None]) @ Zk[:64].double().cpu().numpy().T
+        return (np.abs(k.eigval.cpu().numpy()[1:] - ev64[1:]).max() / lam_max, np.abs(gk - r64).max() / np.abs(r64).max(),
+                np.abs(k(x, x, diag=True).cpu().numpy() / d64 - 1).max(), np.abs(extk[sel] - o64[sel]).max() / np.abs(o64).max())
+
+    e_val, e_gram, e_diag, e_oos = errors(kern)
+    assert e_val < 1e-7 and e_gram < 1e-4 and e_diag < 2e-4 and e_oos < 1e-4, (e_val, e_gram, e_diag, e_oos)
+    kern.eigen_tol = 1e-7
+    kern.eval()
+    assert max(kern.eigen_residuals) <= 2e-7 * lam_max
+    e_val, e_gram, e_diag, e_oos = errors(kern)
+    assert e_val < 5e-8 and e_gram < 5e-6 and e_diag < 1e-5 and e_oos < 5e-6, (e_val, e_gram, e_diag, e_oos)
 
 
 def test_eigensolver_vs_dense_eigh_k50(mgp, golden, dev):
@@ -971,13 +1033,14 @@ def test_riemann_gp_posterior_and_hybrid(mgp, golden, dev, norm):
     Z, Zs = kern.features(x).cpu().numpy(), kern.features(xt).cpu().numpy()
     mean_o, cov_o, _ = gp_posterior_lowrank(Z, g["train_y"], Zs, s, noise)
     scale = max(np.abs(mean_o).max(), 1e-6)
-    np.testing.assert_allclose(model.posterior_mean.cpu().numpy(), mean_o, rtol=0, atol=2e-4 * scale)
-    np.testing.assert_allclose(model.posterior_covar.cpu().numpy(), cov_o, rtol=0, atol=2e-4 * max(np.abs(cov_o).max(), 1e-6))
+    # north-star tolerance is 1e-4; measured 1.2e-7 (mean) / 3.5e-7 (covariance) relative to the largest entry
+    np.testing.assert_allclose(model.posterior_mean.cpu().numpy(), mean_o, rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(model.posterior_covar.cpu().numpy(), cov_o, rtol=0, atol=1e-5 * max(np.abs(cov_o).max(), 1e-6))
     assert float(model.posterior_mean[:5].abs().max()) == 0.0 and float(model.posterior_covar[:5, :5].abs().max()) == 0.0
     # noisy posterior adds the noise on the diagonal (riemann_gp.py:46)
     model.posterior(xt, noisy_posterior=True)
     np.testing.assert_allclose(model.posterior_covar.cpu().numpy(), cov_o + noise * np.eye(40), rtol=0,
-                               atol=2e-4 * max(np.abs(cov_o).max(), noise))
+                               atol=1e-5 * max(np.abs(cov_o).max(), noise))
     # modulation: bump of the distance to the nearest training point (riemann_gp.py:41-43)
     d1, _ = knn_search(g["train_x"], xt_np, 1)
     mod_o = bump_oracle(np.sqrt(d1[:, 0]), float(g["bump"][0]) * float(g["eps"]), float(g["bump"][1]))

@@ -28,9 +28,28 @@ def test_laplacian_pieces(golden, case, norm):
     np.testing.assert_allclose(lap.degree_unnorm, g[p + "degree_unnorm"], rtol=2e-6)
     np.testing.assert_allclose(lap.degree, g[p + "degree"], rtol=5e-6)
     np.testing.assert_allclose(lap.diag, g[p + "diag"], rtol=1e-5, atol=2e-5)
-    r, c = g["edge_index"][0, :64], g["edge_index"][1, :64]
+    r, c = g["edge_index"][0].astype(np.int64), g["edge_index"][1].astype(np.int64)
+    # W, A and every off-diagonal entry against the reference's dense twin (graph_laplacian_operator.py:54-56,
+    # 73-75, 104-106); laplacian_triu is S of L_sym for both normalisations, L_rw[r,c] = -S sqrt(D_c / D_r)
+    np.testing.assert_allclose(lap.adjacency_unnorm, g[p + "adjacency_unnorm_edges"], rtol=2e-6)
+    np.testing.assert_allclose(lap.adjacency, g[p + "adjacency_edges"], rtol=5e-6)
     if norm == "symmetric":
         np.testing.assert_allclose(-lap.triu[:64], g[p + "offdiag64"], rtol=2e-5)
+        np.testing.assert_allclose(-lap.triu, g[p + "offdiag"], rtol=1e-5)
+        np.testing.assert_allclose(-lap.triu, g[p + "offdiagT"], rtol=1e-5)
+    else:
+        ds = np.sqrt(lap.degree)
+        np.testing.assert_allclose(-lap.triu * ds[c] / ds[r], g[p + "offdiag"], rtol=1e-5)
+        np.testing.assert_allclose(-lap.triu * ds[r] / ds[c], g[p + "offdiagT"], rtol=1e-5)
+    # the float64 oracle against the float64 run of the same reference functions: round-off only
+    l64 = _lap(g, norm, np.float64)
+    np.testing.assert_allclose(l64.degree_unnorm, g[p + "degree_unnorm_f64"], rtol=1e-12)
+    np.testing.assert_allclose(l64.degree, g[p + "degree_f64"], rtol=1e-12)
+    np.testing.assert_allclose(l64.diag, g[p + "diag_f64"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(l64.adjacency_unnorm, g[p + "adjacency_unnorm_edges_f64"], rtol=1e-12)
+    np.testing.assert_allclose(l64.adjacency, g[p + "adjacency_edges_f64"], rtol=1e-12)
+    s64 = -l64.triu if norm == "symmetric" else -l64.triu * np.sqrt(l64.degree[c] / l64.degree[r])
+    np.testing.assert_allclose(s64, g[p + "offdiag_f64"], rtol=1e-11)
     # fp32 round-off of the reference's own dense product scales with |L|*|v| (cancellation:
     # L v is small for smooth v), so the tolerance is 2e-6 * max|diag| * max|v|, ~16 ulp
     tol_y = 2e-6 * np.abs(lap.diag).max() * np.abs(g["train_y"]).max()
@@ -79,6 +98,22 @@ def test_precision_and_wrappers(golden, case, norm):
     np.testing.assert_allclose(out, ref, atol=1e-3 * np.abs(ref).max())
     sol = np.linalg.solve(Q.dense(), g["train_y"].astype(np.float64))
     np.testing.assert_allclose(sol, g[p + "solve"], atol=2e-3 * np.abs(g[p + "solve"]).max())
+    # float64 oracle against the float64 run of the reference's dense operators: round-off only
+    y64, P64 = g["train_y"].astype(np.float64), g["probes"].astype(np.float64)
+
+    def close(a, key, tol=1e-10):
+        r = g[p + key]
+        np.testing.assert_allclose(a, r, rtol=0, atol=tol * np.abs(r).max())
+    for nu_ in nus:
+        Qn = PrecisionMaternOracle(lap64, nu_, float(g["kappa"]))
+        close(Qn.matmul(y64), f"Q{nu_}_mv_f64")
+        close(Qn.matmul(P64), f"Q{nu_}_mm_f64")
+    close(lap64.matmul(y64), "mv_f64", 1e-9)
+    close(lap64.matmul(y64, transposed=True), "mvT_f64", 1e-9)
+    close(ScaleWrapperOracle(Q, 0.7, inverse_scale=True).matmul(y64), "Qscaled_mv_f64")
+    close(NoiseWrapperOracle(Q, 1e-2).matmul(y64), "Qnoisy_mv_f64")
+    close(out, "schur_mv_f64", 1e-8)
+    close(sol, "solve_f64", 1e-8)
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -102,12 +137,21 @@ def test_spectrum_features_oos(golden, case, norm):
                           g["knn_test_I"].astype(np.int64), bs, bd)
     b = osp.bump_function(np.sqrt(g["knn_test_D"][:, 0].astype(np.float64)), bs * float(g["eps"]), bd)
     np.testing.assert_allclose(b, g[p + "oos_bump"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(b, g[p + "oos_bump_f64"], rtol=1e-7, atol=1e-12)   # eps: float32(0.05) here, 0.05 there
+    # float64 goldens (the same reference calls on .double() inputs): the oracle agrees to round-off, which is what
+    # lets the GPU tests hold the HIP path to fp32 round-off instead of the error of an fp32 dense eigh
+    np.testing.assert_allclose(evals[1:], g[p + "evals_raw_f64"][1:m], rtol=1e-9, atol=1e-9)
+    ref64 = g[p + "features_gram_64_f64"]
+    np.testing.assert_allclose(gram, ref64, rtol=0, atol=1e-8 * np.abs(ref64).max())
+    np.testing.assert_allclose((Z * Z).sum(-1), g[p + "features_diag_f64"], rtol=1e-8)
     # golden holds the un-bumped dense extension; compare Gram blocks (rotation invariant)
     ext = (Zt / np.where(b > 0, b, 1)[:, None]) @ Z[:64].T
     ref = g[p + "oos_gram"]
     sel = b > 0
     assert sel.any()
     np.testing.assert_allclose(ext[sel], ref[sel], atol=3e-3 * np.abs(ref).max())
+    ref64 = g[p + "oos_gram_f64"]
+    np.testing.assert_allclose(ext[sel], ref64[sel], rtol=0, atol=1e-8 * np.abs(ref64).max())
 
 
 def test_bump_known_answers(golden):
