@@ -130,6 +130,58 @@ def time_spmv_kernel(wl, reps=200):
     return best / reps * 1e-3   # seconds per launch
 
 
+def hbm_streaming_roofline(dev, order, reps=100):
+    """Secondary roofline on a working set that does NOT fit the 256 MiB Infinity Cache: config C5's graph
+    (1M-point swiss roll, k = 64, ~0.55 GB of CSR per SpMV).  One graph build + `reps` back-to-back launches of the
+    same fused C = 1 SpMV kernel, HIP events on the launch stream."""
+    a = argparse.Namespace(workload="s5", nodes=0, s5_order=order)
+    wl = build_workload(a, dev, 0, 1)
+    g = wl["graph"]
+    t_k = time_spmv_kernel(wl, reps=reps)
+    B = spmm_bytes(g.n, g.M)
+    out = dict(workload=wl["name"], nodes=g.n, edges=g.M, bytes_per_launch=B, avg_launch_us=round(t_k * 1e6, 2),
+               achieved=round(B / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(B / t_k / 1e9 / HBM_PEAK_GBS, 4),
+               tile_order=("input order" if g.tiles is None or g.tiles.get("rowid") is None else "locality order (Z-curve)"),
+               entries_per_dictionary_column=round(g.tiles["reuse"], 2) if g.tiles is not None else None,
+               knn_graph_build_s=round(wl["t_graph"], 3))
+    del wl
+    torch.cuda.empty_cache()
+    return out
+
+
+def multi_rhs_solve(wl, columns=100, tol=1e-2):
+    """The largest CG workload of training (precision_matern_operator.py:45-53, `_average_variance`): `columns`
+    random one-hot right-hand sides on Q itself, linear_cg's stopping rule at the notebooks' cg_tolerance."""
+    from manifold_gp_amd.solvers import CgPlan
+    g = wl["graph"]
+    dev = wl["y"].device
+    desc = wl["desc"].with_(scale=1.0, form=0, noise=0.0)
+    torch.manual_seed(1337)
+    idx = torch.randint(0, g.n - 1, (1, columns), device=dev)
+    B = torch.zeros(g.n, columns, device=dev).scatter_(0, idx, 1.0)
+    plan = CgPlan(desc, columns, tol=tol, max_iter=1000, stop_mode=0, check_every=10)
+    for _ in range(2):
+        X = plan.solve(B, copy=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        X = plan.solve(B, copy=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    its = plan.iters
+    spmm = (its + 1) * wl["nu"]
+    Bm = spmm_bytes(g.n, g.M, columns)
+    r = desc.apply(X) - B
+    out = dict(columns=columns, operator="Q = D^1/2 (2 nu / kappa^2 I + L_sym)^nu D^1/2", stop="linear_cg rule, tol %g" % tol,
+               iterations=its, solve_ms=round(dt * 1e3, 3), spmm_launches=spmm, spmm_bytes_per_launch=Bm,
+               spmm_gbs=round(Bm * spmm / dt / 1e9, 1), mean_rel_residual=float(np.mean(plan.resid)),
+               true_mean_rel_residual=float((r.norm(dim=0) / B.norm(dim=0)).mean()),
+               average_variance=float((X * B).sum() / columns))
+    plan.close()
+    return out
+
+
 def cpu_baseline(wl, gpu_iters):
     """Reference-style CPU path (oracle/ref_torch.py) on the host cores: SpMV rate and the same CG
     solve.  Bounded: 20 SpMVs + one CG solve (a few seconds at N=60k)."""
@@ -207,6 +259,7 @@ def _main(quiet):
     ap.add_argument("--workload", default="c3", choices=["c3", "s5"])
     ap.add_argument("--nodes", type=int, default=0, help="override nodes per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cg_multi_rhs / roofline_hbm blocks")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--s5-order", default="morton", choices=["random", "morton"])
     ap.add_argument("--refine", type=int, default=-1, help="CG refinement rounds (-1: 0 for c3, 3 for s5)")
@@ -275,12 +328,18 @@ def _main(quiet):
                       if B < 2.5e8 else "working set %.0f MB streams from HBM") % (B / 1e6))
     # HBM bytes per launch from the PMC passes of the same command (tools/profile.sh ->
     # tools/summarize_profile.py): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc) and args.workload == "c3" and not args.nodes:
-        try:
-            roof["traffic"] = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
-        except Exception:
-            pass
+    # NOT a run-time counter: the figure is read from the committed PMC summary of the same command
+    pmc_name = "r02_pmc_traffic.json" if args.workload == "c3" else "r02_s5_pmc_traffic.json"
+    for cand in (pmc_name, pmc_name.replace("r02", "r01")):
+        pmc = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(pmc) and not args.nodes:
+            try:
+                roof["traffic"] = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
+                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                                         "2 x FETCH_SIZE + WRITE_SIZE; not measured in this run)" % cand
+                break
+            except Exception:
+                pass
     line = dict(metric="CG-solve wall-time + SpMV HBM GB/s, N=60k RMNIST graph", value=round(value, 2),
                 unit="GB/s (algorithmic SpMV bytes inside the CG solve)", n_gpus=1, steps=args.steps,
                 warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
@@ -290,6 +349,17 @@ def _main(quiet):
                             cg_tol=args.tol, cg_iters=its, cg_rel_residual=resid, cg_true_residual_fp32_apply=true_res,
                             spmv_per_solve=spmvs_per_solve, eps=wl["eps"], knn_graph_build_s=round(wl["t_graph"], 3)),
                 cg_solve_ms=round(dt / args.steps * 1e3, 4), roofline=roof)
+    if args.workload == "c3" and not args.nodes and not args.no_extras:
+        line["cg_multi_rhs"] = multi_rhs_solve(wl)
+        hb = hbm_streaming_roofline(dev, "morton")
+        hb["random_order_input"] = {k: v for k, v in hbm_streaming_roofline(dev, "random").items()
+                                    if k in ("avg_launch_us", "achieved", "frac", "tile_order", "entries_per_dictionary_column")}
+        pmc = os.path.join(ROOT, "profiles", "r02_s5_pmc_traffic.json")
+        hb["traffic"], hb["traffic_source"] = None, None
+        if os.path.exists(pmc):
+            hb["traffic"] = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
+            hb["traffic_source"] = "profiles/r02_s5_pmc_traffic.json (bench.py --workload s5 under rocprofv3 --pmc)"
+        line["roofline_hbm"] = hb
     if not args.no_cpu_baseline:
         cb, xs = cpu_baseline(wl, its)
         line["cpu_baseline"] = cb

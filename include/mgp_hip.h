@@ -278,6 +278,10 @@ int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, floa
                       int32_t* status); /* status 1 converged, 2 max_iter, 3 breakdown (NaN) */
 float* mgp_cg_plan_x(void* plan);    /* device pointer of the plan's own solution buffer [n,C]; pass
                                          X = NULL to mgp_cg_plan_solve to skip the copy into X */
+/* refined solves (max_refine > 0, single GPU) accumulate the solution in float64 and form the true residual
+ * from it; the float32 buffer above holds its rounding.  Device pointer of that float64 solution [n,C]
+ * (valid after a refined solve, until the next solve); NULL for a distributed plan. */
+double* mgp_cg_plan_x64(void* plan);
 /* operator applies the last solve actually ran (refinement off).  A plan's first graph is captured for the
  * step count its previous solves needed; for C = 1 its last step -- the one that would only notice
  * ||r|| <= tol after running one more apply for nothing -- is a single-workgroup decision launch, so a

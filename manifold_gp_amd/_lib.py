@@ -111,6 +111,7 @@ SIGNATURES = {
                                    POINTER(c_void_p)]),
     "mgp_cg_plan_solve": (c_int, [_P, _P, _P, POINTER(c_int32), POINTER(c_float), POINTER(c_int32)]),
     "mgp_cg_plan_x": (c_void_p, [_P]),
+    "mgp_cg_plan_x64": (c_void_p, [_P]),
     "mgp_cg_plan_last_applies": (c_int, [_P]),
     "mgp_cg_plan_destroy": (c_int, [_P]),
     "mgp_dist_unique_id_bytes": (c_int, []),

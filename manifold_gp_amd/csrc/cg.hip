@@ -1323,6 +1323,11 @@ extern "C" float* mgp_cg_plan_x(void* plan) {
   return pl ? pl->args.x : nullptr;
 }
 
+extern "C" double* mgp_cg_plan_x64(void* plan) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  return (pl && !pl->is_dist) ? pl->xacc64 : nullptr;
+}
+
 extern "C" int mgp_cg_plan_destroy(void* plan) {
   CgPlan* pl = static_cast<CgPlan*>(plan);
   if (!pl) return MGP_ERR_ARG;

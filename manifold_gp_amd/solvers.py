@@ -58,6 +58,16 @@ class CgPlan:
             self._xview = self.work[off:off + nb].view(torch.float32).view(self.desc.n, self.C)
         return self._xview
 
+    def solution64_view(self):
+        """The float64 solution a refined solve accumulated (mgp_cg_plan_x64): view [n, C], overwritten by the
+        next solve.  Its float32 rounding is what solve() returns."""
+        p = lib().mgp_cg_plan_x64(self.handle)
+        if not p or self.params.max_refine <= 0:
+            raise RuntimeError("no float64 solution: the plan was created without refinement")
+        off = int(p) - self.work.data_ptr()
+        nb = self.desc.n * self.C * 8
+        return self.work[off:off + nb].view(torch.float64).view(self.desc.n, self.C)
+
     def solve(self, B, out=None, copy=True):
         _lib.require_device(B)
         B = _lib.f32c(B)

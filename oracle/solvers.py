@@ -96,3 +96,44 @@ def rmse_nll(error, cov):                                     # test_model.py:20
     iq = error @ np.linalg.solve(cov, error)
     nll = 0.5 * (iq + logdet + error.size * np.log(2 * np.pi)) / error.size
     return rmse, nll
+
+
+def lanczos_tridiag_f64(matmul, q0, steps):
+    """k-step Lanczos with full re-orthogonalisation in float64 (linear_operator.utils.lanczos_tridiag restated;
+    third-party, parity unpinned): returns (alpha[steps], beta[steps - 1])."""
+    q = np.asarray(q0, np.float64)
+    q = q / np.linalg.norm(q)
+    Q = [q]
+    alpha, beta = [], []
+    for j in range(steps):
+        w = matmul(Q[j])
+        a = float(Q[j] @ w)
+        w = w - a * Q[j] - (beta[-1] * Q[j - 1] if j > 0 else 0.0)
+        for _ in range(2):
+            for qq in Q:
+                w = w - (qq @ w) * qq
+        alpha.append(a)
+        b = float(np.linalg.norm(w))
+        if j + 1 < steps:
+            if b < 1e-12 * max(abs(a), 1e-300):
+                break
+            beta.append(b)
+            Q.append(w / b)
+    return np.array(alpha), np.array(beta[:len(alpha) - 1])
+
+
+def slq_logdet_same_probes(matmul, Z, steps, fun=None):
+    """Stochastic Lanczos quadrature of log det with GIVEN probes (columns of Z, ||z||^2 = n):
+    (n / P) sum_p e_1^T log(fun(T_p)) e_1 -- the estimator linear_operator's StochasticLQ evaluates behind
+    `inv_quad_logdet(logdet=True)` (train_model.py:68), restated in float64 so that a device estimate made with the
+    SAME probes can be compared with it tightly (the Monte-Carlo error cancels)."""
+    Z = np.asarray(Z, np.float64)
+    n, P = Z.shape
+    total = 0.0
+    for p in range(P):
+        a, b = lanczos_tridiag_f64(matmul, Z[:, p], steps)
+        T = np.diag(a) + np.diag(b, 1) + np.diag(b, -1)
+        theta, S = np.linalg.eigh(T)
+        theta = fun(theta) if fun is not None else theta
+        total += float(np.sum(S[0, :] ** 2 * np.log(np.maximum(theta, 1e-300))))
+    return n * total / P

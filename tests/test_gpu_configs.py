@@ -1,0 +1,354 @@
+"""GPU parity at the sizes of BASELINE.json's configurations (C2, C3, C4, C5).
+
+tests/test_gpu_parity.py holds the goldens (C1) and the edge cases; this file runs every other configuration at
+its full size through the package classes (-> ctypes -> C-ABI) and checks it against the CPU oracle evaluated on
+the same inputs: the C oracle for sampled k-NN rows (bit-exact), oracle/laplacian.py + oracle/sparse.py in
+float64 for products / solves / eigenvalues, oracle/solvers.py for the GP posterior.  Tolerances are written at
+each assert; the north-star bar is 1e-4 relative for eigenvalues, kernel entries and posterior mean / variance.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def mgp():
+    import manifold_gp_amd
+    from manifold_gp_amd import _lib
+    _lib.lib()
+    return manifold_gp_amd
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _hp(name):
+    with open(os.path.join(ROOT, "tests", "golden", "hyperparameters.json")) as fh:
+        return json.load(fh)[name]
+
+
+def _oracle_lap(graph, eps, norm, self_loops=True):
+    from oracle.laplacian import LaplacianOracle
+    return LaplacianOracle(graph.edge_value.cpu().numpy(), graph.edge_index.cpu().numpy(), graph.n, eps, norm, self_loops,
+                           dtype=np.float64)
+
+
+def _knn_rows_bit_exact(x_np, D, I, k, rows):
+    from oracle import knn as oknn
+    Dr, Ir = oknn.knn_search(x_np, x_np[rows], k)
+    assert np.array_equal(I[rows].cpu().numpy(), Ir)
+    assert np.array_equal(D[rows].cpu().numpy(), Dr)
+
+
+# ============================================================================= C2
+@pytest.mark.parametrize("eps_rule", ["reference_default", "data_scaled"])
+def test_c2_dumbbell_10k_spmv_and_eigensolve(mgp, dev, eps_rule):
+    """C2 (benchmark/bench_sparse_laplacian.py:37-72 shape): dumbbell resampled to N = 10 000, k = 50, symmetric,
+    nu = 1, 100 modes, v = rand(N) with seed 1337.  k-NN rows bit-exact; `mv` against the float64 oracle; the 100
+    smallest eigenvalues against a dense float64 eigvalsh of the oracle's L_sym (what riemann_kernel.py:121-125 does,
+    in double); residuals and orthogonality of the vectors; the Lanczos branch of diagonalization()."""
+    from manifold_gp_amd.solvers import lanczos_smallest
+    from oracle.sparse import SparsePrecision, laplacian_sym_csr
+    from tools import synth
+    n, k, m = 10000, 50, 100
+    x_np, y_np, _ = synth.dumbbell_resampled(n)
+    x = T(x_np, dev)
+    knn = mgp.utils.NearestNeighbors(x)
+    D, I = knn.search(x, k)
+    _knn_rows_bit_exact(x_np, D, I, k, np.random.default_rng(0).choice(n, 400, replace=False))
+    idx, val = knn.graph(k)
+    graph = knn.knn_graph
+    assert 0.5 * n * (k - 1) <= graph.M <= n * (k - 1)
+    if eps_rule == "reference_default":
+        eps = float(np.log(2.0))                                   # softplus(0): riemann_kernel.py:53
+    else:
+        eps = synth.bandwidth_rule(D[:, 1].cpu().numpy(), 0.0)[0]  # notebooks' eps_min rule
+    op = mgp.operators.GraphLaplacianOperator(val, idx, n, torch.tensor([[eps]], device=dev), "symmetric", graph=graph)
+    lo = _oracle_lap(graph, eps, "symmetric")
+    # ---- mv (bench_sparse_laplacian.py:15-19,63-64)
+    torch.manual_seed(1337)
+    v = torch.rand(n)
+    ref = laplacian_sym_csr(lo) @ v.double().numpy()
+    out = op.matmul(v.to(dev).view(-1, 1)).squeeze(-1).cpu().numpy()
+    lmax = 2.0 * float(np.abs(lo.diag).max())
+    # fp32 round-off scale of L: its entries are differences of O(1) terms divided by eps^2 -- diag = (1 - Dt^-2 / D) / eps^2
+    # (graph_laplacian_operator.py:94) -- so a few ulps of 1 / eps^2; with the data-scaled bandwidth every weight is
+    # <= 1e-4, |L| ~ 2e-4 / eps^2 and that cancellation (the reference's own, it computes in fp32) dominates |L| ulps
+    ulp = max(2e-6 * lmax, 4e-7 / eps ** 2)
+    assert np.abs(out - ref).max() < ulp, (np.abs(out - ref).max(), ulp)
+    # ---- eigen (bench_sparse_laplacian.py:30-34; riemann_kernel.py:121-125 in float64)
+    w = torch.linalg.eigvalsh(T(laplacian_sym_csr(lo).toarray(), dev))[:m + 4].cpu().numpy()      # float64, 800 MB
+    evals, evecs, resid = lanczos_smallest(op.data, m, tol=1e-6)
+    ev = evals.cpu().numpy().astype(np.float64)
+    assert np.abs(ev - w[:m]).max() < ulp, (np.abs(ev - w[:m]).max(), ulp)           # |lambda(L + dL) - lambda(L)| <= |dL|
+    assert max(resid) <= 2e-6 * lmax
+    V = evecs.double()
+    assert float((V.t() @ V - torch.eye(m, device=dev, dtype=torch.float64)).abs().max()) < 5e-5
+    R = laplacian_sym_csr(lo) @ V.cpu().numpy() - V.cpu().numpy() * ev[None, :]       # residuals re-evaluated by the oracle
+    assert np.linalg.norm(R, axis=0).max() <= 2 * ulp + 2e-6 * lmax
+    # ---- diagonalization(): N > max_cholesky_size -> the iterative branch (graph_laplacian_operator.py:132-144)
+    ev2, U2 = op.diagonalization(num_modes=m)
+    assert float(ev2[0]) == 0.0 and U2.shape == (n, m)
+    assert np.abs(ev2.cpu().numpy()[1:] - w[1:m]).max() < 1e-4 * lmax + ulp
+    # ---- precision (nu = 1) product and a CG solve of the bench's operator against the float64 oracle
+    kappa = 0.7
+    Q = mgp.operators.PrecisionMaternOperator(op, 1, torch.tensor([[kappa]], device=dev))
+    sq = SparsePrecision(lo, 1, kappa)
+    yv = T(y_np, dev)
+    refq = sq.matmul(y_np.astype(np.float64))
+    assert np.abs(Q.matmul(yv).cpu().numpy() - refq).max() < 2 * ulp * float(np.abs(y_np).max())
+    if eps_rule == "reference_default":
+        # (with the data-scaled bandwidth the fp32 Laplacian is the fp64 one perturbed by ~1e-4 |L| -- see `ulp` -- and
+        # cond(Q) ~ 6e3: a solve with it is a solve with another matrix; the products above are what can be compared)
+        with mgp.settings.cg_tolerance(1e-7), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(20000):
+            sol = Q.solve(yv).cpu().numpy()
+        refs = sq.solve(y_np.astype(np.float64))
+        assert np.abs(sol - refs).max() < 1e-4 * np.abs(refs).max(), np.abs(sol - refs).max() / np.abs(refs).max()
+
+
+# ============================================================================= C3 / C4 (shared 60k graph)
+@pytest.fixture(scope="module")
+def rmnist60k(mgp, dev):
+    """S3/S4 of SURVEY.md section 8(d): RMNIST-like 606 bases x 100 rotations; 600 random rows are held out as test
+    points, the other 60 000 are the graph nodes.  k = 50, random walk, nu = 2, 100 modes, trained hyper-parameters
+    (models/srmnist_manifold_semisupervised.pth) with the bandwidth floored by the notebooks' eps_min rule."""
+    from tools import synth
+    x_all, y_all = synth.rmnist_like(606, 100, seed=1337, device=dev)
+    rng = np.random.default_rng(1337)
+    perm = rng.permutation(x_all.shape[0])
+    test_rows, train_rows = np.sort(perm[:600]), np.sort(perm[600:])
+    x, y = x_all[T(train_rows, dev)].contiguous(), y_all[T(train_rows, dev)].contiguous()
+    xt, yt = x_all[T(test_rows, dev)].contiguous(), y_all[T(test_rows, dev)].contiguous()
+    hp = _hp("srmnist_manifold_semisupervised")
+    kern = mgp.kernels.RiemannMaternKernel(nu=2, x=x, nearest_neighbors=50, laplacian_normalization="randomwalk",
+                                           num_modes=100, bump_scale=3.0, bump_decay=0.01).to(dev)
+    D, I = kern.knn.search(x, 50)
+    eps, eps_min = synth.bandwidth_rule(D[:, 1].cpu().numpy(), hp["graphbandwidth"])
+    kern.initialize(graphbandwidth=eps, lengthscale=hp["lengthscale"])
+    return dict(x=x, y=y, xt=xt, yt=yt, kern=kern, hp=hp, eps=eps, D=D, I=I)
+
+
+def test_c3_rmnist_60k_knn_spectrum_posterior(mgp, dev, rmnist60k):
+    """C3, the north-star target at its size: 60 000 x 784 points, k = 50.
+      * 256 sampled rows of the 60k x 60k k-NN search (matrix-core keys + fp64 re-rank) bit-exact vs the C oracle;
+      * L v against the float64 oracle;
+      * eval(): residuals of sampled eigenpairs re-evaluated by the float64 oracle;
+      * GP posterior mean / covariance at 600 held-out points (out-of-sample features, Woodbury on device, covariance
+        block on the MFMA) within 1e-4 of the float64 closed form on the same features (oracle/solvers.py; what
+        gpytorch evaluates for the reference: riemann_gp.py:45-75);
+      * the posterior mean at the graph nodes in precision form -- the CG solve of (K + s I) x = y, K = Q^-1 --
+        within 1e-4 of a float64 CG on the oracle's operator."""
+    from manifold_gp_amd.models import GaussianLikelihood, RiemannGP, ScaleKernel
+    from manifold_gp_amd.solvers import cg_solve, kernel_block, lowrank_solve
+    from oracle.solvers import gp_posterior_lowrank
+    from oracle.sparse import SparsePrecision
+    w = rmnist60k
+    x, y, xt, kern, hp, eps = w["x"], w["y"], w["xt"], w["kern"], w["hp"], w["eps"]
+    n = x.shape[0]
+    assert n == 60000 and x.shape[1] == 784
+    x_np = x.cpu().numpy()
+    rows = np.random.default_rng(5).choice(n, 256, replace=False)
+    _knn_rows_bit_exact(x_np, w["D"], w["I"], 50, rows)                       # nearest_neighbors.py:35-37
+    graph = kern.knn.knn_graph
+    lo = _oracle_lap(graph, eps, "randomwalk")
+    sq = SparsePrecision(lo, 2, hp["lengthscale"], hp["outputscale"])
+    lmax = 2.0 * float(np.abs(lo.diag).max())
+    # ---- SpMV, both orientations
+    v = torch.randn(n, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():                                  # (the kernel's bandwidth is a Parameter)
+        lap = kern.laplacian()
+        for op, tr in ((lap, False), (lap.T, True)):
+            ref = sq.laplacian_matmul(v.double().numpy(), transposed=tr)
+            out = op.matmul(v.to(dev)).cpu().numpy()
+            assert np.abs(out - ref).max() < 4e-6 * lmax * float(v.abs().max()), tr
+    # ---- eval(): eigenpairs of L_sym (riemann_kernel.py:117-130); phi = normalise(D^-1/2 u)
+    kern.eval()
+    assert float(kern.eigval[0]) == 0.0 and kern.eigvec.shape == (n, 100)
+    assert max(kern.eigen_residuals) <= 2e-5 * lmax
+    cols = [0, 1, 2, 49, 98, 99]
+    Phi = kern.eigvec[:, cols].double().cpu().numpy()
+    U = Phi * np.sqrt(lo.degree)[:, None]
+    U /= np.linalg.norm(U, axis=0, keepdims=True)
+    lam = kern.eigval[cols].double().cpu().numpy()
+    lam[0] = float(U[:, 0] @ (sq.L @ U[:, 0]))                              # eigval[0] is SET to 0 (:126)
+    R = sq.L @ U - U * lam[None, :]
+    assert np.linalg.norm(R, axis=0).max() <= 3e-5 * lmax, np.linalg.norm(R, axis=0) / lmax
+    # ---- spectral posterior at 600 held-out points
+    s, noise = hp["outputscale"], hp["noise"]
+    model = RiemannGP(x, y, GaussianLikelihood(noise).to(dev), ScaleKernel(kern, s).to(dev)).to(dev)
+    model.eval()
+    model.posterior(xt)
+    Z, Zt = kern.features(x), kern.features(xt)
+    assert float((Zt.abs().sum(1) > 0).float().mean()) > 0.9                 # the held-out points lie in the bump support
+    mean_o, cov_o, alpha_o = gp_posterior_lowrank(Z.cpu().numpy(), y.cpu().numpy(), Zt.cpu().numpy(), s, noise)
+    mean, cov = model.posterior_mean.cpu().numpy(), model.posterior_covar.cpu().numpy()
+    e_mean = np.abs(mean - mean_o).max() / np.abs(mean_o).max()
+    e_cov = np.abs(cov - cov_o).max() / np.abs(cov_o).max()
+    e_var = np.abs(np.diag(cov) - np.diag(cov_o)).max() / np.abs(np.diag(cov_o)).max()
+    print("C3 posterior: mean %.2e cov %.2e var %.2e" % (e_mean, e_cov, e_var))
+    assert e_mean < 1e-4 and e_cov < 1e-4 and e_var < 1e-4, (e_mean, e_cov, e_var)
+    alpha = lowrank_solve(Z, y, s, noise).cpu().numpy()                      # (K + noise I)^-1 y at the nodes
+    assert np.abs(alpha - alpha_o).max() < 1e-4 * np.abs(alpha_o).max()
+    # kernel entries: 256 x 60000 and 600 x 60000 blocks of s Z1 Z2^T on the fp32 MFMA against float64 (riemann_kernel.py:92-100)
+    Zd = Z.double()
+    for Z1 in (Z[T(rows, dev)].contiguous(), Zt):
+        Kb = kernel_block(Z1, Z, s).double()
+        Kr = s * (Z1.double() @ Zd.t())
+        assert float((Kb - Kr).abs().max()) < 2e-6 * float(Kr.abs().max())
+    # ---- precision form: (I + noise s Q) x = y by the HIP CG vs float64 CG on the oracle's operator
+    with torch.no_grad():
+        desc = kern.precision()._descriptor().with_(scale=s, form=2, noise=noise)
+        sol, its, res = cg_solve(desc, y, tol=1e-6, stop_mode=1)
+    ref = sq.solve(y.double().cpu().numpy(), matvec=lambda z: sq.posterior_system(z, noise))
+    e_cg = np.abs(sol.cpu().numpy() - ref).max() / np.abs(ref).max()
+    print("C3 precision-form CG: %d iterations, rel err %.2e" % (its, e_cg))
+    assert e_cg < 1e-4 and max(res) <= 1e-6
+
+
+def test_c4_semisupervised_60k_schur(mgp, dev, rmnist60k):
+    """C4: the same 60k graph, 10 % labelled (randperm seed 1337, examples/RMNIST_semisupervised_learning.ipynb:65,99-101).
+    Schur complement matvec (schur_complement_operator.py:26-30, nested HIP CG on the 54k unlabelled block) against
+    the float64 oracle with a converged inner solve; symmetry; S.solve by block elimination: true residual; two
+    epochs of manifold_informed_train (precision-form loss with the Schur complement inside): finite, decreasing."""
+    from manifold_gp_amd.models import GaussianLikelihood, RiemannGP, ScaleKernel
+    from manifold_gp_amd.utils import manifold_informed_train
+    from oracle.sparse import SparsePrecision
+    w = rmnist60k
+    x, y, kern, hp, eps = w["x"], w["y"], w["kern"], w["hp"], w["eps"]
+    n = x.shape[0]
+    torch.manual_seed(1337)
+    labeled = torch.zeros(n, dtype=torch.bool, device=dev)
+    labeled[torch.randperm(n, device=dev)[: n // 10]] = True
+    assert int(labeled.sum()) == 6000
+    mask = labeled.cpu().numpy()
+    Q = kern.precision()
+    S = mgp.operators.SchurComplementOperator(Q, labeled)
+    assert tuple(S.shape) == (6000, 6000)
+    lo = _oracle_lap(kern.knn.knn_graph, eps, "randomwalk")
+    sq = SparsePrecision(lo, 2, hp["lengthscale"])
+    v = y[labeled].contiguous()
+    gen = torch.Generator().manual_seed(3)
+    u = torch.randn(6000, generator=gen).to(dev)
+    with torch.no_grad(), mgp.settings.cg_tolerance(1e-7), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(20000):
+        Sv, Su = S.matmul(v), S.matmul(u)
+        ref = sq.schur_matmul(v.double().cpu().numpy(), mask)
+        e_mv = np.abs(Sv.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert e_mv < 1e-4, e_mv
+        sym = abs(float(torch.dot(u, Sv) - torch.dot(v, Su))) / float(Sv.norm() * u.norm())
+        assert sym < 1e-5, sym
+        xs = S.solve(v)
+        r = S.matmul(xs) - v
+        assert float(r.norm() / v.norm()) < 1e-4
+    full = np.zeros(n)
+    full[mask] = v.double().cpu().numpy()
+    ref_x = sq.solve(full)[mask]                                              # block elimination: (Q^-1 [b; 0])_l = S^-1 b
+    e_solve = np.abs(xs.cpu().numpy() - ref_x).max() / np.abs(ref_x).max()
+    print("C4: Schur matvec err %.2e, symmetry %.2e, solve err %.2e" % (e_mv, sym, e_solve))
+    assert e_solve < 1e-4
+    # ---- two epochs of the semi-supervised training loop (train_model.py:49-109)
+    kern2 = mgp.kernels.RiemannMaternKernel(nu=2, x=x, nearest_neighbors=50, laplacian_normalization="randomwalk",
+                                            num_modes=100).to(dev)
+    kern2.initialize(graphbandwidth=eps, lengthscale=hp["lengthscale"])
+    model = RiemannGP(x[labeled], y[labeled], GaussianLikelihood(hp["noise"]).to(dev),
+                      ScaleKernel(kern2, hp["outputscale"]).to(dev), labeled=labeled).to(dev)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
+    losses = []
+
+    class Rec:
+        def step(self, loss):
+            losses.append(float(loss.detach()))
+    torch.manual_seed(0)
+    last = manifold_informed_train(model, opt, max_iter=2, tolerance=0.0, num_rand_vec=32, max_cholesky=800,
+                                   cg_tolerance=1e-2, cg_max_iter=1000, scheduler=Rec())
+    print("C4 training losses", losses)
+    assert len(losses) == 3 and all(np.isfinite(losses)) and np.isfinite(last)
+    assert losses[-1] < losses[0]
+
+
+# ============================================================================= C5
+def test_c5_swiss_roll_1m_pipeline(mgp, dev):
+    """C5: 1 000 000 points on a swiss roll in R^3 handed over in random order, k = 64, symmetric, nu = 2.
+    400 sampled k-NN rows bit-exact; the graph picks a locality order for its tiles; L v against the float64
+    oracle at full size; adjoint and linearity properties of the precision; CG with fp64-residual refinement:
+    TRUE relative residual (re-evaluated by the float64 oracle) <= a few 1e-6."""
+    from manifold_gp_amd.solvers import CgPlan
+    from oracle.sparse import SparsePrecision
+    from tools import synth
+    n, k = 1000000, 64
+    x_np, y_np = synth.swiss_roll(n, order="random")
+    x, y = T(x_np, dev), T(y_np, dev)
+    knn = mgp.utils.NearestNeighbors(x)
+    D, I = knn.search(x, k)
+    assert knn.last_stats["candidates"] == -1                                  # the slab-free low-d path
+    _knn_rows_bit_exact(x_np, D, I, k, np.random.default_rng(9).choice(n, 400, replace=False))
+    assert bool((I[:, 0] == torch.arange(n, device=dev)).all())
+    idx, val = knn.graph(k)
+    g = knn.knn_graph
+    assert 0.5 * n * (k - 1) <= g.M <= n * (k - 1)
+    assert g.tiles is not None and g.tiles.get("rowid") is not None and g.tiles["reuse"] > 5   # locality order applied
+    eps_min = synth.bandwidth_rule(D[:200000, 1].cpu().numpy(), 0.0)[1]
+    eps = 3.0 * eps_min
+    del D, I
+    lap = mgp.operators.GraphLaplacianOperator(val, idx, n, torch.tensor([[eps]], device=dev), "symmetric", graph=g)
+    lo = _oracle_lap(g, eps, "symmetric")
+    kappa, s, noise = 1.0, 1.0, 0.01
+    sq = SparsePrecision(lo, 2, kappa, s)
+    lmax = 2.0 * float(np.abs(lo.diag).max())
+    v = torch.randn(n, generator=torch.Generator().manual_seed(2))
+    ref = sq.L @ v.double().numpy()
+    out = lap.matmul(v.to(dev)).cpu().numpy()
+    assert np.abs(out - ref).max() < 4e-6 * lmax * float(v.abs().max())
+    Q = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[kappa]], device=dev))
+    a, b = torch.randn(n, device=dev), torch.randn(n, device=dev)
+    Qa, Qb = Q.matmul(a), Q.matmul(b)
+    assert abs(float(torch.dot(b.double(), Qa.double()) - torch.dot(a.double(), Qb.double()))) < 1e-5 * float(Qa.norm() * b.norm())
+    lin = Q.matmul(2.0 * a - 3.0 * b) - (2.0 * Qa - 3.0 * Qb)
+    assert float(lin.norm()) < 1e-5 * float(Qa.norm() + Qb.norm())
+    # ---- posterior mean in precision form: (I + noise s Q) x = y, fp32 CG + fp64-residual refinement
+    desc = Q._descriptor().with_(scale=s, form=2, noise=noise)
+    plan = CgPlan(desc, 1, tol=1e-6, max_iter=5000, stop_mode=1, check_every=8, refine=3)
+    sol = plan.solve(y.view(-1, 1).contiguous()).clone()
+    assert plan.status == 1 and max(plan.resid) <= 2e-6, (plan.status, plan.resid)
+    # the refined solve accumulates x in float64 (mgp_cg_plan_x64); what solve() returns is its float32 rounding.
+    # At this conditioning (noise |Q| ~ 1e3..1e4) rounding x to float32 alone moves the residual by ~1e-4, so the TRUE
+    # residual is re-evaluated by the float64 oracle on the float64 solution
+    x64 = plan.solution64_view()[:, 0]
+    assert torch.equal(x64.float(), sol[:, 0])
+    # The system that is solved is the one with the fp32 Laplacian the path stores (as the reference does); its
+    # entries were checked against the float64 oracle above.  TRUE residual of THAT system, re-evaluated on the host
+    # in float64 from the device's CSR arrays (independent of the device's fp64 apply kernel):
+    import scipy.sparse as sp
+    d = lap.data
+    S_dev = sp.csr_matrix((d.vals.double().cpu().numpy(), g.col.cpu().numpy(), g.rowptr.cpu().numpy()), shape=(n, n))
+    L_dev = sp.diags(d.diag.double().cpu().numpy()) - S_dev
+    tau = 2.0 * 2 / kappa ** 2
+
+    def A_dev(z):
+        t = z
+        for _ in range(2):
+            t = tau * t + L_dev @ t
+        return z + noise * s * t
+    yd = y_np.astype(np.float64)
+    xd = x64.cpu().numpy()
+    true_rel = float(np.linalg.norm(yd - A_dev(xd)) / np.linalg.norm(yd))
+    rel32 = float(np.linalg.norm(yd - A_dev(sol[:, 0].double().cpu().numpy())) / np.linalg.norm(yd))
+    rel_oracle = float(np.linalg.norm(yd - sq.posterior_system(xd, noise)) / np.linalg.norm(yd))
+    print("C5: CG %d iterations; true relative residual %.2e (plan reports %.2e); of the float32 rounding of x: %.2e; "
+          "against the float64-evaluated matrix: %.2e" % (plan.iters, true_rel, max(plan.resid), rel32, rel_oracle))
+    assert true_rel <= 3e-6, true_rel
+    assert rel_oracle <= 1e-3                     # fp32 storage of the matrix: ~1e-7 |A| |x| / |y|
+    plan.close()

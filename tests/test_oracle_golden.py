@@ -187,3 +187,53 @@ def test_knn_ties_and_duplicates():
     assert I[4].tolist() == [0, 4, 1, 2]
     Dn, In = oknn.knn_search_numpy(x, x, 4)
     assert np.array_equal(I, In) and np.array_equal(D, Dn)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("norm", NORMS)
+def test_sparse_form_of_the_oracle(golden, case, norm):
+    """oracle/sparse.py (the scipy CSR form used by the at-size GPU checks) against the float64 goldens and the
+    matrix-free oracle: products, Schur complement, solve, smallest eigenvalues."""
+    from oracle.sparse import SparsePrecision, smallest_eigenvalues
+    g = golden(case)
+    p = norm + "_"
+    lap64 = _lap(g, norm, np.float64)
+    y64 = g["train_y"].astype(np.float64)
+
+    def close(a, key, tol=1e-10):
+        r = g[p + key]
+        np.testing.assert_allclose(a, r, rtol=0, atol=tol * np.abs(r).max())
+    nus = sorted(int(k[len(p) + 1:-7]) for k in g if k.startswith(p + "Q") and k.endswith("_mv_f64") and k[len(p) + 1:-7].isdigit())
+    for nu in nus:
+        sq = SparsePrecision(lap64, nu, float(g["kappa"]))
+        close(sq.matmul(y64), f"Q{nu}_mv_f64")
+        close(sq.matmul(g["probes"].astype(np.float64)), f"Q{nu}_mm_f64")
+    sq = SparsePrecision(lap64, nus[0], float(g["kappa"]))
+    close(sq.laplacian_matmul(y64), "mv_f64", 1e-9)
+    close(sq.laplacian_matmul(y64, transposed=True), "mvT_f64", 1e-9)
+    mask = g[p + "schur_mask"]
+    close(sq.schur_matmul(y64[mask], mask), "schur_mv_f64", 1e-8)
+    close(sq.solve(y64), "solve_f64", 1e-8)
+    m = int(g["modes"])
+    np.testing.assert_allclose(smallest_eigenvalues(_lap(g, "symmetric", np.float64), m)[1:], g[p + "evals_raw_f64"][1:m],
+                               rtol=1e-9, atol=1e-9)
+
+
+def test_slq_oracle_against_dense_logdet():
+    """oracle/solvers.py::slq_logdet_same_probes (the checker of the device SLQ): exact when the Krylov space is
+    exhausted, within Monte-Carlo error of the dense log-determinant otherwise; spectral functions via `fun`."""
+    from oracle.solvers import lanczos_tridiag_f64, slq_logdet_same_probes
+    rng = np.random.default_rng(0)
+    n = 120
+    B = rng.normal(size=(n, n))
+    A = B @ B.T / n + np.eye(n)
+    a, b = lanczos_tridiag_f64(lambda v: A @ v, rng.normal(size=n), n)
+    Tm = np.diag(a) + np.diag(b, 1) + np.diag(b, -1)
+    np.testing.assert_allclose(np.linalg.eigvalsh(Tm), np.linalg.eigvalsh(A), rtol=1e-8)       # full Lanczos = similarity
+    Z = rng.choice([-1.0, 1.0], size=(n, 400))
+    want = np.linalg.slogdet(A)[1]
+    assert abs(slq_logdet_same_probes(lambda v: A @ v, Z, 30) - want) < 0.02 * abs(want)
+    sn = 0.05
+    P = A - sn * A @ A + sn * sn * A @ A @ A
+    got = slq_logdet_same_probes(lambda v: A @ v, Z, 30, fun=lambda th: th - sn * th * th + sn * sn * th ** 3)
+    assert abs(got - np.linalg.slogdet(P)[1]) < 0.03 * abs(np.linalg.slogdet(P)[1])

@@ -129,3 +129,39 @@ def bandwidth_rule(knn_d2_first, floor):
     every node keeps a nearest-neighbour weight >= 1e-4: eps_min = sqrt(max_i d2_i,1nn / (-4 ln 1e-4))."""
     eps_min = float(np.sqrt(np.max(knn_d2_first) / (-4.0 * np.log(1e-4))))
     return max(float(floor), eps_min), eps_min
+
+
+def dumbbell_resampled(n, path=None):
+    """S2 of SURVEY.md section 8(d): the closed dumbbell polyline of the reference's 1-D dataset (1556 nodes, data
+    fixture tests/golden/dumbbell.npz = manifold_gp/data/dumbbell.msh) resampled uniformly by arc length to n points;
+    y = 2 sin(1.5 * geodesic distance from node 0) (load_dataset.py:100-104; on a closed curve the geodesic is the
+    shorter of the two arcs).  Returns x [n, 2] f32, y [n] f32, total length."""
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "dumbbell.npz")
+    d = np.load(path)
+    pts, seg = d["x"].astype(np.float64), d["segments"].astype(np.int64)
+    nbr = [[] for _ in range(len(pts))]
+    for a, b in seg:
+        nbr[a].append(b)
+        nbr[b].append(a)
+    order, prev, cur = [0], -1, 0
+    while True:
+        nxt = [v for v in nbr[cur] if v != prev]
+        nxt = nxt[0] if nxt else nbr[cur][0]
+        if nxt == 0:
+            break
+        order.append(nxt)
+        prev, cur = cur, nxt
+    assert len(order) == len(pts), "the polyline is not one closed curve"
+    loop = pts[order + [0]]
+    segl = np.linalg.norm(np.diff(loop, axis=0), axis=1)
+    cum = np.concatenate([[0.0], np.cumsum(segl)])
+    total = cum[-1]
+    s = np.arange(n) * (total / n)
+    j = np.minimum(np.searchsorted(cum, s, side="right") - 1, len(segl) - 1)
+    t = (s - cum[j]) / segl[j]
+    x = loop[j] * (1 - t)[:, None] + loop[j + 1] * t[:, None]
+    geo = np.minimum(s, total - s)
+    y = 2.0 * np.sin(1.5 * geo)
+    return x.astype(np.float32), y.astype(np.float32), float(total)
