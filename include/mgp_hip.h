@@ -270,6 +270,11 @@ size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);
  * operator apply (one kernel less per step).  Experiment, default 0 (no gain measured at N = 60k);
  * affects plans created afterwards. */
 int mgp_cg_set_fuse(int on);
+/* C == 1 plans on the tile SpMV without a preconditioner start WITHOUT a cg_init launch: the first operator apply
+ * reads the right-hand side itself, copies it to r and leaves ||b||^2 as partials; the first update treats p, s, x
+ * as zero.  One launch (~3.8 us at N = 60k) less per solve.  Default 1; 0 restores the classic start (plans created
+ * afterwards). */
+int mgp_cg_set_init_free(int on);
 /* reusable solver: owns the captured iteration graph; `work` must outlive the plan */
 int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
                        const mgp_cg_params_t* params, void* work, size_t work_bytes, void* stream,

@@ -85,6 +85,9 @@ class settings:
     class num_trace_samples(_Setting):
         _default, _gp_name = 10, "num_trace_samples"
 
+    class max_lanczos_quadrature_iterations(_Setting):
+        _default, _gp_name = 20, "max_lanczos_quadrature_iterations"
+
     class cg_jacobi_preconditioner(_Setting):
         """Extension: Jacobi-preconditioned CG in the HIP solver (reference: unpreconditioned)."""
         _default = False
@@ -180,6 +183,24 @@ class _ProtocolLinearOperator:
     def evaluate(self):
         return self.to_dense()
 
+    def diagonalization(self, method=None):
+        from .solvers import dense_symeig
+        return dense_symeig(self)
+
+    def __add__(self, other):
+        raise NotImplementedError("lazy sums are provided by linear_operator; not needed on the hot path")
+
+
+class _HipEntryPoints:
+    """The solver entry points of the operators, implemented on the HIP solvers (solvers.py).
+
+    They are defined HERE, ahead of the base class in the MRO, for both bases.  With the real
+    linear_operator.LinearOperator underneath this keeps `solve` / `inv_quad_logdet` on the HIP CG, the block
+    Lanczos log-determinant and the surrogate gradients of solvers.inv_quad_logdet instead of linear_operator's
+    own linear_cg / `_bilinear_derivative` machinery, whose calling convention of `_solve` (a (solves, tridiagonals)
+    pair when num_tridiag > 0) the operators honour as well (solvers.solve_with_tridiag) but which has never run
+    against these classes: the image has no linear_operator (INTEGRATION.md section 2 says what is verified)."""
+
     def solve(self, right_tensor, left_tensor=None):
         squeeze = right_tensor.dim() == 1
         rhs = right_tensor.unsqueeze(-1) if squeeze else right_tensor
@@ -189,8 +210,12 @@ class _ProtocolLinearOperator:
         return sol.squeeze(-1) if squeeze else sol
 
     def _solve(self, rhs, preconditioner=None, num_tridiag=0):
-        from .solvers import generic_cg
-        return generic_cg(self, rhs)
+        # `_solve_hip(rhs)`: the operator's own HIP solve (one CG on its polynomial chain, block elimination for the
+        # Schur complement, ...); operators without one take the generic CG over `_matmul`
+        from .solvers import generic_cg, solve_with_tridiag
+        hip = getattr(self, "_solve_hip", None)
+        sol = hip(rhs) if hip is not None else generic_cg(self, rhs)
+        return solve_with_tridiag(self, sol, rhs, num_tridiag)
 
     def inv_quad_logdet(self, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
         from .solvers import inv_quad_logdet
@@ -202,18 +227,13 @@ class _ProtocolLinearOperator:
     def logdet(self):
         return self.inv_quad_logdet(None, True)[1]
 
-    def diagonalization(self, method=None):
-        from .solvers import dense_symeig
-        return dense_symeig(self)
-
-    def __add__(self, other):
-        raise NotImplementedError("lazy sums are provided by linear_operator; not needed on the hot path")
-
 
 if HAVE_LINEAR_OPERATOR:  # pragma: no cover
-    LinearOperator = _RealLinearOperator
+    class LinearOperator(_HipEntryPoints, _RealLinearOperator):
+        pass
 else:
-    LinearOperator = _ProtocolLinearOperator
+    class LinearOperator(_HipEntryPoints, _ProtocolLinearOperator):
+        pass
 
 
 # ------------------------------------------------------------------------------ Kernel

@@ -55,6 +55,10 @@ struct CgArgs {
   int max_iter, min_iter, stop_mode;
   int64_t rows_per_block;
   float *rn, *sn;     // fused step only (else NULL): scratch for the new r / s, committed by the chain's last SpMV
+  // init-free solve (C == 1, tile SpMV, no preconditioner): there is no cg_init launch -- the first apply read the
+  // right-hand side itself, copied it to r and left the partials of ||b||^2 here (one slot per SpMV workgroup);
+  // at iteration 1 the update takes gamma = ||r||^2 from them and treats p, s, x as zero.  NULL: classic start.
+  const float* pd_bb;   // [nbs]
 };
 
 // sh[k][sl * TC + cc] holds the partial of slice sl for column cc; result in sh[k][cc] for cc < TC.
@@ -329,7 +333,7 @@ constexpr int kC1GammaSlots = 2;    // nbv <= kMaxGridVec = 2 * 256
 constexpr int kC1DeltaSlots = 16;   // nbs <= 4096
 
 __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
-  __shared__ float sh_w[kBlock / 64][5];
+  __shared__ float sh_w[kBlock / 64][6];
   __shared__ float sh_o[kBlock / 64][2];
   __shared__ int sh_state[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -357,14 +361,18 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
       rv[h][q] = a.pd_rr[(int64_t)h * a.nbv + bc];
     }
   }
+  float bv[kC1DeltaSlots];
+  const float* __restrict__ pbb = a.pd_bb ? a.pd_bb : a.pd_delta;     // stand-in: unconditional loads
 #pragma unroll
   for (int q = 0; q < kC1DeltaSlots; ++q) {
     const int b = tid + q * kBlock;
-    dv[q] = a.pd_delta[b < a.nbs ? b : a.nbs - 1];
+    const int bc = b < a.nbs ? b : a.nbs - 1;
+    dv[q] = a.pd_delta[bc];
+    bv[q] = pbb[bc];
   }
   const float go0 = sc.go0, go1 = sc.go1, ao0 = sc.ao0, ao1 = sc.ao1;
   const float bb_old = sc.bb;
-  float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float t[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int q = 0; q < kC1GammaSlots; ++q) {
     const bool on = tid + q * kBlock < a.nbv;
@@ -372,12 +380,16 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
     t[2] += on ? rv[0][q] : 0.f; t[3] += on ? rv[1][q] : 0.f;
   }
 #pragma unroll
-  for (int q = 0; q < kC1DeltaSlots; ++q) t[4] += (tid + q * kBlock < a.nbs) ? dv[q] : 0.f;
+  for (int q = 0; q < kC1DeltaSlots; ++q) {
+    const bool on = tid + q * kBlock < a.nbs;
+    t[4] += on ? dv[q] : 0.f;
+    t[5] += on ? bv[q] : 0.f;
+  }
 #pragma unroll
-  for (int k = 0; k < 5; ++k) t[k] = mgp_wave_sum(t[k]);
+  for (int k = 0; k < 6; ++k) t[k] = mgp_wave_sum(t[k]);
   if (lane == 0) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) sh_w[wave][k] = t[k];
+    for (int k = 0; k < 6; ++k) sh_w[wave][k] = t[k];
   }
   // workgroup 0 may raise the done flag while this launch runs: one lane's view of the state is
   // published so that all waves of a workgroup take the same branch
@@ -387,8 +399,9 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   const int it = sh_state[0];
   const int par = it & 1, prev = par ^ 1;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) t[k] = (sh_w[0][k] + sh_w[1][k]) + (sh_w[2][k] + sh_w[3][k]);
-  const float gamma = prev ? t[1] : t[0], rr2 = prev ? t[3] : t[2], delta = t[4];
+  for (int k = 0; k < 6; ++k) t[k] = (sh_w[0][k] + sh_w[1][k]) + (sh_w[2][k] + sh_w[3][k]);
+  const bool fresh = a.pd_bb != nullptr && it == 1;       // init-free solve, first update: r = b, p = s = x = 0
+  const float gamma = fresh ? t[5] : (prev ? t[1] : t[0]), rr2 = fresh ? t[5] : (prev ? t[3] : t[2]), delta = t[4];
   const float bb = (it == 1) ? rr2 : bb_old;
   const float rel = (bb > 0.f) ? sqrtf(rr2 / bb) : 0.f;
   const bool frozen = (a.stop_mode == 0) ? (rel < 1e-10f) : (rel <= a.tol);
@@ -423,13 +436,18 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
       a.host_state[1] = 1;
     }
   }
-  if (done) return;
+  if (done) {
+    // an init-free solve that ends before its first update (b = 0): nobody has zeroed x
+    if (fresh) for (int64_t r = rf; r < r1; r += kBlock) a.x[r] = 0.f;
+    return;
+  }
 
   float ng = 0.f, nrr = 0.f;
   // first element: prefetched in the prologue (the only one at N = 60k); the rest of a long row range in
   // batches of four with all their loads in flight (at N = 1M a lane walks 8 elements: one round trip each
   // made the kernel run at ~1 TB/s)
   auto step = [&](int64_t r, float un, float po, float so, float wo, float xo, float ro, float mo, float pr) {
+    if (fresh) { po = 0.f; so = 0.f; xo = 0.f; }      // whatever the previous solve left there (possibly NaN)
     const float p = fmaf(beta, po, un);
     const float s = fmaf(beta, so, wo);
     a.p[r] = p;
@@ -904,6 +922,9 @@ struct CgPlan {
   const float* patched_rhs;   // rhs the cg_init node currently points at
   int solves;                 // run_cg calls so far (graphs are captured at the second one)
   bool graphs_tried;
+  bool init_free;             // no cg_init launch: the first apply reads the rhs itself (CgArgs::pd_bb)
+  float* pd_bb;               // [nbs] partials of ||b||^2 written by the first apply
+  char first_record[MGP_SPMM_RECORD_BYTES];   // launch arguments of the first graph's root SpMV (rhs patched per solve)
   bool fused;                 // step = (chain tail, fused update + chain head) -- see cg_fused_step_kernel
   CgFuse fuse;
   int fgrid;
@@ -931,13 +952,14 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   b += 4 * nc + 256;                                   // operator chain scratch (global length)
   b += 4 * mgp_align((size_t)kMaxPartials * C * sizeof(float));  // pd_gamma[2], pd_rr[2]
   b += 6 * nc;                                         // fused step: rn, sn, row records [n][4]
-  b += mgp_align((size_t)nbs * C * sizeof(float));              // pd_delta
+  b += 2 * mgp_align((size_t)nbs * C * sizeof(float));          // pd_delta, pd_bb
   b += mgp_align((6 * (size_t)C + 16) * sizeof(float));          // gamma_old[2] alpha_old[2] bb resid state
   b += mgp_align((size_t)256 * C * 2 * sizeof(float));          // refinement partials
   b += 6 * 2 * nc + mgp_align((size_t)256 * C * 2 * sizeof(double));   // fp64 refinement: xacc, A x, 4 chain buffers
   return b + 1024;
 }
 
+int g_cg_init_free = 1;   // C == 1 plans start without a cg_init launch (mgp_cg_set_init_free(0): classic start)
 int g_cg_fuse = 0;   // measured at N = 60k: step 16.3 us fused vs 16.3 us unfused -- off until it wins
 
 // one CG step = operator apply (w = A u, partials of u . w, ticks the iteration counter; skipped once
@@ -965,6 +987,17 @@ int enqueue_body(CgPlan* pl, hipStream_t st) {
   return MGP_OK;
 }
 
+// Init-free solve: the first (apply, update) pair.  The apply reads `rhs` directly (launch 0 scales it by op->pre,
+// copies it to r), leaves the partials of r . A r and ||r||^2 and resets the iteration state; the update then runs
+// as iteration 1 with p = s = x = 0.  One launch (cg_init, ~3.8 us at N = 60k) less per solve.
+int enqueue_first_body(CgPlan* pl, hipStream_t st, const float* rhs, bool record) {
+  MGP_TRY(mgp_operator_apply_first(&pl->op, rhs, pl->args.r, pl->args.w, pl->pd_delta, pl->pd_bb, pl->args.state,
+                                   record ? pl->first_record : nullptr, pl->op_work, pl->op_work_bytes, st));
+  hipLaunchKernelGGL(cg_update_c1_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
 // behind cg_init (fused form only): launch 0 of the first apply, t0 = tau xs + L xs with xs = pre (.) b
 int enqueue_head(CgPlan* pl, hipStream_t st) {
   if (!pl->fused) return MGP_OK;
@@ -985,15 +1018,23 @@ void capture_first(CgPlan* pl, int len) {
   if (!pl->cap_stream || len < 1) return;
   bool ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
   if (ok) {
-    hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, pl->cap_stream, pl->args,
-                       (const float*)pl->args.x);   // placeholder rhs, patched before every launch
-    int rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
-    if (rc == MGP_OK) rc = enqueue_head(pl, pl->cap_stream);
+    int rc = MGP_OK;
     // `len` = steps until the stopping rule fires: the last of them only detects (see cg_decide_c1_kernel)
     const bool decide = len >= 2 && !pl->fused && !pl->is_dist && pl->C == 1 &&
                         pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock;
     const int bodies = decide ? len - 1 : len;
-    for (int i = 0; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
+    int done_bodies = 0;
+    if (pl->init_free) {
+      // root node = launch 0 of the first apply, reading a placeholder rhs that is patched before every launch
+      rc = enqueue_first_body(pl, pl->cap_stream, (const float*)pl->args.x, true);
+      done_bodies = 1;
+    } else {
+      hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, pl->cap_stream, pl->args,
+                         (const float*)pl->args.x);   // placeholder rhs, patched before every launch
+      rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
+      if (rc == MGP_OK) rc = enqueue_head(pl, pl->cap_stream);
+    }
+    for (int i = done_bodies; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
     if (decide && rc == MGP_OK) {
       hipLaunchKernelGGL(cg_decide_c1_kernel, dim3(1), dim3(kBlock), 0, pl->cap_stream, pl->args);
       rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
@@ -1019,6 +1060,14 @@ void capture_first(CgPlan* pl, int len) {
 // point the cg_init node of the first graph at this solve's right-hand side
 bool patch_first_rhs(CgPlan* pl, const float* rhs) {
   if (rhs == pl->patched_rhs) return true;
+  if (pl->init_free) {
+    if (mgp_spmm_patch_node(pl->exec_first, pl->init_node, pl->first_record, (const float*)pl->args.x, rhs) != MGP_OK) {
+      (void)hipGetLastError();
+      return false;
+    }
+    pl->patched_rhs = rhs;
+    return true;
+  }
   hipKernelNodeParams np;
   memset(&np, 0, sizeof(np));
   if (hipGraphKernelNodeGetParams(pl->init_node, &np) != hipSuccess) return false;
@@ -1149,6 +1198,15 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
       if (!pl->t0) pl->fused = false;
     }
   }
+  pl->pd_bb = ar.take<float>((size_t)a.nbs * C);
+  a.pd_bb = nullptr;
+  pl->init_free = false;
+  if (g_cg_init_free && C == 1 && !dist && !minv && !pl->fused && (op->form == 0 || op->form == 2) &&
+      mgp_tile_plan(&op->L, 1, nullptr, nullptr, nullptr) && a.nbv <= kC1GammaSlots * kBlock &&
+      a.nbs <= kC1DeltaSlots * kBlock) {
+    pl->init_free = true;
+    a.pd_bb = pl->pd_bb;
+  }
   if (!ar.ok()) { delete pl; return MGP_ERR_WORKSPACE; }
   hipError_t e = hipHostMalloc((void**)&pl->host_state, 16 * sizeof(int32_t), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_resid, (size_t)C * sizeof(float), hipHostMallocMapped);
@@ -1159,6 +1217,11 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   if (e != hipSuccess) { delete pl; return (int)e; }
 
   *plan_out = pl;
+  return MGP_OK;
+}
+
+extern "C" int mgp_cg_set_init_free(int on) {
+  g_cg_init_free = on ? 1 : 0;
   return MGP_OK;
 }
 
@@ -1195,10 +1258,16 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   bool first = true;
   if (pl->solves++ >= 1 && !pl->graphs_tried) capture_graphs(pl);
   if (pl->has_first && !patch_first_rhs(pl, rhs)) pl->has_first = false;
+  int eager_done = 0;           // bodies of the first eager chunk already enqueued
   if (!pl->has_first) {
-    hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, rhs);
-    MGP_LAUNCH_CHECK();
-    MGP_TRY(enqueue_head(pl, st));
+    if (pl->init_free) {
+      MGP_TRY(enqueue_first_body(pl, st, rhs, false));
+      eager_done = 1;
+    } else {
+      hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, rhs);
+      MGP_LAUNCH_CHECK();
+      MGP_TRY(enqueue_head(pl, st));
+    }
   }
   int guard = 0;
   for (;;) {
@@ -1208,7 +1277,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
       MGP_HIP_TRY(hipGraphLaunch(pl->exec, st));
     } else {
       const int len = (first && pl->chunk > 4) ? 4 : pl->chunk;   // eager path: short solves stop early
-      for (int i = 0; i < len; ++i) MGP_TRY(enqueue_body(pl, st));
+      for (int i = first ? eager_done : 0; i < len; ++i) MGP_TRY(enqueue_body(pl, st));
     }
     first = false;
     // the solution rides behind every chunk so that one synchronisation ends the solve; the

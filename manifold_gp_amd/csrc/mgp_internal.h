@@ -29,6 +29,26 @@ int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X
                           const float* pre, const float* post, const float* base, float cb, float co,
                           const float* dotw, float* dot_partials, const int* skip, int* tick,
                           const MgpCommit* commit, void* stream);
+// Init-free CG solve (cg.hip): the FIRST operator apply of a solve reads the caller's right-hand side directly
+// (no cg_init launch).  Launch 0 of the chain stores its raw input rows to copy_x (r = b); the chain's last launch
+// also writes per-workgroup partials of sum dotw^2 (||b||^2) and resets the iteration state to {1, 0, 0}.
+// record (nullable, MGP_SPMM_RECORD_BYTES): the launch arguments, for mgp_spmm_patch_node.  Tile kernel only.
+#define MGP_SPMM_RECORD_BYTES 512
+struct MgpFirst {
+  float* copy_x;
+  float* dot2_partials;
+  int tick_reset;
+  void* record;
+};
+int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
+                         const float* pre, const float* post, const float* base, float cb, float co,
+                         const float* dotw, float* dot_partials, const int* skip, int* tick,
+                         const MgpCommit* commit, const MgpFirst* first, void* stream);
+int mgp_spmm_patch_node(void* exec, void* node, const void* record, const float* old_ptr, const float* new_ptr);
+// first apply of an init-free solve: launch 0 reads `rhs` (pre-scaled in the kernel by op->pre) and copies it to
+// r_copy; later launches take r_copy as base / dot weight; partials of r . A r and ||r||^2; state reset
+int mgp_operator_apply_first(const mgp_operator_t* op, const float* rhs, float* r_copy, float* Y, float* dot_partials,
+                             float* dot2_partials, int* state, void* record, void* work, size_t work_bytes, void* stream);
 // 1 when the C == 1 tile kernel would run on L; launch geometry of that kernel
 int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, size_t* lds_bytes);
 

@@ -23,6 +23,12 @@ struct Hooks {
   int* tick;
   const MgpCommit* commit;   // nullable: row copies in the epilogue of the chain's last launch
   int first;                 // first launch of the chain to run (1: launch 0 was done by the caller into t0)
+  // init-free CG solve: launch 0 copies its raw input rows to copy_x and leaves its launch record; the last launch
+  // writes the sum dotw^2 partials and resets the iteration state (all nullable / 0)
+  float* copy_x;
+  void* record;
+  float* dot2_partials;
+  int tick_reset;
 };
 
 }  // namespace
@@ -50,20 +56,32 @@ int q2_chain(const mgp_operator_t* op, const MgpDist* d, int nb_loc, const float
     // (x + delta L x) / delta == tau x + L x  with delta = 1/tau (precision_matern_operator.py:31-33)
     float* dp = (last && hk) ? hk->dot_partials : nullptr;
     if (dp && d) dp += (int64_t)d->rank * nb_loc * C;      // this rank's segment of the gathered partials
-    MGP_TRY(mgp_spmm_fused_commit(&op->L, d ? d->row_offset : 0, in, C, out, tau, 1.0f,
-                                  (first && !Xs) ? op->pre : nullptr, last ? op->post : nullptr,
-                                  last ? base : nullptr, cb, last ? co * op->scale : 1.0f,
-                                  (last && hk) ? hk->dotw : nullptr, dp, hk ? hk->skip : nullptr,
-                                  (last && hk) ? hk->tick : nullptr, (last && hk) ? hk->commit : nullptr, stream));
+    MgpFirst fst{(first && hk) ? hk->copy_x : nullptr, (last && hk) ? hk->dot2_partials : nullptr,
+                 (last && hk) ? hk->tick_reset : 0, (first && hk) ? hk->record : nullptr};
+    const bool use_fst = fst.copy_x || fst.dot2_partials || fst.tick_reset || fst.record;
+    MGP_TRY(mgp_spmm_fused_first(&op->L, d ? d->row_offset : 0, in, C, out, tau, 1.0f,
+                                 (first && !Xs) ? op->pre : nullptr, last ? op->post : nullptr,
+                                 last ? base : nullptr, cb, last ? co * op->scale : 1.0f,
+                                 (last && hk) ? hk->dotw : nullptr, dp, hk ? hk->skip : nullptr,
+                                 (last && hk) ? hk->tick : nullptr, (last && hk) ? hk->commit : nullptr,
+                                 use_fst ? &fst : nullptr, stream));
     if (d) {
       // the collectives run unconditionally (also after convergence) so that every rank issues
       // the same sequence; a skipped launch leaves stale but finite data behind them
-      if (dp) ncclGroupStart();
-      MGP_TRY(mgp_dist_allgather_f32(d, out, d->n_loc * C, stream));
+      // an open group is always closed before an error is returned: a rank that left it open would hang or
+      // mis-order its next collective
+      int rc = MGP_OK;
       if (dp) {
-        MGP_TRY(mgp_dist_allgather_f32(d, hk->dot_partials, (int64_t)nb_loc * C, stream));
-        ncclGroupEnd();
+        const ncclResult_t gs = ncclGroupStart();
+        if (gs != ncclSuccess) return 1000 + (int)gs;
       }
+      rc = mgp_dist_allgather_f32(d, out, d->n_loc * C, stream);
+      if (dp) {
+        if (rc == MGP_OK) rc = mgp_dist_allgather_f32(d, hk->dot_partials, (int64_t)nb_loc * C, stream);
+        const ncclResult_t ge = ncclGroupEnd();
+        if (rc == MGP_OK && ge != ncclSuccess) rc = 1000 + (int)ge;
+      }
+      MGP_TRY(rc);
     }
     in = out;
   }
@@ -112,8 +130,8 @@ int mgp_operator_apply_dist(const mgp_operator_t* op, const MgpDist* d, const fl
   float* ua = ar.take<float>(nc);
   float* ub = ar.take<float>(nc);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
-  Hooks hk{dotw, dot_partials, skip, tick, nullptr, 0};
-  Hooks hk_mid{nullptr, nullptr, skip, nullptr, nullptr, 0};
+  Hooks hk{dotw, dot_partials, skip, tick, nullptr, 0, nullptr, nullptr, nullptr, 0};
+  Hooks hk_mid{nullptr, nullptr, skip, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
   switch (op->form) {
     case 0:
       return q2_chain(op, d, nb_loc, X, Xs, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
@@ -153,9 +171,32 @@ int mgp_operator_apply_tail(const mgp_operator_t* op, const float* X, int C, flo
   float* t0 = ar.take<float>(nc);
   float* t1 = ar.take<float>(nc);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
-  Hooks hk{dotw, dot_partials, skip, tick, commit, 1};
+  Hooks hk{dotw, dot_partials, skip, tick, commit, 1, nullptr, nullptr, nullptr, 0};
   if (op->form == 0) return q2_chain(op, nullptr, 0, X, nullptr, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
   return q2_chain(op, nullptr, 0, X, nullptr, C, Y, X, 1.f, op->noise, t0, t1, &hk, stream);
+}
+
+// First operator apply of an init-free CG solve (cg.hip), C == 1, tile kernel, single-chain forms (0 and 2):
+// w = A rhs without a preceding cg_init launch.  Launch 0 reads the caller's right-hand side (scaled by op->pre
+// inside the kernel) and copies the raw rows to r_copy; the last launch takes r_copy as its base / dot weight -- or
+// rhs itself when the chain has a single launch, where the copy is written by the same kernel -- and leaves the
+// partials of r . A r and of ||r||^2 and the iteration state {1, 0, 0}.  No skip flag: this apply opens the solve.
+// `record`: launch arguments of launch 0 (mgp_spmm_patch_node re-points them at the next solve's rhs).
+int mgp_operator_apply_first(const mgp_operator_t* op, const float* rhs, float* r_copy, float* Y, float* dot_partials,
+                             float* dot2_partials, int* state, void* record, void* work, size_t work_bytes, void* stream) {
+  MGP_TRY(check_op(op));
+  if (!rhs || !r_copy || !Y || !dot_partials || !dot2_partials || !state || rhs == Y) return MGP_ERR_ARG;
+  if (op->form != 0 && op->form != 2) return MGP_ERR_UNSUPPORTED;
+  if (!work || work_bytes < 4 * mgp_align((size_t)op->L.n * sizeof(float))) return MGP_ERR_WORKSPACE;
+  MgpArena ar(work, work_bytes);
+  const size_t nc = (size_t)op->L.n;
+  float* t0 = ar.take<float>(nc);
+  float* t1 = ar.take<float>(nc);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  const float* rv = op->nu == 1 ? rhs : r_copy;      // what the last launch reads as r
+  Hooks hk{rv, dot_partials, nullptr, state, nullptr, 0, r_copy, record, dot2_partials, 1};
+  if (op->form == 0) return q2_chain(op, nullptr, 0, rhs, nullptr, 1, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
+  return q2_chain(op, nullptr, 0, rhs, nullptr, 1, Y, rv, 1.f, op->noise, t0, t1, &hk, stream);
 }
 
 // ---------------------------------------------------------------- fp64 apply (iterative refinement only)

@@ -21,6 +21,7 @@
 //     contiguous burst; dot partials go through LDS across the groups of a workgroup;
 //   * grids are capped (<= 4096 workgroups, contiguous row ranges per workgroup) and remapped so
 //     that each XCD streams one contiguous slice of rows (mgp_xcd_block).
+#include <string.h>
 #include "mgp_common.h"
 #include "mgp_internal.h"
 
@@ -51,6 +52,10 @@ struct SpmmArgs {
   int64_t goff;      // row partition: CSR rows are local [0, n), vectors are global -> row r is
                      // element r + goff of X / Y / pre / post / base / dotw (0 on one GPU)
   MgpCommit commit;  // tile kernel only: packed row record written in the epilogue (fused CG step)
+  // tile kernel only (init-free CG solve, cg.hip): the first apply of a solve reads the caller's right-hand side
+  float* copy_x;          // nullable: the epilogue stores the row's raw input x[row] here (r = b)
+  float* dot2_partials;   // nullable: per-workgroup partials of sum dotw[row]^2 (||b||^2)
+  int tick_reset;         // tick != NULL: write {1, 0, 0} (iteration 1, not done, no status) instead of adding 1
 };
 
 typedef int mgp_v4i __attribute__((ext_vector_type(4)));
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
   const int32_t* __restrict__ tile_ptr = t.tile_ptr;
   const uint32_t* __restrict__ tile_cols = reinterpret_cast<const uint32_t*>(t.tile_cols);
   const uint16_t* __restrict__ lid = t.lid;
-  float dsum = 0.f;
+  float dsum = 0.f, dsum2 = 0.f;
   const int64_t t0 = (int64_t)lb * t.tiles_per_block;
   const int64_t t1 = t0 + t.tiles_per_block < t.ntiles ? t0 + t.tiles_per_block : t.ntiles;
   for (int64_t tile = t0; tile < t1; ++tile) {
@@ -294,7 +299,8 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     const int64_t rr = t.rowid ? (int64_t)t.rowid[pr] : pr;              // row of the CSR / of the vectors
     const int64_t grr = rr + p.goff;
     const int rs = rowptr[pr], re = rowptr[pr + 1];
-    float e_x = x[grr];
+    const float raw_x = x[grr];
+    float e_x = raw_x;
     if (PRE) e_x *= prev[grr];
     const float e_diag = p.diag[rr];
     // nullable operands: unconditional load from a valid stand-in + select (no branch around a load)
@@ -357,6 +363,8 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
       const float y = p.co * tt + p.cb * e_base;
       p.Y[grr] = y;
       dsum = fmaf(e_dotw, y, dsum);
+      dsum2 = fmaf(e_dotw, e_dotw, dsum2);
+      if (p.copy_x) p.copy_x[grr] = raw_x;
       if (p.commit.pack4) {
         mgp_v4f rec;
         rec.x = l_cp0; rec.y = y; rec.z = l_cp1; rec.w = p.commit.pre ? l_cp2 : 1.f;
@@ -365,17 +373,22 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     }
     if (tile + 1 < t1) __syncthreads();                // the next tile overwrites xl / part
   }
-  if (p.tick && blockIdx.x == 0 && tid == 0 && !skipv) *p.tick = tickv + 1;
+  if (p.tick && blockIdx.x == 0 && tid == 0 && !skipv) {
+    if (p.tick_reset) { p.tick[0] = 1; p.tick[1] = 0; p.tick[2] = 0; }
+    else *p.tick = tickv + 1;
+  }
   if (p.dot_partials) {
-    __shared__ float red[BS / MGP_WAVE];
+    __shared__ float red[2][BS / MGP_WAVE];
     dsum = mgp_wave_sum(dsum);
-    if ((tid & 63) == 0) red[tid >> 6] = dsum;
+    if (p.dot2_partials) dsum2 = mgp_wave_sum(dsum2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = dsum; red[1][tid >> 6] = dsum2; }
     __syncthreads();
     if (tid == 0) {
-      float s = 0.f;
+      float s = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int w = 0; w < BS / MGP_WAVE; ++w) s += red[w];
+      for (int w = 0; w < BS / MGP_WAVE; ++w) { s += red[0][w]; s2 += red[1][w]; }
       p.dot_partials[lb] = s;
+      if (p.dot2_partials) p.dot2_partials[lb] = s2;
     }
   }
 }
@@ -725,21 +738,69 @@ int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X
                           const float* pre, const float* post, const float* base, float cb, float co,
                           const float* dotw, float* dot_partials, const int* skip, int* tick,
                           const MgpCommit* commit, void* stream) {
+  return mgp_spmm_fused_first(L, row_offset, X, C, Y, a, b, pre, post, base, cb, co, dotw, dot_partials, skip, tick, commit,
+                              nullptr, stream);
+}
+
+namespace {
+// what a tile-kernel launch was made with: kept by the CG plan for the one graph node whose input pointer
+// changes from solve to solve (mgp_spmm_patch_node)
+struct TileLaunchRecord {
+  SpmmArgs p;
+  TileArgs t;
+};
+static_assert(sizeof(TileLaunchRecord) <= MGP_SPMM_RECORD_BYTES, "MGP_SPMM_RECORD_BYTES too small");
+}  // namespace
+
+// Re-point a captured tile-SpMV node at another input: every pointer operand of the recorded launch that equals
+// `old_ptr` (X, base, dotw) becomes `new_ptr` in the executable graph; the record keeps the original.
+int mgp_spmm_patch_node(void* exec, void* node, const void* record, const float* old_ptr, const float* new_ptr) {
+  if (!exec || !node || !record) return MGP_ERR_ARG;
+  TileLaunchRecord rec;
+  memcpy(&rec, record, sizeof(rec));
+  if (rec.p.X == old_ptr) rec.p.X = new_ptr;
+  if (rec.p.base == old_ptr) rec.p.base = new_ptr;
+  if (rec.p.dotw == old_ptr) rec.p.dotw = new_ptr;
+  hipKernelNodeParams np;
+  memset(&np, 0, sizeof(np));
+  MGP_HIP_TRY(hipGraphKernelNodeGetParams(static_cast<hipGraphNode_t>(node), &np));
+  void* kp[2] = {(void*)&rec.p, (void*)&rec.t};
+  np.kernelParams = kp;
+  np.extra = nullptr;
+  MGP_HIP_TRY(hipGraphExecKernelNodeSetParams(static_cast<hipGraphExec_t>(exec), static_cast<hipGraphNode_t>(node), &np));
+  return MGP_OK;
+}
+
+int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
+                         const float* pre, const float* post, const float* base, float cb, float co,
+                         const float* dotw, float* dot_partials, const int* skip, int* tick,
+                         const MgpCommit* commit, const MgpFirst* first, void* stream) {
   if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !X || !Y) return MGP_ERR_ARG;
   if (L->n <= 0 || C <= 0 || C > 256) return C > 256 ? MGP_ERR_UNSUPPORTED : MGP_ERR_ARG;
   if (X == Y) return MGP_ERR_ARG;  // rows gather other rows of X: never in place
   hipStream_t st = mgp_stream(stream);
   SpmmArgs p{L->n, L->rowptr, L->col, L->vals, L->diag, X, Y, C, a, b, pre, post, base, cb, co,
-             dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset, MgpCommit{nullptr, nullptr, nullptr, nullptr}};
+             dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset, MgpCommit{nullptr, nullptr, nullptr, nullptr},
+             nullptr, nullptr, 0};
   if (commit) {
     if (!use_tiles(L, C)) return MGP_ERR_UNSUPPORTED;   // the row records ride in the tile kernel only
     p.commit = *commit;
+  }
+  if (first) {
+    if (!use_tiles(L, C)) return MGP_ERR_UNSUPPORTED;
+    p.copy_x = first->copy_x;
+    p.dot2_partials = (dotw && dot_partials) ? first->dot2_partials : nullptr;
+    p.tick_reset = first->tick_reset;
   }
   if (use_tiles(L, C)) {
     TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
                 L->tile_rowptr, L->tile_vals, L->tile_rowid};
     const int grid = tile_grid(L, &ta.tiles_per_block);
     const size_t lds = tile_lds_bytes(L);
+    if (first && first->record) {
+      TileLaunchRecord rec{p, ta};
+      memcpy(first->record, &rec, sizeof(rec));
+    }
 #define MGP_TILE_LAUNCH(BS)                                                                              \
   do {                                                                                                   \
     if (pre) hipLaunchKernelGGL((spmv_tile_kernel<true, BS>), dim3(grid), dim3(BS), lds, st, p, ta);      \

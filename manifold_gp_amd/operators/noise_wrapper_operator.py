@@ -44,7 +44,7 @@ class NoiseWrapperOperator(LinearOperator):
     def _transpose_nonbatch(self):
         return NoiseWrapperOperator(self.operator._transpose_nonbatch(), self.noise)
 
-    def _solve(self, rhs, preconditioner=None, num_tridiag=0):
+    def _solve_hip(self, rhs):
         d = self._descriptor()
         if d is not None:
             from ..solvers import cg_solve

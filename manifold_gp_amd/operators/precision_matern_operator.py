@@ -52,7 +52,7 @@ class PrecisionMaternOperator(LinearOperator):
     def _transpose_nonbatch(self):
         return self
 
-    def _solve(self, rhs, preconditioner=None, num_tridiag=0):
+    def _solve_hip(self, rhs):
         from ..solvers import cg_solve
         return cg_solve(self._descriptor(), rhs)[0]
 

@@ -45,7 +45,7 @@ class ScaleWrapperOperator(LinearOperator):
     def _transpose_nonbatch(self):
         return ScaleWrapperOperator(self.operator._transpose_nonbatch(), self.scale, self.inverse_scale)
 
-    def _solve(self, rhs, preconditioner=None, num_tridiag=0):
+    def _solve_hip(self, rhs):
         d = self._descriptor()
         if d is not None:
             from ..solvers import cg_solve

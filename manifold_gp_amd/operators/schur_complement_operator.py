@@ -106,7 +106,7 @@ class SchurComplementOperator(LinearOperator):
             res = self._apply_parts(v)[0]
         return res.squeeze(-1) if squeeze else res
 
-    def _solve(self, rhs, preconditioner=None, num_tridiag=0):
+    def _solve_hip(self, rhs):
         """S^-1 b without nesting: by block elimination the labelled part of Q^-1 [b; 0] IS S^-1 b, so one
         HIP CG on the full precision replaces a CG on S whose every matvec hides another CG on Q_uu
         (SURVEY.md section 8f-3)."""

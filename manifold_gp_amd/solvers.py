@@ -107,10 +107,13 @@ _PLAN_CACHE_MAX = 8
 def _cached_plan(desc, C, kw):
     """Plans own a captured hipGraph (~ms to build): reuse them for repeated solves with the same
     operator (the nested CG of a Schur-complement matvec, _average_variance in a training loop)."""
+    # a plan is bound to the stream that was current when it was created (its launches, its graph replays and the
+    # copy of X are ordered there only): a solve issued under another torch.cuda.stream gets its own plan
     key = (id(desc.data), desc.nu, desc.kappa, desc.scale, desc.form, desc.noise,
            desc.pre.data_ptr() if desc.pre is not None else 0, desc.post.data_ptr() if desc.post is not None else 0,
            int(C), settings.cg_tolerance.value(), settings.max_cg_iterations.value(), settings.cg_stop_mode.value(),
-           settings.cg_jacobi_preconditioner.value(), tuple(sorted(kw.items())))
+           settings.cg_jacobi_preconditioner.value(), tuple(sorted(kw.items())),
+           int(torch.cuda.current_stream(desc.data.graph.device).cuda_stream))
     plan = _PLAN_CACHE.get(key)
     if plan is None:
         if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
@@ -187,6 +190,35 @@ def generic_cg(operator, rhs, tol=None, max_iter=None, x0=None, precond=None):
     return x.squeeze(-1) if squeeze else x
 
 
+def solve_with_tridiag(operator, sol, rhs, num_tridiag):
+    """linear_operator's convention for `_solve(rhs, preconditioner, num_tridiag)`: the solution alone when
+    num_tridiag == 0, else (solution, T) with T [num_tridiag, k, k] the Lanczos tridiagonals of the operator started
+    at the first `num_tridiag` columns of rhs (what linear_cg assembles from its CG coefficients for the stochastic
+    Lanczos quadrature; k = max_lanczos_quadrature_iterations).  The tridiagonals come from the HIP block Lanczos."""
+    if not num_tridiag:
+        return sol
+    from .slq import _lanczos_block_generic, lanczos_tridiag_block
+    k = min(int(settings.max_lanczos_quadrature_iterations.value()), operator.shape[-1])
+    Z = _lib.f32c(rhs[:, :num_tridiag])
+    desc = getattr(operator, "_descriptor", lambda: None)()
+    with torch.no_grad():
+        if desc is not None and k + 1 <= 48:
+            parts = [lanczos_tridiag_block(desc, Z[:, c0:c0 + 16].contiguous(), k) for c0 in range(0, num_tridiag, 16)]
+            a = torch.cat([torch.from_numpy(p[0]) for p in parts], 1)
+            b = torch.cat([torch.from_numpy(p[1]) for p in parts], 1)
+        else:
+            an, bn = _lanczos_block_generic(operator, Z, k)
+            a, b = torch.from_numpy(an), torch.from_numpy(bn)
+    T = torch.zeros(num_tridiag, k, k, dtype=torch.float32, device=rhs.device)
+    idx = torch.arange(k, device=rhs.device)
+    T[:, idx, idx] = a.t().float().to(rhs.device)
+    if k > 1:
+        off = b[:k - 1].t().float().to(rhs.device)
+        T[:, idx[:-1], idx[1:]] = off
+        T[:, idx[1:], idx[:-1]] = off
+    return sol, T
+
+
 # ------------------------------------------------------------------------------ inv_quad / logdet
 def inv_quad_logdet(operator, inv_quad_rhs=None, logdet=False, reduce_inv_quad=True):
     """linear_operator's inv_quad_logdet as the reference uses it (precision_matern_operator.py:53,
@@ -216,8 +248,12 @@ def inv_quad_logdet(operator, inv_quad_rhs=None, logdet=False, reduce_inv_quad=T
             iq = (rhs * sol).sum(0)
         else:
             with torch.no_grad():
-                sol = operator.solve(rhs)
-            iq = (rhs * sol).sum(0)
+                sol = operator.solve(rhs.detach())
+            if rhs.requires_grad and torch.is_grad_enabled():
+                # value b^T A^-1 b with d/db = 2 A^-1 b (sol detached): the dense branch differentiates the same way
+                iq = 2.0 * (rhs * sol).sum(0) - (rhs.detach() * sol).sum(0)
+            else:
+                iq = (rhs * sol).sum(0)
             if grad:
                 sur = -(sol * operator.matmul(sol)).sum(0)
                 iq = iq + (sur - sur.detach())

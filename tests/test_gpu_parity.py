@@ -1030,6 +1030,64 @@ def test_cg_fused_step_matches_unfused(mgp, golden, dev, norm, form, nu):
     assert torch.equal(out[1][0][0], out[1][1][0]) and torch.equal(out[1][0][0], out[1][3][0])
 
 
+@pytest.mark.parametrize("nu", [1, 2, 3])
+@pytest.mark.parametrize("form", [0, 2])
+@pytest.mark.parametrize("norm", NORMS)
+def test_cg_init_free_start_matches_classic(mgp, golden, dev, norm, form, nu):
+    """C == 1 solves open without a cg_init launch (the first operator apply reads the right-hand side, copies it to
+    r, leaves ||b||^2 as partials; mgp_cg_set_init_free) against the classic start: same iteration count, same
+    solution to round-off (gamma_1 is summed over another partition), true residual at tolerance; graph replay ==
+    eager launches bit for bit; right-hand sides at changing addresses (the graph's root node is re-pointed); a
+    zero right-hand side (x must come out zero although nobody initialised it); refinement rounds."""
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.solvers import CgPlan
+    g = golden("dumbbell_k10_loop")
+    lap = _operator(mgp, g, dev, norm)
+    Q = mgp.operators.PrecisionMaternOperator(lap, nu, torch.tensor([[float(g["kappa"])]], device=dev))
+    desc = Q._descriptor()
+    desc = desc.with_(scale=0.7, form=2, noise=1e-2) if form == 2 else desc
+    n = lap.shape[0]
+    y = T(g["train_y"], dev).view(-1, 1).contiguous()
+    y2 = torch.randn(n, 1, device=dev)
+    z = torch.zeros(n, 1, device=dev)
+    lib = _lib.lib()
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib.mgp_cg_set_init_free(mode)
+            for use_graph in (True, False):
+                plan = CgPlan(desc, 1, tol=1e-6, max_iter=20000, stop_mode=1, check_every=8, use_graph=use_graph)
+                sols = []
+                for rhs in (y, y, y2, z, y, y.clone(), y):     # repeats -> graph capture / re-capture; new addresses
+                    x = plan.solve(rhs).clone()
+                    sols.append((x, plan.iters, plan.status))
+                out[(mode, use_graph)] = sols
+                plan.close()
+    finally:
+        lib.mgp_cg_set_init_free(1)
+    rhss = (y, y, y2, z, y, y, y)
+    for k, rhs in enumerate(rhss):
+        x1, it1, st1 = out[(1, True)][k]
+        x0, it0, st0 = out[(0, True)][k]
+        assert st0 == 1 and st1 == 1
+        assert torch.equal(x1, out[(1, False)][k][0])                       # graph replay == eager launches
+        if float(rhs.abs().max()) == 0.0:
+            assert float(x1.abs().max()) == 0.0 and float(x0.abs().max()) == 0.0
+            continue
+        assert abs(it0 - it1) <= max(1, it0 // 50), (it0, it1)
+        r1 = desc.apply(x1) - rhs
+        r0 = desc.apply(x0) - rhs
+        assert float(r1.norm() / rhs.norm()) < max(5e-6, 3 * float(r0.norm() / rhs.norm()))
+        assert float((x0 - x1).abs().max()) < 2e-4 * float(x0.abs().max())
+    assert torch.equal(out[(1, True)][0][0], out[(1, True)][4][0]) and torch.equal(out[(1, True)][0][0], out[(1, True)][5][0])
+    # refinement rounds restart the recurrence from the residual buffer
+    plan = CgPlan(desc, 1, tol=1e-6, max_iter=20000, stop_mode=1, refine=2)
+    xr = plan.solve(y).clone()
+    assert plan.status == 1 and max(plan.resid) <= 2e-6
+    assert float((xr - out[(0, True)][0][0]).abs().max()) < 2e-4 * float(xr.abs().max())
+    plan.close()
+
+
 @pytest.mark.parametrize("norm", NORMS)
 def test_riemann_gp_posterior_and_hybrid(mgp, golden, dev, norm):
     """RiemannGP (manifold_gp/models/riemann_gp.py:10-75): Woodbury posterior on device against the
@@ -1748,3 +1806,66 @@ def test_knn_lowdim_large_random_order_surface(mgp, dev):
     Dr, Ir = oknn.knn_search(x_np, x_np[rows], 64)
     assert np.array_equal(I[rows].cpu().numpy(), Ir) and np.array_equal(D[rows].cpu().numpy(), Dr)
     assert bool((I[:, 0] == torch.arange(x_np.shape[0], device=dev)).all())
+
+
+def test_rebuilt_operators_compute_the_same(mgp, golden, dev):
+    """The rebuild contract of linear_operator (cls(*args, **kwargs) from the constructor record, INTEGRATION.md
+    section 2) on the device: a rebuilt operator gives the same product bit for bit -- including the Laplacian whose
+    prebuilt `graph=` is not part of the record (the CSR is re-derived from (idx, x))."""
+    O = mgp.operators
+    g = golden("dumbbell_k10_loop")
+    x = T(g["train_x"], dev)
+    knn = mgp.utils.NearestNeighbors(x)
+    idx, val = knn.graph(int(g["k"]))
+    n = x.shape[0]
+    lap = O.GraphLaplacianOperator(val, idx, n, torch.tensor([[float(g["eps"])]], device=dev), "randomwalk", graph=knn.knn_graph)
+    Q = O.PrecisionMaternOperator(lap, 2, torch.tensor([[float(g["kappa"])]], device=dev))
+    mask = T(g["symmetric_schur_mask"], dev)
+    ops = [lap, lap.T, Q, O.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev)),
+           O.NoiseWrapperOperator(O.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev)), torch.tensor(1e-3, device=dev)),
+           O.SchurComplementOperator(Q, mask)]
+    torch.manual_seed(0)
+    for op in ops:
+        re_op = type(op)(*op._args, **op._kwargs)
+        v = torch.randn(op.shape[0], 3, device=dev)
+        with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(4000):
+            a, b = op.matmul(v), re_op.matmul(v)
+        assert torch.equal(a, b), type(op).__name__
+
+
+def test_solve_hook_honours_num_tridiag(mgp, golden, dev):
+    """`_solve(rhs, preconditioner, num_tridiag)` as linear_operator calls it from inv_quad_logdet: the solution alone,
+    or (solution, T [num_tridiag, k, k]); T is the Lanczos tridiagonal of the operator started at the probe columns:
+    Q^T A Q = T checked through e_1^T f(T) e_1 = z^T f(A) z / |z|^2 for f = identity and square."""
+    O = mgp.operators
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = O.PrecisionMaternOperator(lap, 1, torch.tensor([[float(g["kappa"])]], device=dev))
+    A = O.NoiseWrapperOperator(O.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev)), torch.tensor(1e-2, device=dev))
+    n = A.shape[0]
+    torch.manual_seed(1)
+    rhs = torch.cat([torch.randint(0, 2, (n, 3), device=dev).float() * 2 - 1, T(g["train_y"], dev).view(-1, 1)], 1)
+    with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(4000):
+        plain = A._solve(rhs)
+        sol, Tm = A._solve(rhs, None, 3)
+    assert torch.is_tensor(plain) and torch.equal(plain, sol)
+    k = Tm.shape[-1]
+    assert Tm.shape == (3, k, k) and k == 20
+    assert torch.equal(Tm, Tm.transpose(1, 2))
+    Az = A.matmul(rhs[:, :3])
+    for p in range(3):
+        z = rhs[:, p]
+        m1 = float(torch.dot(z, Az[:, p]) / torch.dot(z, z))                     # z^T A z / |z|^2 = T[0, 0]
+        m2 = float(torch.dot(Az[:, p], Az[:, p]) / torch.dot(z, z))              # z^T A^2 z / |z|^2 = (T^2)[0, 0]
+        Tp = Tm[p].double().cpu().numpy()
+        assert abs(Tp[0, 0] - m1) < 1e-4 * abs(m1)
+        assert abs((Tp @ Tp)[0, 0] - m2) < 1e-4 * abs(m2)
+    # generic operators (a Schur complement underneath) take the torch-side block Lanczos
+    S = O.SchurComplementOperator(Q, T(g["symmetric_schur_mask"], dev))
+    b = torch.randn(S.shape[0], 2, device=dev)
+    with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(4000), \
+            mgp.settings.max_lanczos_quadrature_iterations(6):
+        sol2, T2 = S._solve(b, None, 2)
+        Sb = S.matmul(b)
+    assert sol2.shape == b.shape and T2.shape == (2, 6, 6)
+    assert abs(float(T2[0, 0, 0]) - float(torch.dot(b[:, 0], Sb[:, 0]) / torch.dot(b[:, 0], b[:, 0]))) < 1e-3 * abs(float(T2[0, 0, 0]))

@@ -253,3 +253,39 @@ def test_slq_quadrature_batched_equals_scalar_and_spectral_function():
     w, V = np.linalg.eigh(T)
     want = float(np.sum(V[0] ** 2 * np.log(fun(w))))
     assert abs(got - want) <= 1e-12 * max(1.0, abs(want))
+
+
+def test_operators_rebuild_from_their_constructor_record(monkeypatch):
+    """linear_operator rebuilds an operator as cls(*args, **kwargs) from what its constructor forwarded to
+    LinearOperator.__init__ (representation_tree; the reference forwards every argument, graph_laplacian_operator.py:35-43).
+    Construct the five operators (no compute: the device check is stubbed out), rebuild each from its record and
+    compare every attribute the reference's constructors set."""
+    import manifold_gp_amd as mgp
+    from manifold_gp_amd import _lib
+    monkeypatch.setattr(_lib, "require_device", lambda *a: None)
+    O = mgp.operators
+    val = torch.rand(3)
+    idx = torch.tensor([[0, 0, 1], [1, 2, 2]])
+    eps, ls = torch.tensor([[0.5]]), torch.tensor([[1.3]])
+    lap = O.GraphLaplacianOperator(val, idx, 3, eps, "randomwalk", True, False)
+    Q = O.PrecisionMaternOperator(lap, 2, ls)
+    mask = torch.tensor([True, False, True])
+    ops = [lap, lap._transpose_nonbatch(), Q, O.ScaleWrapperOperator(Q, torch.tensor(0.7), inverse_scale=True),
+           O.NoiseWrapperOperator(Q, torch.tensor(1e-2)), O.SchurComplementOperator(Q, mask)]
+
+    def same(a, b):
+        if torch.is_tensor(a):
+            return torch.is_tensor(b) and a.data_ptr() == b.data_ptr()
+        return a is b or a == b
+
+    for op in ops:
+        re_op = type(op)(*op._args, **op._kwargs)
+        assert type(re_op) is type(op) and tuple(re_op.shape) == tuple(op.shape)
+        names = [k for k in vars(op) if not k.startswith("_")]
+        assert names, type(op).__name__
+        for k in names:
+            assert same(getattr(op, k), getattr(re_op, k)), (type(op).__name__, k)
+        # the tensors the record holds are what representation() hands to autograd
+        assert all(torch.is_tensor(t) for t in op.representation())
+    assert lap._kwargs["normalization"] == "randomwalk" and "graph" not in lap._kwargs
+    assert ops[1].transposed is True and ops[1]._kwargs["transposed"] is True

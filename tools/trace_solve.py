@@ -1,13 +1,22 @@
 #!/usr/bin/env python
-"""Print the kernel timeline of the last CG solve in a rocprofv3 --kernel-trace CSV (start offset, duration, gap)."""
-import csv, glob, os, sys
+"""Print the kernel timeline of the last CG solve in a rocprofv3 --kernel-trace CSV: start offset, duration, gap to the
+previous kernel, name.  The solve is located by its closing cg_decide launch (or, for the classic start, cg_init)."""
+import csv, glob, os, re, sys
 base = sys.argv[1]
 f = max(glob.glob(base + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = max(i for i, r in enumerate(rows) if "cg_init" in r["Kernel_Name"])
-t0 = int(rows[idx]["Start_Timestamp"]); prev_end = t0
-for r in rows[max(0, idx - 3):idx + 60]:
+end = max(i for i, r in enumerate(rows) if "cg_decide" in r["Kernel_Name"] or "cg_update" in r["Kernel_Name"])
+# walk back to the start of that solve: the gap before its first kernel is a host round trip (>= 8 us)
+start = end
+while start > 0 and int(rows[start]["Start_Timestamp"]) - int(rows[start - 1]["End_Timestamp"]) < 8000:
+    start -= 1
+t0 = int(rows[start]["Start_Timestamp"])
+prev_end = t0
+total = 0
+for r in rows[start:end + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0][-60:]
+    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void (anonymous namespace)::", "")[:70]
     print("%8.2f us  dur %6.2f  gap %6.2f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name))
     prev_end = e
+    total += e - s
+print("solve: %d kernels, %.2f us of kernel time, %.2f us first start -> last end" % (end - start + 1, total / 1e3, (prev_end - t0) / 1e3))
