@@ -407,6 +407,35 @@ int mgp_cg_plan_create_dist(const mgp_operator_t* op_local, int C, const float* 
                             void* work, size_t work_bytes, void* stream, void** plan_out);
 /* solve / x / destroy: mgp_cg_plan_solve, mgp_cg_plan_x, mgp_cg_plan_destroy (B, X global length) */
 
+/* ---------------------------------------------------------------------------------------------
+ * Partitioned pipelined CG (csrc/pcg.hip): the multi-GPU form that can scale -- vectors AND rows partitioned,
+ * ONE grouped RCCL all-gather per iteration (the w slices + the dot partials), ghost layers instead of a second
+ * exchange for nu >= 2, the iteration loop captured in a hipGraph.  C = 1, forms 0 and 2.  Same call sites as
+ * mgp_cg_plan_* above (the (K + s I) x = y solve in precision form).
+ *   op->L        tile view of the WHOLE padded graph over this rank's row order [own rows, ghost layer 1, ...,
+ *                rest] (mgp_graph_tiles with `order`: tile_rowptr / tile_vals / tile_rowid set); L.n = global
+ *                (padded) node count; pre / post / diag at the global length
+ *   launch_rows  [nu]: rows of that view launch s of the SpMV chain covers = own rows + (nu - 1 - s) ghost layers,
+ *                rounded up to the tile height; launch_rows[nu - 1] >= n_loc
+ *   row0, n_loc  this rank's contiguous row block (row0 = rank * n_loc, equal blocks); n_real: rows >= n_real are
+ *                padding
+ *   comm         ncclComm_t, or NULL: world == 1, or VIRTUAL ranks of one process sharing `shared`
+ *                (mgp_pcg_shared_floats floats: gathered w and partials, double-buffered), driven phase by phase
+ *                with mgp_pcg_plan_enqueue -- what the single-GPU tests of the partition logic use
+ *   B            right-hand side at the global length on every rank; the solution's own rows are valid in
+ *                mgp_pcg_plan_x()[row0 .. row0 + n_loc) and copied to X_loc when given */
+size_t mgp_pcg_shared_floats(int64_t n_glob, int64_t n_loc, int world);
+size_t mgp_pcg_workspace_bytes(int64_t n_glob, int64_t n_loc, int world);
+int mgp_pcg_plan_create(const mgp_operator_t* op, const int64_t* launch_rows, int64_t row0, int64_t n_loc,
+                        int64_t n_real, void* comm, int rank, int world, float* shared,
+                        const mgp_cg_params_t* params, void* work, size_t work_bytes, void* stream,
+                        void** plan_out);
+int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int32_t* iters, float* resid, int32_t* status);
+int mgp_pcg_plan_enqueue(void* plan, int phase, int par, const float* B); /* 0: start (first apply), 1: one iteration */
+int mgp_pcg_plan_poll(void* plan, int32_t* iters, float* resid, int32_t* status); /* 1 = undecided */
+float* mgp_pcg_plan_x(void* plan);
+int mgp_pcg_plan_destroy(void* plan);
+
 #ifdef __cplusplus
 }
 #endif

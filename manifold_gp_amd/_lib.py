@@ -124,6 +124,15 @@ SIGNATURES = {
     "mgp_cg_dist_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int, c_int]),
     "mgp_cg_plan_create_dist": (c_int, [POINTER(OperatorT), c_int, _P, POINTER(CgParamsT), _P, c_int, c_int, _P,
                                         c_size_t, _P, POINTER(c_void_p)]),
+    "mgp_pcg_shared_floats": (c_size_t, [c_int64, c_int64, c_int]),
+    "mgp_pcg_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "mgp_pcg_plan_create": (c_int, [POINTER(OperatorT), POINTER(c_int64), c_int64, c_int64, c_int64, _P, c_int, c_int, _P,
+                                    POINTER(CgParamsT), _P, c_size_t, _P, POINTER(c_void_p)]),
+    "mgp_pcg_plan_solve": (c_int, [_P, _P, _P, POINTER(c_int32), POINTER(c_float), POINTER(c_int32)]),
+    "mgp_pcg_plan_enqueue": (c_int, [_P, c_int, c_int, _P]),
+    "mgp_pcg_plan_poll": (c_int, [_P, POINTER(c_int32), POINTER(c_float), POINTER(c_int32)]),
+    "mgp_pcg_plan_x": (c_void_p, [_P]),
+    "mgp_pcg_plan_destroy": (c_int, [_P]),
     "mgp_lanczos_workspace_bytes": (c_size_t, [c_int64, c_int, POINTER(LanczosParamsT)]),
     "mgp_lanczos_smallest": (c_int, [POINTER(CsrT), c_int, POINTER(LanczosParamsT), POINTER(c_float), _P,
                                      POINTER(c_float), POINTER(c_int32), _P, c_size_t, _P]),

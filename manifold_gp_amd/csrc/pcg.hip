@@ -1,0 +1,622 @@
+// Pipelined conjugate gradients (Ghysels-Vanroose recurrence) with PARTITIONED vectors: the row-partitioned
+// multi-GPU form of the (K + s I) x = y solve -- one process per GPU, ONE RCCL collective per iteration -- and,
+// with world = 1, a single-GPU variant of the solver in cg.hip.
+//
+// The reference has no distributed code; the solve it replaces is linear_cg behind
+// precision_matern_operator.py:53 / train_model.py:68.  Why this recurrence for the partitioned form:
+//   classic / Chronopoulos-Gear CG needs the WHOLE new search vector for the next SpMV and, separately, the dot
+//   products of that SpMV's output for the next update: two global synchronisations per iteration (a vector
+//   gather and a scalar reduction).  In the pipelined recurrence
+//       gamma_i = (r_i, r_i),  delta_i = (w_i, r_i),  q_i = A w_i                     [w_i = A r_i by recurrence]
+//       beta_i = gamma_i / gamma_{i-1},  alpha_i = gamma_i / (delta_i - beta_i gamma_i / alpha_{i-1})
+//       z = q + beta z,  s = w + beta s,  p = r + beta p,  x += alpha p,  r -= alpha s,  w -= alpha z
+//   both the dots and the SpMV input depend only on (r_i, w_i), i.e. on the previous vector update.  So per iteration
+//   every rank: updates ITS rows of x, r, p, s, z, w and writes its partial dots; ONE grouped all-gather moves the
+//   w slices and the partials; the SpMVs of A w follow.  The update needs alpha_i, beta_i -- sums of the gathered
+//   partials, re-reduced in a fixed order by every workgroup: all ranks take bit-identical decisions, hence issue
+//   identical collective sequences.
+//
+// Row partition with ghost layers (nu >= 2 without a second exchange): A w = (I +) c D^1/2 (tau I + L)^nu D^1/2 w is a
+// chain of nu SpMVs.  Rank p owns a contiguous row block R_p; launch s of the chain must produce its output on
+// R_p grown by (nu - 1 - s) neighbour layers.  The host orders the rows as [R_p, G_1, G_2, ..., rest] and builds the
+// tile view of the graph over that order (mgp_graph_tiles with `order`): launch s simply runs the tile SpMV on the
+// first launch_rows[s] rows of the view.  All vectors live at the global length and are indexed by global row id
+// (the tile view's row ids); a rank touches its own rows of them, the full gathered w, and the chain's
+// intermediate on R_p + ghosts.
+//
+// Attainable accuracy.  The pipelined recurrence carries two more vector recurrences (w, z) than classic CG and
+// its residual stagnates EARLIER in fp32 (measured on the dumbbell test systems, cond 3e3 .. 1e5: recurrence residual
+// 2e-4 .. 4e-2 where the Chronopoulos-Gear solver of cg.hip reaches a true residual of 2e-4 .. 3e-3), and past that
+// point the iterates drift.  Two guards: (1) stagnation detection -- the smallest residual norm seen and its
+// iteration are tracked; no new minimum for 50 + it_best / 4 iterations ends the solve with status 4; (2) with
+// max_refine > 0 the solve is the inner solver of an iterative refinement: the accumulated solution's TRUE residual
+// b - A x is formed (one more gather + apply), and A d = residual is solved again until the true residual meets the
+// tolerance -- every round restarts the recurrences, which is also what repairs the drift.  `resid` then reports
+// the true relative residual.  Well-conditioned systems (the C3 / C4 posterior: 3 iterations) never see either.
+//
+// `comm == NULL` with world > 1 is the VIRTUAL mode of the tests: several plans (one per virtual rank) live in one
+// process on one GPU and share the double-buffered w / partial arrays, so that the all-gather is the identity;
+// the host enqueues the phases of every virtual rank in lock step (mgp_pcg_plan_enqueue).
+#include <math.h>
+#include <new>
+#include <rccl/rccl.h>
+#include <string.h>
+#include "mgp_common.h"
+#include "mgp_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kMaxNu = 8;
+constexpr int kMaxSlots = 16;        // partial slots per lane of the consuming kernels: <= 4096 workgroups in all
+
+struct PcgArgs {
+  int64_t row0, n_loc;     // this rank's rows [row0, row0 + n_loc) (global ids)
+  int64_t n_real;          // rows >= n_real are padding (isolated nodes, b = 0)
+  float *x, *r, *p, *s, *z;         // global length, own rows touched
+  const float* q;          // A w on own rows
+  float* w[2];             // gathered w, double-buffered by the iteration parity
+  float* pd[2];            // [2][world * nbu]: gamma partials then delta partials
+  int nbu;                 // workgroups of this kernel per rank
+  int world, rank;
+  float* scal;             // [0..1] gamma_old by parity, [2..3] alpha_old by parity, [4] bb, [5] resid,
+                           // [6] tolerance of this round, [8..9] best residual by parity, [10..11] its iteration
+  int* state;              // [0] operator applies of the iteration loop so far (ticked by the chain's last SpMV:
+                           //     the update of iteration i reads i + 1), [1] done, [2] status
+  int* host_state;         // host-mapped mirror
+  float* host_resid;
+  float tol;
+  int max_iter, min_iter, stop_mode;
+};
+
+// fixed-order reduction of the gathered partials: lane slots in order, DPP wave sum, (w0 + w1) + (w2 + w3)
+__device__ __forceinline__ void reduce_two(const float* __restrict__ pg, const float* __restrict__ pdl, int count,
+                                           float (*sh)[2], float* g_out, float* d_out) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float gv[kMaxSlots], dv[kMaxSlots];
+#pragma unroll
+  for (int k = 0; k < kMaxSlots; ++k) {
+    const int b = tid + k * kBlock;
+    const int bc = b < count ? b : count - 1;
+    gv[k] = pg[bc];
+    dv[k] = pdl[bc];
+  }
+  float g = 0.f, d = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxSlots; ++k) {
+    const bool on = tid + k * kBlock < count;
+    g += on ? gv[k] : 0.f;
+    d += on ? dv[k] : 0.f;
+  }
+  g = mgp_wave_sum(g);
+  d = mgp_wave_sum(d);
+  if (lane == 0) { sh[wave][0] = g; sh[wave][1] = d; }
+  __syncthreads();
+  *g_out = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+  *d_out = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+}
+
+// after the first apply (w_0 = A b on this rank's rows, already in w[0]): r = b, x = p = s = z = 0 on own rows,
+// partials of gamma_0 = (b, b) and delta_0 = (w_0, b); iteration state reset by workgroup 0
+__global__ __launch_bounds__(kBlock) void pcg_start_kernel(PcgArgs a, const float* __restrict__ B, int round) {
+  __shared__ float sh[kBlock / 64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && tid == 0) {
+    a.state[0] = 0; a.state[1] = 0; a.state[2] = 0;
+    if (round == 0) a.scal[6] = a.tol;                  // later rounds: set by the refinement's finalize kernel
+    a.scal[8] = 3.0e38f; a.scal[9] = 3.0e38f;
+    reinterpret_cast<int*>(a.scal)[10] = 0; reinterpret_cast<int*>(a.scal)[11] = 0;
+  }
+  const int64_t rows_per = (a.n_loc + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
+  const int64_t l0 = (int64_t)blockIdx.x * rows_per;
+  int64_t l1 = l0 + rows_per;
+  if (l1 > a.n_loc) l1 = a.n_loc;
+  float g = 0.f, d = 0.f;
+  for (int64_t l = l0 + tid; l < l1; l += kBlock) {
+    const int64_t r = a.row0 + l;
+    const float b = r < a.n_real ? B[r] : 0.f;
+    const float w0 = a.w[0][r];
+    a.r[r] = b; a.x[r] = 0.f; a.p[r] = 0.f; a.s[r] = 0.f; a.z[r] = 0.f;
+    g = fmaf(b, b, g);
+    d = fmaf(w0, b, d);
+  }
+  g = mgp_wave_sum(g);
+  d = mgp_wave_sum(d);
+  if (lane == 0) { sh[wave][0] = g; sh[wave][1] = d; }
+  __syncthreads();
+  if (tid == 0) {
+    const int slot = a.rank * a.nbu + blockIdx.x;
+    a.pd[0][slot] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+    a.pd[0][a.world * a.nbu + slot] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+  }
+}
+
+// one pipelined-CG vector update on this rank's rows (see the file header); takes the stopping decision on
+// ||r_i|| BEFORE updating, so that x is the iterate the decision was taken on
+__global__ __launch_bounds__(kBlock) void pcg_update_kernel(PcgArgs a) {
+  __shared__ float sh[kBlock / 64][2];
+  __shared__ float sh2[kBlock / 64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // everything another workgroup of THIS launch may rewrite is read through the parity: workgroup 0 stores
+  // gamma / alpha of iteration i in slot i & 1 while the others still read slot (i - 1) & 1; the iteration counter
+  // is ticked by the SpMV launch in front, never here; bb is written at i = 0 only and read from i = 1 on
+  __shared__ int sh_done;
+  const int it = a.state[0] - 1;
+  if (tid == 0) sh_done = a.state[1];                    // one lane's view, so that all waves take the same branch
+  const int par = it & 1;
+  const float gamma_old = a.scal[par ^ 1], alpha_old = a.scal[2 + (par ^ 1)], bb_old = a.scal[4];
+  const float tol = a.scal[6];
+  const float best_old = a.scal[8 + (par ^ 1)];
+  const int it_best_old = reinterpret_cast<const int*>(a.scal)[10 + (par ^ 1)];
+  const int count = a.world * a.nbu;
+  float gamma, delta;
+  reduce_two(a.pd[par], a.pd[par] + count, count, sh, &gamma, &delta);
+  if (sh_done) return;                                   // (published before the barrier inside reduce_two)
+  const float bb = it == 0 ? gamma : bb_old;
+  const float rel = bb > 0.f ? sqrtf(gamma / bb) : 0.f;
+  int done = 0, status = 0;
+  if (a.stop_mode == 0) {
+    if (it >= a.min_iter && rel < tol) { done = 1; status = 1; }
+  } else if (rel <= tol) { done = 1; status = 1; }
+  if (!isfinite(rel)) { done = 1; status = 3; }
+  if (!done && it >= a.max_iter) { done = 1; status = 2; }
+  // stagnation: no new minimum of the residual norm for 50 + it_best / 4 iterations (file header)
+  const float best = rel < best_old ? rel : best_old;
+  const int it_best = rel < best_old ? it : it_best_old;
+  if (!done && it - it_best >= 50 + it_best / 4) { done = 1; status = 4; }
+  float alpha = 0.f, beta = 0.f;
+  if (!done) {
+    if (it == 0) {
+      alpha = delta != 0.f ? gamma / delta : 0.f;
+    } else {
+      beta = gamma_old != 0.f ? gamma / gamma_old : 0.f;
+      const float den = delta - (alpha_old != 0.f ? beta * gamma / alpha_old : 0.f);
+      alpha = den != 0.f ? gamma / den : 0.f;
+    }
+    if (!isfinite(alpha) || !isfinite(beta)) { alpha = 0.f; beta = 0.f; }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    a.scal[5] = rel;
+    if (it == 0) a.scal[4] = bb;
+    if (done) {
+      // (a workgroup that starts late and reads done = 1 returns at once: it would have decided the same)
+      a.state[2] = status; a.state[1] = 1;
+      a.host_resid[0] = rel;
+      a.host_state[0] = it; a.host_state[2] = status;
+      __threadfence_system();
+      a.host_state[1] = 1;
+    } else {
+      a.scal[par] = gamma; a.scal[2 + par] = alpha;
+      a.scal[8 + par] = best;
+      reinterpret_cast<int*>(a.scal)[10 + par] = it_best;
+    }
+  }
+  if (done) return;
+  const float* __restrict__ wc = a.w[par];
+  float* __restrict__ wn = a.w[par ^ 1];
+  const int64_t rows_per = (a.n_loc + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
+  const int64_t l0 = (int64_t)blockIdx.x * rows_per;
+  int64_t l1 = l0 + rows_per;
+  if (l1 > a.n_loc) l1 = a.n_loc;
+  float ng = 0.f, nd = 0.f;
+  for (int64_t l = l0 + tid; l < l1; l += kBlock) {
+    const int64_t r = a.row0 + l;
+    const float q = a.q[r], w = wc[r], rr = a.r[r];
+    const float z = fmaf(beta, a.z[r], q);
+    const float s = fmaf(beta, a.s[r], w);
+    const float p = fmaf(beta, a.p[r], rr);
+    a.z[r] = z; a.s[r] = s; a.p[r] = p;
+    a.x[r] = fmaf(alpha, p, a.x[r]);
+    const float rn = fmaf(-alpha, s, rr);
+    const float wv = fmaf(-alpha, z, w);
+    a.r[r] = rn;
+    wn[r] = wv;
+    ng = fmaf(rn, rn, ng);
+    nd = fmaf(wv, rn, nd);
+  }
+  ng = mgp_wave_sum(ng);
+  nd = mgp_wave_sum(nd);
+  if (lane == 0) { sh2[wave][0] = ng; sh2[wave][1] = nd; }
+  __syncthreads();
+  if (tid == 0) {
+    const int slot = a.rank * a.nbu + blockIdx.x;
+    a.pd[par ^ 1][slot] = (sh2[0][0] + sh2[1][0]) + (sh2[2][0] + sh2[3][0]);
+    a.pd[par ^ 1][count + slot] = (sh2[0][1] + sh2[1][1]) + (sh2[2][1] + sh2[3][1]);
+  }
+}
+
+// ---- iterative refinement around the pipelined solve (own rows; fp64 accumulation of the solution)
+__global__ void pcg_accumulate_kernel(PcgArgs a, double* __restrict__ xacc, float* __restrict__ xfull, int first) {
+  for (int64_t l = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; l < a.n_loc; l += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = a.row0 + l;
+    const double v = first ? (double)a.x[r] : xacc[r] + (double)a.x[r];
+    xacc[r] = v;
+    xfull[r] = (float)v;
+  }
+}
+
+// R = B - A xacc on own rows (A xacc in t), partials of sum R^2 and sum B^2 in the slots of pd[0]
+__global__ __launch_bounds__(kBlock) void pcg_residual_kernel(PcgArgs a, const float* __restrict__ B, const float* __restrict__ t,
+                                                              float* __restrict__ rfull) {
+  __shared__ float sh[kBlock / 64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t rows_per = (a.n_loc + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
+  const int64_t l0 = (int64_t)blockIdx.x * rows_per;
+  int64_t l1 = l0 + rows_per;
+  if (l1 > a.n_loc) l1 = a.n_loc;
+  float rr = 0.f, bb = 0.f;
+  for (int64_t l = l0 + tid; l < l1; l += kBlock) {
+    const int64_t r = a.row0 + l;
+    const float b = r < a.n_real ? B[r] : 0.f;
+    const float d = r < a.n_real ? b - t[r] : 0.f;
+    rfull[r] = d;
+    rr = fmaf(d, d, rr);
+    bb = fmaf(b, b, bb);
+  }
+  rr = mgp_wave_sum(rr);
+  bb = mgp_wave_sum(bb);
+  if (lane == 0) { sh[wave][0] = rr; sh[wave][1] = bb; }
+  __syncthreads();
+  if (tid == 0) {
+    const int slot = a.rank * a.nbu + blockIdx.x;
+    a.pd[0][slot] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+    a.pd[0][a.world * a.nbu + slot] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+  }
+}
+
+// every rank: true relative residual from the gathered partials (same order everywhere) -> host; tolerance of
+// the next round relative to ITS right-hand side (the residual): half of what is still missing, within [tol, 0.1]
+__global__ __launch_bounds__(kBlock) void pcg_refine_finalize_kernel(PcgArgs a, float* __restrict__ host_true_rel) {
+  __shared__ float sh[kBlock / 64][2];
+  float rr, bb;
+  const int count = a.world * a.nbu;
+  reduce_two(a.pd[0], a.pd[0] + count, count, sh, &rr, &bb);
+  if (threadIdx.x == 0) {
+    const float rel = bb > 0.f ? sqrtf(rr / bb) : 0.f;
+    float next = rel > 0.f ? 0.5f * a.tol / rel : a.tol;
+    next = next < a.tol ? a.tol : (next > 0.1f ? 0.1f : next);
+    a.scal[6] = next;
+    host_true_rel[0] = rel;
+  }
+}
+
+__global__ void pcg_publish_kernel(PcgArgs a, const double* __restrict__ xacc) {
+  for (int64_t l = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; l < a.n_loc; l += (int64_t)gridDim.x * blockDim.x)
+    a.x[a.row0 + l] = (float)xacc[a.row0 + l];
+}
+
+struct PcgPlan {
+  mgp_operator_t op;
+  int64_t launch_rows[kMaxNu];
+  PcgArgs args;
+  ncclComm_t comm;
+  int world, rank;
+  bool virt;                 // world > 1 without a communicator: buffers shared with the other virtual ranks
+  float *t0, *t1;            // chain intermediates, global length
+  float* q;
+  double* xacc;              // refinement: accumulated solution (own rows)
+  float *xfull, *rfull;      // refinement: gathered solution / residual (global length)
+  float* host_true_rel;      // host-mapped
+  float* dev_true_rel;
+  mgp_cg_params_t prm;
+  hipStream_t stream, cap_stream;
+  hipGraphExec_t exec;       // `chunk` iterations (SpMV chain, update, collective)
+  bool has_graph, graphs_tried;
+  int chunk, solves;
+  int32_t* host_state;
+  float* host_resid;
+  int64_t n_glob;
+};
+
+size_t pcg_private_floats(int64_t n_glob) { return 12 * (size_t)n_glob + 256; }   // x r p s z q t0 t1 xfull rfull xacc(f64) + scalars
+
+int nbu_for(int64_t n_loc) {
+  int64_t nb = mgp_cdiv(n_loc, kBlock);
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+// launch `s` of the chain on the first launch_rows[s] rows of the tile view
+int chain_launch(PcgPlan* pl, int s, const float* in, float* out, const float* base, const int* skip, int* tick,
+                 hipStream_t st) {
+  const mgp_operator_t& op = pl->op;
+  const float tau = 2.0f * (float)op.nu / (op.kappa * op.kappa);
+  const bool first = s == 0, last = s == op.nu - 1;
+  mgp_csr_t L = op.L;
+  L.n = pl->launch_rows[s];
+  float cb = 0.f, co = 1.f;
+  const float* bs = nullptr;
+  if (last) {
+    co = op.scale;
+    if (op.form == 2) { bs = base; cb = 1.f; co = op.noise * op.scale; }
+  }
+  return mgp_spmm_fused_first(&L, 0, in, 1, out, tau, 1.0f, first ? op.pre : nullptr, last ? op.post : nullptr, bs, cb, co,
+                              nullptr, nullptr, skip, last ? tick : nullptr, nullptr, nullptr, st);
+}
+
+// q (or w_0) = A v on this rank's rows; v gathered at the global length
+int enqueue_apply(PcgPlan* pl, const float* v, float* out, const int* skip, int* tick, hipStream_t st) {
+  const float* in = v;
+  for (int s = 0; s < pl->op.nu; ++s) {
+    const bool last = s == pl->op.nu - 1;
+    float* o = last ? out : ((s & 1) ? pl->t1 : pl->t0);
+    MGP_TRY(chain_launch(pl, s, in, o, v, skip, tick, st));
+    in = o;
+  }
+  return MGP_OK;
+}
+
+// the one collective of an iteration: this rank's slice of w[par] and its partials, grouped
+int enqueue_gather(PcgPlan* pl, int par, hipStream_t st) {
+  if (!pl->comm) return MGP_OK;        // no communicator: a single rank, or virtual ranks sharing the buffers
+  // (with a communicator of size 1 the in-place gathers are issued all the same: that is how the RCCL path and its
+  // graph capture are exercised on a one-GPU box)
+  const PcgArgs& a = pl->args;
+  const int count = a.world * a.nbu;
+  ncclResult_t r = ncclGroupStart();
+  if (r != ncclSuccess) return 1000 + (int)r;
+  int rc = MGP_OK;
+  r = ncclAllGather(a.w[par] + a.row0, a.w[par], (size_t)a.n_loc, ncclFloat, pl->comm, st);
+  if (r != ncclSuccess) rc = 1000 + (int)r;
+  for (int k = 0; k < 2 && rc == MGP_OK; ++k) {
+    float* seg = a.pd[par] + (size_t)k * count;
+    r = ncclAllGather(seg + (size_t)a.rank * a.nbu, seg, (size_t)a.nbu, ncclFloat, pl->comm, st);
+    if (r != ncclSuccess) rc = 1000 + (int)r;
+  }
+  r = ncclGroupEnd();                                  // always closed, also on error
+  if (rc == MGP_OK && r != ncclSuccess) rc = 1000 + (int)r;
+  return rc;
+}
+
+// all-gather of one global-length vector whose own rows this rank has just written (+ the partials of pd[0])
+int enqueue_gather_vec(PcgPlan* pl, float* buf, bool with_partials, hipStream_t st) {
+  if (!pl->comm) return MGP_OK;
+  const PcgArgs& a = pl->args;
+  const int count = a.world * a.nbu;
+  ncclResult_t r = ncclGroupStart();
+  if (r != ncclSuccess) return 1000 + (int)r;
+  int rc = MGP_OK;
+  r = ncclAllGather(buf + a.row0, buf, (size_t)a.n_loc, ncclFloat, pl->comm, st);
+  if (r != ncclSuccess) rc = 1000 + (int)r;
+  for (int k = 0; with_partials && k < 2 && rc == MGP_OK; ++k) {
+    float* seg = a.pd[0] + (size_t)k * count;
+    r = ncclAllGather(seg + (size_t)a.rank * a.nbu, seg, (size_t)a.nbu, ncclFloat, pl->comm, st);
+    if (r != ncclSuccess) rc = 1000 + (int)r;
+  }
+  r = ncclGroupEnd();
+  if (rc == MGP_OK && r != ncclSuccess) rc = 1000 + (int)r;
+  return rc;
+}
+
+int enqueue_start(PcgPlan* pl, const float* B, int round, hipStream_t st) {
+  MGP_TRY(enqueue_apply(pl, B, pl->args.w[0], nullptr, nullptr, st));   // w_0 = A b on own rows
+  hipLaunchKernelGGL(pcg_start_kernel, dim3(pl->args.nbu), dim3(kBlock), 0, st, pl->args, B, round);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+// one iteration of parity `par`: q = A w[par] (own rows), update -> w[par ^ 1] slice + partials
+int enqueue_iteration(PcgPlan* pl, int par, hipStream_t st) {
+  MGP_TRY(enqueue_apply(pl, pl->args.w[par], pl->q, pl->args.state + 1, pl->args.state, st));
+  hipLaunchKernelGGL(pcg_update_kernel, dim3(pl->args.nbu), dim3(kBlock), 0, st, pl->args);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+void try_capture(PcgPlan* pl) {
+  pl->graphs_tried = true;
+  if (!pl->prm.use_graph || pl->virt) return;
+  if (hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
+  bool ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+  if (ok) {
+    int rc = MGP_OK;
+    // a chunk is an even number of iterations: it starts and ends on parity 0
+    for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) {
+      rc = enqueue_iteration(pl, i & 1, pl->cap_stream);
+      if (rc == MGP_OK) rc = enqueue_gather(pl, (i & 1) ^ 1, pl->cap_stream);
+    }
+    hipGraph_t graph = nullptr;
+    const hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
+    ok = rc == MGP_OK && e2 == hipSuccess && graph != nullptr;
+    if (ok) ok = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0) == hipSuccess;
+    if (graph) (void)hipGraphDestroy(graph);
+  }
+  (void)hipGetLastError();
+  pl->has_graph = ok;
+}
+
+}  // namespace
+
+// floats of the buffers that virtual ranks share (w[2] and pd[2]); real ranks keep them in their own workspace
+extern "C" size_t mgp_pcg_shared_floats(int64_t n_glob, int64_t n_loc, int world) {
+  if (n_glob <= 0 || n_loc <= 0 || world < 1) return 0;
+  return 2 * (size_t)n_glob + 2 * 2 * (size_t)world * nbu_for(n_loc) + 64;
+}
+
+extern "C" size_t mgp_pcg_workspace_bytes(int64_t n_glob, int64_t n_loc, int world) {
+  if (n_glob <= 0 || n_loc <= 0 || world < 1) return 0;
+  return (pcg_private_floats(n_glob) + mgp_pcg_shared_floats(n_glob, n_loc, world)) * sizeof(float) + 16 * 256;
+}
+
+// op->L: the tile view of the WHOLE (padded) graph over this rank's row order [own rows, ghost layers, rest]
+// (mgp_graph_tiles with `order`; tile_rowptr / tile_vals / tile_rowid set), vectors pre / post / diag at the global
+// length.  launch_rows[s]: rows of the view launch s of the chain covers (own rows + (nu - 1 - s) ghost layers, a
+// multiple of the tile height; launch_rows[nu - 1] = n_loc).  shared (nullable): w / partial buffers shared between
+// virtual ranks (mgp_pcg_shared_floats).  Forms 0 and 2, C = 1.
+extern "C" int mgp_pcg_plan_create(const mgp_operator_t* op, const int64_t* launch_rows, int64_t row0, int64_t n_loc,
+                                   int64_t n_real, void* comm, int rank, int world, float* shared,
+                                   const mgp_cg_params_t* params, void* work, size_t work_bytes, void* stream,
+                                   void** plan_out) {
+  if (!op || !launch_rows || !params || !work || !plan_out) return MGP_ERR_ARG;
+  if (op->nu < 1 || op->nu > kMaxNu || (op->form != 0 && op->form != 2)) return MGP_ERR_UNSUPPORTED;
+  if (world < 1 || rank < 0 || rank >= world || n_loc <= 0 || row0 < 0) return MGP_ERR_ARG;
+  const int64_t n_glob = op->L.n;
+  if (row0 + n_loc > n_glob || n_real > n_glob) return MGP_ERR_ARG;
+  if (!op->L.tile_ptr || !op->L.tile_cols || !op->L.lid || op->L.tile_rows <= 0) return MGP_ERR_UNSUPPORTED;
+  if (world > 1 && (!op->L.tile_rowptr || !op->L.tile_vals || !op->L.tile_rowid)) return MGP_ERR_ARG;
+  if (world > 1 && row0 != (int64_t)rank * n_loc) return MGP_ERR_ARG;     // equal contiguous blocks (all-gather layout)
+  for (int s = 0; s < op->nu; ++s) {
+    if (launch_rows[s] <= 0 || launch_rows[s] > n_glob) return MGP_ERR_ARG;
+    if (launch_rows[s] % op->L.tile_rows != 0 && launch_rows[s] != n_glob) return MGP_ERR_ARG;
+    if (s > 0 && launch_rows[s] > launch_rows[s - 1]) return MGP_ERR_ARG;
+  }
+  if (launch_rows[op->nu - 1] < n_loc) return MGP_ERR_ARG;
+  if ((int64_t)world * nbu_for(n_loc) > (int64_t)kMaxSlots * kBlock) return MGP_ERR_UNSUPPORTED;
+  const bool own_shared = shared == nullptr;
+  const size_t need = (pcg_private_floats(n_glob) + (own_shared ? mgp_pcg_shared_floats(n_glob, n_loc, world) : 0)) * sizeof(float) + 16 * 256;
+  if (work_bytes < need) return MGP_ERR_WORKSPACE;
+  PcgPlan* pl = new (std::nothrow) PcgPlan();
+  if (!pl) return MGP_ERR_ARG;
+  memset(pl, 0, sizeof(*pl));
+  pl->op = *op;
+  memcpy(pl->launch_rows, launch_rows, sizeof(int64_t) * op->nu);
+  pl->comm = static_cast<ncclComm_t>(comm);
+  pl->world = world; pl->rank = rank;
+  pl->virt = world > 1 && comm == nullptr;
+  pl->prm = *params;
+  if (pl->prm.max_iter <= 0) pl->prm.max_iter = 1000;
+  if (pl->prm.min_iter < 0) pl->prm.min_iter = 0;
+  pl->chunk = pl->prm.check_every > 0 ? pl->prm.check_every : 8;
+  pl->chunk += pl->chunk & 1;                                    // even: a chunk starts and ends on parity 0
+  pl->stream = mgp_stream(stream);
+  pl->n_glob = n_glob;
+  MgpArena ar(work, work_bytes);
+  PcgArgs& a = pl->args;
+  a.row0 = row0; a.n_loc = n_loc; a.n_real = n_real;
+  a.x = ar.take<float>(n_glob); a.r = ar.take<float>(n_glob); a.p = ar.take<float>(n_glob);
+  a.s = ar.take<float>(n_glob); a.z = ar.take<float>(n_glob);
+  pl->q = ar.take<float>(n_glob); a.q = pl->q;
+  pl->t0 = ar.take<float>(n_glob); pl->t1 = ar.take<float>(n_glob);
+  pl->xfull = ar.take<float>(n_glob); pl->rfull = ar.take<float>(n_glob);
+  pl->xacc = ar.take<double>(n_glob);
+  a.scal = ar.take<float>(16);
+  a.state = reinterpret_cast<int*>(ar.take<float>(16));
+  a.nbu = nbu_for(n_loc);
+  a.world = world; a.rank = rank;
+  const size_t npd = 2 * (size_t)world * a.nbu;
+  float* sh = shared ? shared : ar.take<float>(mgp_pcg_shared_floats(n_glob, n_loc, world));
+  if (sh) {
+    a.w[0] = sh; a.w[1] = sh + n_glob;
+    a.pd[0] = sh + 2 * (size_t)n_glob; a.pd[1] = a.pd[0] + npd;
+  }
+  a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter; a.stop_mode = pl->prm.stop_mode;
+  if (!ar.ok() || !sh) { delete pl; return MGP_ERR_WORKSPACE; }
+  hipError_t e = hipHostMalloc((void**)&pl->host_state, 16 * sizeof(int32_t), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_resid, 4 * sizeof(float), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&a.host_state, pl->host_state, 0);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&a.host_resid, pl->host_resid, 0);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_true_rel, 4 * sizeof(float), hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&pl->dev_true_rel, pl->host_true_rel, 0);
+  if (e != hipSuccess) { delete pl; return (int)e; }
+  *plan_out = pl;
+  return MGP_OK;
+}
+
+// Lock-step driver for virtual ranks (and building block of the solve): phase 0 = first apply + start kernel (B read
+// at the global length), phase 1 = one iteration of the parity the device state is at, given by the caller as `par`
+// (0 for the first iteration after phase 0, alternating).  No collective is issued here.
+extern "C" int mgp_pcg_plan_enqueue(void* plan, int phase, int par, const float* B) {
+  PcgPlan* pl = static_cast<PcgPlan*>(plan);
+  if (!pl || (phase == 0 && !B)) return MGP_ERR_ARG;
+  if (phase == 0) { pl->host_state[1] = 0; return enqueue_start(pl, B, 0, pl->stream); }
+  return enqueue_iteration(pl, par & 1, pl->stream);
+}
+
+extern "C" int mgp_pcg_plan_poll(void* plan, int32_t* iters, float* resid, int32_t* status) {
+  PcgPlan* pl = static_cast<PcgPlan*>(plan);
+  if (!pl) return MGP_ERR_ARG;
+  if (!pl->host_state[1]) return 1;                       // undecided
+  if (iters) *iters = pl->host_state[0];
+  if (status) *status = pl->host_state[2];
+  if (resid) *resid = pl->host_resid[0];
+  return MGP_OK;
+}
+
+// full solve (single rank, or one rank of an RCCL job): the solution is left in the plan's x buffer at the global
+// length, own rows valid (mgp_pcg_plan_x); X (nullable): own rows copied to X[0 .. n_loc)
+extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int32_t* iters, float* resid, int32_t* status) {
+  PcgPlan* pl = static_cast<PcgPlan*>(plan);
+  if (!pl || !B) return MGP_ERR_ARG;
+  if (pl->virt) return MGP_ERR_UNSUPPORTED;               // virtual ranks are driven by mgp_pcg_plan_enqueue
+  hipStream_t st = pl->stream;
+  if (pl->solves++ >= 1 && !pl->graphs_tried) try_capture(pl);
+  const int max_refine = pl->prm.max_refine > 0 ? pl->prm.max_refine : 0;
+  const PcgArgs& a = pl->args;
+  const int egrid = (int)(mgp_cdiv(a.n_loc, kBlock) > 1024 ? 1024 : mgp_cdiv(a.n_loc, kBlock));
+  volatile int32_t* flag = pl->host_state + 1;
+  int total_iters = 0, last_status = 0;
+  const float* rhs = B;
+  for (int round = 0; round <= max_refine; ++round) {
+    pl->host_state[1] = 0;
+    MGP_TRY(enqueue_start(pl, rhs, round, st));
+    MGP_TRY(enqueue_gather(pl, 0, st));
+    int guard = 0;
+    for (;;) {
+      if (pl->has_graph) {
+        MGP_HIP_TRY(hipGraphLaunch(pl->exec, st));
+      } else {
+        for (int i = 0; i < pl->chunk; ++i) {
+          MGP_TRY(enqueue_iteration(pl, i & 1, st));
+          MGP_TRY(enqueue_gather(pl, (i & 1) ^ 1, st));
+        }
+      }
+      // every rank launches whole chunks and checks the flag only once its chunk has drained: the decisions are
+      // bit-identical on all ranks, so all ranks stop behind the same chunk and their collective sequences match
+      MGP_HIP_TRY(hipStreamSynchronize(st));
+      if (*flag) break;
+      if (++guard > pl->prm.max_iter / pl->chunk + 2) break;
+    }
+    total_iters += pl->host_state[0];
+    last_status = pl->host_state[2];
+    if (max_refine == 0) break;
+    // accumulate, gather the accumulated solution, true residual of the ORIGINAL system on own rows, gather it
+    hipLaunchKernelGGL(pcg_accumulate_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->args, pl->xacc, pl->xfull, round == 0 ? 1 : 0);
+    MGP_LAUNCH_CHECK();
+    MGP_TRY(enqueue_gather_vec(pl, pl->xfull, false, st));
+    MGP_TRY(enqueue_apply(pl, pl->xfull, pl->q, nullptr, nullptr, st));
+    hipLaunchKernelGGL(pcg_residual_kernel, dim3(a.nbu), dim3(kBlock), 0, st, pl->args, B, pl->q, pl->rfull);
+    MGP_LAUNCH_CHECK();
+    MGP_TRY(enqueue_gather_vec(pl, pl->rfull, true, st));
+    hipLaunchKernelGGL(pcg_refine_finalize_kernel, dim3(1), dim3(kBlock), 0, st, pl->args, pl->dev_true_rel);
+    MGP_LAUNCH_CHECK();
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    pl->host_resid[0] = pl->host_true_rel[0];                         // `resid` reports the TRUE relative residual
+    if (pl->host_true_rel[0] <= 2.0f * pl->prm.tol) { last_status = 1; break; }
+    if (round == max_refine || last_status == 3) { if (last_status == 1) last_status = 2; break; }
+    rhs = pl->rfull;
+  }
+  if (max_refine > 0) {
+    hipLaunchKernelGGL(pcg_publish_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->args, pl->xacc);
+    MGP_LAUNCH_CHECK();
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    pl->host_state[0] = total_iters;
+    pl->host_state[2] = last_status;
+  }
+  if (X_loc) {
+    MGP_HIP_TRY(hipMemcpyAsync(X_loc, pl->args.x + pl->args.row0, (size_t)pl->args.n_loc * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+  }
+  if (iters) *iters = pl->host_state[0];
+  if (status) *status = pl->host_state[2];
+  if (resid) *resid = pl->host_resid[0];
+  return MGP_OK;
+}
+
+extern "C" float* mgp_pcg_plan_x(void* plan) {
+  PcgPlan* pl = static_cast<PcgPlan*>(plan);
+  return pl ? pl->args.x : nullptr;
+}
+
+extern "C" int mgp_pcg_plan_destroy(void* plan) {
+  PcgPlan* pl = static_cast<PcgPlan*>(plan);
+  if (!pl) return MGP_ERR_ARG;
+  if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
+  if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
+  if (pl->host_state) (void)hipHostFree(pl->host_state);
+  if (pl->host_resid) (void)hipHostFree(pl->host_resid);
+  if (pl->host_true_rel) (void)hipHostFree(pl->host_true_rel);
+  delete pl;
+  return MGP_OK;
+}

@@ -1,11 +1,21 @@
 """Row-partitioned multi-GPU CG (one process per GPU, RCCL over xGMI).
 
-The reference has no distributed code.  Design (csrc/operator.hip, cg.hip):
-rank p owns the CSR rows [p*n_loc, (p+1)*n_loc) of the Laplacian, every vector is replicated at the
-global (padded) length, each SpMM launch computes the local row slice and ONE grouped RCCL
-all-gather assembles the output (plus, on the last launch of an operator chain, the dot-product
-partials) on every rank.  The vector updates of the Chronopoulos-Gear recurrence are replicated, so
-all ranks take bit-identical convergence decisions and issue identical collective sequences.
+The reference has no distributed code.  Two forms live here:
+
+* `PcgPlan` / `PartitionedOperator` (csrc/pcg.hip) -- the form meant to scale: rows AND vectors partitioned, the
+  pipelined CG recurrence, ONE grouped RCCL all-gather per iteration (the w slices and the dot partials), ghost
+  layers so that the nu SpMVs of an operator apply need no exchange in between, the iteration loop in a hipGraph.
+  `virtual_pcg_solve` runs the same plans for several virtual ranks in one process on one GPU (shared buffers stand
+  in for the all-gather): the partition logic is tested without a multi-GPU box.  `solve_columns_sharded` covers
+  the other multi-GPU axis of the path: independent right-hand sides (the 100 one-hot columns of
+  `_average_variance`, SLQ probes) are dealt to the ranks and solved with the single-GPU plan -- no data-path
+  collective at all, one all-gather of the results.
+* `DistCgPlan` (csrc/operator.hip, cg.hip) -- round 1's form: rank p owns the CSR rows [p*n_loc, (p+1)*n_loc),
+  every vector is REPLICATED at the global length, each SpMM launch computes the local row slice and one grouped
+  all-gather per SpMV assembles the output plus the dot partials; the Chronopoulos-Gear vector updates are
+  replicated.  Kept for multi-column solves; it cannot speed up the vector work.
+
+In both, all ranks take bit-identical convergence decisions and issue identical collective sequences.
 
 This module holds the host logic: the partition, padding the graph with isolated nodes so that it
 divides evenly, slicing the local operator, creating the RCCL communicator from a unique id
@@ -166,6 +176,261 @@ def apply_partitioned(desc, part, rank, comm, X_pad):
     check(lib().mgp_operator_apply_part(ctypes.byref(op), comm, rank, part.world, ptr(X), X.shape[1], ptr(Y),
                                         ptr(work), work.numel(), stream()), "mgp_operator_apply_part")
     return Y
+
+
+# ------------------------------------------------------------------------------ partitioned pipelined CG
+def ghost_layers(graph, r0, r1, layers):
+    """Neighbour layers of the row block [r0, r1): layer k = nodes referenced by the rows of (block + layers < k)
+    that are not in them yet.  Returns a list of `layers` int64 tensors of global ids (ascending)."""
+    n = graph.n
+    dev = graph.col.device
+    entry_row = getattr(graph, "_entry_row", None)
+    if entry_row is None:
+        counts = (graph.rowptr[1:] - graph.rowptr[:-1]).long()
+        entry_row = torch.repeat_interleave(torch.arange(n, device=dev, dtype=torch.int32), counts)
+        graph._entry_row = entry_row
+    inc = torch.zeros(n, dtype=torch.bool, device=dev)
+    inc[r0:r1] = True
+    newest = inc.clone()
+    out = []
+    for _ in range(layers):
+        sel = newest[entry_row.long()]
+        cols = graph.col[sel].long()
+        ref = torch.zeros(n, dtype=torch.bool, device=dev)
+        ref[cols] = True
+        newest = ref & ~inc
+        out.append(torch.nonzero(newest, as_tuple=False).squeeze(-1))
+        inc |= newest
+    return out
+
+
+class PartitionedOperator:
+    """One rank's view of a precision-family operator (forms 0 / 2) for the partitioned pipelined CG: the tile view
+    of the padded graph over the row order [own rows, ghost layer 1, ..., ghost layer nu - 1, rest], the number of
+    rows each launch of the SpMV chain covers, and the mgp_operator_t over it.  `desc.data` must be the LaplacianData
+    of the PADDED graph (pad_graph), the same on every rank."""
+
+    def __init__(self, desc, part, rank):
+        from .graph import build_tiles
+        if desc.form not in (0, 2):
+            raise ValueError("the partitioned solver takes single-chain operators (forms 0 and 2)")
+        d = desc.data
+        g = d.graph
+        if g.n != part.n_pad:
+            raise ValueError("the operator must live on the padded graph (pad_graph): %d != %d" % (g.n, part.n_pad))
+        self.desc, self.part, self.rank = desc, part, rank
+        r0, r1 = part.range(rank)
+        nu = int(desc.nu)
+        if part.world == 1:
+            # one rank: every launch covers all rows; the graph's own tile view (row order or its locality order)
+            self.tiles, self.vals_t = g.tiles, d.vals_t
+            if self.tiles is None:
+                raise RuntimeError("the partitioned solver needs the tile view of the graph")
+            self.launch_rows = [g.n] * nu
+            self.ghosts = [torch.empty(0, dtype=torch.int64, device=g.device) for _ in range(nu - 1)]
+        else:
+            self.ghosts = ghost_layers(g, r0, r1, nu - 1)
+            inc = torch.zeros(g.n, dtype=torch.bool, device=g.device)
+            inc[r0:r1] = True
+            for gl in self.ghosts:
+                inc[gl] = True
+            rest = torch.nonzero(~inc, as_tuple=False).squeeze(-1)
+            order = torch.cat([torch.arange(r0, r1, device=g.device)] + self.ghosts + [rest]).to(torch.int32)
+            self.tiles = build_tiles(g.n, g.rowptr, g.col, g.nnz, order=order)
+            if self.tiles is None:
+                raise RuntimeError("no tile view for this row order (a tile exceeds the LDS budget)")
+            self.vals_t = d.vals.index_select(0, self.tiles["emap"])
+            tr = self.tiles["rows"]
+            sizes = [part.n_loc]
+            for gl in self.ghosts:
+                sizes.append(sizes[-1] + int(gl.numel()))
+            # launch s produces its output on own rows + (nu - 1 - s) ghost layers
+            self.launch_rows = [min(g.n, -(-sizes[nu - 1 - s] // tr) * tr) for s in range(nu)]
+        self.op = desc.struct()
+        self.op.L = _lib.csr_struct(g.n, g.rowptr, g.col, d.vals, d.diag, tiles=self.tiles, tile_vals=self.vals_t)
+        self.ghost_rows = sum(int(gl.numel()) for gl in self.ghosts)
+
+
+class PcgPlan:
+    """Partitioned pipelined CG (mgp_pcg_plan_*): one rank of an RCCL job (`comm`), a single GPU (world 1), or a
+    virtual rank sharing `shared` with its siblings (comm None, world > 1; driven by `virtual_pcg_solve`)."""
+
+    def __init__(self, desc, part, rank, comm=None, shared=None, tol=1e-6, max_iter=1000, stop_mode=1, check_every=8,
+                 use_graph=True, refine=0):
+        """refine > 0: the pipelined solve becomes the inner solver of up to `refine` rounds of iterative refinement on
+        the TRUE residual (csrc/pcg.hip, "Attainable accuracy"); status 4 = the recurrence stagnated (no refinement)."""
+        self.pop = PartitionedOperator(desc, part, rank)
+        self.part, self.rank = part, rank
+        dev = desc.data.graph.device
+        self.params = CgParamsT(float(tol), int(max_iter), 10 if stop_mode == 0 else 0, int(stop_mode), int(check_every),
+                                int(bool(use_graph)), int(refine))
+        nu = int(desc.nu)
+        self._rows = (ctypes.c_int64 * nu)(*self.pop.launch_rows)
+        wb = lib().mgp_pcg_workspace_bytes(part.n_pad, part.n_loc, part.world)
+        self.work = torch.zeros(wb, dtype=torch.uint8, device=dev)
+        self.shared = shared
+        self.handle = ctypes.c_void_p(0)
+        r0, _ = part.range(rank)
+        check(lib().mgp_pcg_plan_create(ctypes.byref(self.pop.op), self._rows, r0, part.n_loc, part.n, comm, rank, part.world,
+                                        ptr(shared), ctypes.byref(self.params), ptr(self.work), self.work.numel(), stream(),
+                                        ctypes.byref(self.handle)), "mgp_pcg_plan_create")
+        self.iters, self.status, self.resid = 0, 0, None
+
+    @staticmethod
+    def shared_buffer(part, device):
+        """The buffers virtual ranks share (gathered w and dot partials, double-buffered)."""
+        return torch.zeros(int(lib().mgp_pcg_shared_floats(part.n_pad, part.n_loc, part.world)), dtype=torch.float32,
+                           device=device)
+
+    def x_view(self):
+        off = int(lib().mgp_pcg_plan_x(self.handle)) - self.work.data_ptr()
+        return self.work[off:off + self.part.n_pad * 4].view(torch.float32)
+
+    def solve(self, B_pad):
+        """B_pad [n_pad] on every rank.  Returns this rank's rows of the solution [n_loc] (a view)."""
+        B = _lib.f32c(B_pad.reshape(-1))
+        assert B.shape[0] == self.part.n_pad
+        iters, status, resid = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_float(0.0)
+        check(lib().mgp_pcg_plan_solve(self.handle, ptr(B), None, ctypes.byref(iters), ctypes.byref(resid),
+                                       ctypes.byref(status)), "mgp_pcg_plan_solve")
+        self.iters, self.status, self.resid = iters.value, status.value, resid.value
+        r0, r1 = self.part.range(self.rank)
+        return self.x_view()[r0:r1]
+
+    def enqueue(self, phase, par=0, B=None):
+        check(lib().mgp_pcg_plan_enqueue(self.handle, int(phase), int(par), ptr(B)), "mgp_pcg_plan_enqueue")
+
+    def poll(self):
+        iters, status, resid = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_float(0.0)
+        rc = lib().mgp_pcg_plan_poll(self.handle, ctypes.byref(iters), ctypes.byref(resid), ctypes.byref(status))
+        if rc == 1:
+            return None
+        check(rc, "mgp_pcg_plan_poll")
+        self.iters, self.status, self.resid = iters.value, status.value, resid.value
+        return self.iters, self.status, self.resid
+
+    def close(self):
+        if self.handle:
+            lib().mgp_pcg_plan_destroy(self.handle)
+            self.handle = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def virtual_pcg_solve(desc, part, B_pad, tol=1e-6, max_iter=1000, stop_mode=1, check_every=8):
+    """The partitioned solve with `part.world` VIRTUAL ranks in this process on one GPU: one plan per rank, all sharing
+    the gathered-w / partial buffers (each rank writes its slice: the all-gather is the identity), phases enqueued in
+    lock step on the current stream.  Exactly the kernels, row orders, ghost layers and decisions of the RCCL job.
+    Returns (x [n_pad] assembled from every rank's own rows, iterations, status, plans' ghost row counts)."""
+    dev = B_pad.device
+    B = _lib.f32c(B_pad.reshape(-1))
+    shared = PcgPlan.shared_buffer(part, dev)
+    plans = [PcgPlan(desc, part, r, comm=None, shared=shared, tol=tol, max_iter=max_iter, stop_mode=stop_mode,
+                     check_every=check_every) for r in range(part.world)]
+    try:
+        for pl in plans:
+            pl.enqueue(0, B=B)
+        it = 0
+        res = None
+        while res is None and it <= max_iter + 2 * check_every:
+            for _ in range(check_every):
+                for pl in plans:
+                    pl.enqueue(1, par=it & 1)
+                it += 1
+            torch.cuda.synchronize()
+            polled = [pl.poll() for pl in plans]
+            if all(p is not None for p in polled):
+                assert all(p == polled[0] for p in polled), "virtual ranks disagree: %r" % (polled,)
+                res = polled[0]
+        x = torch.empty(part.n_pad, device=dev)
+        for r, pl in enumerate(plans):
+            r0, r1 = part.range(r)
+            x[r0:r1] = pl.x_view()[r0:r1]
+        ghosts = [pl.pop.ghost_rows for pl in plans]
+    finally:
+        for pl in plans:
+            pl.close()
+    if res is None:
+        raise RuntimeError("virtual ranks undecided after %d iterations" % it)
+    return x, res[0], res[1], ghosts
+
+
+def solve_columns_sharded(desc, B, rank, world, group=None, **kw):
+    """Independent right-hand sides dealt to the ranks: columns [rank::world] are solved here with the single-GPU
+    plan (solvers.cg_solve), the results are all-gathered once.  No collective inside the solves: this is how the
+    multi-column workloads of the path (`_average_variance`, SLQ probes) use several GPUs.  B [n, C] replicated."""
+    from .solvers import cg_solve
+    import torch.distributed as dist
+    C = B.shape[1]
+    mine = list(range(rank, C, world))
+    per = -(-C // world)
+    Xl = torch.zeros(B.shape[0], per, device=B.device)
+    its = 0
+    if mine:
+        X, its, _ = cg_solve(desc, B[:, mine].contiguous(), **kw)
+        Xl[:, :len(mine)] = X
+    if world == 1:
+        return Xl[:, :C], its
+    parts = [torch.empty_like(Xl) for _ in range(world)]
+    dist.all_gather(parts, Xl, group=group)
+    out = torch.empty_like(B)
+    for r in range(world):
+        cols = list(range(r, C, world))
+        out[:, cols] = parts[r][:, :len(cols)]
+    return out, its
+
+
+def distributed_pcg_reference(local_apply, b_loc, part, rank, tol=1e-10, max_iter=1000, group=None):
+    """The algorithm of csrc/pcg.hip in plain torch, backend-agnostic (the gloo CPU tests run it with the oracle as
+    local operator): partitioned vectors, pipelined recurrence, ONE all-gather per iteration carrying the w slice
+    and this rank's two dot partials; every rank derives the same alpha / beta / decision from the gathered sums.
+    local_apply(v_full) -> rows [r0, r1) of A v.  b_loc: this rank's rows of b.  Returns (x_loc, iterations)."""
+    import torch.distributed as dist
+    n_loc = part.n_loc
+
+    def gather(w_loc, g, d):
+        send = torch.cat([w_loc, torch.stack([g, d]).to(w_loc)])
+        if part.world == 1:
+            recv = send.unsqueeze(0)
+        else:
+            buf = [torch.empty_like(send) for _ in range(part.world)]
+            dist.all_gather(buf, send, group=group)
+            recv = torch.stack(buf)
+        return recv[:, :n_loc].reshape(-1), recv[:, n_loc].sum(), recv[:, n_loc + 1].sum()
+
+    r = b_loc.clone()
+    x, p, s, z = (torch.zeros_like(r) for _ in range(4))
+    b_full, _, _ = gather(r, r.new_zeros(()), r.new_zeros(()))
+    w = local_apply(b_full)
+    w_full, gamma, delta = gather(w, (r * r).sum(), (w * r).sum())
+    bb = gamma
+    gamma_old = alpha_old = None
+    it = 0
+    while it < max_iter:
+        rel = torch.sqrt(gamma / bb) if bb > 0 else gamma * 0
+        if bool(rel <= tol):
+            break
+        q = local_apply(w_full)
+        if it == 0:
+            beta = gamma * 0
+            alpha = gamma / delta
+        else:
+            beta = gamma / gamma_old
+            alpha = gamma / (delta - beta * gamma / alpha_old)
+        z = q + beta * z
+        s = w + beta * s
+        p = r + beta * p
+        x = x + alpha * p
+        r = r - alpha * s
+        w = w - alpha * z
+        gamma_old, alpha_old = gamma, alpha
+        w_full, gamma, delta = gather(w, (r * r).sum(), (w * r).sum())
+        it += 1
+    return x, it
 
 
 # ------------------------------------------------------------------------------ reference (gloo tests)

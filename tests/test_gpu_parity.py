@@ -1869,3 +1869,130 @@ def test_solve_hook_honours_num_tridiag(mgp, golden, dev):
         Sb = S.matmul(b)
     assert sol2.shape == b.shape and T2.shape == (2, 6, 6)
     assert abs(float(T2[0, 0, 0]) - float(torch.dot(b[:, 0], Sb[:, 0]) / torch.dot(b[:, 0], b[:, 0]))) < 1e-3 * abs(float(T2[0, 0, 0]))
+
+
+# ----------------------------------------------------------------------------- partitioned pipelined CG (multi-GPU form)
+def _padded_descriptor(mgp, g, dev, norm, nu, form, world):
+    """(descriptor on the graph as given, the same operator on the graph padded for `world` ranks, the partition)"""
+    from manifold_gp_amd.graph import LaplacianData
+    from manifold_gp_amd.parallel import RowPartition, pad_graph
+    lap = _operator(mgp, g, dev, norm)
+    Q = mgp.operators.PrecisionMaternOperator(lap, nu, torch.tensor([[float(g["kappa"])]], device=dev))
+    desc = Q._descriptor()
+    desc = desc.with_(scale=0.7, form=2, noise=1e-2) if form == 2 else desc
+    part = RowPartition(desc.n, world)
+    gp = pad_graph(lap.graph, part.n_pad)
+    data = LaplacianData(gp, float(g["eps"]), bool(g["self_loops"]))
+    sq = data.dsqrt if norm == "randomwalk" else None
+    return desc, desc.with_(data=data, pre=sq, post=sq), part
+
+
+@pytest.mark.parametrize("nu", [1, 2, 3])
+@pytest.mark.parametrize("form", [0, 2])
+@pytest.mark.parametrize("norm", NORMS)
+def test_pcg_single_rank_matches_cg(mgp, golden, dev, norm, form, nu):
+    """csrc/pcg.hip with one rank (no communicator) against the Chronopoulos-Gear solver of cg.hip: same system,
+    same tolerance -> same solution to round-off, true residual at tolerance, comparable iteration count; graph
+    replay == eager launches bit for bit; a zero right-hand side."""
+    from manifold_gp_amd.parallel import PcgPlan
+    from manifold_gp_amd.solvers import cg_solve
+    g = golden("dumbbell_k50_noloop")          # eps = 0.5: cond(A) of a few hundred at most, 1e-6 is attainable in fp32
+    desc, dd, part = _padded_descriptor(mgp, g, dev, norm, nu, form, 1)
+    n = desc.n
+    y = part.pad(T(g["train_y"], dev))
+    xs, its, _ = cg_solve(desc, T(g["train_y"], dev), tol=1e-6, stop_mode=1, max_iter=20000)
+    sols = {}
+    for use_graph in (True, False):
+        plan = PcgPlan(dd, part, 0, tol=1e-6, max_iter=20000, stop_mode=1, use_graph=use_graph)
+        for _ in range(3):                                    # the graph is captured at the second solve
+            x = plan.solve(y).clone()
+        assert plan.status == 1 and abs(plan.iters - its) <= max(2, its // 20), (plan.iters, its)
+        sols[use_graph] = x
+        z = plan.solve(torch.zeros_like(y)).clone()
+        assert plan.status == 1 and plan.iters == 0 and float(z.abs().max()) == 0.0
+        plan.close()
+    assert torch.equal(sols[True], sols[False])
+    x = sols[True][:n]
+    r = desc.apply(x) - T(g["train_y"], dev)
+    r0 = desc.apply(xs) - T(g["train_y"], dev)
+    assert float(r.norm()) < max(5e-6 * float(T(g["train_y"], dev).norm()), 4 * float(r0.norm()))
+    assert float((x - xs).abs().max()) < 2e-4 * float(xs.abs().max())
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("nu,form,norm", [(1, 0, "symmetric"), (2, 2, "randomwalk"), (3, 2, "symmetric"), (2, 0, "randomwalk")])
+def test_pcg_virtual_ranks_partition_vectors_and_ghost_layers(mgp, golden, dev, world, nu, form, norm):
+    """The multi-GPU form on one GPU: `world` virtual ranks, each with its own row block, row order [own, ghost
+    layers, rest], tile view and plan; vectors partitioned; the gathered-w / partial buffers shared (each rank writes
+    its slice: the all-gather is the identity).  Against the one-rank solve: same solution to round-off (the dot
+    partials are summed over another partition), same iteration count +-1, all ranks reach the same decision in the
+    same iteration; ghost layers are non-empty for nu >= 2 and ranks that own only padding rows take part."""
+    from manifold_gp_amd.parallel import PcgPlan, virtual_pcg_solve
+    g = golden("dumbbell_k50_noloop")
+    desc, dd, part = _padded_descriptor(mgp, g, dev, norm, nu, form, world)
+    n = desc.n
+    y = part.pad(T(g["train_y"], dev))
+    x, its, status, ghosts = virtual_pcg_solve(dd, part, y, tol=1e-6, max_iter=20000, stop_mode=1)
+    assert status == 1
+    assert (sum(ghosts) > 0) == (nu >= 2), ghosts
+    _, d1, p1 = _padded_descriptor(mgp, g, dev, norm, nu, form, 1)
+    plan = PcgPlan(d1, p1, 0, tol=1e-6, max_iter=20000, stop_mode=1)
+    x1 = plan.solve(p1.pad(T(g["train_y"], dev))).clone()[:n]
+    assert abs(plan.iters - its) <= max(1, its // 50), (plan.iters, its)
+    plan.close()
+    assert float(x[n:].abs().max()) == 0.0                                   # padding rows: b = 0 -> x = 0
+    assert float((x[:n] - x1).abs().max()) < 2e-4 * float(x1.abs().max())
+    r = desc.apply(x[:n]) - T(g["train_y"], dev)
+    assert float(r.norm() / T(g["train_y"], dev).norm()) < 2e-5
+
+
+def test_pcg_rccl_world1_and_sharded_columns(mgp, golden, dev):
+    """The RCCL path with a communicator of size 1: the grouped in-place all-gathers are issued (and captured in the
+    iteration graph) all the same; iterates equal the communicator-free plan bit for bit.  Plus the column-sharded
+    multi-right-hand-side helper at world 1."""
+    from manifold_gp_amd.parallel import PcgPlan, init_comm, solve_columns_sharded
+    from manifold_gp_amd.solvers import cg_solve
+    g = golden("dumbbell_k50_noloop")
+    desc, dd, part = _padded_descriptor(mgp, g, dev, "randomwalk", 2, 2, 1)
+    y = part.pad(T(g["train_y"], dev))
+    comm = init_comm(0, 1)
+    a = PcgPlan(dd, part, 0, comm=comm, tol=1e-6, max_iter=20000, stop_mode=1)
+    b = PcgPlan(dd, part, 0, comm=None, tol=1e-6, max_iter=20000, stop_mode=1)
+    for _ in range(3):
+        xa, xb = a.solve(y).clone(), b.solve(y).clone()
+        assert torch.equal(xa, xb) and a.iters == b.iters and a.status == 1
+    a.close(), b.close()
+    B = T(g["probes"], dev)
+    with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1):
+        X, _ = solve_columns_sharded(desc, B, 0, 1)
+        Xr, _, _ = cg_solve(desc, B)
+    assert torch.equal(X, Xr)
+
+
+def test_pcg_stagnation_guard_and_refinement_on_an_ill_conditioned_system(mgp, golden, dev):
+    """eps = 0.05, nu = 2, Q itself (cond ~ 3e3): in fp32 the pipelined recurrence stalls at ~2e-4 where 1e-6 is asked
+    (cg.hip's recurrence reaches a TRUE residual of ~2e-4 as well).  Without refinement the stagnation guard ends the
+    solve (status 4) a few dozen iterations past the best residual instead of drifting for max_iter iterations; with
+    refinement rounds (restarts on the true residual) a tolerance within fp32's reach is met and `resid` is the TRUE
+    relative residual."""
+    from manifold_gp_amd.parallel import PcgPlan
+    from manifold_gp_amd.solvers import cg_solve
+    g = golden("dumbbell_k10_loop")
+    desc, dd, part = _padded_descriptor(mgp, g, dev, "symmetric", 2, 0, 1)
+    n = desc.n
+    yv = T(g["train_y"], dev)
+    y = part.pad(yv)
+    xs, its, _ = cg_solve(desc, yv, tol=1e-6, stop_mode=1, max_iter=20000)
+    ref_true = float((desc.apply(xs) - yv).norm() / yv.norm())
+    plan = PcgPlan(dd, part, 0, tol=1e-6, max_iter=20000, stop_mode=1)
+    x = plan.solve(y).clone()[:n]
+    assert plan.status == 4 and plan.iters < 4 * its, (plan.status, plan.iters, its)
+    true0 = float((desc.apply(x) - yv).norm() / yv.norm())
+    assert true0 < 50 * ref_true, (true0, ref_true)                       # stopped near its best, not after drifting
+    plan.close()
+    plan = PcgPlan(dd, part, 0, tol=1e-3, max_iter=20000, stop_mode=1, refine=6)
+    x = plan.solve(y).clone()[:n]
+    true1 = float((desc.apply(x) - yv).norm() / yv.norm())
+    assert plan.status == 1 and plan.resid <= 2e-3, (plan.status, plan.resid)
+    assert true1 <= 3e-3 and abs(true1 - plan.resid) < 1e-3, (true1, plan.resid)
+    plan.close()

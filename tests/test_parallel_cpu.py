@@ -155,3 +155,86 @@ def test_distributed_cg_world2_gloo_matches_single_process(golden):
     A = np.eye(n) + 1e-2 * 0.7 * PrecisionMaternOracle(lap, 2, float(g["kappa"])).dense()
     ref = np.linalg.solve(A, np.stack([g["train_y"], g["probes"][:, 0]], 1).astype(np.float64))
     assert np.abs(out["x"] - ref).max() < 1e-9 * np.abs(ref).max()
+
+
+def _worker_pcg(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from manifold_gp_amd.parallel import RowPartition, distributed_pcg_reference
+        from oracle.laplacian import LaplacianOracle
+        from oracle.sparse import SparsePrecision
+        g = dict(np.load(os.path.join(ROOT, "tests", "golden", "dumbbell_k10_loop.npz")))
+        n = g["train_x"].shape[0]
+        lap = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "randomwalk", True, dtype=np.float64)
+        sq = SparsePrecision(lap, 2, float(g["kappa"]), 0.7)
+        noise = 1e-2
+        part = RowPartition(n, world)
+        r0, r1 = part.range(rank)
+
+        def local_apply(v_full):         # this rank's rows of A v on the padded space (padding rows: identity)
+            out = v_full.clone()
+            out[:n] = torch.from_numpy(sq.posterior_system(v_full[:n].numpy(), noise))
+            return out[r0:r1]
+
+        b = torch.zeros(part.n_pad, dtype=torch.float64)
+        b[:n] = torch.from_numpy(g["train_y"].astype(np.float64))
+        x_loc, its = distributed_pcg_reference(local_apply, b[r0:r1].clone(), part, rank, tol=1e-11, max_iter=3000)
+        xs = [torch.empty_like(x_loc) for _ in range(world)]
+        dist.all_gather(xs, x_loc)
+        if rank == 0:
+            q.put(dict(ok=True, its=its, x=torch.cat(xs)[:n].numpy(), pad=float(torch.cat(xs)[n:].abs().max())))
+    except Exception as e:  # pragma: no cover
+        if rank == 0:
+            q.put(dict(ok=False, err=repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_partitioned_pipelined_cg_world2_gloo(golden):
+    """The algorithm of csrc/pcg.hip (partitioned vectors, pipelined recurrence, ONE all-gather per iteration) under
+    gloo with two processes, the float64 oracle as local operator, against the dense solve."""
+    from oracle.laplacian import LaplacianOracle
+    from oracle.precision import PrecisionMaternOracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pcg, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert out["ok"], out.get("err")
+    g = golden("dumbbell_k10_loop")
+    n = g["train_x"].shape[0]
+    lap = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "randomwalk", True, dtype=np.float64)
+    A = np.eye(n) + 1e-2 * 0.7 * PrecisionMaternOracle(lap, 2, float(g["kappa"])).dense()
+    ref = np.linalg.solve(A, g["train_y"].astype(np.float64))
+    assert out["pad"] == 0.0
+    assert np.abs(out["x"] - ref).max() < 1e-8 * np.abs(ref).max(), np.abs(out["x"] - ref).max() / np.abs(ref).max()
+
+
+def test_ghost_layers_and_rank_order_on_cpu_tensors():
+    """parallel.ghost_layers is index bookkeeping: on a path graph with two extra chords the layers of a row block
+    are its successive neighbour shells."""
+    from manifold_gp_amd.parallel import ghost_layers
+
+    class G:
+        pass
+    n = 12
+    nbrs = {i: {(i - 1) % n, (i + 1) % n} for i in range(n)}
+    nbrs[2].add(9), nbrs[9].add(2)
+    rowptr, col = [0], []
+    for i in range(n):
+        col += sorted(nbrs[i])
+        rowptr.append(len(col))
+    g = G()
+    g.n, g.rowptr, g.col = n, torch.tensor(rowptr, dtype=torch.int32), torch.tensor(col, dtype=torch.int32)
+    l1, l2 = ghost_layers(g, 0, 4, 2)
+    assert l1.tolist() == [4, 9, 11]                       # neighbours of {0,1,2,3}: 11, 4 and the chord 2-9
+    assert l2.tolist() == [5, 8, 10]
