@@ -15,9 +15,10 @@ inputs.  `value` = algorithmic SpMV bytes streamed by the solves / wall time (wh
 back to back with HIP events on the launch stream; `cpu_baseline` times the reference-style torch
 CPU operator (oracle/ref_torch.py, kind "port") on the host cores in the same run.
 
-N>1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- N x 60 000 points, rows of
-the graph partitioned across ranks, one RCCL all-gather (carrying the dot-product partials) per
-SpMV (manifold_gp_amd/parallel.py).
+N>1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling by default -- the same 60 000-node graph
+(the metric's configuration), rows and vectors partitioned across ranks, partitioned pipelined CG with one grouped
+RCCL all-gather per iteration (manifold_gp_amd/parallel.py, csrc/pcg.hip); `--scaling weak` keeps N x 60 000 points
+with round 1's replicated-vector plan.  `--workload s5` is the 1M-node graph that is expected to scale.
 """
 import argparse
 import json
@@ -45,20 +46,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_workload(args, dev, rank, world, shard_knn=False):
+def build_workload(args, dev, rank, world, shard_knn=False, scale_nodes=True):
+    """scale_nodes: weak scaling (world x the per-GPU node count); False: the same graph on every world size."""
     import manifold_gp_amd as mgp
     from tools import synth
     t0 = time.time()
+    if not scale_nodes:
+        nodes_mult = 1
+    else:
+        nodes_mult = world
     if args.workload == "c3":
         bases = args.nodes // 100 if args.nodes else 600
-        x_t, y_t = synth.rmnist_like(bases * world, 100, seed=1337, device=dev)
+        x_t, y_t = synth.rmnist_like(bases * nodes_mult, 100, seed=1337, device=dev)
         k, nu, norm = 50, 2, "randomwalk"
         with open(os.path.join(ROOT, "tests", "golden", "hyperparameters.json")) as fh:
             hp = json.load(fh)["srmnist_manifold_semisupervised"]
         name = "C3 RMNIST-like N=%d d=784 k=50 nu=2 randomwalk" % x_t.shape[0]
     elif args.workload == "s5":
         n = args.nodes or 1000000
-        x_np, y_np = synth.swiss_roll(n * world, order=args.s5_order)
+        x_np, y_np = synth.swiss_roll(n * nodes_mult, order=args.s5_order)
         x_t, y_t = torch.from_numpy(x_np).to(dev), torch.from_numpy(y_np).to(dev)
         k, nu, norm = 64, 2, "symmetric"
         hp = dict(graphbandwidth=0.0, lengthscale=1.0, outputscale=1.0, noise=0.01, eps_scale=3.0)
@@ -260,6 +266,8 @@ def _main(quiet):
     ap.add_argument("--nodes", type=int, default=0, help="override nodes per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the cg_multi_rhs / roofline_hbm blocks")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = the SAME graph on every world size (the metric's N = 60k), weak = N x nodes")
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--s5-order", default="morton", choices=["random", "morton"])
     ap.add_argument("--refine", type=int, default=-1, help="CG refinement rounds (-1: 0 for c3, 3 for s5)")

@@ -280,6 +280,49 @@ __global__ __launch_bounds__(kBlock) void pcg_refine_finalize_kernel(PcgArgs a, 
   }
 }
 
+// ---- residual replacement (own rows): dst = src, dst = b - t, and the partials of (r, r), (w, r)
+__global__ void pcg_copy_rows_kernel(PcgArgs a, float* __restrict__ dst, const float* __restrict__ src) {
+  for (int64_t l = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; l < a.n_loc; l += (int64_t)gridDim.x * blockDim.x)
+    dst[a.row0 + l] = src[a.row0 + l];
+}
+
+__global__ void pcg_sub_rows_kernel(PcgArgs a, float* __restrict__ dst, const float* __restrict__ b, const float* __restrict__ t) {
+  for (int64_t l = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; l < a.n_loc; l += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = a.row0 + l;
+    dst[r] = r < a.n_real ? b[r] - t[r] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void pcg_dots_kernel(PcgArgs a, int par) {
+  __shared__ float sh[kBlock / 64][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && tid == 0) {
+    // the replaced residual is the TRUE one: the stagnation window restarts from it
+    a.scal[8] = 3.0e38f; a.scal[9] = 3.0e38f;
+    reinterpret_cast<int*>(a.scal)[10] = a.state[0]; reinterpret_cast<int*>(a.scal)[11] = a.state[0];
+  }
+  const int64_t rows_per = (a.n_loc + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
+  const int64_t l0 = (int64_t)blockIdx.x * rows_per;
+  int64_t l1 = l0 + rows_per;
+  if (l1 > a.n_loc) l1 = a.n_loc;
+  float g = 0.f, d = 0.f;
+  for (int64_t l = l0 + tid; l < l1; l += kBlock) {
+    const int64_t r = a.row0 + l;
+    const float rv = a.r[r];
+    g = fmaf(rv, rv, g);
+    d = fmaf(a.w[par][r], rv, d);
+  }
+  g = mgp_wave_sum(g);
+  d = mgp_wave_sum(d);
+  if (lane == 0) { sh[wave][0] = g; sh[wave][1] = d; }
+  __syncthreads();
+  if (tid == 0) {
+    const int slot = a.rank * a.nbu + blockIdx.x;
+    a.pd[par][slot] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+    a.pd[par][a.world * a.nbu + slot] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+  }
+}
+
 __global__ void pcg_publish_kernel(PcgArgs a, const double* __restrict__ xacc) {
   for (int64_t l = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; l < a.n_loc; l += (int64_t)gridDim.x * blockDim.x)
     a.x[a.row0 + l] = (float)xacc[a.row0 + l];
@@ -402,6 +445,33 @@ int enqueue_iteration(PcgPlan* pl, int par, hipStream_t st) {
   hipLaunchKernelGGL(pcg_update_kernel, dim3(pl->args.nbu), dim3(kBlock), 0, st, pl->args);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
+}
+
+// Residual replacement at a chunk boundary (parity 0): the recurrences of r, w, s, z are re-anchored on what they
+// stand for -- r = rhs - A x, w = A r, s = A p, z = A s -- which is what keeps the pipelined recurrence at the
+// attainable accuracy of classic CG on ill-conditioned systems (file header).  4 applies + 5 gathers per chunk.
+int enqueue_replacement(PcgPlan* pl, const float* rhs, hipStream_t st) {
+  const PcgArgs& a = pl->args;
+  const int egrid = (int)(mgp_cdiv(a.n_loc, kBlock) > 1024 ? 1024 : mgp_cdiv(a.n_loc, kBlock));
+  float* tmp = pl->xfull;
+  auto full_of = [&](const float* own) -> int {
+    hipLaunchKernelGGL(pcg_copy_rows_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->args, tmp, own);
+    MGP_LAUNCH_CHECK();
+    return enqueue_gather_vec(pl, tmp, false, st);
+  };
+  MGP_TRY(full_of(a.x));
+  MGP_TRY(enqueue_apply(pl, tmp, pl->q, nullptr, nullptr, st));
+  hipLaunchKernelGGL(pcg_sub_rows_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->args, a.r, rhs, (const float*)pl->q);
+  MGP_LAUNCH_CHECK();
+  MGP_TRY(full_of(a.r));
+  MGP_TRY(enqueue_apply(pl, tmp, a.w[0], nullptr, nullptr, st));
+  MGP_TRY(full_of(a.p));
+  MGP_TRY(enqueue_apply(pl, tmp, a.s, nullptr, nullptr, st));
+  MGP_TRY(full_of(a.s));
+  MGP_TRY(enqueue_apply(pl, tmp, a.z, nullptr, nullptr, st));
+  hipLaunchKernelGGL(pcg_dots_kernel, dim3(a.nbu), dim3(kBlock), 0, st, pl->args, 0);
+  MGP_LAUNCH_CHECK();
+  return enqueue_gather(pl, 0, st);
 }
 
 void try_capture(PcgPlan* pl) {
@@ -566,6 +636,7 @@ extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int3
       MGP_HIP_TRY(hipStreamSynchronize(st));
       if (*flag) break;
       if (++guard > pl->prm.max_iter / pl->chunk + 2) break;
+      if (pl->chunk >= 16) MGP_TRY(enqueue_replacement(pl, rhs, st));     // long solves: re-anchor the recurrences
     }
     total_iters += pl->host_state[0];
     last_status = pl->host_state[2];

@@ -486,16 +486,20 @@ def distributed_cg_reference(local_matvec, b_pad, part, rank, tol=1e-10, max_ite
 
 # ------------------------------------------------------------------------------ bench (N > 1)
 def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_peak, emit=print):
-    """bench.py body for world > 1 (also reachable at world == 1 with MGP_FORCE_DIST=1): weak scaling,
-    `world` x 60 000 points; k-NN queries sharded by rows, lists all-gathered, graph + Laplacian
-    built redundantly per rank (setup, untimed), rows of the operator partitioned for the CG."""
+    """bench.py body for world > 1 (also reachable at world == 1 with MGP_FORCE_DIST=1).
+
+    --scaling strong (default; BASELINE.json's metric is the N = 60k graph on 1/2/4/8 GPUs): the SAME graph on every
+    world size, rows and vectors partitioned, partitioned pipelined CG (PcgPlan: one grouped RCCL all-gather per
+    iteration).  --scaling weak: `world` x the per-GPU node count, round 1's replicated-vector plan (DistCgPlan).
+    Setup (untimed): k-NN queries sharded by rows, lists all-gathered, graph + Laplacian built on every rank."""
     import torch.distributed as dist
 
     def log(*a):
         if rank == 0:
             print(*a, file=sys.stderr, flush=True)
 
-    wl = build_workload(args, dev, rank, world, shard_knn=True)
+    strong = args.scaling == "strong"
+    wl = build_workload(args, dev, rank, world, shard_knn=True, scale_nodes=not strong)
     g = wl["graph"]
     part = RowPartition(g.n, world)
     comm = init_comm(rank, world)
@@ -506,13 +510,24 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
     base = wl["desc"]
     pre = data.dsqrt if base.pre is not None else None
     desc = base.with_(data=data, pre=pre, post=pre)
-    plan = DistCgPlan(desc, part, rank, comm, C=1, tol=args.tol, max_iter=2000, stop_mode=1)
     y = part.pad(wl["y"].view(-1, 1)).contiguous()
+    if strong:
+        # short well-conditioned solves (C3: 3 iterations): small chunks, no refinement; the ill-conditioned 1M-node
+        # system: chunks of 32 iterations with residual replacement, refinement rounds on the true residual
+        long_solve = args.workload != "c3"
+        plan = PcgPlan(desc, part, rank, comm=comm, tol=args.tol, max_iter=4000, stop_mode=1,
+                       check_every=32 if long_solve else 4, refine=4 if long_solve else 0)
+        solve = lambda: plan.solve(y.view(-1))          # noqa: E731
+        ghost = plan.pop.ghost_rows
+    else:
+        plan = DistCgPlan(desc, part, rank, comm, C=1, tol=args.tol, max_iter=2000, stop_mode=1)
+        solve = lambda: plan.solve(y)                   # noqa: E731
+        ghost = 0
     import gc
     gc.collect()
     gc.disable()          # a generation-2 collection (tens of ms) otherwise lands inside a long timed loop
     for _ in range(args.warmup):
-        out = plan.solve(y)
+        out = solve()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -520,7 +535,7 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
     t0 = time.perf_counter()
     iters = 0
     for _ in range(args.steps):
-        out = plan.solve(y)
+        out = solve()
         iters += plan.iters
     torch.cuda.synchronize()
     if world > 1:
@@ -534,21 +549,37 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
     dt = float(tmax.item())
     its = iters / args.steps
     B = spmm_bytes(g.n, g.M)                   # whole (all ranks) operator, one SpMV
-    spmvs = (its + 1) * wl["nu"]
+    spmvs = (its + 1) * wl["nu"]               # pipelined: the start apply + one per iteration; classic: its + 1 as well
     value = B * spmvs * args.steps / dt / 1e9
-    # true residual with one partitioned apply
-    r = apply_partitioned(desc, part, rank, comm, out.contiguous()) - y
+    # true residual of the assembled solution (one more partitioned apply; every rank holds the gathered solution)
+    if strong:
+        xg = torch.zeros(part.n_pad, device=dev)
+        r0, r1 = part.range(rank)
+        xg[r0:r1] = out
+        if world > 1:
+            dist.all_reduce(xg)
+        xg = xg.view(-1, 1)
+    else:
+        xg = out.contiguous()
+    r = apply_partitioned(desc, part, rank, comm, xg) - y
     true_res = float(r.norm() / y.norm())
     if rank == 0:
+        how = ("rows AND vectors partitioned over %d ranks, pipelined CG, one grouped RCCL all-gather per iteration "
+               "(w slices + dot partials), %d ghost rows on rank 0" % (world, ghost)) if strong else \
+              ("rows of L partitioned over %d ranks, vectors replicated, one grouped RCCL all-gather per SpMV" % world)
         line = dict(metric="CG-solve wall-time + SpMV HBM GB/s, N=60k RMNIST graph", value=round(value, 2),
                     unit="GB/s (algorithmic SpMV bytes inside the CG solve, all ranks)", n_gpus=world,
                     steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4),
-                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                    higher_is_better=True, scaling="strong" if strong else "weak", vs_baseline=None, dtype="f32",
+                    data="synthetic",
                     config=dict(workload=wl["name"], nodes=g.n, nodes_per_gpu=part.n_loc, edges=g.M,
-                                rhs_columns=1, parallelism="rows of L partitioned over %d ranks, vectors replicated, "
-                                "one grouped RCCL all-gather per SpMV" % world,
-                                cg_tol=args.tol, cg_iters=its, cg_rel_residual=max(plan.resid),
-                                cg_true_residual_fp32_apply=true_res, spmv_per_solve=spmvs, eps=wl["eps"]),
+                                rhs_columns=1, parallelism=how,
+                                cg_tol=args.tol, cg_iters=its, cg_rel_residual=float(plan.resid if strong else max(plan.resid)),
+                                cg_true_residual_fp32_apply=true_res, spmv_per_solve=spmvs, eps=wl["eps"],
+                                expectation="N = 60k is latency-bound: one GPU runs an iteration in ~16 us, an RCCL "
+                                            "all-gather over xGMI costs about as much by itself, so more GPUs are expected to be "
+                                            "SLOWER on this graph (SURVEY.md section 7); the path that scales is the 1M-node "
+                                            "workload (--workload s5) and the column-sharded multi-rhs solves"),
                     cg_solve_ms=round(dt / args.steps * 1e3, 4),
                     roofline=dict(bound="hbm", achieved=round(value / world, 1), peak=hbm_peak, unit="GB/s",
                                   frac=round(value / world / hbm_peak, 4), traffic=None,

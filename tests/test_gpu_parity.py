@@ -1990,9 +1990,11 @@ def test_pcg_stagnation_guard_and_refinement_on_an_ill_conditioned_system(mgp, g
     true0 = float((desc.apply(x) - yv).norm() / yv.norm())
     assert true0 < 50 * ref_true, (true0, ref_true)                       # stopped near its best, not after drifting
     plan.close()
-    plan = PcgPlan(dd, part, 0, tol=1e-3, max_iter=20000, stop_mode=1, refine=6)
-    x = plan.solve(y).clone()[:n]
-    true1 = float((desc.apply(x) - yv).norm() / yv.norm())
-    assert plan.status == 1 and plan.resid <= 2e-3, (plan.status, plan.resid)
-    assert true1 <= 3e-3 and abs(true1 - plan.resid) < 1e-3, (true1, plan.resid)
-    plan.close()
+    for chunk in (8, 32):          # chunks >= 16 iterations also re-anchor r, w, s, z at every chunk boundary
+        plan = PcgPlan(dd, part, 0, tol=1e-3, max_iter=20000, stop_mode=1, refine=6, check_every=chunk)
+        x = plan.solve(y).clone()[:n]
+        true1 = float((desc.apply(x) - yv).norm() / yv.norm())
+        assert plan.status == 1 and plan.resid <= 2e-3, (chunk, plan.status, plan.resid)
+        assert true1 <= 3e-3 and abs(true1 - plan.resid) < 1e-3, (chunk, true1, plan.resid)
+        assert float((x - xs).abs().max()) < 2e-2 * float(xs.abs().max())
+        plan.close()
