@@ -179,6 +179,8 @@ typedef struct {
 /* workgroups that write dot partials for this CSR (format aware; use this one to size dot_partials) */
 int mgp_spmm_dot_blocks_csr(const mgp_csr_t* L, int C);
 int mgp_spmm_set_tile_mode(int on);          /* C == 1: use the tile dictionaries when present (default 1) */
+int mgp_spmm_set_tile_small_mode(int on);    /* C in {4,8,12,16}: LDS-dictionary multi-column kernel on 64-row tiles
+                                                (default 1; 0 = the per-entry gather kernel) */
 
 int mgp_spmm_dot_blocks(int64_t n, int C);   /* workgroups that write dot partials */
 int mgp_spmm_set_group_hint(int lanes);      /* C == 1: lanes per row, one of 4,8,16,32,64 */

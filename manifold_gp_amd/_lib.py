@@ -78,6 +78,7 @@ SIGNATURES = {
     "mgp_graph_bfs_order": (c_int, [c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "mgp_spmm_dot_blocks_csr": (c_int, [POINTER(CsrT), c_int]),
     "mgp_spmm_set_tile_mode": (c_int, [c_int]),
+    "mgp_spmm_set_tile_small_mode": (c_int, [c_int]),
     "mgp_cg_set_fuse": (c_int, [c_int]),
     "mgp_cg_set_init_free": (c_int, [c_int]),
     "mgp_host_symeig": (c_int, [c_int, _P, _P, _P]),

@@ -219,6 +219,7 @@ struct TileArgs {
   const int32_t* rowptr_t;
   const float* vals_t;
   const int32_t* rowid;
+  int max_entries;   // multi-column tile kernel: entries of the largest tile (LDS carving)
 };
 
 typedef unsigned short mgp_v4h __attribute__((ext_vector_type(4)));
@@ -585,6 +586,179 @@ __global__ __launch_bounds__(kBlock) void spmm_row16_kernel(SpmmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------- C in {4, 8, 12, 16}, row tiles + LDS dictionary
+// The multi-column workloads of training run at 12 columns (the probes of the stochastic log-determinant, the
+// inner solves of the Schur complement): spmm_row16_kernel above fetches a 64-byte X row PER ENTRY (3.7 M texture
+// accesses, 235 MB through L1 / L2 per launch at N = 60k: 27 us).  With the tile dictionaries of the C = 1 kernel an X
+// row is fetched once per TILE.  The kernel is spmv_tile_kernel with float4 elements, run as C / 4 PASSES over the
+// tile ("quarters" of 4 columns): the matrix stream (values + 16-bit local ids, one quad of entries per lane and
+// slot, fully coalesced) and ALL quarters of the dictionary's X rows are loaded once into registers; per pass the
+// quarter's dictionary goes to LDS (16 bytes per column), every lane forms the float4 partial sums of its quads
+// (ds_read_b128 gathers through the local ids) into LDS, four lanes per row add the row's quads, and lane `pass` of
+// the row's quad runs the epilogue for its 4 columns and stores 16 bytes.  LDS: (max_cols + max_entries / 4) x 16
+// bytes whatever C is (49 KB on the C3 graph whose largest tile has 1 209 columns and 7 468 entries).
+template <int C4, bool PRE>
+__global__ __launch_bounds__(256) void spmm_tile_q_kernel(SpmmArgs p, TileArgs t) {
+  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+  constexpr int BS = 256, TR = 64, NQ = 4, C = 4 * C4;
+  const int skipv = p.skip ? *p.skip : 0;
+  const int tickv = (p.tick && blockIdx.x == 0) ? *p.tick : 0;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x, sub = tid & 3;
+  mgp_v4f* __restrict__ xl = reinterpret_cast<mgp_v4f*>(tile_lds);
+  mgp_v4f* __restrict__ part = xl + t.max_cols;
+  const mgp_v4f* __restrict__ X4 = reinterpret_cast<const mgp_v4f*>(p.X);
+  const float* __restrict__ prev = p.pre;
+  const int32_t* __restrict__ rowptr = t.rowptr_t ? t.rowptr_t : p.rowptr;
+  const float* __restrict__ vals = t.vals_t ? t.vals_t : p.vals;
+  const int32_t* __restrict__ tile_ptr = t.tile_ptr;
+  const uint32_t* __restrict__ tile_cols = reinterpret_cast<const uint32_t*>(t.tile_cols);
+  const uint16_t* __restrict__ lid = t.lid;
+  mgp_v4f dsum = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+  const int64_t t0 = (int64_t)lb * t.tiles_per_block;
+  const int64_t t1 = t0 + t.tiles_per_block < t.ntiles ? t0 + t.tiles_per_block : t.ntiles;
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int64_t r0 = tile * TR;
+    const int64_t r1 = r0 + TR < p.n ? r0 + TR : p.n;
+    const int e0 = rowptr[r0], e1 = rowptr[r1];
+    const int dp = tile_ptr[tile];
+    const int D = tile_ptr[tile + 1] - dp;
+    const int qb = e0 >> 2, Q = (e1 - e0) >> 2;
+    if (skipv) return;
+    unsigned c[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int j = tid + k * BS;
+      c[k] = (unsigned)tile_cols[j < D ? dp + j : 0];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mgp_v4f v[NQ];
+    mgp_v4h l[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int q = tid + k * BS;
+      const int qi = q < Q ? qb + q : 0;
+      v[k] = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)qi);
+      l[k] = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)qi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // all quarters of the dictionary rows this lane stages (the ids are back by now: loads retire in order)
+    mgp_v4f g[NQ][C4];
+    float gp[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+#pragma unroll
+      for (int u = 0; u < C4; ++u) g[k][u] = X4[(int64_t)c[k] * C4 + u];
+      gp[k] = PRE ? prev[c[k]] : 1.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // row operands: lane `sub` of a row's quad owns quarter `sub` (columns 4 sub .. 4 sub + 3)
+    const int64_t row = r0 + (tid >> 2);
+    const bool valid = row < r1;
+    const int64_t pr = valid ? row : r0;
+    const int64_t rr = t.rowid ? (int64_t)t.rowid[pr] : pr;
+    const int64_t grr = rr + p.goff;
+    const int rs = rowptr[pr], re = rowptr[pr + 1];
+    const int qs = sub < C4 ? sub : 0;
+    const mgp_v4f e_x = X4[grr * C4 + qs];
+    const float e_pre = PRE ? prev[grr] : 1.f;
+    const float e_diag = p.diag[rr];
+    const float l_post = p.post ? p.post[grr] : 1.f;
+    const mgp_v4f l_base = *reinterpret_cast<const mgp_v4f*>((p.base ? p.base : p.X) + grr * C + 4 * qs);
+    const mgp_v4f l_dotw = *reinterpret_cast<const mgp_v4f*>((p.dotw ? p.dotw : p.X) + grr * C + 4 * qs);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < C4; ++u) {
+      // ---- quarter u of the dictionary -> LDS
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        const int j = tid + k * BS;
+        if (j < D) {
+          mgp_v4f w = g[k][u];
+          if (PRE) { w.x *= gp[k]; w.y *= gp[k]; w.z *= gp[k]; w.w *= gp[k]; }
+          xl[j] = w;
+        }
+      }
+      for (int j = tid + NQ * BS; j < D; j += BS) {        // dictionaries longer than NQ * BS (rare)
+        const unsigned cc = tile_cols[dp + j];
+        mgp_v4f w = X4[(int64_t)cc * C4 + u];
+        if (PRE) { const float sc = prev[cc]; w.x *= sc; w.y *= sc; w.z *= sc; w.w *= sc; }
+        xl[j] = w;
+      }
+      __syncthreads();
+      // ---- quad partial sums of this quarter
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        const int q = tid + k * BS;
+        if (q < Q) {
+          const mgp_v4f a0 = xl[l[k].x], a1 = xl[l[k].y], a2 = xl[l[k].z], a3 = xl[l[k].w];
+          mgp_v4f sq;
+          sq.x = v[k].x * a0.x; sq.y = v[k].x * a0.y; sq.z = v[k].x * a0.z; sq.w = v[k].x * a0.w;
+          sq.x = fmaf(v[k].y, a1.x, sq.x); sq.y = fmaf(v[k].y, a1.y, sq.y); sq.z = fmaf(v[k].y, a1.z, sq.z); sq.w = fmaf(v[k].y, a1.w, sq.w);
+          sq.x = fmaf(v[k].z, a2.x, sq.x); sq.y = fmaf(v[k].z, a2.y, sq.y); sq.z = fmaf(v[k].z, a2.z, sq.z); sq.w = fmaf(v[k].z, a2.w, sq.w);
+          sq.x = fmaf(v[k].w, a3.x, sq.x); sq.y = fmaf(v[k].w, a3.y, sq.y); sq.z = fmaf(v[k].w, a3.z, sq.z); sq.w = fmaf(v[k].w, a3.w, sq.w);
+          part[q] = sq;
+        }
+      }
+      for (int q = tid + NQ * BS; q < Q; q += BS) {        // tiles with more than 4 * NQ * BS entries (rare)
+        const mgp_v4f vv = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)(qb + q));
+        const mgp_v4h ll = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)(qb + q));
+        const mgp_v4f a0 = xl[ll.x], a1 = xl[ll.y], a2 = xl[ll.z], a3 = xl[ll.w];
+        mgp_v4f sq;
+        sq.x = vv.x * a0.x; sq.y = vv.x * a0.y; sq.z = vv.x * a0.z; sq.w = vv.x * a0.w;
+        sq.x = fmaf(vv.y, a1.x, sq.x); sq.y = fmaf(vv.y, a1.y, sq.y); sq.z = fmaf(vv.y, a1.z, sq.z); sq.w = fmaf(vv.y, a1.w, sq.w);
+        sq.x = fmaf(vv.z, a2.x, sq.x); sq.y = fmaf(vv.z, a2.y, sq.y); sq.z = fmaf(vv.z, a2.z, sq.z); sq.w = fmaf(vv.z, a2.w, sq.w);
+        sq.x = fmaf(vv.w, a3.x, sq.x); sq.y = fmaf(vv.w, a3.y, sq.y); sq.z = fmaf(vv.w, a3.z, sq.z); sq.w = fmaf(vv.w, a3.w, sq.w);
+        part[q] = sq;
+      }
+      __syncthreads();
+      // ---- rows: four lanes add the row's quads (stride 4), quad tree; lane u finishes quarter u
+      mgp_v4f acc = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+      {
+        int i = (rs >> 2) - qb + sub;
+        const int e = (re >> 2) - qb;
+        for (; i + 4 < e; i += 8) {
+          const mgp_v4f a0 = part[i], a1 = part[i + 4];
+          acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+          acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+        }
+        for (; i < e; i += 4) {
+          const mgp_v4f a0 = part[i];
+          acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+        }
+      }
+      acc.x = mgp_quad_sum(acc.x); acc.y = mgp_quad_sum(acc.y); acc.z = mgp_quad_sum(acc.z); acc.w = mgp_quad_sum(acc.w);
+      if (valid && sub == u) {
+        const float xs0 = e_x.x * e_pre, xs1 = e_x.y * e_pre, xs2 = e_x.z * e_pre, xs3 = e_x.w * e_pre;
+        mgp_v4f y;
+        y.x = p.co * ((p.a * xs0 + p.b * (e_diag * xs0 - acc.x)) * l_post) + (p.base ? p.cb * l_base.x : 0.f);
+        y.y = p.co * ((p.a * xs1 + p.b * (e_diag * xs1 - acc.y)) * l_post) + (p.base ? p.cb * l_base.y : 0.f);
+        y.z = p.co * ((p.a * xs2 + p.b * (e_diag * xs2 - acc.z)) * l_post) + (p.base ? p.cb * l_base.z : 0.f);
+        y.w = p.co * ((p.a * xs3 + p.b * (e_diag * xs3 - acc.w)) * l_post) + (p.base ? p.cb * l_base.w : 0.f);
+        *reinterpret_cast<mgp_v4f*>(p.Y + grr * C + 4 * u) = y;
+        if (p.dotw) {
+          dsum.x = fmaf(l_dotw.x, y.x, dsum.x); dsum.y = fmaf(l_dotw.y, y.y, dsum.y);
+          dsum.z = fmaf(l_dotw.z, y.z, dsum.z); dsum.w = fmaf(l_dotw.w, y.w, dsum.w);
+        }
+      }
+      if (u + 1 < C4 || tile + 1 < t1) __syncthreads();    // the next pass / tile overwrites xl and part
+    }
+  }
+  if (p.tick && blockIdx.x == 0 && tid == 0 && !skipv) *p.tick = tickv + 1;
+  if (p.dot_partials) {
+    // red[row][column]: lane `sub` of every row leaves its quarter, then C threads add the 64 rows in a fixed order
+    __syncthreads();
+    float* red = tile_lds;
+    if (sub < C4) *reinterpret_cast<mgp_v4f*>(red + (size_t)(tid >> 2) * C + 4 * sub) = dsum;
+    __syncthreads();
+    if (tid < C) {
+      float sacc = 0.f;
+      for (int r = 0; r < TR; ++r) sacc += red[r * C + tid];
+      p.dot_partials[(int64_t)lb * C + tid] = sacc;
+    }
+  }
+}
+
 struct Plan {
   int grid;
   int64_t rows_per_block;
@@ -677,9 +851,30 @@ int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, si
   return 1;
 }
 
+// C in {4, 8, 12, 16} on 64-row tiles whose staged data (dictionary rows + matrix stream) fits the LDS budget
+int g_tile_small_mode = 1;
+static size_t tile_small_lds_bytes(const mgp_csr_t* L, int C) {
+  size_t b = ((size_t)L->tile_max_cols + (size_t)(L->tile_max_entries >> 2)) * 16;
+  const size_t red = (size_t)64 * C * sizeof(float);        // dot-partial staging reuses the same LDS
+  return b > red ? b : red;
+}
+static bool use_tiles_small(const mgp_csr_t* L, int C) {
+  const int ord = (L->tile_rowptr != nullptr) + (L->tile_vals != nullptr) + (L->tile_rowid != nullptr);
+  if (ord != 0 && ord != 3) return false;
+  if (!(C == 4 || C == 8 || C == 12 || C == 16) || !g_tile_mode || !g_tile_small_mode) return false;
+  if (!L->lid || !L->tile_ptr || !L->tile_cols || L->tile_rows != 64) return false;
+  if ((L->tile_max_entries & 3) != 0) return false;
+  return tile_small_lds_bytes(L, C) <= 65536 - 64;
+}
+
+extern "C" int mgp_spmm_set_tile_small_mode(int on) {
+  g_tile_small_mode = on ? 1 : 0;
+  return MGP_OK;
+}
+
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (!L) return MGP_ERR_ARG;
-  if (use_tiles(L, C)) return tile_grid(L, nullptr);
+  if (use_tiles(L, C) || use_tiles_small(L, C)) return tile_grid(L, nullptr);
   return mgp_spmm_dot_blocks(L->n, C);
 }
 
@@ -794,7 +989,7 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
   }
   if (use_tiles(L, C)) {
     TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
-                L->tile_rowptr, L->tile_vals, L->tile_rowid};
+                L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries};
     const int grid = tile_grid(L, &ta.tiles_per_block);
     const size_t lds = tile_lds_bytes(L);
     if (first && first->record) {
@@ -810,6 +1005,24 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     else if (L->tile_rows == 64) MGP_TILE_LAUNCH(256);
     else MGP_TILE_LAUNCH(512);
 #undef MGP_TILE_LAUNCH
+  } else if (use_tiles_small(L, C)) {
+    if (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(base) |
+          reinterpret_cast<uintptr_t>(dotw)) & 15) != 0)
+      return MGP_ERR_ARG;                  // [n, C] blocks with C a multiple of 4 are 16-byte aligned row by row
+    TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
+                L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries};
+    const int grid = tile_grid(L, &ta.tiles_per_block);
+    const size_t lds = tile_small_lds_bytes(L, C);
+#define MGP_TILE_SMALL_LAUNCH(C4)                                                                                 \
+  do {                                                                                                            \
+    if (pre) hipLaunchKernelGGL((spmm_tile_q_kernel<C4, true>), dim3(grid), dim3(256), lds, st, p, ta);        \
+    else hipLaunchKernelGGL((spmm_tile_q_kernel<C4, false>), dim3(grid), dim3(256), lds, st, p, ta);           \
+  } while (0)
+    if (C == 4) MGP_TILE_SMALL_LAUNCH(1);
+    else if (C == 8) MGP_TILE_SMALL_LAUNCH(2);
+    else if (C == 12) MGP_TILE_SMALL_LAUNCH(3);
+    else MGP_TILE_SMALL_LAUNCH(4);
+#undef MGP_TILE_SMALL_LAUNCH
   } else if (C == 1) {
     const int G = g_row_group_hint;
     const int R = spmv_rows_in_flight();

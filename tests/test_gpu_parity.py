@@ -1679,7 +1679,7 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
     rowptr, col = graph.rowptr.cpu().numpy(), graph.col.cpu().numpy()
     vals = data.vals.cpu().numpy().astype(np.float64)
     rows = np.repeat(np.arange(n), np.diff(rowptr))
-    for C in (20, 100, 152, 256):
+    for C in (4, 8, 12, 16, 20, 100, 152, 256):      # 4 .. 16: the LDS-dictionary multi-column kernel when tiles are on
         X = torch.randn(n, C, device=dev)
         pre = torch.rand(n, device=dev) + 0.5
         base = torch.randn(n, C, device=dev)
