@@ -50,16 +50,46 @@ class NoiseWrapperOperator(LinearOperator):
             from ..solvers import cg_solve
             return cg_solve(d, rhs)[0]
         # Not one polynomial chain (a Schur complement underneath): every matvec of this operator is three nested
-        # inner solves.  It is the second-order Neumann form of (Q^-1 + s I)^-1: with M = Q^-1 + s I -- ONE solve with
-        # the wrapped operator, which the Schur complement answers with a single non-nested CG on the full
-        # precision -- the spectrum of M A is 1 + (s q)^3, within [1, 1.07] for s |Q| ~ 0.4.  Preconditioned by M and
-        # started from M b the CG needs one or two iterations (8 solves) where the cold, unpreconditioned
-        # recurrence took linear_cg's 10+ iterations and the start from M b alone 17 (each 3 nested solves).
+        # inner solves.  With q = the wrapped operator, t = s q and M = q^-1 + s I (ONE solve with the wrapped operator,
+        # which the Schur complement answers with a single non-nested CG on the full precision):
+        #     A = q - s q^2 + s^2 q^3 = q (1 + t^3) / (1 + t)     =>     A^-1 = M (1 + t^3)^-1 = M (1 - t^3 + t^6 - ...)
+        # The noise model needs |t| < 1 anyway (it is the Neumann form of (q^-1 + s I)^-1); in training |t| ~ 0.4,
+        # t^3 ~ 0.07.  x_J = M (b - t^3 b + ... +- t^3J b) has the TRUE residual b - A x_J = -+ t^3(J+1) b, i.e. the norm
+        # of the next term, which is estimated from the ratio of the last two: the series stops as soon as that estimate
+        # is under the CG tolerance (one host read per TERM -- a term is three Schur matvecs, each a nested solve -- where
+        # the preconditioned CG this replaces synchronised every iteration and spent two more solves with M on the same
+        # accuracy).  A ratio >= 1 (noise model outside its range) falls back to that CG.
+        from .. import _lib
+        from .._compat import settings
         from ..solvers import generic_cg
         s = _scalar(self.noise)
         inner = self.operator
+        tol = float(settings.cg_tolerance.value())
 
         def M(v):
             with torch.no_grad():
                 return inner._solve(v) + s * v
+
+        squeeze = rhs.dim() == 1
+        B = _lib.f32c(rhs.unsqueeze(-1) if squeeze else rhs)
+        with torch.no_grad():
+            bn = B.norm(dim=0).clamp_min(1e-30)
+            y, term, prev = B.clone(), B, 1.0
+            ok = False
+            for _ in range(12):
+                for _k in range(3):
+                    term = s * inner._matmul(term)
+                term = -term
+                rel = float((term.norm(dim=0) / bn).mean())
+                ratio = rel / prev
+                if not (ratio < 0.9):
+                    break
+                y = y + term
+                if rel * ratio / (1.0 - ratio) < tol:
+                    ok = True
+                    break
+                prev = rel
+            if ok:
+                x = M(y)
+                return x.squeeze(-1) if squeeze else x
         return generic_cg(self, rhs, x0=M(rhs), precond=M)
