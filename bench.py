@@ -309,10 +309,10 @@ def _main(quiet):
     for _ in range(args.steps):
         out = plan.solve(y, copy=False)      # solution stays in the plan's device buffer
         iters += plan.iters
-        applies += plan.applies
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     gc.enable()
+    applies = plan.applies * args.steps       # the same right-hand side every step: every solve runs the same launches
     its = iters / args.steps
     B = spmm_bytes(g.n, g.M)
     # SpMVs that actually ran: nu per operator apply; the plan reports its applies (a solve of k iterations

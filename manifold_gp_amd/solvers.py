@@ -41,14 +41,22 @@ class CgPlan:
                                        ptr(self.work), self.work.numel(), stream(), ctypes.byref(self.handle)),
               "mgp_cg_plan_create")
         self.iters = 0
-        self.applies = 0
         self._xview = None
         self._iters, self._status = ctypes.c_int32(0), ctypes.c_int32(0)
         self._iters_ref, self._status_ref = ctypes.byref(self._iters), ctypes.byref(self._status)
         self._resid = (ctypes.c_float * self.C)()
         self._solve_fn, self._applies_fn = lib().mgp_cg_plan_solve, lib().mgp_cg_plan_last_applies
         self.status = 0
-        self.resid = None
+
+    # read on demand: a solve is ~60 us, every ctypes call / list conversion on its way back is a visible fraction
+    @property
+    def applies(self):
+        """operator applies the last solve actually ran (mgp_cg_plan_last_applies)"""
+        return self._applies_fn(self.handle)
+
+    @property
+    def resid(self):
+        return list(self._resid)
 
     def solution_view(self):
         """The plan's own solution buffer as a tensor view (no copy; overwritten by the next solve)."""
@@ -69,8 +77,10 @@ class CgPlan:
         return self.work[off:off + nb].view(torch.float64).view(self.desc.n, self.C)
 
     def solve(self, B, out=None, copy=True):
-        _lib.require_device(B)
-        B = _lib.f32c(B)
+        if B.device.type != "cuda":
+            _lib.require_device(B)
+        if B.dtype != torch.float32 or not B.is_contiguous():
+            B = _lib.f32c(B)
         assert B.shape == (self.desc.n, self.C)
         if copy:
             X = torch.empty_like(B) if out is None else out
@@ -84,8 +94,6 @@ class CgPlan:
         if X is None:
             X = self.solution_view()
         self.iters, self.status = self._iters.value, self._status.value
-        self.applies = self._applies_fn(self.handle)                       # operator applies that actually ran
-        self.resid = list(self._resid)
         return X
 
     def close(self):
