@@ -428,12 +428,17 @@ int mgp_cg_plan_create_dist(const mgp_operator_t* op_local, int C, const float* 
  *                mgp_pcg_plan_x()[row0 .. row0 + n_loc) and copied to X_loc when given */
 size_t mgp_pcg_shared_floats(int64_t n_glob, int64_t n_loc, int world);
 size_t mgp_pcg_workspace_bytes(int64_t n_glob, int64_t n_loc, int world);
+/* recurrence: 0 = pipelined (ONE grouped all-gather per iteration; stagnates early on ill-conditioned systems in
+ *             fp32: residual replacement for chunks >= 16 iterations, refinement rounds with max_refine),
+ *             1 = Chronopoulos-Gear, the recurrence of mgp_cg_plan_* (robust; TWO collectives per iteration: the
+ *             gathered vector + gamma partials, and ~n_loc / 64 delta partials per rank) */
 int mgp_pcg_plan_create(const mgp_operator_t* op, const int64_t* launch_rows, int64_t row0, int64_t n_loc,
-                        int64_t n_real, void* comm, int rank, int world, float* shared,
+                        int64_t n_real, void* comm, int rank, int world, float* shared, int recurrence,
                         const mgp_cg_params_t* params, void* work, size_t work_bytes, void* stream,
                         void** plan_out);
 int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int32_t* iters, float* resid, int32_t* status);
-int mgp_pcg_plan_enqueue(void* plan, int phase, int par, const float* B); /* 0: start (first apply), 1: one iteration */
+int mgp_pcg_plan_enqueue(void* plan, int phase, int par, const float* B); /* 0: start; 1: iteration (recurrence 1: its
+                                                                             SpMV chain); 2: recurrence 1: its update */
 int mgp_pcg_plan_poll(void* plan, int32_t* iters, float* resid, int32_t* status); /* 1 = undecided */
 float* mgp_pcg_plan_x(void* plan);
 int mgp_pcg_plan_destroy(void* plan);

@@ -127,7 +127,7 @@ SIGNATURES = {
                                         c_size_t, _P, POINTER(c_void_p)]),
     "mgp_pcg_shared_floats": (c_size_t, [c_int64, c_int64, c_int]),
     "mgp_pcg_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
-    "mgp_pcg_plan_create": (c_int, [POINTER(OperatorT), POINTER(c_int64), c_int64, c_int64, c_int64, _P, c_int, c_int, _P,
+    "mgp_pcg_plan_create": (c_int, [POINTER(OperatorT), POINTER(c_int64), c_int64, c_int64, c_int64, _P, c_int, c_int, _P, c_int,
                                     POINTER(CgParamsT), _P, c_size_t, _P, POINTER(c_void_p)]),
     "mgp_pcg_plan_solve": (c_int, [_P, _P, _P, POINTER(c_int32), POINTER(c_float), POINTER(c_int32)]),
     "mgp_pcg_plan_enqueue": (c_int, [_P, c_int, c_int, _P]),

@@ -40,6 +40,7 @@
 #include <math.h>
 #include <new>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 #include "mgp_common.h"
 #include "mgp_internal.h"
@@ -57,6 +58,8 @@ struct PcgArgs {
   const float* q;          // A w on own rows
   float* w[2];             // gathered w, double-buffered by the iteration parity
   float* pd[2];            // [2][world * nbu]: gamma partials then delta partials
+  float* pdd;              // Chronopoulos-Gear form: [world * nb2] partials of (u, A u) from the SpMV epilogue
+  int nb2;                 // SpMV workgroups per rank that write them
   int nbu;                 // workgroups of this kernel per rank
   int world, rank;
   float* scal;             // [0..1] gamma_old by parity, [2..3] alpha_old by parity, [4] bb, [5] resid,
@@ -328,7 +331,139 @@ __global__ void pcg_publish_kernel(PcgArgs a, const double* __restrict__ xacc) {
     a.x[a.row0 + l] = (float)xacc[a.row0 + l];
 }
 
+// ---- Chronopoulos-Gear recurrence with partitioned vectors (recurrence = 1): the recurrence of cg.hip -- robust on
+// ill-conditioned systems where the pipelined one stagnates early (file header) -- at the price of a second, tiny
+// collective per iteration.  w[.] holds the gathered u = r; the SpMV chain's last launch leaves the partials of
+// delta = (u, A u) (pdd, gathered: collective A, ~100 floats per rank); this update takes gamma = (r, r) from the
+// partials gathered WITH the vector (collective B), updates own rows and writes the new r into w[par ^ 1].
+__global__ __launch_bounds__(kBlock) void cgp_start_kernel(PcgArgs a, const float* __restrict__ B, int round) {
+  __shared__ float sh[kBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && tid == 0) {
+    a.state[0] = 0; a.state[1] = 0; a.state[2] = 0;
+    if (round == 0) a.scal[6] = a.tol;
+    a.scal[8] = 3.0e38f; a.scal[9] = 3.0e38f;
+    reinterpret_cast<int*>(a.scal)[10] = 0; reinterpret_cast<int*>(a.scal)[11] = 0;
+  }
+  const int64_t rows_per = (a.n_loc + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
+  const int64_t l0 = (int64_t)blockIdx.x * rows_per;
+  int64_t l1 = l0 + rows_per;
+  if (l1 > a.n_loc) l1 = a.n_loc;
+  float g = 0.f;
+  for (int64_t l = l0 + tid; l < l1; l += kBlock) {
+    const int64_t r = a.row0 + l;
+    const float b = r < a.n_real ? B[r] : 0.f;
+    a.r[r] = b; a.x[r] = 0.f; a.p[r] = 0.f; a.s[r] = 0.f;
+    a.w[0][r] = b;                                    // own slice of u_0 = b (gathered next)
+    g = fmaf(b, b, g);
+  }
+  g = mgp_wave_sum(g);
+  if (lane == 0) sh[wave] = g;
+  __syncthreads();
+  if (tid == 0) a.pd[0][a.rank * a.nbu + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(kBlock) void cgp_update_kernel(PcgArgs a) {
+  __shared__ float sh[kBlock / 64][2];
+  __shared__ float sh2[kBlock / 64];
+  __shared__ int sh_done;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int it = a.state[0] - 1;
+  if (tid == 0) sh_done = a.state[1];
+  const int par = it & 1;
+  const float gamma_old = a.scal[par ^ 1], alpha_old = a.scal[2 + (par ^ 1)], bb_old = a.scal[4];
+  const float tol = a.scal[6];
+  const float best_old = a.scal[8 + (par ^ 1)];
+  const int it_best_old = reinterpret_cast<const int*>(a.scal)[10 + (par ^ 1)];
+  // gamma from the update-kernel partials (world * nbu), delta from the SpMV partials (world * nb2)
+  float gamma, delta;
+  {
+    const int cg = a.world * a.nbu, cd = a.world * a.nb2;
+    float gv[kMaxSlots], dv[kMaxSlots];
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; ++k) {
+      const int b = tid + k * kBlock;
+      gv[k] = a.pd[par][b < cg ? b : cg - 1];
+      dv[k] = a.pdd[b < cd ? b : cd - 1];
+    }
+    float g = 0.f, d = 0.f;
+#pragma unroll
+    for (int k = 0; k < kMaxSlots; ++k) {
+      g += (tid + k * kBlock < cg) ? gv[k] : 0.f;
+      d += (tid + k * kBlock < cd) ? dv[k] : 0.f;
+    }
+    g = mgp_wave_sum(g);
+    d = mgp_wave_sum(d);
+    if (lane == 0) { sh[wave][0] = g; sh[wave][1] = d; }
+    __syncthreads();
+    gamma = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+    delta = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+  }
+  if (sh_done) return;
+  const float bb = it == 0 ? gamma : bb_old;
+  const float rel = bb > 0.f ? sqrtf(gamma / bb) : 0.f;
+  int done = 0, status = 0;
+  if (a.stop_mode == 0) {
+    if (it >= a.min_iter && rel < tol) { done = 1; status = 1; }
+  } else if (rel <= tol) { done = 1; status = 1; }
+  if (!isfinite(rel)) { done = 1; status = 3; }
+  if (!done && it >= a.max_iter) { done = 1; status = 2; }
+  const float best = rel < best_old ? rel : best_old;
+  const int it_best = rel < best_old ? it : it_best_old;
+  if (!done && it - it_best >= 50 + it_best / 4) { done = 1; status = 4; }
+  float alpha = 0.f, beta = 0.f;
+  if (!done) {
+    if (it == 0) {
+      alpha = delta != 0.f ? gamma / delta : 0.f;
+    } else {
+      beta = gamma_old != 0.f ? gamma / gamma_old : 0.f;
+      const float den = delta - (alpha_old != 0.f ? beta * gamma / alpha_old : 0.f);
+      alpha = den != 0.f ? gamma / den : 0.f;
+    }
+    if (!isfinite(alpha) || !isfinite(beta)) { alpha = 0.f; beta = 0.f; }
+  }
+  if (blockIdx.x == 0 && tid == 0) {
+    a.scal[5] = rel;
+    if (it == 0) a.scal[4] = bb;
+    if (done) {
+      a.state[2] = status; a.state[1] = 1;
+      a.host_resid[0] = rel;
+      a.host_state[0] = it; a.host_state[2] = status;
+      __threadfence_system();
+      a.host_state[1] = 1;
+    } else {
+      a.scal[par] = gamma; a.scal[2 + par] = alpha;
+      a.scal[8 + par] = best;
+      reinterpret_cast<int*>(a.scal)[10 + par] = it_best;
+    }
+  }
+  if (done) return;
+  float* __restrict__ un = a.w[par ^ 1];
+  const int64_t rows_per = (a.n_loc + (int64_t)gridDim.x - 1) / (int64_t)gridDim.x;
+  const int64_t l0 = (int64_t)blockIdx.x * rows_per;
+  int64_t l1 = l0 + rows_per;
+  if (l1 > a.n_loc) l1 = a.n_loc;
+  float ng = 0.f;
+  for (int64_t l = l0 + tid; l < l1; l += kBlock) {
+    const int64_t r = a.row0 + l;
+    const float rr = a.r[r], w = a.q[r];
+    const float p = fmaf(beta, a.p[r], rr);
+    const float sv = fmaf(beta, a.s[r], w);
+    a.p[r] = p; a.s[r] = sv;
+    a.x[r] = fmaf(alpha, p, a.x[r]);
+    const float rn = fmaf(-alpha, sv, rr);
+    a.r[r] = rn;
+    un[r] = rn;
+    ng = fmaf(rn, rn, ng);
+  }
+  ng = mgp_wave_sum(ng);
+  if (lane == 0) sh2[wave] = ng;
+  __syncthreads();
+  if (tid == 0) a.pd[par ^ 1][a.rank * a.nbu + blockIdx.x] = (sh2[0] + sh2[1]) + (sh2[2] + sh2[3]);
+}
+
 struct PcgPlan {
+  int recurrence;            // 0 pipelined (one collective per iteration), 1 Chronopoulos-Gear (two)
   mgp_operator_t op;
   int64_t launch_rows[kMaxNu];
   PcgArgs args;
@@ -362,7 +497,7 @@ int nbu_for(int64_t n_loc) {
 
 // launch `s` of the chain on the first launch_rows[s] rows of the tile view
 int chain_launch(PcgPlan* pl, int s, const float* in, float* out, const float* base, const int* skip, int* tick,
-                 hipStream_t st) {
+                 hipStream_t st, const float* dotw = nullptr, float* dot_partials = nullptr) {
   const mgp_operator_t& op = pl->op;
   const float tau = 2.0f * (float)op.nu / (op.kappa * op.kappa);
   const bool first = s == 0, last = s == op.nu - 1;
@@ -375,16 +510,19 @@ int chain_launch(PcgPlan* pl, int s, const float* in, float* out, const float* b
     if (op.form == 2) { bs = base; cb = 1.f; co = op.noise * op.scale; }
   }
   return mgp_spmm_fused_first(&L, 0, in, 1, out, tau, 1.0f, first ? op.pre : nullptr, last ? op.post : nullptr, bs, cb, co,
-                              nullptr, nullptr, skip, last ? tick : nullptr, nullptr, nullptr, st);
+                              last ? dotw : nullptr, last ? dot_partials : nullptr, skip, last ? tick : nullptr, nullptr,
+                              nullptr, st);
 }
 
 // q (or w_0) = A v on this rank's rows; v gathered at the global length
-int enqueue_apply(PcgPlan* pl, const float* v, float* out, const int* skip, int* tick, hipStream_t st) {
+int enqueue_apply(PcgPlan* pl, const float* v, float* out, const int* skip, int* tick, hipStream_t st,
+                  bool delta_partials = false) {
   const float* in = v;
   for (int s = 0; s < pl->op.nu; ++s) {
     const bool last = s == pl->op.nu - 1;
     float* o = last ? out : ((s & 1) ? pl->t1 : pl->t0);
-    MGP_TRY(chain_launch(pl, s, in, o, v, skip, tick, st));
+    MGP_TRY(chain_launch(pl, s, in, o, v, skip, tick, st, delta_partials ? v : nullptr,
+                         delta_partials ? pl->args.pdd + (size_t)pl->args.rank * pl->args.nb2 : nullptr));
     in = o;
   }
   return MGP_OK;
@@ -432,7 +570,38 @@ int enqueue_gather_vec(PcgPlan* pl, float* buf, bool with_partials, hipStream_t 
   return rc;
 }
 
+// collective A of the Chronopoulos-Gear form: the delta partials of every rank
+int enqueue_gather_delta(PcgPlan* pl, hipStream_t st) {
+  if (!pl->comm) return MGP_OK;
+  const PcgArgs& a = pl->args;
+  ncclResult_t r = ncclAllGather(a.pdd + (size_t)a.rank * a.nb2, a.pdd, (size_t)a.nb2, ncclFloat, pl->comm, st);
+  return r == ncclSuccess ? MGP_OK : 1000 + (int)r;
+}
+
+// collective B: the u = r slices of w[par] and the gamma partials of pd[par], grouped
+int enqueue_gather_u(PcgPlan* pl, int par, hipStream_t st) {
+  if (!pl->comm) return MGP_OK;
+  const PcgArgs& a = pl->args;
+  ncclResult_t r = ncclGroupStart();
+  if (r != ncclSuccess) return 1000 + (int)r;
+  int rc = MGP_OK;
+  r = ncclAllGather(a.w[par] + a.row0, a.w[par], (size_t)a.n_loc, ncclFloat, pl->comm, st);
+  if (r != ncclSuccess) rc = 1000 + (int)r;
+  if (rc == MGP_OK) {
+    r = ncclAllGather(a.pd[par] + (size_t)a.rank * a.nbu, a.pd[par], (size_t)a.nbu, ncclFloat, pl->comm, st);
+    if (r != ncclSuccess) rc = 1000 + (int)r;
+  }
+  r = ncclGroupEnd();
+  if (rc == MGP_OK && r != ncclSuccess) rc = 1000 + (int)r;
+  return rc;
+}
+
 int enqueue_start(PcgPlan* pl, const float* B, int round, hipStream_t st) {
+  if (pl->recurrence == 1) {
+    hipLaunchKernelGGL(cgp_start_kernel, dim3(pl->args.nbu), dim3(kBlock), 0, st, pl->args, B, round);
+    MGP_LAUNCH_CHECK();
+    return MGP_OK;
+  }
   MGP_TRY(enqueue_apply(pl, B, pl->args.w[0], nullptr, nullptr, st));   // w_0 = A b on own rows
   hipLaunchKernelGGL(pcg_start_kernel, dim3(pl->args.nbu), dim3(kBlock), 0, st, pl->args, B, round);
   MGP_LAUNCH_CHECK();
@@ -445,6 +614,28 @@ int enqueue_iteration(PcgPlan* pl, int par, hipStream_t st) {
   hipLaunchKernelGGL(pcg_update_kernel, dim3(pl->args.nbu), dim3(kBlock), 0, st, pl->args);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
+}
+
+// Chronopoulos-Gear form, the two halves of an iteration (a collective sits behind each)
+int enqueue_cgp_apply(PcgPlan* pl, int par, hipStream_t st) {
+  return enqueue_apply(pl, pl->args.w[par], pl->q, pl->args.state + 1, pl->args.state, st, true);
+}
+int enqueue_cgp_update(PcgPlan* pl, hipStream_t st) {
+  hipLaunchKernelGGL(cgp_update_kernel, dim3(pl->args.nbu), dim3(kBlock), 0, st, pl->args);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+// one whole iteration of either recurrence WITH its collective(s): parity `par` in, `par ^ 1` out
+int enqueue_step(PcgPlan* pl, int par, hipStream_t st) {
+  if (pl->recurrence == 1) {
+    MGP_TRY(enqueue_cgp_apply(pl, par, st));
+    MGP_TRY(enqueue_gather_delta(pl, st));
+    MGP_TRY(enqueue_cgp_update(pl, st));
+    return enqueue_gather_u(pl, par ^ 1, st);
+  }
+  MGP_TRY(enqueue_iteration(pl, par, st));
+  return enqueue_gather(pl, par ^ 1, st);
 }
 
 // Residual replacement at a chunk boundary (parity 0): the recurrences of r, w, s, z are re-anchored on what they
@@ -477,15 +668,18 @@ int enqueue_replacement(PcgPlan* pl, const float* rhs, hipStream_t st) {
 void try_capture(PcgPlan* pl) {
   pl->graphs_tried = true;
   if (!pl->prm.use_graph || pl->virt) return;
+  // Capture with RCCL calls inside is validated with a communicator of size 1 only (the build box has one GPU):
+  // with more ranks the loop is launched eagerly unless MGP_PCG_GRAPH_DIST=1 asks for the capture
+  if (pl->comm && pl->world > 1) {
+    const char* e = getenv("MGP_PCG_GRAPH_DIST");
+    if (!e || e[0] != '1') return;
+  }
   if (hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return; }
   bool ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
   if (ok) {
     int rc = MGP_OK;
     // a chunk is an even number of iterations: it starts and ends on parity 0
-    for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) {
-      rc = enqueue_iteration(pl, i & 1, pl->cap_stream);
-      if (rc == MGP_OK) rc = enqueue_gather(pl, (i & 1) ^ 1, pl->cap_stream);
-    }
+    for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) rc = enqueue_step(pl, i & 1, pl->cap_stream);
     hipGraph_t graph = nullptr;
     const hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
     ok = rc == MGP_OK && e2 == hipSuccess && graph != nullptr;
@@ -501,7 +695,9 @@ void try_capture(PcgPlan* pl) {
 // floats of the buffers that virtual ranks share (w[2] and pd[2]); real ranks keep them in their own workspace
 extern "C" size_t mgp_pcg_shared_floats(int64_t n_glob, int64_t n_loc, int world) {
   if (n_glob <= 0 || n_loc <= 0 || world < 1) return 0;
-  return 2 * (size_t)n_glob + 2 * 2 * (size_t)world * nbu_for(n_loc) + 64;
+  // w[2], pd[2] (gamma + delta partials per update workgroup), pdd (delta partials per SpMV workgroup: <= one per
+  // 64 rows)
+  return 2 * (size_t)n_glob + 2 * 2 * (size_t)world * nbu_for(n_loc) + (size_t)world * (mgp_cdiv(n_loc, 64) + 1) + 64;
 }
 
 extern "C" size_t mgp_pcg_workspace_bytes(int64_t n_glob, int64_t n_loc, int world) {
@@ -515,10 +711,11 @@ extern "C" size_t mgp_pcg_workspace_bytes(int64_t n_glob, int64_t n_loc, int wor
 // multiple of the tile height; launch_rows[nu - 1] = n_loc).  shared (nullable): w / partial buffers shared between
 // virtual ranks (mgp_pcg_shared_floats).  Forms 0 and 2, C = 1.
 extern "C" int mgp_pcg_plan_create(const mgp_operator_t* op, const int64_t* launch_rows, int64_t row0, int64_t n_loc,
-                                   int64_t n_real, void* comm, int rank, int world, float* shared,
+                                   int64_t n_real, void* comm, int rank, int world, float* shared, int recurrence,
                                    const mgp_cg_params_t* params, void* work, size_t work_bytes, void* stream,
                                    void** plan_out) {
   if (!op || !launch_rows || !params || !work || !plan_out) return MGP_ERR_ARG;
+  if (recurrence != 0 && recurrence != 1) return MGP_ERR_ARG;
   if (op->nu < 1 || op->nu > kMaxNu || (op->form != 0 && op->form != 2)) return MGP_ERR_UNSUPPORTED;
   if (world < 1 || rank < 0 || rank >= world || n_loc <= 0 || row0 < 0) return MGP_ERR_ARG;
   const int64_t n_glob = op->L.n;
@@ -540,6 +737,7 @@ extern "C" int mgp_pcg_plan_create(const mgp_operator_t* op, const int64_t* laun
   if (!pl) return MGP_ERR_ARG;
   memset(pl, 0, sizeof(*pl));
   pl->op = *op;
+  pl->recurrence = recurrence;
   memcpy(pl->launch_rows, launch_rows, sizeof(int64_t) * op->nu);
   pl->comm = static_cast<ncclComm_t>(comm);
   pl->world = world; pl->rank = rank;
@@ -565,10 +763,17 @@ extern "C" int mgp_pcg_plan_create(const mgp_operator_t* op, const int64_t* laun
   a.nbu = nbu_for(n_loc);
   a.world = world; a.rank = rank;
   const size_t npd = 2 * (size_t)world * a.nbu;
+  {
+    mgp_csr_t Ll = op->L;
+    Ll.n = launch_rows[op->nu - 1];
+    a.nb2 = mgp_spmm_dot_blocks_for(&Ll, 1);
+  }
+  if (a.nb2 <= 0 || (int64_t)world * a.nb2 > (int64_t)kMaxSlots * kBlock) { delete pl; return MGP_ERR_UNSUPPORTED; }
   float* sh = shared ? shared : ar.take<float>(mgp_pcg_shared_floats(n_glob, n_loc, world));
   if (sh) {
     a.w[0] = sh; a.w[1] = sh + n_glob;
     a.pd[0] = sh + 2 * (size_t)n_glob; a.pd[1] = a.pd[0] + npd;
+    a.pdd = a.pd[1] + npd;
   }
   a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter; a.stop_mode = pl->prm.stop_mode;
   if (!ar.ok() || !sh) { delete pl; return MGP_ERR_WORKSPACE; }
@@ -590,7 +795,8 @@ extern "C" int mgp_pcg_plan_enqueue(void* plan, int phase, int par, const float*
   PcgPlan* pl = static_cast<PcgPlan*>(plan);
   if (!pl || (phase == 0 && !B)) return MGP_ERR_ARG;
   if (phase == 0) { pl->host_state[1] = 0; return enqueue_start(pl, B, 0, pl->stream); }
-  return enqueue_iteration(pl, par & 1, pl->stream);
+  if (pl->recurrence == 1) return phase == 1 ? enqueue_cgp_apply(pl, par & 1, pl->stream) : enqueue_cgp_update(pl, pl->stream);
+  return phase == 1 ? enqueue_iteration(pl, par & 1, pl->stream) : MGP_OK;
 }
 
 extern "C" int mgp_pcg_plan_poll(void* plan, int32_t* iters, float* resid, int32_t* status) {
@@ -620,23 +826,20 @@ extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int3
   for (int round = 0; round <= max_refine; ++round) {
     pl->host_state[1] = 0;
     MGP_TRY(enqueue_start(pl, rhs, round, st));
-    MGP_TRY(enqueue_gather(pl, 0, st));
+    MGP_TRY(pl->recurrence == 1 ? enqueue_gather_u(pl, 0, st) : enqueue_gather(pl, 0, st));
     int guard = 0;
     for (;;) {
       if (pl->has_graph) {
         MGP_HIP_TRY(hipGraphLaunch(pl->exec, st));
       } else {
-        for (int i = 0; i < pl->chunk; ++i) {
-          MGP_TRY(enqueue_iteration(pl, i & 1, st));
-          MGP_TRY(enqueue_gather(pl, (i & 1) ^ 1, st));
-        }
+        for (int i = 0; i < pl->chunk; ++i) MGP_TRY(enqueue_step(pl, i & 1, st));
       }
       // every rank launches whole chunks and checks the flag only once its chunk has drained: the decisions are
       // bit-identical on all ranks, so all ranks stop behind the same chunk and their collective sequences match
       MGP_HIP_TRY(hipStreamSynchronize(st));
       if (*flag) break;
       if (++guard > pl->prm.max_iter / pl->chunk + 2) break;
-      if (pl->chunk >= 16) MGP_TRY(enqueue_replacement(pl, rhs, st));     // long solves: re-anchor the recurrences
+      if (pl->chunk >= 16 && pl->recurrence == 0) MGP_TRY(enqueue_replacement(pl, rhs, st));   // long pipelined solves: re-anchor the recurrences
     }
     total_iters += pl->host_state[0];
     last_status = pl->host_state[2];

@@ -256,8 +256,9 @@ class PcgPlan:
     virtual rank sharing `shared` with its siblings (comm None, world > 1; driven by `virtual_pcg_solve`)."""
 
     def __init__(self, desc, part, rank, comm=None, shared=None, tol=1e-6, max_iter=1000, stop_mode=1, check_every=8,
-                 use_graph=True, refine=0):
-        """refine > 0: the pipelined solve becomes the inner solver of up to `refine` rounds of iterative refinement on
+                 use_graph=True, refine=0, recurrence="pipelined"):
+        """recurrence: "pipelined" (one collective per iteration) or "chronopoulos-gear" (two; robust on ill-conditioned
+        systems).  refine > 0: the pipelined solve becomes the inner solver of up to `refine` rounds of iterative refinement on
         the TRUE residual (csrc/pcg.hip, "Attainable accuracy"); status 4 = the recurrence stagnated (no refinement)."""
         self.pop = PartitionedOperator(desc, part, rank)
         self.part, self.rank = part, rank
@@ -271,9 +272,10 @@ class PcgPlan:
         self.shared = shared
         self.handle = ctypes.c_void_p(0)
         r0, _ = part.range(rank)
+        self.recurrence = {"pipelined": 0, "chronopoulos-gear": 1}[recurrence]
         check(lib().mgp_pcg_plan_create(ctypes.byref(self.pop.op), self._rows, r0, part.n_loc, part.n, comm, rank, part.world,
-                                        ptr(shared), ctypes.byref(self.params), ptr(self.work), self.work.numel(), stream(),
-                                        ctypes.byref(self.handle)), "mgp_pcg_plan_create")
+                                        ptr(shared), self.recurrence, ctypes.byref(self.params), ptr(self.work),
+                                        self.work.numel(), stream(), ctypes.byref(self.handle)), "mgp_pcg_plan_create")
         self.iters, self.status, self.resid = 0, 0, None
 
     @staticmethod
@@ -321,7 +323,7 @@ class PcgPlan:
             pass
 
 
-def virtual_pcg_solve(desc, part, B_pad, tol=1e-6, max_iter=1000, stop_mode=1, check_every=8):
+def virtual_pcg_solve(desc, part, B_pad, tol=1e-6, max_iter=1000, stop_mode=1, check_every=8, recurrence="pipelined"):
     """The partitioned solve with `part.world` VIRTUAL ranks in this process on one GPU: one plan per rank, all sharing
     the gathered-w / partial buffers (each rank writes its slice: the all-gather is the identity), phases enqueued in
     lock step on the current stream.  Exactly the kernels, row orders, ghost layers and decisions of the RCCL job.
@@ -330,7 +332,7 @@ def virtual_pcg_solve(desc, part, B_pad, tol=1e-6, max_iter=1000, stop_mode=1, c
     B = _lib.f32c(B_pad.reshape(-1))
     shared = PcgPlan.shared_buffer(part, dev)
     plans = [PcgPlan(desc, part, r, comm=None, shared=shared, tol=tol, max_iter=max_iter, stop_mode=stop_mode,
-                     check_every=check_every) for r in range(part.world)]
+                     check_every=check_every, recurrence=recurrence) for r in range(part.world)]
     try:
         for pl in plans:
             pl.enqueue(0, B=B)
@@ -340,6 +342,9 @@ def virtual_pcg_solve(desc, part, B_pad, tol=1e-6, max_iter=1000, stop_mode=1, c
             for _ in range(check_every):
                 for pl in plans:
                     pl.enqueue(1, par=it & 1)
+                if plans[0].recurrence == 1:           # the update half sits behind the (virtual) gather of the partials
+                    for pl in plans:
+                        pl.enqueue(2, par=it & 1)
                 it += 1
             torch.cuda.synchronize()
             polled = [pl.poll() for pl in plans]

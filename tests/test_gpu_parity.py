@@ -1887,10 +1887,11 @@ def _padded_descriptor(mgp, g, dev, norm, nu, form, world):
     return desc, desc.with_(data=data, pre=sq, post=sq), part
 
 
+@pytest.mark.parametrize("recurrence", ["pipelined", "chronopoulos-gear"])
 @pytest.mark.parametrize("nu", [1, 2, 3])
 @pytest.mark.parametrize("form", [0, 2])
 @pytest.mark.parametrize("norm", NORMS)
-def test_pcg_single_rank_matches_cg(mgp, golden, dev, norm, form, nu):
+def test_pcg_single_rank_matches_cg(mgp, golden, dev, norm, form, nu, recurrence):
     """csrc/pcg.hip with one rank (no communicator) against the Chronopoulos-Gear solver of cg.hip: same system,
     same tolerance -> same solution to round-off, true residual at tolerance, comparable iteration count; graph
     replay == eager launches bit for bit; a zero right-hand side."""
@@ -1903,7 +1904,7 @@ def test_pcg_single_rank_matches_cg(mgp, golden, dev, norm, form, nu):
     xs, its, _ = cg_solve(desc, T(g["train_y"], dev), tol=1e-6, stop_mode=1, max_iter=20000)
     sols = {}
     for use_graph in (True, False):
-        plan = PcgPlan(dd, part, 0, tol=1e-6, max_iter=20000, stop_mode=1, use_graph=use_graph)
+        plan = PcgPlan(dd, part, 0, tol=1e-6, max_iter=20000, stop_mode=1, use_graph=use_graph, recurrence=recurrence)
         for _ in range(3):                                    # the graph is captured at the second solve
             x = plan.solve(y).clone()
         assert plan.status == 1 and abs(plan.iters - its) <= max(2, its // 20), (plan.iters, its)
@@ -1919,9 +1920,10 @@ def test_pcg_single_rank_matches_cg(mgp, golden, dev, norm, form, nu):
     assert float((x - xs).abs().max()) < 2e-4 * float(xs.abs().max())
 
 
+@pytest.mark.parametrize("recurrence", ["pipelined", "chronopoulos-gear"])
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("nu,form,norm", [(1, 0, "symmetric"), (2, 2, "randomwalk"), (3, 2, "symmetric"), (2, 0, "randomwalk")])
-def test_pcg_virtual_ranks_partition_vectors_and_ghost_layers(mgp, golden, dev, world, nu, form, norm):
+def test_pcg_virtual_ranks_partition_vectors_and_ghost_layers(mgp, golden, dev, world, nu, form, norm, recurrence):
     """The multi-GPU form on one GPU: `world` virtual ranks, each with its own row block, row order [own, ghost
     layers, rest], tile view and plan; vectors partitioned; the gathered-w / partial buffers shared (each rank writes
     its slice: the all-gather is the identity).  Against the one-rank solve: same solution to round-off (the dot
@@ -1932,11 +1934,11 @@ def test_pcg_virtual_ranks_partition_vectors_and_ghost_layers(mgp, golden, dev, 
     desc, dd, part = _padded_descriptor(mgp, g, dev, norm, nu, form, world)
     n = desc.n
     y = part.pad(T(g["train_y"], dev))
-    x, its, status, ghosts = virtual_pcg_solve(dd, part, y, tol=1e-6, max_iter=20000, stop_mode=1)
+    x, its, status, ghosts = virtual_pcg_solve(dd, part, y, tol=1e-6, max_iter=20000, stop_mode=1, recurrence=recurrence)
     assert status == 1
     assert (sum(ghosts) > 0) == (nu >= 2), ghosts
     _, d1, p1 = _padded_descriptor(mgp, g, dev, norm, nu, form, 1)
-    plan = PcgPlan(d1, p1, 0, tol=1e-6, max_iter=20000, stop_mode=1)
+    plan = PcgPlan(d1, p1, 0, tol=1e-6, max_iter=20000, stop_mode=1, recurrence=recurrence)
     x1 = plan.solve(p1.pad(T(g["train_y"], dev))).clone()[:n]
     assert abs(plan.iters - its) <= max(1, its // 50), (plan.iters, its)
     plan.close()
@@ -1956,12 +1958,13 @@ def test_pcg_rccl_world1_and_sharded_columns(mgp, golden, dev):
     desc, dd, part = _padded_descriptor(mgp, g, dev, "randomwalk", 2, 2, 1)
     y = part.pad(T(g["train_y"], dev))
     comm = init_comm(0, 1)
-    a = PcgPlan(dd, part, 0, comm=comm, tol=1e-6, max_iter=20000, stop_mode=1)
-    b = PcgPlan(dd, part, 0, comm=None, tol=1e-6, max_iter=20000, stop_mode=1)
-    for _ in range(3):
-        xa, xb = a.solve(y).clone(), b.solve(y).clone()
-        assert torch.equal(xa, xb) and a.iters == b.iters and a.status == 1
-    a.close(), b.close()
+    for rec in ("pipelined", "chronopoulos-gear"):
+        a = PcgPlan(dd, part, 0, comm=comm, tol=1e-6, max_iter=20000, stop_mode=1, recurrence=rec)
+        b = PcgPlan(dd, part, 0, comm=None, tol=1e-6, max_iter=20000, stop_mode=1, recurrence=rec)
+        for _ in range(3):
+            xa, xb = a.solve(y).clone(), b.solve(y).clone()
+            assert torch.equal(xa, xb) and a.iters == b.iters and a.status == 1
+        a.close(), b.close()
     B = T(g["probes"], dev)
     with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1):
         X, _ = solve_columns_sharded(desc, B, 0, 1)
@@ -1989,6 +1992,13 @@ def test_pcg_stagnation_guard_and_refinement_on_an_ill_conditioned_system(mgp, g
     assert plan.status == 4 and plan.iters < 4 * its, (plan.status, plan.iters, its)
     true0 = float((desc.apply(x) - yv).norm() / yv.norm())
     assert true0 < 50 * ref_true, (true0, ref_true)                       # stopped near its best, not after drifting
+    plan.close()
+    # the partitioned Chronopoulos-Gear recurrence behaves like cg.hip: the recurrence residual reaches 1e-6 in about as
+    # many iterations, the true residual stalls at the fp32 level
+    plan = PcgPlan(dd, part, 0, tol=1e-6, max_iter=20000, stop_mode=1, recurrence="chronopoulos-gear")
+    x = plan.solve(y).clone()[:n]
+    assert plan.status == 1 and abs(plan.iters - its) <= max(3, its // 10), (plan.status, plan.iters, its)
+    assert float((desc.apply(x) - yv).norm() / yv.norm()) < 3 * ref_true + 1e-5
     plan.close()
     for chunk in (8, 32):          # chunks >= 16 iterations also re-anchor r, w, s, z at every chunk boundary
         plan = PcgPlan(dd, part, 0, tol=1e-3, max_iter=20000, stop_mode=1, refine=6, check_every=chunk)

@@ -31,9 +31,21 @@ for world in (1,):
         print("pcg world 1 refine %d chunk %d: its %d status %d resid %.2e true(fp32 apply) %.2e diff vs cg %.2e  %.1f ms"
               % (refine, chunk, p.iters, p.status, p.resid, tr(x[:g.n]), float((x[:g.n] - xs).abs().max() / xs.abs().max()), dt * 1e3))
         p.close()
+part1 = RowPartition(g.n, 1)
+data1 = LaplacianData(pad_graph(g, part1.n_pad), wl["lap"].data.eps, True)
+for refine in (0, 3):
+    p = PcgPlan(desc.with_(data=data1), part1, 0, tol=1e-6, max_iter=5000, stop_mode=1, check_every=8, refine=refine, recurrence="chronopoulos-gear")
+    yp = part1.pad(y)
+    x = p.solve(yp).clone()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    x = p.solve(yp).clone()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print("partitioned Chronopoulos-Gear world 1 refine %d: its %d status %d resid %.2e true(fp32 apply) %.2e diff vs cg %.2e  %.1f ms"
+          % (refine, p.iters, p.status, p.resid, tr(x[:g.n]), float((x[:g.n] - xs).abs().max() / xs.abs().max()), dt * 1e3))
+    p.close()
 part = RowPartition(g.n, 8)
 data = LaplacianData(pad_graph(g, part.n_pad), wl["lap"].data.eps, True)
 dd = desc.with_(data=data)
 t0 = time.perf_counter()
-x8, its, status, ghosts = virtual_pcg_solve(dd, part, part.pad(y), tol=3e-2, max_iter=400, stop_mode=1)
-print("8 virtual ranks: its %d status %d ghosts/rank %s (n_loc %d) true %.2e  (%.1f s incl. setup)" % (its, status, ghosts, part.n_loc, tr(x8[:g.n]), time.perf_counter() - t0))
+x8, its, status, ghosts = virtual_pcg_solve(dd, part, part.pad(y), tol=1e-4, max_iter=800, stop_mode=1, recurrence="chronopoulos-gear")
+print("8 virtual ranks (Chronopoulos-Gear): its %d status %d ghosts/rank %s (n_loc %d) true %.2e  (%.1f s incl. setup)" % (its, status, ghosts, part.n_loc, tr(x8[:g.n]), time.perf_counter() - t0))
