@@ -58,8 +58,9 @@ struct PcgArgs {
   const float* q;          // A w on own rows
   float* w[2];             // gathered w, double-buffered by the iteration parity
   float* pd[2];            // [2][world * nbu]: gamma partials then delta partials
-  float* pdd;              // Chronopoulos-Gear form: [world * nb2] partials of (u, A u) from the SpMV epilogue
-  int nb2;                 // SpMV workgroups per rank that write them
+  float* pdd;              // Chronopoulos-Gear form: [world] delta = (u, A u) of every rank's rows (gathered)
+  float* pdd_loc;          // [nb2] this rank's SpMV-epilogue partials, folded into pdd[rank] by cgp_delta_kernel
+  int nb2;                 // SpMV workgroups of this rank that write them (<= 4096)
   int nbu;                 // workgroups of this kernel per rank
   int world, rank;
   float* scal;             // [0..1] gamma_old by parity, [2..3] alpha_old by parity, [4] bb, [5] resid,
@@ -363,6 +364,25 @@ __global__ __launch_bounds__(kBlock) void cgp_start_kernel(PcgArgs a, const floa
   if (tid == 0) a.pd[0][a.rank * a.nbu + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// this rank's delta partials (one per SpMV workgroup, up to 4096) -> ONE float, fixed order: what is gathered
+__global__ __launch_bounds__(kBlock) void cgp_delta_kernel(PcgArgs a) {
+  __shared__ float sh[kBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float dv[kMaxSlots];
+#pragma unroll
+  for (int k = 0; k < kMaxSlots; ++k) {
+    const int b = tid + k * kBlock;
+    dv[k] = a.pdd_loc[b < a.nb2 ? b : a.nb2 - 1];
+  }
+  float d = 0.f;
+#pragma unroll
+  for (int k = 0; k < kMaxSlots; ++k) d += (tid + k * kBlock < a.nb2) ? dv[k] : 0.f;
+  d = mgp_wave_sum(d);
+  if (lane == 0) sh[wave] = d;
+  __syncthreads();
+  if (tid == 0) a.pdd[a.rank] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 __global__ __launch_bounds__(kBlock) void cgp_update_kernel(PcgArgs a) {
   __shared__ float sh[kBlock / 64][2];
   __shared__ float sh2[kBlock / 64];
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void cgp_update_kernel(PcgArgs a) {
   // gamma from the update-kernel partials (world * nbu), delta from the SpMV partials (world * nb2)
   float gamma, delta;
   {
-    const int cg = a.world * a.nbu, cd = a.world * a.nb2;
+    const int cg = a.world * a.nbu, cd = a.world;
     float gv[kMaxSlots], dv[kMaxSlots];
 #pragma unroll
     for (int k = 0; k < kMaxSlots; ++k) {
@@ -486,7 +506,7 @@ struct PcgPlan {
   int64_t n_glob;
 };
 
-size_t pcg_private_floats(int64_t n_glob) { return 12 * (size_t)n_glob + 256; }   // x r p s z q t0 t1 xfull rfull xacc(f64) + scalars
+size_t pcg_private_floats(int64_t n_glob) { return 12 * (size_t)n_glob + 4096 + 256; }   // x r p s z q t0 t1 xfull rfull xacc(f64) + scalars
 
 int nbu_for(int64_t n_loc) {
   int64_t nb = mgp_cdiv(n_loc, kBlock);
@@ -522,7 +542,7 @@ int enqueue_apply(PcgPlan* pl, const float* v, float* out, const int* skip, int*
     const bool last = s == pl->op.nu - 1;
     float* o = last ? out : ((s & 1) ? pl->t1 : pl->t0);
     MGP_TRY(chain_launch(pl, s, in, o, v, skip, tick, st, delta_partials ? v : nullptr,
-                         delta_partials ? pl->args.pdd + (size_t)pl->args.rank * pl->args.nb2 : nullptr));
+                         delta_partials ? pl->args.pdd_loc : nullptr));
     in = o;
   }
   return MGP_OK;
@@ -574,7 +594,7 @@ int enqueue_gather_vec(PcgPlan* pl, float* buf, bool with_partials, hipStream_t 
 int enqueue_gather_delta(PcgPlan* pl, hipStream_t st) {
   if (!pl->comm) return MGP_OK;
   const PcgArgs& a = pl->args;
-  ncclResult_t r = ncclAllGather(a.pdd + (size_t)a.rank * a.nb2, a.pdd, (size_t)a.nb2, ncclFloat, pl->comm, st);
+  ncclResult_t r = ncclAllGather(a.pdd + a.rank, a.pdd, 1, ncclFloat, pl->comm, st);
   return r == ncclSuccess ? MGP_OK : 1000 + (int)r;
 }
 
@@ -618,7 +638,10 @@ int enqueue_iteration(PcgPlan* pl, int par, hipStream_t st) {
 
 // Chronopoulos-Gear form, the two halves of an iteration (a collective sits behind each)
 int enqueue_cgp_apply(PcgPlan* pl, int par, hipStream_t st) {
-  return enqueue_apply(pl, pl->args.w[par], pl->q, pl->args.state + 1, pl->args.state, st, true);
+  MGP_TRY(enqueue_apply(pl, pl->args.w[par], pl->q, pl->args.state + 1, pl->args.state, st, true));
+  hipLaunchKernelGGL(cgp_delta_kernel, dim3(1), dim3(kBlock), 0, st, pl->args);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
 }
 int enqueue_cgp_update(PcgPlan* pl, hipStream_t st) {
   hipLaunchKernelGGL(cgp_update_kernel, dim3(pl->args.nbu), dim3(kBlock), 0, st, pl->args);
@@ -695,9 +718,8 @@ void try_capture(PcgPlan* pl) {
 // floats of the buffers that virtual ranks share (w[2] and pd[2]); real ranks keep them in their own workspace
 extern "C" size_t mgp_pcg_shared_floats(int64_t n_glob, int64_t n_loc, int world) {
   if (n_glob <= 0 || n_loc <= 0 || world < 1) return 0;
-  // w[2], pd[2] (gamma + delta partials per update workgroup), pdd (delta partials per SpMV workgroup: <= one per
-  // 64 rows)
-  return 2 * (size_t)n_glob + 2 * 2 * (size_t)world * nbu_for(n_loc) + (size_t)world * (mgp_cdiv(n_loc, 64) + 1) + 64;
+  // w[2], pd[2] (gamma + delta partials per update workgroup), pdd (one delta per rank)
+  return 2 * (size_t)n_glob + 2 * 2 * (size_t)world * nbu_for(n_loc) + (size_t)world + 64;
 }
 
 extern "C" size_t mgp_pcg_workspace_bytes(int64_t n_glob, int64_t n_loc, int world) {
@@ -768,7 +790,8 @@ extern "C" int mgp_pcg_plan_create(const mgp_operator_t* op, const int64_t* laun
     Ll.n = launch_rows[op->nu - 1];
     a.nb2 = mgp_spmm_dot_blocks_for(&Ll, 1);
   }
-  if (a.nb2 <= 0 || (int64_t)world * a.nb2 > (int64_t)kMaxSlots * kBlock) { delete pl; return MGP_ERR_UNSUPPORTED; }
+  if (a.nb2 <= 0 || a.nb2 > kMaxSlots * kBlock || world > kMaxSlots * kBlock) { delete pl; return MGP_ERR_UNSUPPORTED; }
+  a.pdd_loc = ar.take<float>(a.nb2);
   float* sh = shared ? shared : ar.take<float>(mgp_pcg_shared_floats(n_glob, n_loc, world));
   if (sh) {
     a.w[0] = sh; a.w[1] = sh + n_glob;

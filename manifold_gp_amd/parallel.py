@@ -521,7 +521,8 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
         # system: chunks of 32 iterations with residual replacement, refinement rounds on the true residual
         long_solve = args.workload != "c3"
         plan = PcgPlan(desc, part, rank, comm=comm, tol=args.tol, max_iter=4000, stop_mode=1,
-                       check_every=32 if long_solve else 4, refine=4 if long_solve else 0)
+                       check_every=16 if long_solve else 4, refine=3 if long_solve else 0,
+                       recurrence="chronopoulos-gear" if long_solve else "pipelined")
         solve = lambda: plan.solve(y.view(-1))          # noqa: E731
         ghost = plan.pop.ghost_rows
     else:
@@ -569,8 +570,10 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
     r = apply_partitioned(desc, part, rank, comm, xg) - y
     true_res = float(r.norm() / y.norm())
     if rank == 0:
-        how = ("rows AND vectors partitioned over %d ranks, pipelined CG, one grouped RCCL all-gather per iteration "
-               "(w slices + dot partials), %d ghost rows on rank 0" % (world, ghost)) if strong else \
+        how = ("rows AND vectors partitioned over %d ranks, %s, %d ghost rows on rank 0"
+               % (world, "Chronopoulos-Gear recurrence: two RCCL collectives per iteration (gathered vector + gamma partials; "
+                  "one delta per rank), refinement on the true residual" if long_solve else
+                  "pipelined CG: one grouped RCCL all-gather per iteration (w slices + dot partials)", ghost)) if strong else \
               ("rows of L partitioned over %d ranks, vectors replicated, one grouped RCCL all-gather per SpMV" % world)
         line = dict(metric="CG-solve wall-time + SpMV HBM GB/s, N=60k RMNIST graph", value=round(value, 2),
                     unit="GB/s (algorithmic SpMV bytes inside the CG solve, all ranks)", n_gpus=world,
