@@ -102,3 +102,33 @@ def torch_laplacian_from_edges(val, idx, n, eps, self_loops=True):
     diag = (1.0 - self_a / deg) / (eps * eps) if self_loops else torch.ones(n) / (eps * eps)   # :94-97
     triu = a / (deg[idx[0]].sqrt() * deg[idx[1]].sqrt()) / (eps * eps)        # :105-106 (stored positive)
     return diag, triu, deg
+
+
+def dense_model_precision(val, idx, n, eps, kappa, outputscale, noise, nu, normalization="randomwalk", self_loops=True):
+    """The model precision of riemann_gp.py:32-39 as a DENSE differentiable float64 matrix (test oracle for gradients):
+    L from torch_laplacian_from_edges (graph_laplacian_operator.py:52-124), Q = (2 nu / kappa^2 I + L)^nu (x D for
+    random walk, precision_matern_operator.py:26-37), Q2 = outputscale * Q (scale_wrapper_operator.py:27),
+    Q3 = Q2 - noise Q2^2 + noise^2 Q2^3 (noise_wrapper_operator.py:22).  eps, kappa, outputscale, noise: 0-d float64
+    tensors (may require grad)."""
+    val = torch.as_tensor(val, dtype=torch.float64)
+    idx = torch.as_tensor(idx, dtype=torch.int64)
+    w = torch.exp(-val / (4.0 * eps * eps))
+    base = torch.ones(n, dtype=torch.float64) if self_loops else torch.zeros(n, dtype=torch.float64)
+    dt = base.index_add(0, idx[0], w).index_add(0, idx[1], w)
+    a = w / (dt[idx[0]] * dt[idx[1]])
+    self_a = dt.pow(-2) if self_loops else torch.zeros(n, dtype=torch.float64)
+    deg = self_a.index_add(0, idx[0], a).index_add(0, idx[1], a)
+    diag = (1.0 - self_a / deg) / (eps * eps) if self_loops else torch.ones(n, dtype=torch.float64) / (eps * eps)
+    triu = a / (deg[idx[0]].sqrt() * deg[idx[1]].sqrt()) / (eps * eps)
+    S = torch.zeros(n, n, dtype=torch.float64).index_put((idx[0], idx[1]), triu, accumulate=True)
+    Lsym = torch.diag(diag) - S - S.t()
+    if normalization == "randomwalk":
+        ds = deg.sqrt()
+        L = Lsym * ds.view(1, -1) / ds.view(-1, 1)             # D^-1/2 L_sym D^1/2
+    else:
+        L = Lsym
+    Q = torch.linalg.matrix_power(torch.eye(n, dtype=torch.float64) * (2.0 * nu / (kappa * kappa)) + L, nu)
+    if normalization == "randomwalk":
+        Q = deg.view(-1, 1) * Q
+    Q2 = Q * outputscale
+    return Q2 - noise * (Q2 @ Q2) + noise * noise * (Q2 @ Q2 @ Q2)

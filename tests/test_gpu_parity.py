@@ -767,7 +767,21 @@ def test_stochastic_gradients_large_n_branch(mgp, golden, dev):
     assert abs(logdet.item() - float(g[p + "ml_logdet"])) < 0.03 * abs(float(g[p + "ml_logdet"]))
     got = np.array([eps_t.grad.item(), kap_t.grad.item(), s_t.grad.item(), z_t.grad.item()])
     ref = g[p + "ml_grads"]
-    assert (np.abs(got - ref) < 0.08 * np.abs(ref) + 0.02 * np.abs(ref).max()).all(), (got, ref)
+    assert (np.abs(got - ref) < 0.08 * np.abs(ref) + 0.02 * np.abs(ref).max()).all(), (got, ref)   # Monte-Carlo (200 probes)
+    # The SAME estimator with the SAME probes in float64 (the Monte-Carlo error cancels): the surrogate of
+    # solvers.inv_quad_logdet, d logdet = (1/P) sum_p (A^-1 z_p)^T dA z_p with the probes of seed 4321, on the dense
+    # differentiable oracle (oracle/ref_torch.py::dense_model_precision, pinned on the reference-autograd goldens)
+    from manifold_gp_amd.slq import rademacher_probes
+    from oracle.ref_torch import dense_model_precision
+    th = [torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for v in (g["eps"], g["kappa"], 0.7, 1e-3)]
+    Ad = dense_model_precision(g["edge_value"], g["edge_index"], n, *th, int(g[p + "ml_nu"]), "randomwalk", False)
+    Z = rademacher_probes(n, 200, 4321, dev).double().cpu()
+    Sz = torch.linalg.solve(Ad.detach(), Z)
+    yd = torch.from_numpy(g["train_y"].astype(np.float64))
+    surrogate = 0.5 * (yd @ (Ad @ yd) - (Sz * (Ad @ Z)).sum() / Z.shape[1])
+    want = np.array([t.item() for t in torch.autograd.grad(surrogate, th)])
+    print("stochastic gradients, same probes: HIP", got, "oracle", want)
+    assert (np.abs(got - want) < 2e-3 * np.abs(want) + 2e-4 * np.abs(want).max()).all(), (got, want)
 
 
 def test_schur_solve_by_block_elimination(mgp, golden, dev):
@@ -1135,11 +1149,15 @@ def test_riemann_gp_posterior_and_hybrid(mgp, golden, dev, norm):
     model.posterior(xt, base_model=base)
     b = base(xt)
     w = 1.0 - mod_o
-    np.testing.assert_allclose(model.posterior_mean.cpu().numpy(), mean_o + w * b.mean.cpu().numpy(), rtol=0, atol=3e-4 * scale)
-    np.testing.assert_allclose(model.posterior_covar.cpu().numpy(),
-                               cov_o + np.outer(w, w) * b.covariance_matrix.cpu().numpy(), rtol=0, atol=3e-4)
-    np.testing.assert_allclose(model.posterior_stddev.cpu().numpy(),
-                               np.sqrt(np.clip(np.diag(cov_o), 0, None)) + w * b.stddev.cpu().numpy(), rtol=0, atol=2e-3)
+    hm = mean_o + w * b.mean.cpu().numpy()
+    hc = cov_o + np.outer(w, w) * b.covariance_matrix.cpu().numpy()
+    hs = np.sqrt(np.clip(np.diag(cov_o), 0, None)) + w * b.stddev.cpu().numpy()
+    e_hm = np.abs(model.posterior_mean.cpu().numpy() - hm).max() / scale
+    e_hc = np.abs(model.posterior_covar.cpu().numpy() - hc).max() / np.abs(hc).max()
+    e_hs = np.abs(model.posterior_stddev.cpu().numpy() - hs).max() / np.abs(hs).max()
+    print("hybrid posterior errors: mean %.2e cov %.2e stddev %.2e" % (e_hm, e_hc, e_hs))
+    # north-star tolerance 1e-4; the stddev is a square root of variances that cancel to ~1e-3 of the prior's
+    assert e_hm < 1e-5 and e_hc < 1e-5 and e_hs < 1e-4, (e_hm, e_hc, e_hs)
     # test_model (utils/test_model.py:10-29): RMSE / NLL of the noisy hybrid posterior vs the oracle's metrics
     from manifold_gp_amd.utils import test_model as run_test_model
     from oracle.solvers import rmse_nll
@@ -1147,8 +1165,9 @@ def test_riemann_gp_posterior_and_hybrid(mgp, golden, dev, norm):
     rmse, nll = run_test_model(model, xt, yt, noisy_test=True, base_model=base)
     cov_h = cov_o + noise * np.eye(40) + np.outer(w, w) * (b.covariance_matrix.cpu().numpy() + noise * np.eye(40))
     rmse_o, nll_o = rmse_nll(yt.cpu().numpy().astype(np.float64) - (mean_o + w * b.mean.cpu().numpy()), cov_h)
-    assert abs(float(rmse) - rmse_o) <= 1e-4 * max(1.0, rmse_o)
-    assert abs(float(nll) - nll_o) <= 2e-3 * max(1.0, abs(nll_o)), (float(nll), nll_o)
+    print("test_model: rmse %.6f vs %.6f, nll %.6f vs %.6f" % (float(rmse), rmse_o, float(nll), nll_o))
+    assert abs(float(rmse) - rmse_o) <= 1e-5 * max(1.0, rmse_o)
+    assert abs(float(nll) - nll_o) <= 1e-4 * max(1.0, abs(nll_o)), (float(nll), nll_o)
     # precision(): Schur (if labelled) -> Scale -> Noise (riemann_gp.py:32-39)
     Qn = model.precision()
     assert isinstance(Qn, O.NoiseWrapperOperator) and isinstance(model.precision(noise=False), O.ScaleWrapperOperator)

@@ -237,3 +237,25 @@ def test_slq_oracle_against_dense_logdet():
     P = A - sn * A @ A + sn * sn * A @ A @ A
     got = slq_logdet_same_probes(lambda v: A @ v, Z, 30, fun=lambda th: th - sn * th * th + sn * sn * th ** 3)
     assert abs(got - np.linalg.slogdet(P)[1]) < 0.03 * abs(np.linalg.slogdet(P)[1])
+
+
+@pytest.mark.parametrize("norm", NORMS)
+def test_dense_differentiable_precision_oracle_matches_reference_autograd(golden, norm):
+    """oracle/ref_torch.py::dense_model_precision (the float64 checker of the stochastic gradient estimators):
+    loss and its four hyper-parameter gradients against the goldens, which are torch autograd through the reference's
+    own dense operators (test/_test_functions.py:77-104 `test_ml`)."""
+    import torch
+    from oracle.ref_torch import dense_model_precision
+    g = golden("dumbbell_k50_noloop")
+    p = norm + "_"
+    th = [torch.tensor(float(v), dtype=torch.float64, requires_grad=True) for v in (g["eps"], g["kappa"], 0.7, 1e-3)]
+    n = g["train_x"].shape[0]
+    A = dense_model_precision(g["edge_value"], g["edge_index"], n, *th, int(g[p + "ml_nu"]), norm, bool(g["self_loops"]))
+    y = torch.from_numpy(g["train_y"].astype(np.float64))
+    quad = y @ (A @ y)
+    logdet = torch.logdet(A)
+    loss = 0.5 * (quad - logdet + n * np.log(2 * np.pi))
+    loss.backward()
+    assert abs(quad.item() - float(g[p + "ml_quad"])) < 1e-9 * abs(float(g[p + "ml_quad"]))
+    assert abs(logdet.item() - float(g[p + "ml_logdet"])) < 1e-9 * abs(float(g[p + "ml_logdet"]))
+    np.testing.assert_allclose([t.grad.item() for t in th], g[p + "ml_grads"], rtol=1e-8)
