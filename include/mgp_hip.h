@@ -272,6 +272,10 @@ size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);
  * operator apply (one kernel less per step).  Experiment, default 0 (no gain measured at N = 60k);
  * affects plans created afterwards. */
 int mgp_cg_set_fuse(int on);
+/* Plans with more than 16 columns sum the dot-product partials of a step ONCE (cg_reduce_kernel, one small launch
+ * ahead of the update) instead of in every workgroup of the update kernel.  Default 1; 0 = the every-workgroup
+ * scheme at any C (A/B measurements, tests); affects plans created afterwards. */
+int mgp_cg_set_reduce_once(int on);
 /* C == 1 plans on the tile SpMV without a preconditioner start WITHOUT a cg_init launch: the first operator apply
  * reads the right-hand side itself, copies it to r and leaves ||b||^2 as partials; the first update treats p, s, x
  * as zero.  One launch (~3.8 us at N = 60k) less per solve.  Default 1; 0 restores the classic start (plans created

@@ -59,6 +59,9 @@ struct CgArgs {
   // right-hand side itself, copied it to r and left the partials of ||b||^2 here (one slot per SpMV workgroup);
   // at iteration 1 the update takes gamma = ||r||^2 from them and treats p, s, x as zero.  NULL: classic start.
   const float* pd_bb;   // [nbs]
+  // many columns (C > 16): cg_reduce_kernel has summed the partials of this step -> [3][C] gamma, ||r||^2, delta;
+  // the update kernel reads 3 C floats instead of re-reducing (2 nbv + nbs) C of them in every workgroup.  NULL: off.
+  float* tot;
 };
 
 // sh[k][sl * TC + cc] holds the partial of slice sl for column cc; result in sh[k][cc] for cc < TC.
@@ -132,6 +135,42 @@ __global__ __launch_bounds__(kBlock) void cg_init_kernel(CgArgs a, const float* 
   }
 }
 
+// ---- Partial sums of one step, many columns.  cg_update_kernel lets every workgroup re-reduce all partials, which is
+// the cheapest scheme while they are few: at C = 100 on the 60k graph it is 256 workgroups x (2 x 2 x 256 + 3750
+// SpMM blocks) x 100 columns = 490 MB of L2 reads per launch, more than the vectors themselves (240 MB) -- profiled:
+// 103 us per update against 89 us per SpMM.  Here each (array, 4-column group) is summed ONCE by one workgroup --
+// 64 slices x 4 columns, slice sl takes blocks sl, sl + 64, ... in batches of 16 independent loads, xor tree inside
+// the wave, four waves through LDS: a fixed order -- and the update reads the 3 C totals.
+__global__ __launch_bounds__(kBlock) void cg_reduce_kernel(CgArgs a) {
+  __shared__ float sh[kBlock / 64][4];
+  const int st_it = a.state[0], st_done = a.state[1];
+  if (st_done) return;
+  const int prev = (st_it & 1) ^ 1;
+  const int tid = threadIdx.x, cc = tid & 3, sl = tid >> 2;
+  const int c = blockIdx.x * 4 + cc;
+  const int cl = c < a.C ? c : a.C - 1;
+  const int k = blockIdx.y;
+  const int nb = (k == 2) ? a.nbs : a.nbv;
+  const float* __restrict__ src = (k == 0) ? a.pd_gamma + (int64_t)prev * a.nbv * a.C
+                                : (k == 1) ? a.pd_rr + (int64_t)prev * a.nbv * a.C : a.pd_delta;
+  float t = 0.f;
+  constexpr int U = 16;
+  for (int b0 = sl; b0 < nb; b0 += U * 64) {
+    float v[U];
+#pragma unroll
+    for (int q = 0; q < U; ++q) {
+      const int b = b0 + q * 64;
+      v[q] = src[(int64_t)(b < nb ? b : nb - 1) * a.C + cl];
+    }
+#pragma unroll
+    for (int q = 0; q < U; ++q) t += (b0 + q * 64 < nb) ? v[q] : 0.f;
+  }
+  for (int o = 4; o < 64; o <<= 1) t += __shfl_xor(t, o, 64);
+  if ((tid & 63) < 4) sh[tid >> 6][cc] = t;
+  __syncthreads();
+  if (tid < 4 && c < a.C) a.tot[(int64_t)k * a.C + c] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
+}
+
 __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   __shared__ float sh[3][kBlock];
   __shared__ float sh_alpha[kMaxC], sh_beta[kMaxC], sh_rel[kMaxC];
@@ -153,7 +192,14 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   // partials sl, sl+TS, ... of column cc with independent loads, LDS combines the TS slices
   float g2[2] = {0.f, 0.f}, rr2[2] = {0.f, 0.f}, d = 0.f;
   float go2[2] = {0.f, 0.f}, ao2[2] = {0.f, 0.f}, bb_old = 0.f;
-  if (cc < C) {
+  if (a.tot) {
+    // totals of this step from cg_reduce_kernel: slice 0 carries them through the slice reduction below
+    if (cc < C && sl == 0) {
+      g2[0] = g2[1] = a.tot[cc];
+      rr2[0] = rr2[1] = a.tot[C + cc];
+      d = a.tot[2 * C + cc];
+    }
+  } else if (cc < C) {
     // batches of 8 / 32 loads on clamped indices, masked afterwards: all in flight together (one round trip per
     // batch: with 256 workgroups and TS = 16 slices the gamma / rr partials are two batches, the ~940 delta
     // partials of a 12-column SpMM two as well)
@@ -954,11 +1000,14 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   b += 6 * nc;                                         // fused step: rn, sn, row records [n][4]
   b += 2 * mgp_align((size_t)nbs * C * sizeof(float));          // pd_delta, pd_bb
   b += mgp_align((6 * (size_t)C + 16) * sizeof(float));          // gamma_old[2] alpha_old[2] bb resid state
+  b += mgp_align(3 * (size_t)C * sizeof(float));                 // tot (cg_reduce_kernel)
   b += mgp_align((size_t)256 * C * 2 * sizeof(float));          // refinement partials
   b += 6 * 2 * nc + mgp_align((size_t)256 * C * 2 * sizeof(double));   // fp64 refinement: xacc, A x, 4 chain buffers
   return b + 1024;
 }
 
+constexpr int kReduceOnceAbove = 16;
+int g_cg_reduce_once = 1;   // mgp_cg_set_reduce_once(0): every update workgroup re-reduces the partials at any C (A/B, tests)
 int g_cg_init_free = 1;   // C == 1 plans start without a cg_init launch (mgp_cg_set_init_free(0): classic start)
 int g_cg_fuse = 0;   // measured at N = 60k: step 16.3 us fused vs 16.3 us unfused -- off until it wins
 
@@ -979,10 +1028,15 @@ int enqueue_body(CgPlan* pl, hipStream_t st) {
   MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
                                   pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, pl->args.state + 1,
                                   pl->args.state, pl->op_work, pl->op_work_bytes, st));
-  if (pl->C == 1 && pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock)
+  if (pl->C == 1 && pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock) {
     hipLaunchKernelGGL(cg_update_c1_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
-  else
+  } else {
+    if (pl->args.tot) {
+      hipLaunchKernelGGL(cg_reduce_kernel, dim3((unsigned)mgp_cdiv(pl->C, 4), 3), dim3(kBlock), 0, st, pl->args);
+      MGP_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(cg_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+  }
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
@@ -1150,7 +1204,9 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   // contiguous row ranges per workgroup, at most kMaxGridVec workgroups.  C > 1: every workgroup of the
   // update kernel re-reduces ALL dot partials of ALL columns (nbv x (2 nbv + nbs) x C loads per launch),
   // so the grid is kept to one workgroup per CU (their loads go out in batches of 8 / 32 per lane)
-  const int max_grid_vec = (C == 1) ? kMaxGridVec : 256;
+  // C > 16: the partials are summed once by cg_reduce_kernel, the update grid is free to fill the chip
+  const bool reduce_once = C > kReduceOnceAbove && g_cg_reduce_once;
+  const int max_grid_vec = (C == 1) ? kMaxGridVec : (reduce_once ? 2048 : 256);
   int64_t rpb = a.TS;
   int64_t nbv = mgp_cdiv(n, rpb);
   if (nbv > max_grid_vec) { rpb = mgp_cdiv(mgp_cdiv(n, max_grid_vec), a.TS) * a.TS; nbv = mgp_cdiv(n, rpb); }
@@ -1169,6 +1225,10 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   a.bb = blk + 4 * (size_t)C;
   a.resid = blk + 5 * (size_t)C;
   a.state = reinterpret_cast<int*>(blk + 6 * (size_t)C);
+  {
+    float* tot = ar.take<float>(3 * (size_t)C);
+    a.tot = reduce_once ? tot : nullptr;
+  }
   pl->xacc = ar.take<float>(nc); pl->rbuf = ar.take<float>(nc); pl->tbuf = ar.take<float>(nc);
   pl->rpart = ar.take<float>((size_t)256 * C * 2);
   pl->xacc64 = ar.take<double>(nc); pl->t64 = ar.take<double>(nc); pl->work64 = ar.take<double>(4 * nc);
@@ -1222,6 +1282,11 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
 
 extern "C" int mgp_cg_set_init_free(int on) {
   g_cg_init_free = on ? 1 : 0;
+  return MGP_OK;
+}
+
+extern "C" int mgp_cg_set_reduce_once(int on) {
+  g_cg_reduce_once = on ? 1 : 0;
   return MGP_OK;
 }
 
