@@ -441,8 +441,14 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   // published so that all waves of a workgroup take the same branch
   if (tid == 0) { sh_state[0] = st_it; sh_state[1] = st_done; }
   __syncthreads();
-  if (sh_state[1]) return;
   const int it = sh_state[0];
+  if (sh_state[1]) {
+    // init-free solve, iteration 1, flag already up: the first apply reset it, so workgroup 0 raised it in THIS launch
+    // (b = 0 or not finite) before this workgroup started -- the solve ends here and x, which nobody has
+    // initialised, must still come out zero (every workgroup that gets to the decision itself does the same below)
+    if (a.pd_bb != nullptr && it == 1) for (int64_t r = rf; r < r1; r += kBlock) a.x[r] = 0.f;
+    return;
+  }
   const int par = it & 1, prev = par ^ 1;
 #pragma unroll
   for (int k = 0; k < 6; ++k) t[k] = (sh_w[0][k] + sh_w[1][k]) + (sh_w[2][k] + sh_w[3][k]);

@@ -220,6 +220,7 @@ struct TileArgs {
   const float* vals_t;
   const int32_t* rowid;
   int max_entries;   // multi-column tile kernel: entries of the largest tile (LDS carving)
+  int part_window;   // multi-column tile kernel: quads of partial sums staged per window (multiple of 256)
 };
 
 typedef unsigned short mgp_v4h __attribute__((ext_vector_type(4)));
@@ -586,19 +587,55 @@ __global__ __launch_bounds__(kBlock) void spmm_row16_kernel(SpmmArgs p) {
   }
 }
 
+// value (.) float4 products of one quad of entries: sq = v.x a0 + v.y a1 + v.z a2 + v.w a3 (mul, then three fmas per
+// component, in this order).  Written with v_pk_*_f32 and the op_sel broadcast of ONE half of the (x, y) / (z, w) value
+// pair: hipcc selects the packed instructions by itself but materialises every multiplier as an (x, x) register pair
+// (4 copies per value seen in the .s: 54 extra VGPRs in spmm_tile_q_kernel, which then ran at two workgroups per CU).
+typedef float mgp_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mgp_v2f pk_mul_lo(mgp_v2f s, mgp_v2f a) {
+  mgp_v2f d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(s), "v"(a));
+  return d;
+}
+__device__ __forceinline__ mgp_v2f pk_fma_lo(mgp_v2f s, mgp_v2f a, mgp_v2f c) {
+  mgp_v2f d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(s), "v"(a), "v"(c));
+  return d;
+}
+__device__ __forceinline__ mgp_v2f pk_fma_hi(mgp_v2f s, mgp_v2f a, mgp_v2f c) {
+  mgp_v2f d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(s), "v"(a), "v"(c));
+  return d;
+}
+__device__ __forceinline__ mgp_v4f quad_products(mgp_v4f vv, mgp_v4f a0, mgp_v4f a1, mgp_v4f a2, mgp_v4f a3) {
+  const mgp_v2f vlo = mgp_v2f{vv.x, vv.y}, vhi = mgp_v2f{vv.z, vv.w};
+  mgp_v2f lo = pk_mul_lo(vlo, mgp_v2f{a0.x, a0.y}), hi = pk_mul_lo(vlo, mgp_v2f{a0.z, a0.w});
+  lo = pk_fma_hi(vlo, mgp_v2f{a1.x, a1.y}, lo); hi = pk_fma_hi(vlo, mgp_v2f{a1.z, a1.w}, hi);
+  lo = pk_fma_lo(vhi, mgp_v2f{a2.x, a2.y}, lo); hi = pk_fma_lo(vhi, mgp_v2f{a2.z, a2.w}, hi);
+  lo = pk_fma_hi(vhi, mgp_v2f{a3.x, a3.y}, lo); hi = pk_fma_hi(vhi, mgp_v2f{a3.z, a3.w}, hi);
+  return mgp_v4f{lo.x, lo.y, hi.x, hi.y};
+}
+
 // ---------------------------------------------------------------- C in {4, 8, 12, 16}, row tiles + LDS dictionary
 // The multi-column workloads of training run at 12 columns (the probes of the stochastic log-determinant, the
 // inner solves of the Schur complement): spmm_row16_kernel above fetches a 64-byte X row PER ENTRY (3.7 M texture
 // accesses, 235 MB through L1 / L2 per launch at N = 60k: 27 us).  With the tile dictionaries of the C = 1 kernel an X
 // row is fetched once per TILE.  The kernel is spmv_tile_kernel with float4 elements, run as C / 4 PASSES over the
 // tile ("quarters" of 4 columns): the matrix stream (values + 16-bit local ids, one quad of entries per lane and
-// slot, fully coalesced) and ALL quarters of the dictionary's X rows are loaded once into registers; per pass the
-// quarter's dictionary goes to LDS (16 bytes per column), every lane forms the float4 partial sums of its quads
-// (ds_read_b128 gathers through the local ids) into LDS, four lanes per row add the row's quads, and lane `pass` of
-// the row's quad runs the epilogue for its 4 columns and stores 16 bytes.  LDS: (max_cols + max_entries / 4) x 16
-// bytes whatever C is (49 KB on the C3 graph whose largest tile has 1 209 columns and 7 468 entries).
+// slot, fully coalesced) is loaded once into registers; per pass the quarter's dictionary goes to LDS (16 bytes per
+// column; the next quarter's X rows are requested right behind it), every lane forms the float4 partial sums of its
+// quads (ds_read_b128 gathers through the local ids) into LDS, four lanes per row add the row's quads, and lane
+// `pass` of the row's quad runs the epilogue for its 4 columns and stores 16 bytes.  LDS: (max_cols + window) x 16
+// bytes whatever C is, the partial sums staged `window` quads at a time (tile_small_window: 39.8 KB on the C3 graph
+// whose largest tile has 1 209 columns and 7 468 entries, four workgroups per CU, <= 128 VGPRs).
+// Measured on the C3 graph (tools/lab/ab_variants.py, round 2): 7.1 / 11.4 / 16.4 / 22.0 us at C = 4 / 8 / 12 / 16, and
+// the same within 0.5 us at 2, 3 or 4 workgroups per CU, with all quarters of the dictionary prefetched into registers
+// or one at a time, with the epilogue operands loaded per tile or per pass: a pass costs ~4.7 us whatever is
+// overlapped with it.  Counters (tools/pmc_kernel.sh, C = 12): LDS array busy 12 k cycles per CU (51 % of them bank
+// conflicts of the random gathers), 3.2 M L1 accesses, 2.1 M VALU wave-instructions, waves 42 % waiting on a
+// counter and 20 % issuing: no unit is saturated, the phases between the three barriers of a pass do not overlap.
 template <int C4, bool PRE>
-__global__ __launch_bounds__(256) void spmm_tile_q_kernel(SpmmArgs p, TileArgs t) {
+__global__ __launch_bounds__(256, 4) void spmm_tile_q_kernel(SpmmArgs p, TileArgs t) {
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
   constexpr int BS = 256, TR = 64, NQ = 4, C = 4 * C4;
   const int skipv = p.skip ? *p.skip : 0;
@@ -642,13 +679,14 @@ __global__ __launch_bounds__(256) void spmm_tile_q_kernel(SpmmArgs p, TileArgs t
       l[k] = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)qi);
     }
     __builtin_amdgcn_sched_barrier(0);
-    // all quarters of the dictionary rows this lane stages (the ids are back by now: loads retire in order)
-    mgp_v4f g[NQ][C4];
+    // quarter 0 of the dictionary rows this lane stages (the ids are back by now: loads retire in order); quarter
+    // u + 1 is requested while pass u runs.  (All C / 4 quarters up front cost 16 C / 4 registers: 192 VGPRs at
+    // C = 12, two workgroups per CU and the 938 workgroups of the 60k graph in two rounds.)
+    mgp_v4f g[NQ];
     float gp[NQ];
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
-#pragma unroll
-      for (int u = 0; u < C4; ++u) g[k][u] = X4[(int64_t)c[k] * C4 + u];
+      g[k] = X4[(int64_t)c[k] * C4];
       gp[k] = PRE ? prev[c[k]] : 1.f;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -659,25 +697,30 @@ __global__ __launch_bounds__(256) void spmm_tile_q_kernel(SpmmArgs p, TileArgs t
     const int64_t rr = t.rowid ? (int64_t)t.rowid[pr] : pr;
     const int64_t grr = rr + p.goff;
     const int rs = rowptr[pr], re = rowptr[pr + 1];
-    const int qs = sub < C4 ? sub : 0;
-    const mgp_v4f e_x = X4[grr * C4 + qs];
     const float e_pre = PRE ? prev[grr] : 1.f;
     const float e_diag = p.diag[rr];
     const float l_post = p.post ? p.post[grr] : 1.f;
-    const mgp_v4f l_base = *reinterpret_cast<const mgp_v4f*>((p.base ? p.base : p.X) + grr * C + 4 * qs);
-    const mgp_v4f l_dotw = *reinterpret_cast<const mgp_v4f*>((p.dotw ? p.dotw : p.X) + grr * C + 4 * qs);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < C4; ++u) {
+      // epilogue operands of quarter u (used by lane u of the row's quad at the end of the pass; the four lanes read
+      // the same 16 bytes): requested here, they are live for one pass instead of the whole tile
+      const mgp_v4f e_x = X4[grr * C4 + u];
+      const mgp_v4f l_base = *reinterpret_cast<const mgp_v4f*>((p.base ? p.base : p.X) + grr * C + 4 * u);
+      const mgp_v4f l_dotw = *reinterpret_cast<const mgp_v4f*>((p.dotw ? p.dotw : p.X) + grr * C + 4 * u);
       // ---- quarter u of the dictionary -> LDS
 #pragma unroll
       for (int k = 0; k < NQ; ++k) {
         const int j = tid + k * BS;
         if (j < D) {
-          mgp_v4f w = g[k][u];
+          mgp_v4f w = g[k];
           if (PRE) { w.x *= gp[k]; w.y *= gp[k]; w.z *= gp[k]; w.w *= gp[k]; }
           xl[j] = w;
         }
+      }
+      if (u + 1 < C4) {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) g[k] = X4[(int64_t)c[k] * C4 + (u + 1)];
       }
       for (int j = tid + NQ * BS; j < D; j += BS) {        // dictionaries longer than NQ * BS (rare)
         const unsigned cc = tile_cols[dp + j];
@@ -685,46 +728,51 @@ __global__ __launch_bounds__(256) void spmm_tile_q_kernel(SpmmArgs p, TileArgs t
         if (PRE) { const float sc = prev[cc]; w.x *= sc; w.y *= sc; w.z *= sc; w.w *= sc; }
         xl[j] = w;
       }
-      __syncthreads();
-      // ---- quad partial sums of this quarter
-#pragma unroll
-      for (int k = 0; k < NQ; ++k) {
-        const int q = tid + k * BS;
-        if (q < Q) {
-          const mgp_v4f a0 = xl[l[k].x], a1 = xl[l[k].y], a2 = xl[l[k].z], a3 = xl[l[k].w];
-          mgp_v4f sq;
-          sq.x = v[k].x * a0.x; sq.y = v[k].x * a0.y; sq.z = v[k].x * a0.z; sq.w = v[k].x * a0.w;
-          sq.x = fmaf(v[k].y, a1.x, sq.x); sq.y = fmaf(v[k].y, a1.y, sq.y); sq.z = fmaf(v[k].y, a1.z, sq.z); sq.w = fmaf(v[k].y, a1.w, sq.w);
-          sq.x = fmaf(v[k].z, a2.x, sq.x); sq.y = fmaf(v[k].z, a2.y, sq.y); sq.z = fmaf(v[k].z, a2.z, sq.z); sq.w = fmaf(v[k].z, a2.w, sq.w);
-          sq.x = fmaf(v[k].w, a3.x, sq.x); sq.y = fmaf(v[k].w, a3.y, sq.y); sq.z = fmaf(v[k].w, a3.z, sq.z); sq.w = fmaf(v[k].w, a3.w, sq.w);
-          part[q] = sq;
-        }
-      }
-      for (int q = tid + NQ * BS; q < Q; q += BS) {        // tiles with more than 4 * NQ * BS entries (rare)
-        const mgp_v4f vv = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)(qb + q));
-        const mgp_v4h ll = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)(qb + q));
-        const mgp_v4f a0 = xl[ll.x], a1 = xl[ll.y], a2 = xl[ll.z], a3 = xl[ll.w];
-        mgp_v4f sq;
-        sq.x = vv.x * a0.x; sq.y = vv.x * a0.y; sq.z = vv.x * a0.z; sq.w = vv.x * a0.w;
-        sq.x = fmaf(vv.y, a1.x, sq.x); sq.y = fmaf(vv.y, a1.y, sq.y); sq.z = fmaf(vv.y, a1.z, sq.z); sq.w = fmaf(vv.y, a1.w, sq.w);
-        sq.x = fmaf(vv.z, a2.x, sq.x); sq.y = fmaf(vv.z, a2.y, sq.y); sq.z = fmaf(vv.z, a2.z, sq.z); sq.w = fmaf(vv.z, a2.w, sq.w);
-        sq.x = fmaf(vv.w, a3.x, sq.x); sq.y = fmaf(vv.w, a3.y, sq.y); sq.z = fmaf(vv.w, a3.z, sq.z); sq.w = fmaf(vv.w, a3.w, sq.w);
-        part[q] = sq;
-      }
-      __syncthreads();
-      // ---- rows: four lanes add the row's quads (stride 4), quad tree; lane u finishes quarter u
+      // ---- quad partial sums of this quarter, staged `W` quads at a time (one window for most tiles: the staging
+      // area is sized so that four workgroups share a CU's LDS -- with the largest tile's 1 867 quads staged at once it
+      // was three, and the 938 workgroups of the 60k graph ran as a full round plus a 170-workgroup tail)
       mgp_v4f acc = mgp_v4f{0.f, 0.f, 0.f, 0.f};
-      {
-        int i = (rs >> 2) - qb + sub;
-        const int e = (re >> 2) - qb;
-        for (; i + 4 < e; i += 8) {
-          const mgp_v4f a0 = part[i], a1 = part[i + 4];
-          acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
-          acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+      const int W = t.part_window;
+      for (int w0 = 0; w0 == 0 || w0 < Q; w0 += W) {
+        const int w1 = Q < w0 + W ? Q : w0 + W;
+        __syncthreads();     // first window: the dictionary is staged; later ones: the rows have read the previous window
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+          const int q = tid + k * BS;
+          if (q >= w0 && q < w1) {
+            const mgp_v4f a0 = xl[l[k].x], a1 = xl[l[k].y], a2 = xl[l[k].z], a3 = xl[l[k].w];
+            part[q - w0] = quad_products(v[k], a0, a1, a2, a3);
+          }
+          // one slot's four ds_read_b128 in flight at a time: with all 16 hoisted (64 registers) the kernel needs
+          // ~190 VGPRs; the other waves of the CU cover the LDS latency instead
+          if (k & 1) __builtin_amdgcn_sched_barrier(0);
         }
-        for (; i < e; i += 4) {
-          const mgp_v4f a0 = part[i];
-          acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+        {                                                    // quads past the NQ * BS held in registers
+          int q = tid + NQ * BS;
+          if (q < w0) q += (w0 - q + BS - 1) / BS * BS;
+          for (; q < w1; q += BS) {
+            const mgp_v4f vv = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)(qb + q));
+            const mgp_v4h ll = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)(qb + q));
+            const mgp_v4f a0 = xl[ll.x], a1 = xl[ll.y], a2 = xl[ll.z], a3 = xl[ll.w];
+            part[q - w0] = quad_products(vv, a0, a1, a2, a3);
+          }
+        }
+        __syncthreads();
+        // ---- rows: four lanes add the row's quads (stride 4) that lie in this window, in increasing order
+        {
+          int i = (rs >> 2) - qb + sub;
+          if (i < w0) i += (w0 - i + 3) / 4 * 4;
+          int e = (re >> 2) - qb;
+          if (e > w1) e = w1;
+          for (; i + 4 < e; i += 8) {
+            const mgp_v4f a0 = part[i - w0], a1 = part[i + 4 - w0];
+            acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+            acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
+          }
+          for (; i < e; i += 4) {
+            const mgp_v4f a0 = part[i - w0];
+            acc.x += a0.x; acc.y += a0.y; acc.z += a0.z; acc.w += a0.w;
+          }
         }
       }
       acc.x = mgp_quad_sum(acc.x); acc.y = mgp_quad_sum(acc.y); acc.z = mgp_quad_sum(acc.z); acc.w = mgp_quad_sum(acc.w);
@@ -853,8 +901,19 @@ int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, si
 
 // C in {4, 8, 12, 16} on 64-row tiles whose staged data (dictionary rows + matrix stream) fits the LDS budget
 int g_tile_small_mode = 1;
+// quads of partial sums staged at once: what is left of a quarter of the CU's LDS (160 KB, four workgroups) behind the
+// dictionary, in steps of 256, at least 1024 (the quads a workgroup holds in registers), at most the largest tile
+static int tile_small_window(const mgp_csr_t* L) {
+  const int max_q = L->tile_max_entries >> 2;
+  const long budget = 40448 - (long)L->tile_max_cols * 16;
+  long w = budget > 0 ? budget / 16 / 256 * 256 : 0;
+  if (w < 1024) w = 1024;
+  if (w > max_q) w = (max_q + 255) / 256 * 256;
+  return (int)(w > 0 ? w : 256);
+}
 static size_t tile_small_lds_bytes(const mgp_csr_t* L, int C) {
-  size_t b = ((size_t)L->tile_max_cols + (size_t)(L->tile_max_entries >> 2)) * 16;
+  const size_t max_q = (size_t)(L->tile_max_entries >> 2), w = (size_t)tile_small_window(L);
+  size_t b = ((size_t)L->tile_max_cols + (max_q < w ? max_q : w)) * 16;
   const size_t red = (size_t)64 * C * sizeof(float);        // dot-partial staging reuses the same LDS
   return b > red ? b : red;
 }
@@ -989,7 +1048,7 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
   }
   if (use_tiles(L, C)) {
     TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
-                L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries};
+                L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries, 0};
     const int grid = tile_grid(L, &ta.tiles_per_block);
     const size_t lds = tile_lds_bytes(L);
     if (first && first->record) {
@@ -1010,7 +1069,7 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
           reinterpret_cast<uintptr_t>(dotw)) & 15) != 0)
       return MGP_ERR_ARG;                  // [n, C] blocks with C a multiple of 4 are 16-byte aligned row by row
     TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
-                L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries};
+                L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries, tile_small_window(L)};
     const int grid = tile_grid(L, &ta.tiles_per_block);
     const size_t lds = tile_small_lds_bytes(L, C);
 #define MGP_TILE_SMALL_LAUNCH(C4)                                                                                 \

@@ -1132,7 +1132,8 @@ def test_cg_init_free_start_matches_classic(mgp, golden, dev, norm, form, nu):
         x1, it1, st1 = out[(1, True)][k]
         x0, it0, st0 = out[(0, True)][k]
         assert st0 == 1 and st1 == 1
-        assert torch.equal(x1, out[(1, False)][k][0])                       # graph replay == eager launches
+        xe = out[(1, False)][k][0]                                          # graph replay == eager launches
+        assert torch.equal(x1, xe), (k, int((x1 != xe).sum()), float((x1 - xe).abs().max()), it1, out[(1, False)][k][1])
         if float(rhs.abs().max()) == 0.0:
             assert float(x1.abs().max()) == 0.0 and float(x0.abs().max()) == 0.0
             continue
