@@ -230,6 +230,39 @@ __global__ void spmm_f64_kernel(int64_t n, const int32_t* __restrict__ rowptr, c
   }
 }
 
+// C == 1: G lanes per row (entries strided over the lanes, coalesced col / value loads, G gathers of X in flight per
+// row), xor-shuffle tree in fp64.  The one-lane-per-row kernel above walks a row serially: 2.4 ms per launch on the
+// 1M-node k = 64 graph, 8 launches per refined solve = 14 % of the 136 ms S5 solve (profiles/r02_s5_kernel_stats.csv).
+template <int G>
+__global__ __launch_bounds__(256) void spmv_f64_kernel(int64_t n, const int32_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col, const float* __restrict__ vals,
+                                                       const float* __restrict__ diag, const double* __restrict__ X,
+                                                       double* __restrict__ Y, double a, double b,
+                                                       const float* __restrict__ pre, const float* __restrict__ post,
+                                                       const double* __restrict__ base, double cb, double co) {
+  const int lane = threadIdx.x & (G - 1);
+  const int64_t rows_per_pass = (int64_t)gridDim.x * (256 / G);
+  for (int64_t r = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G; r < n; r += rows_per_pass) {
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    double acc = 0.0;
+    for (int e = e0 + lane; e < e1; e += G) {
+      const int j = col[e];
+      double xj = X[j];
+      if (pre) xj *= (double)pre[j];
+      acc += (double)vals[e] * xj;
+    }
+#pragma unroll
+    for (int o = G >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, G);
+    if (lane == 0) {
+      double xs = X[r];
+      if (pre) xs *= (double)pre[r];
+      double t = a * xs + b * ((double)diag[r] * xs - acc);
+      if (post) t *= (double)post[r];
+      Y[r] = (base ? cb * base[r] : 0.0) + co * t;
+    }
+  }
+}
+
 int q2_chain_f64(const mgp_operator_t* op, const double* X, int C, double* Y, const double* base, double cb, double co,
                  double* t0, double* t1, hipStream_t st) {
   const double tau = 2.0 * (double)op->nu / ((double)op->kappa * (double)op->kappa);
@@ -240,9 +273,17 @@ int q2_chain_f64(const mgp_operator_t* op, const double* X, int C, double* Y, co
   for (int s = 0; s < op->nu; ++s) {
     const bool first = (s == 0), last = (s == op->nu - 1);
     double* out = last ? Y : ((s & 1) ? t1 : t0);
-    hipLaunchKernelGGL(spmm_f64_kernel, dim3((unsigned)grid), dim3(256), 0, st, n, op->L.rowptr, op->L.col, op->L.vals,
-                       op->L.diag, in, out, C, tau, 1.0, first ? op->pre : nullptr, last ? op->post : nullptr,
-                       last ? base : nullptr, cb, last ? co * (double)op->scale : 1.0);
+    if (C == 1) {
+      int64_t g1 = mgp_cdiv(n, 16);
+      if (g1 > 65535 * 4) g1 = 65535 * 4;
+      hipLaunchKernelGGL((spmv_f64_kernel<16>), dim3((unsigned)g1), dim3(256), 0, st, n, op->L.rowptr, op->L.col,
+                         op->L.vals, op->L.diag, in, out, tau, 1.0, first ? op->pre : nullptr, last ? op->post : nullptr,
+                         last ? base : nullptr, cb, last ? co * (double)op->scale : 1.0);
+    } else {
+      hipLaunchKernelGGL(spmm_f64_kernel, dim3((unsigned)grid), dim3(256), 0, st, n, op->L.rowptr, op->L.col, op->L.vals,
+                         op->L.diag, in, out, C, tau, 1.0, first ? op->pre : nullptr, last ? op->post : nullptr,
+                         last ? base : nullptr, cb, last ? co * (double)op->scale : 1.0);
+    }
     MGP_LAUNCH_CHECK();
     in = out;
   }
