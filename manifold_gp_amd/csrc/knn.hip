@@ -522,13 +522,17 @@ constexpr int kExactBatch = 16;
 
 int64_t chunk_rows(int64_t N, int64_t n) {
   const int64_t ld = mgp_cdiv(N, 4) * 4;
-  // fp32 distance slab: 1 GiB for small N (cache friendly), up to 8 GiB for large N so that a chunk
-  // still holds >= 2048 query rows and the per-chunk launch + host poll is amortised (288 GB of HBM)
-  int64_t slab_floats = (int64_t)1 << 28;
+  // fp32 distance slab: 2 GiB (8 192 query rows at N = 60k: 8 query tiles per XCD share a point tile in L2, and half
+  // the chunks / host polls of the 1 GiB slab -- measured 3 % faster), up to 8 GiB for large N so that a chunk still
+  // holds >= 2048 query rows and the per-chunk launch + host poll is amortised (288 GB of HBM)
+  int64_t slab_floats = (int64_t)1 << 29;
   if (ld * 2048 > slab_floats) slab_floats = ld * 2048;
   if (slab_floats > ((int64_t)1 << 31)) slab_floats = (int64_t)1 << 31;
   int64_t qc = slab_floats / ld;
   qc = qc / kTile * kTile;
+  // whole rounds of 8 XCDs x 128-row query tiles, the same number for every XCD (knn_mfma.hip deals query tiles to
+  // XCDs: 34 tiles are 2 x 5 + 6 x 4 and the launch takes as long as the XCDs with 5)
+  if (qc >= 2048) qc = qc / 2048 * 2048;
   if (qc < kTile) qc = kTile;
   const int64_t ncap = mgp_cdiv(n, kTile) * kTile;
   return qc < ncap ? qc : ncap;

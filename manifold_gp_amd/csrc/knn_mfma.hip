@@ -219,21 +219,43 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
   float* qn_s = reinterpret_cast<float*>(&sm[0][0][0]);
   if (tid < kMT) qn_s[tid] = qn2[q0 + tid < nq ? q0 + tid : nq - 1];
   __syncthreads();
+  // every load first (4 point norms, 16 query norms as 4 x 16 bytes from LDS), then the 64 stores back to back: on
+  // gfx9 stores count in vmcnt too, and a load between them made each group of stores wait for all earlier ones
+  float pn[4];
+  knn_f32x4 qn[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int64_t pcol = p0 + wn * 64 + j * 16 + r;
-    const float pn = pn2[pcol < N ? pcol : N - 1];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int rl = wm * 64 + i * 16 + g * 4 + e;
-        const float v = (qn_s[rl] + pn) - 2.f * acc[i][j][e];
-        if (q0 + rl < nq && pcol < N) out[(q0 + rl) * ld + pcol] = v > 0.f ? v : 0.f;
-      }
+    pn[j] = pn2[pcol < N ? pcol : N - 1];
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qn[i] = *reinterpret_cast<const knn_f32x4*>(&qn_s[wm * 64 + i * 16 + g * 4]);
+  // ... and waited for HERE: the stores sit under exec masks (tile edges), behind such a branch the compiler cannot
+  // count how many stores follow a load and falls back to vmcnt(0) in front of every use
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rl = wm * 64 + i * 16 + g * 4 + e;
+      float* orow = out + (q0 + rl) * ld + p0 + wn * 64 + r;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float v = (qn[i][e] + pn[j]) - 2.f * acc[i][j][e];
+        if (q0 + rl < nq && p0 + wn * 64 + j * 16 + r < N) orow[j * 16] = v > 0.f ? v : 0.f;
+      }
+    }
 #endif
 }
+
+// Tried in round 2 and removed (tools/lab notes in DESIGN.md section 4): a 256 x 128 tile shared by eight waves with a
+// three-stage LDS ring (144 KB, one workgroup per CU; copies requested two stages ahead, the next stage's fragments read
+// into a second register set during the MFMAs, three separate __shared__ arrays so that the compiler's LDS-DMA alias
+// check lets copies stay in flight across a stage), also as a persistent kernel.  Bit-identical keys, 131 instead of 98
+// flop per byte copied -- and 1.19 ms per 4 096-row chunk against 0.94 ms for the kernel above: with one workgroup per
+// CU nothing covers a stage whose point tile misses L2 (half of those requests do: a point tile is shared by only
+// ny_per_xcd workgroups of an XCD at a time), and two stages of prefetch are shorter than that miss.
 
 constexpr int kMaxPartialBlocks = 1024;
 
