@@ -276,6 +276,12 @@ int mgp_cg_set_fuse(int on);
  * ahead of the update) instead of in every workgroup of the update kernel.  Default 1; 0 = the every-workgroup
  * scheme at any C (A/B measurements, tests); affects plans created afterwards. */
 int mgp_cg_set_reduce_once(int on);
+/* The host learns of the end of a solve from a host-mapped word the deciding kernel writes.  While the first graph of
+ * a plan runs -- it is sized to end in the stopping decision -- the host reads only that word, for up to twice the
+ * time the previous solve took (`spins` reads between two looks at the clock, default 64); hipStreamQuery, the guard
+ * against a chunk that ends undecided, comes after that window and for continuation chunks.  0: no window, one
+ * query per read as in round 1. */
+int mgp_cg_set_poll_spin(int spins);
 /* C == 1 plans on the tile SpMV without a preconditioner start WITHOUT a cg_init launch: the first operator apply
  * reads the right-hand side itself, copies it to r and leaves ||b||^2 as partials; the first update treats p, s, x
  * as zero.  One launch (~3.8 us at N = 60k) less per solve.  Default 1; 0 restores the classic start (plans created

@@ -81,6 +81,7 @@ SIGNATURES = {
     "mgp_spmm_set_tile_small_mode": (c_int, [c_int]),
     "mgp_cg_set_fuse": (c_int, [c_int]),
     "mgp_cg_set_reduce_once": (c_int, [c_int]),
+    "mgp_cg_set_poll_spin": (c_int, [c_int]),
     "mgp_cg_set_init_free": (c_int, [c_int]),
     "mgp_host_symeig": (c_int, [c_int, _P, _P, _P]),
     "mgp_lanczos_tridiag_block_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int, c_int]),

@@ -236,6 +236,13 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
   constexpr int NQ = 4;
   const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
   const int tid = threadIdx.x, sub = tid & 3;
+#ifdef MGP_STAMP   // lab build (tools/lab/stamp_solve.py): block 0 leaves its start / end time behind the CG state words
+  int* st_base = p.skip ? const_cast<int*>(p.skip) - 1 : p.tick;
+  if (st_base && blockIdx.x == 0 && tid == 0) {
+    const int si = atomicAdd(st_base + 8, 1);
+    reinterpret_cast<unsigned long long*>(st_base + 16)[si & 255] = wall_clock64() * 8 + 0;
+  }
+#endif
   float* __restrict__ xl = tile_lds;
   float* __restrict__ part = tile_lds + t.max_cols;
   // restrict-qualified read-only views: wave-uniform addresses become scalar (s_load) reads
@@ -393,6 +400,12 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
       if (p.dot2_partials) p.dot2_partials[lb] = s2;
     }
   }
+#ifdef MGP_STAMP
+  if (st_base && blockIdx.x == 0 && tid == 0) {
+    const int si = atomicAdd(st_base + 8, 1);
+    reinterpret_cast<unsigned long long*>(st_base + 16)[si & 255] = wall_clock64() * 8 + 1;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------- C > 1

@@ -1,0 +1,41 @@
+"""Lab: GPU-side timeline of one C3 CG solve WITHOUT a profiler.  Needs a library built with -DMGP_STAMP (block 0 of every
+kernel of the solve leaves wall_clock64 at its start and end behind the CG state words):
+    python tools/lab/stamp_solve.py build_variants/stamp/libmgp_hip.so"""
+import ctypes, os, sys, argparse, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+from manifold_gp_amd import _lib
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+import torch
+import bench
+from manifold_gp_amd.solvers import CgPlan
+dev = torch.device("cuda:0")
+wl = bench.build_workload(argparse.Namespace(workload="c3", nodes=0, s5_order="morton"), dev, 0, 1)
+use_graph = not (len(sys.argv) > 2 and sys.argv[2] == "eager")
+plan = CgPlan(wl["desc"], 1, tol=1e-6, max_iter=5000, stop_mode=1, check_every=8, refine=0, use_graph=use_graph)
+y = wl["y"].view(-1, 1).contiguous()
+for _ in range(12):
+    plan.solve(y, copy=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    plan.solve(y, copy=False)
+torch.cuda.synchronize()
+print("ms per solve (host clock, stamped build): %.4f" % ((time.perf_counter() - t0) / 50 * 1e3))
+h = ctypes.CDLL(_lib.LIB_PATH)
+h.mgp_cg_plan_debug_stamps.restype = ctypes.c_int
+h.mgp_cg_plan_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_int)]
+buf = (ctypes.c_ulonglong * 256)(); cnt = ctypes.c_int(0)
+assert h.mgp_cg_plan_debug_stamps(plan.handle, buf, ctypes.byref(cnt)) == 0
+n = cnt.value
+vals = [(buf[(n - 1 - i) & 255]) for i in range(min(n, 250))][::-1]       # oldest .. newest of the ring
+ev = [(v >> 3, v & 7) for v in vals]
+kinds = {0: "spmv  start", 1: "spmv  end", 2: "update start", 3: "update end", 4: "decide"}
+# the last solve ends with the last 'decide'
+last = max(i for i, e in enumerate(ev) if e[1] == 4)
+prev = max([i for i, e in enumerate(ev[:last]) if e[1] == 4] or [max(0, last - 40)])
+sol = ev[prev + 1:last + 1]
+t0 = sol[0][0]
+tick_ns = 10.0        # wall_clock64: 100 MHz
+for t, k in sol:
+    print("%8.2f us  %s" % ((t - t0) * tick_ns / 1e3, kinds[k]))
+print("previous decide -> first kernel of this solve: %.2f us" % ((sol[0][0] - ev[prev][0]) * tick_ns / 1e3))

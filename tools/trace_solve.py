@@ -15,7 +15,7 @@ prev_end = t0
 total = 0
 for r in rows[start:end + 1]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void (anonymous namespace)::", "")[:70]
+    name = re.sub(r"\(.*", "", r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", ""))[:70]
     print("%8.2f us  dur %6.2f  gap %6.2f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name))
     prev_end = e
     total += e - s
