@@ -1025,7 +1025,7 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   b += 4 * mgp_align((size_t)kMaxPartials * C * sizeof(float));  // pd_gamma[2], pd_rr[2]
   b += 6 * nc;                                         // fused step: rn, sn, row records [n][4]
   b += 2 * mgp_align((size_t)nbs * C * sizeof(float));          // pd_delta, pd_bb
-  b += mgp_align((6 * (size_t)C + 16 + 1024) * sizeof(float));   // gamma_old[2] alpha_old[2] bb resid state (+ lab stamps)
+  b += mgp_align((6 * (size_t)C + 16 + 1024 + 8192) * sizeof(float));   // gamma_old[2] alpha_old[2] bb resid state (+ lab stamps)
   b += mgp_align(3 * (size_t)C * sizeof(float));                 // tot (cg_reduce_kernel)
   b += mgp_align((size_t)256 * C * 2 * sizeof(float));          // refinement partials
   b += 6 * 2 * nc + mgp_align((size_t)256 * C * 2 * sizeof(double));   // fp64 refinement: xacc, A x, 4 chain buffers
@@ -1247,8 +1247,8 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   // one contiguous block: for C == 1 {gamma_old[2], alpha_old[2], bb, resid, state[0], state[1]} are 32
   // consecutive bytes, which the C == 1 kernels fetch with a single scalar load (CgScalars)
 #ifdef MGP_STAMP
-  float* blk = ar.take<float>(6 * (size_t)C + 16 + 1024);
-  MGP_HIP_TRY(hipMemsetAsync(blk, 0, (6 * (size_t)C + 16 + 1024) * sizeof(float), pl->stream));
+  float* blk = ar.take<float>(6 * (size_t)C + 16 + 1024 + 8192);
+  MGP_HIP_TRY(hipMemsetAsync(blk, 0, (6 * (size_t)C + 16 + 1024 + 8192) * sizeof(float), pl->stream));
 #else
   float* blk = ar.take<float>(6 * (size_t)C + 16);
 #endif
@@ -1513,6 +1513,14 @@ extern "C" float* mgp_cg_plan_x(void* plan) {
 
 #ifdef MGP_STAMP
 // lab build: the stamp ring of the plan (256 x uint64: 8 * wall_clock64 + kind) and how many were written
+extern "C" int mgp_cg_plan_debug_block_stamps(void* plan, unsigned long long* out, int nblocks) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  if (!pl || !out || nblocks > 2048) return MGP_ERR_ARG;
+  MGP_HIP_TRY(hipStreamSynchronize(pl->stream));
+  MGP_HIP_TRY(hipMemcpy(out, reinterpret_cast<unsigned long long*>(pl->args.state + 16) + 256, (size_t)nblocks * 2 * sizeof(unsigned long long),
+                        hipMemcpyDeviceToHost));
+  return MGP_OK;
+}
 extern "C" int mgp_cg_plan_debug_stamps(void* plan, unsigned long long* out256, int* count) {
   CgPlan* pl = static_cast<CgPlan*>(plan);
   if (!pl || !out256 || !count) return MGP_ERR_ARG;

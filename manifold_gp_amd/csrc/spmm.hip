@@ -242,6 +242,7 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     const int si = atomicAdd(st_base + 8, 1);
     reinterpret_cast<unsigned long long*>(st_base + 16)[si & 255] = wall_clock64() * 8 + 0;
   }
+  if (st_base && tid == 0 && blockIdx.x < 2048) reinterpret_cast<unsigned long long*>(st_base + 16)[256 + 2 * blockIdx.x] = wall_clock64();
 #endif
   float* __restrict__ xl = tile_lds;
   float* __restrict__ part = tile_lds + t.max_cols;
@@ -405,6 +406,7 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     const int si = atomicAdd(st_base + 8, 1);
     reinterpret_cast<unsigned long long*>(st_base + 16)[si & 255] = wall_clock64() * 8 + 1;
   }
+  if (st_base && tid == 0 && blockIdx.x < 2048) reinterpret_cast<unsigned long long*>(st_base + 16)[256 + 2 * blockIdx.x + 1] = wall_clock64();
 #endif
 }
 

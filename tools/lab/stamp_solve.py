@@ -39,3 +39,31 @@ tick_ns = 10.0        # wall_clock64: 100 MHz
 for t, k in sol:
     print("%8.2f us  %s" % ((t - t0) * tick_ns / 1e3, kinds[k]))
 print("previous decide -> first kernel of this solve: %.2f us" % ((sol[0][0] - ev[prev][0]) * tick_ns / 1e3))
+
+# per-block start / end of the LAST SpMV launch of the last solve
+import numpy as np
+g = wl["graph"]
+nb = int(_lib.lib().mgp_spmm_dot_blocks_csr(ctypes.byref(wl["lap"].data.csr()), 1))
+h.mgp_cg_plan_debug_block_stamps.restype = ctypes.c_int
+h.mgp_cg_plan_debug_block_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+bb = (ctypes.c_ulonglong * (2 * nb))()
+assert h.mgp_cg_plan_debug_block_stamps(plan.handle, bb, nb) == 0
+a = np.array(list(bb), dtype=np.int64).reshape(nb, 2)
+st, en = (a[:, 0] - a[:, 0].min()) * 0.01, (a[:, 1] - a[:, 0].min()) * 0.01
+dur = en - st
+print("blocks %d: start min/median/p90/max %.2f %.2f %.2f %.2f us; duration min/median/p90/max %.2f %.2f %.2f %.2f us; last end %.2f us"
+      % (nb, st.min(), np.median(st), np.percentile(st, 90), st.max(), dur.min(), np.median(dur), np.percentile(dur, 90), dur.max(), en.max()))
+rp = g.rowptr.cpu().numpy().astype(np.int64)
+ent = np.array([rp[min(len(rp) - 1, (t + 1) * 64)] - rp[t * 64] for t in range(nb)])
+# launch index -> tile: mgp_xcd_block
+per, rem = nb // 8, nb % 8
+def lb(pb):
+    x, i = pb % 8, pb // 8
+    return x * per + min(x, rem) + i
+tile_of = np.array([lb(b) for b in range(nb)])
+e = ent[tile_of]
+print("corr(duration, tile entries) = %.3f; mean duration for tiles <= 4096 entries %.2f us (%d), > 4096 entries %.2f us (%d), > 6000 %.2f us (%d)"
+      % (np.corrcoef(dur, e)[0, 1], dur[e <= 4096].mean(), (e <= 4096).sum(), dur[e > 4096].mean(), (e > 4096).sum(),
+         dur[e > 6000].mean() if (e > 6000).any() else 0.0, (e > 6000).sum()))
+order = np.argsort(en)[-8:]
+print("last 8 blocks to end: start, duration, entries:", [(round(float(st[i]), 2), round(float(dur[i]), 2), int(e[i])) for i in order])
