@@ -822,6 +822,176 @@ __global__ __launch_bounds__(256, 4) void spmm_tile_q_kernel(SpmmArgs p, TileArg
   }
 }
 
+// ---------------------------------------------------------------- 16 < C <= 256, C % 4 == 0: row tiles + LDS dictionary
+// The eigensolver's 128-column blocks and the 100 right-hand sides of `_average_variance` ran on spmm_kernel above: one
+// 256-byte piece of an X row per entry and 64 columns through L1 -- 1.9 GB per launch at C = 128 on the 60k graph, 99 us,
+// 343 launches = two thirds of an eigensolve.  A tile's rows share their neighbours (486 distinct columns for 3 910
+// entries), so here an X row goes to LDS once per tile and 16-column CHUNK, and the per-entry gather is a ds_read_b128:
+//   * a workgroup owns a 64-row tile, wave w its rows 16 w .. 16 w + 15, four lanes per row, lane `sub` the float4
+//     4 sub .. 4 sub + 3 of the chunk: the 16 rows of a wave advance together, one entry per step;
+//   * per chunk: the dictionary's X pieces (64 bytes per column, x pre) are staged by all 256 lanes (four lanes per
+//     column: 64-byte segments), barrier, then every lane walks its row's quads -- 16 bytes of values + 8 bytes of local
+//     ids per 4 entries straight from global memory (the four lanes of a row read the same address; the next quad is
+//     requested before the current one is used), four ds_read_b128 + packed fmas per quad -- and finishes with the
+//     epilogue of its 4 columns (16-byte store: the four lanes of a row write 64 contiguous bytes);
+//   * no partial sums through LDS and no barrier inside a chunk's row walk (the 12-column kernel's three phases per
+//     pass did not overlap); dot partials: the chunk's 64 x 16 products cross LDS once per chunk;
+//   * LDS: 64 bytes x min(dictionary, 1024 columns): 64 KB on the C3 graph (two workgroups per CU), 40 KB on the 1M swiss
+//     roll.  The 0.7 % of tiles with more than 1024 columns take a second slice pass per chunk (entries whose id lies
+//     outside the staged slice contribute value 0 through a clamped id).
+constexpr int kWideCap = 1024;     // dictionary columns staged per slice (64 bytes each)
+constexpr int kWideRQ = 16;        // quads of a row held in registers for all chunks of a tile
+
+template <bool PRE>
+__global__ __launch_bounds__(256, 2) void spmm_tile_wide_kernel(SpmmArgs p, TileArgs t, int dict_cap) {
+  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+  constexpr int BS = 256, TR = 64;
+  const int skipv = p.skip ? *p.skip : 0;
+  const int tickv = (p.tick && blockIdx.x == 0) ? *p.tick : 0;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x, sub = tid & 3;
+  const int C = p.C, C4 = C >> 2;
+  mgp_v4f* __restrict__ xl = reinterpret_cast<mgp_v4f*>(tile_lds);
+  const mgp_v4f* __restrict__ X4 = reinterpret_cast<const mgp_v4f*>(p.X);
+  const float* __restrict__ prev = p.pre;
+  const int32_t* __restrict__ rowptr = t.rowptr_t ? t.rowptr_t : p.rowptr;
+  const float* __restrict__ vals = t.vals_t ? t.vals_t : p.vals;
+  const int32_t* __restrict__ tile_ptr = t.tile_ptr;
+  const uint32_t* __restrict__ tile_cols = reinterpret_cast<const uint32_t*>(t.tile_cols);
+  const uint16_t* __restrict__ lid = t.lid;
+  if (skipv) return;
+  const int64_t t0 = (int64_t)lb * t.tiles_per_block;
+  const int64_t t1 = t0 + t.tiles_per_block < t.ntiles ? t0 + t.tiles_per_block : t.ntiles;
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int64_t r0 = tile * TR;
+    const int64_t r1 = r0 + TR < p.n ? r0 + TR : p.n;
+    const int dp = tile_ptr[tile];
+    const int D = tile_ptr[tile + 1] - dp;
+    const int64_t row = r0 + (tid >> 2);
+    const bool valid = row < r1;
+    const int64_t pr = valid ? row : r0;
+    const int64_t rr = t.rowid ? (int64_t)t.rowid[pr] : pr;
+    const int64_t grr = rr + p.goff;
+    const int qs = rowptr[pr] >> 2, qe = valid ? rowptr[pr + 1] >> 2 : qs;      // the row's quads (rows are padded to quads)
+    const float e_pre = PRE ? prev[grr] : 1.f;
+    const float e_diag = p.diag[rr];
+    const float l_post = p.post ? p.post[grr] : 1.f;
+    // the first RQ quads of the row (64 entries: most rows whole) stay in registers for all chunks of the tile: loaded
+    // once, all in flight together.  (Loaded per chunk, one quad ahead of its use, every step of the row walk waited
+    // out a memory round trip: 29 us per chunk.)
+    mgp_v4f rv[kWideRQ];
+    mgp_v4h rl[kWideRQ];
+#pragma unroll
+    for (int k = 0; k < kWideRQ; ++k) {
+      const int qi = qs + k < qe ? qs + k : qs;
+      rv[k] = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)qi);
+      rl[k] = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)qi);
+    }
+    for (int c4 = 0; c4 < C4; c4 += 4) {
+      const int f = c4 + sub;                       // this lane's float4 of the X / Y rows
+      const bool fon = f < C4;
+      const int fc = fon ? f : c4;
+      // epilogue operands of this chunk: in flight with the staging below
+      const mgp_v4f e_x = X4[grr * C4 + fc];
+      const mgp_v4f l_base = *reinterpret_cast<const mgp_v4f*>((p.base ? p.base : p.X) + grr * C + 4 * fc);
+      const mgp_v4f l_dotw = *reinterpret_cast<const mgp_v4f*>((p.dotw ? p.dotw : p.X) + grr * C + 4 * fc);
+      mgp_v4f acc = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+      for (int s0 = 0; s0 < D || s0 == 0; s0 += dict_cap) {
+        const int Ds = D - s0 < dict_cap ? D - s0 : dict_cap;
+        // ---- stage the slice's X pieces: lane (j, sub) -> 16 bytes, 8 pieces per lane in flight
+        for (int i0 = tid; i0 < 4 * Ds; i0 += 8 * BS) {
+          unsigned cc[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * BS;
+            cc[k] = tile_cols[dp + s0 + (i < 4 * Ds ? i >> 2 : 0)];
+          }
+          mgp_v4f w[8];
+          float sc[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            w[k] = X4[(int64_t)cc[k] * C4 + fc];
+            sc[k] = PRE ? prev[cc[k]] : 1.f;
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * BS;
+            if (i < 4 * Ds) {
+              mgp_v4f v = w[k];
+              if (PRE) { v.x *= sc[k]; v.y *= sc[k]; v.z *= sc[k]; v.w *= sc[k]; }
+              xl[i] = fon ? v : mgp_v4f{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
+        __syncthreads();
+        // ---- the row's quads: ids outside the staged slice -> clamped id, value 0 (only tiles with more than
+        // dict_cap columns take more than one slice)
+        auto quad = [&](const mgp_v4f vq, const mgp_v4h lq) __attribute__((always_inline)) {
+          const unsigned i0 = (unsigned)lq.x - (unsigned)s0, i1 = (unsigned)lq.y - (unsigned)s0,
+                         i2 = (unsigned)lq.z - (unsigned)s0, i3 = (unsigned)lq.w - (unsigned)s0;
+          const bool o0 = i0 < (unsigned)Ds, o1 = i1 < (unsigned)Ds, o2 = i2 < (unsigned)Ds, o3 = i3 < (unsigned)Ds;
+          const mgp_v4f a0 = xl[(o0 ? i0 : 0u) * 4 + sub], a1 = xl[(o1 ? i1 : 0u) * 4 + sub],
+                        a2 = xl[(o2 ? i2 : 0u) * 4 + sub], a3 = xl[(o3 ? i3 : 0u) * 4 + sub];
+          const mgp_v4f vv = mgp_v4f{o0 ? vq.x : 0.f, o1 ? vq.y : 0.f, o2 ? vq.z : 0.f, o3 ? vq.w : 0.f};
+          const mgp_v4f sq = quad_products(vv, a0, a1, a2, a3);
+          acc.x += sq.x; acc.y += sq.y; acc.z += sq.z; acc.w += sq.w;
+        };
+        // (no branch per quad: a quad past the row's end holds a copy of the row's first quad and counts with value 0,
+        // so that the LDS reads of several quads are in flight together)
+#pragma unroll
+        for (int k = 0; k < kWideRQ; ++k) {
+          const bool on = qs + k < qe;
+          quad(mgp_v4f{on ? rv[k].x : 0.f, on ? rv[k].y : 0.f, on ? rv[k].z : 0.f, on ? rv[k].w : 0.f}, rl[k]);
+        }
+        // rows longer than 4 RQ entries: the rest in batches of four quads from global memory, their loads in flight
+        // together (a memory round trip per batch and chunk: 60 of 158 us at C = 128 on the 60k graph, whose tiles
+        // nearly all hold such a row -- keeping these tails in LDS, walked quad by quad, was no faster)
+        for (int q = qs + kWideRQ; q < qe; q += 4) {
+          mgp_v4f bv[4];
+          mgp_v4h bl[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int qi = q + k < qe ? q + k : q;
+            bv[k] = *reinterpret_cast<const mgp_v4f*>(vals + 4 * (int64_t)qi);
+            bl[k] = *reinterpret_cast<const mgp_v4h*>(lid + 4 * (int64_t)qi);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (q + k < qe) quad(bv[k], bl[k]);
+        }
+        __syncthreads();                               // the next slice / chunk / tile overwrites xl
+      }
+      // ---- epilogue of this lane's 4 columns
+      mgp_v4f y = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+      if (valid && fon) {
+        const float xs0 = e_x.x * e_pre, xs1 = e_x.y * e_pre, xs2 = e_x.z * e_pre, xs3 = e_x.w * e_pre;
+        y.x = p.co * ((p.a * xs0 + p.b * (e_diag * xs0 - acc.x)) * l_post) + (p.base ? p.cb * l_base.x : 0.f);
+        y.y = p.co * ((p.a * xs1 + p.b * (e_diag * xs1 - acc.y)) * l_post) + (p.base ? p.cb * l_base.y : 0.f);
+        y.z = p.co * ((p.a * xs2 + p.b * (e_diag * xs2 - acc.z)) * l_post) + (p.base ? p.cb * l_base.z : 0.f);
+        y.w = p.co * ((p.a * xs3 + p.b * (e_diag * xs3 - acc.w)) * l_post) + (p.base ? p.cb * l_base.w : 0.f);
+        *reinterpret_cast<mgp_v4f*>(p.Y + grr * C + 4 * f) = y;
+      }
+      if (p.dot_partials) {
+        // red[row][16]: the chunk's products of the tile's 64 rows, then 16 lanes add the rows in a fixed order
+        // (tiles_per_block > 1: accumulated over the workgroup's tiles in tile order)
+        mgp_v4f d = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+        if (valid && fon && p.dotw) { d.x = l_dotw.x * y.x; d.y = l_dotw.y * y.y; d.z = l_dotw.z * y.z; d.w = l_dotw.w * y.w; }
+        xl[tid] = d;                                   // tid = row-in-tile * 4 + sub
+        __syncthreads();
+        if (tid < 16 && c4 * 4 + tid < C) {
+          const float* red = tile_lds;
+          float sacc = 0.f;
+          for (int r = 0; r < TR; ++r) sacc += red[r * 16 + tid];
+          float* dst = p.dot_partials + (int64_t)lb * C + c4 * 4 + tid;
+          *dst = (tile == t0 ? 0.f : *dst) + sacc;
+        }
+        __syncthreads();
+      }
+    }
+  }
+  if (p.tick && blockIdx.x == 0 && tid == 0) *p.tick = tickv + 1;
+}
+
 struct Plan {
   int grid;
   int64_t rows_per_block;
@@ -941,6 +1111,37 @@ static bool use_tiles_small(const mgp_csr_t* L, int C) {
   return tile_small_lds_bytes(L, C) <= 65536 - 64;
 }
 
+// 16 < C <= 256, C % 4 == 0 on 64-row tiles: the wide tile kernel (mgp_spmm_set_tile_wide_mode(0): spmm_kernel)
+int g_tile_wide_mode = 1;
+static int tile_wide_cap(const mgp_csr_t* L) {
+  int cap = (L->tile_max_cols + 63) / 64 * 64;
+  if (cap > kWideCap) cap = kWideCap;
+  if (cap < 64) cap = 64;
+  return cap;
+}
+static size_t tile_wide_lds_bytes(const mgp_csr_t* L) {
+  const size_t b = (size_t)tile_wide_cap(L) * 64;
+  return b > 4096 ? b : 4096;                                // (dot-partial staging: 64 x 16 floats)
+}
+static bool use_tiles_wide(const mgp_csr_t* L, int C) {
+  const int ord = (L->tile_rowptr != nullptr) + (L->tile_vals != nullptr) + (L->tile_rowid != nullptr);
+  if (ord != 0 && ord != 3) return false;
+  if (C <= 16 || C > 256 || (C & 3) != 0 || !g_tile_mode || !g_tile_wide_mode) return false;
+  if (!L->lid || !L->tile_ptr || !L->tile_cols || L->tile_rows != 64) return false;
+  if ((L->tile_max_entries & 3) != 0) return false;
+  // measured (tools/lab/time_spmm_wide.py): on the 60k graph the per-entry gather kernel reads its X rows out of L2 and
+  // wins from 64 columns up (63 vs 84 us at C = 64, 91 vs 158 us at C = 128; 47 vs 59 us at C = 32 the other way); on
+  // the 1M graph, whose X block does not fit the caches, the dictionary kernel is 1.5-2.4x faster at every width
+  // (1.48 vs 3.04 ms at C = 128).  mode 2 forces it at any size (tests, A/B).
+  if (g_tile_wide_mode == 2) return true;
+  return C <= 32 || (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20);
+}
+
+extern "C" int mgp_spmm_set_tile_wide_mode(int on) {
+  g_tile_wide_mode = on == 2 ? 2 : (on ? 1 : 0);
+  return MGP_OK;
+}
+
 extern "C" int mgp_spmm_set_tile_small_mode(int on) {
   g_tile_small_mode = on ? 1 : 0;
   return MGP_OK;
@@ -948,7 +1149,7 @@ extern "C" int mgp_spmm_set_tile_small_mode(int on) {
 
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (!L) return MGP_ERR_ARG;
-  if (use_tiles(L, C) || use_tiles_small(L, C)) return tile_grid(L, nullptr);
+  if (use_tiles(L, C) || use_tiles_small(L, C) || use_tiles_wide(L, C)) return tile_grid(L, nullptr);
   return mgp_spmm_dot_blocks(L->n, C);
 }
 
@@ -1097,6 +1298,16 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     else if (C == 12) MGP_TILE_SMALL_LAUNCH(3);
     else MGP_TILE_SMALL_LAUNCH(4);
 #undef MGP_TILE_SMALL_LAUNCH
+  } else if (use_tiles_wide(L, C) &&
+             ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(base) |
+               reinterpret_cast<uintptr_t>(dotw)) & 15) == 0) {
+    TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
+                L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries, 0};
+    const int grid = tile_grid(L, &ta.tiles_per_block);
+    const size_t lds = tile_wide_lds_bytes(L);
+    const int cap = tile_wide_cap(L);
+    if (pre) hipLaunchKernelGGL((spmm_tile_wide_kernel<true>), dim3(grid), dim3(256), lds, st, p, ta, cap);
+    else hipLaunchKernelGGL((spmm_tile_wide_kernel<false>), dim3(grid), dim3(256), lds, st, p, ta, cap);
   } else if (C == 1) {
     const int G = g_row_group_hint;
     const int R = spmv_rows_in_flight();

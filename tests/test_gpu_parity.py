@@ -1706,8 +1706,10 @@ def test_knn_matrix_core_keys_paths(mgp, dev):
 @pytest.mark.parametrize("shape", ["golden", "n65", "hub", "dense_small", "ordered"])
 def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
     """C > 16: the multi-column SpMM against a dense fp64 reference with every epilogue operand in play (pre / post
-    scalings, base term, weighted dot partials), with and without tile dictionaries on the CSR; ragged row
-    counts, a hub row, a dense block, a graph whose tiles follow a locality order."""
+    scalings, base term, weighted dot partials), with and without tile dictionaries on the CSR and with the wide
+    dictionary kernel forced (16-column chunks; the hub row's tile has more than 1024 dictionary columns: two slices,
+    and rows longer than the 64 entries kept in registers); ragged row counts, a hub row, a dense block, a graph whose
+    tiles follow a locality order."""
     import ctypes
     from manifold_gp_amd import _lib
     from manifold_gp_amd.graph import KnnGraph, LaplacianData
@@ -1754,8 +1756,9 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
         W = torch.randn(n, C, device=dev)
         outs = []
         try:
-            for mode in (0, 1):
-                lib.mgp_spmm_set_tile_mode(mode)
+            for mode in (0, 1, 2):      # no tiles; tiles, kernels picked as in production; the wide dictionary kernel forced
+                lib.mgp_spmm_set_tile_mode(1 if mode else 0)
+                lib.mgp_spmm_set_tile_wide_mode(2 if mode == 2 else 1)
                 csr = data.csr()
                 nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), C)
                 part = torch.full((max(nb, 1), C), float("nan"), device=dev)
@@ -1766,6 +1769,7 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
                 outs.append((Y.cpu().double().numpy(), part.double().sum(0).cpu().numpy(), nb))
         finally:
             lib.mgp_spmm_set_tile_mode(1)
+            lib.mgp_spmm_set_tile_wide_mode(1)
         Xs = (pre.cpu().double().view(-1, 1) * X.cpu().double()).numpy()
         SX = np.zeros((n, C))
         np.add.at(SX, rows, vals[:, None] * Xs[col])
