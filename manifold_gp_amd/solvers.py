@@ -312,8 +312,11 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
         inv[order] = torch.arange(order.numel(), device=dev)
         col_p = inv.index_select(0, g.col.long().index_select(0, t["emap"])).to(torch.int32)
         diag_p = lap_data.diag.index_select(0, order).contiguous()
-        keep = (t["tile_rowptr"], col_p, lap_data.vals_t, diag_p)      # referenced until the call returns
-        csr = _lib.csr_struct(g.n, keep[0], keep[1], keep[2], keep[3])
+        # the tile dictionaries describe this very row order; only their column ids are in the old labelling
+        tiles_p = dict(tile_ptr=t["tile_ptr"], tile_cols=inv.index_select(0, t["tile_cols"].long()).to(torch.int32),
+                       lid=t["lid"], rows=t["rows"], max_cols=t["max_cols"], max_entries=t["max_entries"])
+        keep = (t["tile_rowptr"], col_p, lap_data.vals_t, diag_p, tiles_p)      # referenced until the call returns
+        csr = _lib.csr_struct(g.n, keep[0], keep[1], keep[2], keep[3], tiles=tiles_p)
     else:
         csr = lap_data.csr()
     prm = LanczosParamsT(int(max_basis), int(degree), int(max_restarts), float(tol), int(seed))
