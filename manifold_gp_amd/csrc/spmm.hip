@@ -504,6 +504,125 @@ __global__ __launch_bounds__(kBlock) void spmm_kernel(SpmmArgs p) {
   }
 }
 
+// value (.) float4 products of one quad of entries: sq = v.x a0 + v.y a1 + v.z a2 + v.w a3 (mul, then three fmas per
+// component, in this order).  Written with v_pk_*_f32 and the op_sel broadcast of ONE half of the (x, y) / (z, w) value
+// pair: hipcc selects the packed instructions by itself but materialises every multiplier as an (x, x) register pair
+// (4 copies per value seen in the .s: 54 extra VGPRs in spmm_tile_q_kernel, which then ran at two workgroups per CU).
+typedef float mgp_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mgp_v2f pk_mul_lo(mgp_v2f s, mgp_v2f a) {
+  mgp_v2f d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(s), "v"(a));
+  return d;
+}
+__device__ __forceinline__ mgp_v2f pk_fma_lo(mgp_v2f s, mgp_v2f a, mgp_v2f c) {
+  mgp_v2f d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(s), "v"(a), "v"(c));
+  return d;
+}
+__device__ __forceinline__ mgp_v2f pk_fma_hi(mgp_v2f s, mgp_v2f a, mgp_v2f c) {
+  mgp_v2f d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(s), "v"(a), "v"(c));
+  return d;
+}
+__device__ __forceinline__ mgp_v4f quad_products(mgp_v4f vv, mgp_v4f a0, mgp_v4f a1, mgp_v4f a2, mgp_v4f a3) {
+  const mgp_v2f vlo = mgp_v2f{vv.x, vv.y}, vhi = mgp_v2f{vv.z, vv.w};
+  mgp_v2f lo = pk_mul_lo(vlo, mgp_v2f{a0.x, a0.y}), hi = pk_mul_lo(vlo, mgp_v2f{a0.z, a0.w});
+  lo = pk_fma_hi(vlo, mgp_v2f{a1.x, a1.y}, lo); hi = pk_fma_hi(vlo, mgp_v2f{a1.z, a1.w}, hi);
+  lo = pk_fma_lo(vhi, mgp_v2f{a2.x, a2.y}, lo); hi = pk_fma_lo(vhi, mgp_v2f{a2.z, a2.w}, hi);
+  lo = pk_fma_hi(vhi, mgp_v2f{a3.x, a3.y}, lo); hi = pk_fma_hi(vhi, mgp_v2f{a3.z, a3.w}, hi);
+  return mgp_v4f{lo.x, lo.y, hi.x, hi.y};
+}
+
+// ---------------------------------------------------------------- 16 < C <= 256, C % 4 == 0: float4 lanes
+// spmm_kernel above spends ~12 instructions per entry and 64 columns (two readlanes, 64-bit scalar address arithmetic,
+// one 4-byte load and one fma per lane) against 4 cycles of texture-path time: it runs at half the rate the 64 B/clk
+// L1 path allows (91 us at C = 128 on the 60k graph; 48 us of L1 time).  Here a lane owns one float4 of the row
+// (LPR = pow2 >= C / 4 lanes per row, 64 / LPR rows per wave side by side); every lane of a row
+// reads the row's (column, value) quads itself -- the same address across the row's lanes: one request -- and then the
+// 16 bytes of each of the four X rows that are its own; two quads = eight X pieces per lane are in flight while the
+// next quads' ids are fetched.  Per entry and 4 columns: a quarter of a 16-byte id load, one 64-bit address, one
+// 16-byte load, two packed fmas.
+template <int LPR, bool PRE>
+__global__ __launch_bounds__(kBlock) void spmm_v4_kernel(SpmmArgs p) {
+  if (p.skip && *p.skip) return;
+  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
+  constexpr int kGroups = kBlock / LPR;                 // rows a workgroup walks side by side
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int l = threadIdx.x & (LPR - 1), grp = threadIdx.x / LPR;
+  const int C = p.C, C4 = C >> 2;
+  const bool lon = l < C4;
+  const int lc = lon ? l : 0;
+  const int64_t r0 = (int64_t)lb * p.rows_per_block;
+  int64_t r1 = r0 + p.rows_per_block;
+  if (r1 > p.n) r1 = p.n;
+  const mgp_v4f* __restrict__ X4 = reinterpret_cast<const mgp_v4f*>(p.X);
+  const mgp_v4i* __restrict__ col4 = reinterpret_cast<const mgp_v4i*>(p.col);
+  const mgp_v4f* __restrict__ val4 = reinterpret_cast<const mgp_v4f*>(p.vals);
+  mgp_v4f dsum = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0 + grp; r < r1; r += kGroups) {
+    const int qs = p.rowptr[r] >> 2, qe = p.rowptr[r + 1] >> 2;      // rows are padded to quads of entries
+    const int64_t gr = r + p.goff;
+    // epilogue operands: in flight with the row walk
+    const mgp_v4f e_x = X4[gr * C4 + lc];
+    const float e_pre = PRE ? p.pre[gr] : 1.f;
+    const float e_diag = p.diag[r];
+    const float l_post = p.post ? p.post[gr] : 1.f;
+    const mgp_v4f l_base = *reinterpret_cast<const mgp_v4f*>((p.base ? p.base : p.X) + gr * C + 4 * lc);
+    const mgp_v4f l_dotw = *reinterpret_cast<const mgp_v4f*>((p.dotw ? p.dotw : p.X) + gr * C + 4 * lc);
+    mgp_v4f acc = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+    if (qs < qe) {
+      mgp_v4i c0 = col4[qs], c1 = col4[qs + 1 < qe ? qs + 1 : qs];
+      mgp_v4f v0 = val4[qs], v1 = val4[qs + 1 < qe ? qs + 1 : qs];
+      for (int q = qs; q < qe; q += 2) {
+        const bool two = q + 1 < qe;
+        mgp_v4f x[8];
+        x[0] = X4[(int64_t)c0.x * C4 + lc]; x[1] = X4[(int64_t)c0.y * C4 + lc];
+        x[2] = X4[(int64_t)c0.z * C4 + lc]; x[3] = X4[(int64_t)c0.w * C4 + lc];
+        x[4] = X4[(int64_t)c1.x * C4 + lc]; x[5] = X4[(int64_t)c1.y * C4 + lc];
+        x[6] = X4[(int64_t)c1.z * C4 + lc]; x[7] = X4[(int64_t)c1.w * C4 + lc];
+        mgp_v4f w0 = v0, w1 = v1;
+        if (PRE) {
+          w0.x *= p.pre[c0.x]; w0.y *= p.pre[c0.y]; w0.z *= p.pre[c0.z]; w0.w *= p.pre[c0.w];
+          w1.x *= p.pre[c1.x]; w1.y *= p.pre[c1.y]; w1.z *= p.pre[c1.z]; w1.w *= p.pre[c1.w];
+        }
+        if (!two) w1 = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+        // the next two quads' ids and values: requested before this pair's products wait for its X pieces
+        const int qa = q + 2 < qe ? q + 2 : q, qb = q + 3 < qe ? q + 3 : qa;
+        c0 = col4[qa]; c1 = col4[qb];
+        v0 = val4[qa]; v1 = val4[qb];
+        const mgp_v4f s0 = quad_products(w0, x[0], x[1], x[2], x[3]);
+        const mgp_v4f s1 = quad_products(w1, x[4], x[5], x[6], x[7]);
+        acc.x += s0.x; acc.y += s0.y; acc.z += s0.z; acc.w += s0.w;
+        acc.x += s1.x; acc.y += s1.y; acc.z += s1.z; acc.w += s1.w;
+      }
+    }
+    if (lon) {
+      const float xs0 = e_x.x * e_pre, xs1 = e_x.y * e_pre, xs2 = e_x.z * e_pre, xs3 = e_x.w * e_pre;
+      mgp_v4f y;
+      y.x = p.co * ((p.a * xs0 + p.b * (e_diag * xs0 - acc.x)) * l_post) + (p.base ? p.cb * l_base.x : 0.f);
+      y.y = p.co * ((p.a * xs1 + p.b * (e_diag * xs1 - acc.y)) * l_post) + (p.base ? p.cb * l_base.y : 0.f);
+      y.z = p.co * ((p.a * xs2 + p.b * (e_diag * xs2 - acc.z)) * l_post) + (p.base ? p.cb * l_base.z : 0.f);
+      y.w = p.co * ((p.a * xs3 + p.b * (e_diag * xs3 - acc.w)) * l_post) + (p.base ? p.cb * l_base.w : 0.f);
+      *reinterpret_cast<mgp_v4f*>(p.Y + gr * C + 4 * l) = y;
+      if (p.dotw) {
+        dsum.x = fmaf(l_dotw.x, y.x, dsum.x); dsum.y = fmaf(l_dotw.y, y.y, dsum.y);
+        dsum.z = fmaf(l_dotw.z, y.z, dsum.z); dsum.w = fmaf(l_dotw.w, y.w, dsum.w);
+      }
+    }
+  }
+  if (p.dot_partials) {
+    // red[group][4 LPR]: the row groups' sums per column, added in group order by the first 4 LPR lanes
+    __shared__ __attribute__((aligned(16))) float red[kBlock * 4];
+    *reinterpret_cast<mgp_v4f*>(red + (grp * LPR + l) * 4) = dsum;
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+      float tsum = 0.f;
+      for (int g = 0; g < kGroups; ++g) tsum += red[g * LPR * 4 + c];
+      p.dot_partials[(int64_t)lb * C + c] = tsum;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- C in {4, 8, 12, 16}
 // Lanes are laid over ENTRIES, not over columns.  spmm_kernel above broadcasts every (col, val) pair to
 // the lanes of a row group with __shfl, which hipcc lowers to ds_bpermute_b32: two LDS-pipe round trips
@@ -600,35 +719,6 @@ __global__ __launch_bounds__(kBlock) void spmm_row16_kernel(SpmmArgs p) {
       p.dot_partials[(int64_t)lb * C + threadIdx.x] = t;
     }
   }
-}
-
-// value (.) float4 products of one quad of entries: sq = v.x a0 + v.y a1 + v.z a2 + v.w a3 (mul, then three fmas per
-// component, in this order).  Written with v_pk_*_f32 and the op_sel broadcast of ONE half of the (x, y) / (z, w) value
-// pair: hipcc selects the packed instructions by itself but materialises every multiplier as an (x, x) register pair
-// (4 copies per value seen in the .s: 54 extra VGPRs in spmm_tile_q_kernel, which then ran at two workgroups per CU).
-typedef float mgp_v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ mgp_v2f pk_mul_lo(mgp_v2f s, mgp_v2f a) {
-  mgp_v2f d;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(s), "v"(a));
-  return d;
-}
-__device__ __forceinline__ mgp_v2f pk_fma_lo(mgp_v2f s, mgp_v2f a, mgp_v2f c) {
-  mgp_v2f d;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(s), "v"(a), "v"(c));
-  return d;
-}
-__device__ __forceinline__ mgp_v2f pk_fma_hi(mgp_v2f s, mgp_v2f a, mgp_v2f c) {
-  mgp_v2f d;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(s), "v"(a), "v"(c));
-  return d;
-}
-__device__ __forceinline__ mgp_v4f quad_products(mgp_v4f vv, mgp_v4f a0, mgp_v4f a1, mgp_v4f a2, mgp_v4f a3) {
-  const mgp_v2f vlo = mgp_v2f{vv.x, vv.y}, vhi = mgp_v2f{vv.z, vv.w};
-  mgp_v2f lo = pk_mul_lo(vlo, mgp_v2f{a0.x, a0.y}), hi = pk_mul_lo(vlo, mgp_v2f{a0.z, a0.w});
-  lo = pk_fma_hi(vlo, mgp_v2f{a1.x, a1.y}, lo); hi = pk_fma_hi(vlo, mgp_v2f{a1.z, a1.w}, hi);
-  lo = pk_fma_lo(vhi, mgp_v2f{a2.x, a2.y}, lo); hi = pk_fma_lo(vhi, mgp_v2f{a2.z, a2.w}, hi);
-  lo = pk_fma_hi(vhi, mgp_v2f{a3.x, a3.y}, lo); hi = pk_fma_hi(vhi, mgp_v2f{a3.z, a3.w}, hi);
-  return mgp_v4f{lo.x, lo.y, hi.x, hi.y};
 }
 
 // ---------------------------------------------------------------- C in {4, 8, 12, 16}, row tiles + LDS dictionary
@@ -1113,6 +1203,7 @@ static bool use_tiles_small(const mgp_csr_t* L, int C) {
 
 // 16 < C <= 256, C % 4 == 0 on 64-row tiles: the wide tile kernel (mgp_spmm_set_tile_wide_mode(0): spmm_kernel)
 int g_tile_wide_mode = 1;
+int g_spmm_v4_mode = 1;     // float4-lane gather kernel for 16 < C <= 256 (mgp_spmm_set_v4_mode(0): spmm_kernel)
 static int tile_wide_cap(const mgp_csr_t* L) {
   int cap = (L->tile_max_cols + 63) / 64 * 64;
   if (cap > kWideCap) cap = kWideCap;
@@ -1135,6 +1226,11 @@ static bool use_tiles_wide(const mgp_csr_t* L, int C) {
   // (1.48 vs 3.04 ms at C = 128).  mode 2 forces it at any size (tests, A/B).
   if (g_tile_wide_mode == 2) return true;
   return C <= 32 || (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20);
+}
+
+extern "C" int mgp_spmm_set_v4_mode(int on) {
+  g_spmm_v4_mode = on == 2 ? 2 : (on ? 1 : 0);
+  return MGP_OK;
 }
 
 extern "C" int mgp_spmm_set_tile_wide_mode(int on) {
@@ -1341,6 +1437,28 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     else if (C == 12) MGP_ROW16_LAUNCH(3);
     else MGP_ROW16_LAUNCH(4);
 #undef MGP_ROW16_LAUNCH
+  } else if (g_spmm_v4_mode && C > 16 && C <= 256 && (C & 3) == 0 &&
+             // measured (tools/lab/time_spmm_wide.py): 33 vs 59 us at C = 32 and 54 vs 63 us at C = 64 on the 60k graph, but
+             // 101 vs 91 us at C = 128 (the X block no longer sits in L2 and the per-column kernel's whole-line pieces use
+             // the Infinity Cache path better); on the 1M graph, when the dictionaries are not there, it wins at every width
+             (g_spmm_v4_mode == 2 || C <= 64 || (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20)) &&
+             ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(base) |
+               reinterpret_cast<uintptr_t>(dotw) | reinterpret_cast<uintptr_t>(L->col) | reinterpret_cast<uintptr_t>(L->vals)) & 15) == 0 &&
+             (L->tile_max_entries & 3) == 0 && L->lid != nullptr) {
+    // (quad-padded rows are what the tile builder guarantees: the CSR of a graph without dictionaries keeps the
+    // per-column kernel below)
+    Plan pl = make_plan(L->n, spmm_rows_per_pass(C));        // the same row ranges / dot-partial blocks as spmm_kernel
+    p.rows_per_block = pl.rows_per_block;
+#define MGP_V4_LAUNCH(LPR)                                                                          \
+  do {                                                                                              \
+    if (pre) hipLaunchKernelGGL((spmm_v4_kernel<LPR, true>), dim3(pl.grid), dim3(kBlock), 0, st, p);  \
+    else hipLaunchKernelGGL((spmm_v4_kernel<LPR, false>), dim3(pl.grid), dim3(kBlock), 0, st, p);     \
+  } while (0)
+    if (C <= 32) MGP_V4_LAUNCH(8);
+    else if (C <= 64) MGP_V4_LAUNCH(16);
+    else if (C <= 128) MGP_V4_LAUNCH(32);
+    else MGP_V4_LAUNCH(64);
+#undef MGP_V4_LAUNCH
   } else {
     const int G = spmm_cols_group(C);
     const int nacc = (int)mgp_cdiv(C, G);

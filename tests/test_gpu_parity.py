@@ -1756,9 +1756,12 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
         W = torch.randn(n, C, device=dev)
         outs = []
         try:
-            for mode in (0, 1, 2):      # no tiles; tiles, kernels picked as in production; the wide dictionary kernel forced
-                lib.mgp_spmm_set_tile_mode(1 if mode else 0)
+            # 0: no tile kernels (C > 16: the float4-lane gather kernel); 1: kernels picked as in production; 2: the wide
+            # dictionary kernel forced; 3: no tile kernels, per-column gather kernel
+            for mode in (0, 1, 2, 3):
+                lib.mgp_spmm_set_tile_mode(1 if mode in (1, 2) else 0)
                 lib.mgp_spmm_set_tile_wide_mode(2 if mode == 2 else 1)
+                lib.mgp_spmm_set_v4_mode(0 if mode == 3 else (2 if mode == 0 else 1))
                 csr = data.csr()
                 nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), C)
                 part = torch.full((max(nb, 1), C), float("nan"), device=dev)
@@ -1770,6 +1773,7 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
         finally:
             lib.mgp_spmm_set_tile_mode(1)
             lib.mgp_spmm_set_tile_wide_mode(1)
+            lib.mgp_spmm_set_v4_mode(1)
         Xs = (pre.cpu().double().view(-1, 1) * X.cpu().double()).numpy()
         SX = np.zeros((n, C))
         np.add.at(SX, rows, vals[:, None] * Xs[col])

@@ -14,8 +14,9 @@ csr = lap.data.csr()
 for C in (20, 32, 64, 100, 128, 256):
     X = torch.randn(g.n, C, device=dev); Y = torch.empty_like(X)
     out = []
-    for mode in (2, 0):
-        lib.mgp_spmm_set_tile_wide_mode(mode)
+    for mode in (2, 0, 3):
+        lib.mgp_spmm_set_tile_wide_mode(2 if mode == 2 else 0)
+        lib.mgp_spmm_set_v4_mode(0 if mode == 3 else 2)
         ms = ctypes.c_float(0.0)
         _lib.check(lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y), 5, None, _lib.stream()), "repeat")
         best = 1e9
@@ -24,5 +25,5 @@ for C in (20, 32, 64, 100, 128, 256):
             best = min(best, ms.value)
         out.append(best / 30 * 1e3)
     B = bench.spmm_bytes(g.n, g.M, C)
-    print("C %3d  wide tile %.1f us (%.0f GB/s algorithmic)   gather %.1f us" % (C, out[0], B / out[0] / 1e3, out[1]))
-lib.mgp_spmm_set_tile_wide_mode(1)
+    print("C %3d  wide tile %.1f us   float4 gather %.1f us (%.0f GB/s algorithmic)   per-column gather %.1f us" % (C, out[0], out[1], B / out[1] / 1e3, out[2]))
+lib.mgp_spmm_set_tile_wide_mode(1); lib.mgp_spmm_set_v4_mode(1)
