@@ -1232,7 +1232,7 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   // update kernel re-reduces ALL dot partials of ALL columns (nbv x (2 nbv + nbs) x C loads per launch),
   // so the grid is kept to one workgroup per CU (their loads go out in batches of 8 / 32 per lane)
   // C > 16: the partials are summed once by cg_reduce_kernel, the update grid is free to fill the chip
-  const bool reduce_once = C > kReduceOnceAbove && g_cg_reduce_once;
+  const bool reduce_once = g_cg_reduce_once && C > (g_cg_reduce_once == 2 ? 1 : kReduceOnceAbove);
   const int max_grid_vec = (C == 1) ? kMaxGridVec : (reduce_once ? 2048 : 256);
   int64_t rpb = a.TS;
   int64_t nbv = mgp_cdiv(n, rpb);
@@ -1323,7 +1323,7 @@ extern "C" int mgp_cg_set_poll_spin(int spins) {
 }
 
 extern "C" int mgp_cg_set_reduce_once(int on) {
-  g_cg_reduce_once = on ? 1 : 0;
+  g_cg_reduce_once = on == 2 ? 2 : (on ? 1 : 0);      // 2: from two columns up (A/B runs)
   return MGP_OK;
 }
 

@@ -1221,11 +1221,12 @@ static bool use_tiles_wide(const mgp_csr_t* L, int C) {
   if (!L->lid || !L->tile_ptr || !L->tile_cols || L->tile_rows != 64) return false;
   if ((L->tile_max_entries & 3) != 0) return false;
   // measured (tools/lab/time_spmm_wide.py): on the 60k graph the per-entry gather kernel reads its X rows out of L2 and
-  // wins from 64 columns up (63 vs 84 us at C = 64, 91 vs 158 us at C = 128; 47 vs 59 us at C = 32 the other way); on
+  // wins from 64 columns up (63 vs 84 us at C = 64, 91 vs 158 us at C = 128; 47 vs 59 us at C = 32 the other way, but see below); on
   // the 1M graph, whose X block does not fit the caches, the dictionary kernel is 1.5-2.4x faster at every width
   // (1.48 vs 3.04 ms at C = 128).  mode 2 forces it at any size (tests, A/B).
+  // (and up to 64 columns the float4-lane gather kernel beats both on a cache-resident X block: 33 us at C = 32)
   if (g_tile_wide_mode == 2) return true;
-  return C <= 32 || (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20);
+  return (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20);
 }
 
 extern "C" int mgp_spmm_set_v4_mode(int on) {

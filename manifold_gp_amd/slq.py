@@ -124,23 +124,29 @@ def _lanczos_block_generic(operator, Z, steps):
     """The same P independent Lanczos runs for an operator that is NOT one polynomial chain (wrappers around
     a Schur complement): torch vector algebra around `operator.matmul` on [n, P] blocks -- every matmul
     underneath is still HIP launches (the Schur matvec runs its inner HIP CG with P right-hand sides)."""
+    # The basis lives as Qt [P, steps + 1, n] (one [steps + 1, n] matrix per probe), so that the two passes of
+    # Gram-Schmidt against q_0 .. q_j are four batched matrix-vector products per step whatever j is, and alpha / beta
+    # stay on the device until the end.  (A Python loop over the basis vectors -- a product, a column sum and an update
+    # each -- was 4 (j + 1) small launches per step, 840 per 20-step run, plus two host reads per step: ~9 ms of an
+    # 80 ms semi-supervised epoch.)
     n, P = Z.shape
-    Q = [Z / Z.norm(dim=0, keepdim=True).clamp_min(1e-30)]
-    alpha = np.zeros((steps, P))
-    beta = np.zeros((steps, P))
+    Qt = torch.empty(P, steps + 1, n, dtype=Z.dtype, device=Z.device)
+    Qt[:, 0, :] = (Z / Z.norm(dim=0, keepdim=True).clamp_min(1e-30)).t()
+    A = torch.zeros(steps, P, dtype=Z.dtype, device=Z.device)
+    B = torch.zeros(steps, P, dtype=Z.dtype, device=Z.device)
     for j in range(steps):
-        W = operator.matmul(Q[j])
-        a = torch.zeros(P, device=Z.device)
-        for _ in range(2):                                     # classical Gram-Schmidt against q_0..q_j, twice
-            for i, q in enumerate(Q):
-                h = (W * q).sum(0)
-                W = W - q * h
-                if i == j:
-                    a = a + h
-        b = W.norm(dim=0)
-        alpha[j], beta[j] = a.double().cpu().numpy(), b.double().cpu().numpy()
-        Q.append(W / b.clamp_min(1e-30))
-    return alpha, beta
+        W = operator.matmul(Qt[:, j, :].t().contiguous())
+        Wt = W.t().contiguous().unsqueeze(-1)                 # [P, n, 1]
+        Qj = Qt[:, :j + 1, :]                                  # [P, j + 1, n]
+        a = torch.zeros(P, dtype=Z.dtype, device=Z.device)
+        for _ in range(2):                                     # classical Gram-Schmidt against q_0 .. q_j, twice
+            h = torch.bmm(Qj, Wt)                              # [P, j + 1, 1]
+            Wt = Wt - torch.bmm(Qj.transpose(1, 2), h)
+            a = a + h[:, j, 0]
+        b = Wt.squeeze(-1).norm(dim=1)
+        A[j], B[j] = a, b
+        Qt[:, j + 1, :] = Wt.squeeze(-1) / b.clamp_min(1e-30).unsqueeze(1)
+    return A.double().cpu().numpy(), B.double().cpu().numpy()
 
 
 def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
