@@ -38,6 +38,7 @@
 // process on one GPU and share the double-buffered w / partial arrays, so that the all-gather is the identity;
 // the host enqueues the phases of every virtual rank in lock step (mgp_pcg_plan_enqueue).
 #include <math.h>
+#include <chrono>
 #include <new>
 #include <rccl/rccl.h>
 #include <stdlib.h>
@@ -502,6 +503,7 @@ struct PcgPlan {
   bool has_graph, graphs_tried;
   int chunk, solves;
   int32_t* host_state;
+  int64_t last_solve_ns;       // host time of the previous solve when its first chunk took the decision (0: it did not)
   float* host_resid;
   int64_t n_glob;
 };
@@ -846,6 +848,7 @@ extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int3
   volatile int32_t* flag = pl->host_state + 1;
   int total_iters = 0, last_status = 0;
   const float* rhs = B;
+  const auto t_begin = std::chrono::steady_clock::now();
   for (int round = 0; round <= max_refine; ++round) {
     pl->host_state[1] = 0;
     MGP_TRY(enqueue_start(pl, rhs, round, st));
@@ -857,10 +860,25 @@ extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int3
       } else {
         for (int i = 0; i < pl->chunk; ++i) MGP_TRY(enqueue_step(pl, i & 1, st));
       }
-      // every rank launches whole chunks and checks the flag only once its chunk has drained: the decisions are
-      // bit-identical on all ranks, so all ranks stop behind the same chunk and their collective sequences match
-      MGP_HIP_TRY(hipStreamSynchronize(st));
-      if (*flag) break;
+      // every rank launches whole chunks; the decisions are bit-identical on all ranks and the flag only ever rises
+      // inside the chunk that takes the decision, so all ranks stop behind the same chunk and their collective
+      // sequences match -- whether a rank sees the flag while that chunk still drains (first chunk: the host reads
+      // nothing but the flag for up to twice the previous solve's time, as in cg.hip) or after it has (blocking wait)
+      if (guard == 0 && pl->last_solve_ns > 0) {
+        const int64_t budget = 2 * pl->last_solve_ns + 20000;
+        const auto t_spin = std::chrono::steady_clock::now();
+        while (!*flag) {
+          for (int spin = 0; spin < 64 && !*flag; ++spin) __builtin_ia32_pause();
+          if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_spin).count() > budget) break;
+        }
+      }
+      if (!*flag) MGP_HIP_TRY(hipStreamSynchronize(st));
+      if (*flag) {
+        if (guard == 0 && round == 0)
+          pl->last_solve_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+        break;
+      }
+      pl->last_solve_ns = 0;
       if (++guard > pl->prm.max_iter / pl->chunk + 2) break;
       if (pl->chunk >= 16 && pl->recurrence == 0) MGP_TRY(enqueue_replacement(pl, rhs, st));   // long pipelined solves: re-anchor the recurrences
     }
