@@ -5,6 +5,13 @@ import torch
 from .._compat import LinearOperator
 
 
+# When the wrapped operator is one polynomial chain the solve below can also run as HIP CG on the cubic polynomial itself
+# (form 1 of the descriptor: 3 nu SpMMs per iteration).  Measured on the supervised 60k epoch (tools/lab/ab_neumann.py):
+# ~100 such iterations per 12-probe solve, 600 SpMM launches, against ~30 iterations of the better conditioned wrapped
+# operator plus two or three series terms: 25 -> 18 ms per epoch.  False restores that CG (A/B runs).
+_NEUMANN_FOR_CHAINS = [True]
+
+
 def _scalar(t):
     return float(t.reshape(-1)[0].item()) if torch.is_tensor(t) else float(t)
 
@@ -46,12 +53,12 @@ class NoiseWrapperOperator(LinearOperator):
 
     def _solve_hip(self, rhs):
         d = self._descriptor()
-        if d is not None:
+        if d is not None and not _NEUMANN_FOR_CHAINS[0]:
             from ..solvers import cg_solve
             return cg_solve(d, rhs)[0]
-        # Not one polynomial chain (a Schur complement underneath): every matvec of this operator is three nested
-        # inner solves.  With q = the wrapped operator, t = s q and M = q^-1 + s I (ONE solve with the wrapped operator,
-        # which the Schur complement answers with a single non-nested CG on the full precision):
+        # With q = the wrapped operator, t = s q and M = q^-1 + s I (ONE solve with the wrapped operator -- a Schur
+        # complement, every matvec of which is a nested solve, answers it with a single non-nested CG on the full
+        # precision; a polynomial chain with HIP CG on the chain itself):
         #     A = q - s q^2 + s^2 q^3 = q (1 + t^3) / (1 + t)     =>     A^-1 = M (1 + t^3)^-1 = M (1 - t^3 + t^6 - ...)
         # The noise model needs |t| < 1 anyway (it is the Neumann form of (q^-1 + s I)^-1); in training |t| ~ 0.4,
         # t^3 ~ 0.07.  x_J = M (b - t^3 b + ... +- t^3J b) has the TRUE residual b - A x_J = -+ t^3(J+1) b, i.e. the norm
@@ -92,4 +99,7 @@ class NoiseWrapperOperator(LinearOperator):
             if ok:
                 x = M(y)
                 return x.squeeze(-1) if squeeze else x
+        if d is not None:
+            from ..solvers import cg_solve
+            return cg_solve(d, rhs)[0]
         return generic_cg(self, rhs, x0=M(rhs), precond=M)

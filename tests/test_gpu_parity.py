@@ -833,6 +833,43 @@ def test_noise_wrapped_schur_solve_and_logdet(mgp, golden, dev):
     assert sign > 0 and abs(ld - want) < 0.03 * abs(want) + 0.02 * Ad.shape[0], (ld, want)
 
 
+@pytest.mark.parametrize("tmax", [0.4, 2.0])
+@pytest.mark.parametrize("norm", NORMS)
+def test_noise_wrapped_chain_solve_series_and_cg(mgp, golden, dev, norm, tmax):
+    """NoiseWrapper(ScaleWrapper(PrecisionMatern)) -- the supervised model's operator, one polynomial chain: its solve
+    as M (1 - t^3 + t^6 ...) b with M = q^-1 + s I (one HIP CG on the wrapped chain + a few applies; default) and as
+    HIP CG on the cubic polynomial itself (form 1), both against the dense float64 solve; the noise is set from the
+    largest eigenvalue of q so that |s q| <= 0.4 (training's regime) or 2.0, where the series does not converge and the
+    solve must fall back to the CG by itself."""
+    from manifold_gp_amd.operators import noise_wrapper_operator as nw
+    O = mgp.operators
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, norm)
+    Q = O.PrecisionMaternOperator(lap, 2, torch.tensor([[float(g["kappa"])]], device=dev))
+    sc = 0.6
+    Q2 = sc * Q.to_dense().double().cpu().numpy()
+    Q2 = 0.5 * (Q2 + Q2.T) if norm == "symmetric" else Q2
+    noise = float(tmax / np.abs(np.linalg.eigvals(Q2)).max())
+    A = O.NoiseWrapperOperator(O.ScaleWrapperOperator(Q, torch.tensor(sc, device=dev)), torch.tensor(noise, device=dev))
+    assert A._descriptor() is not None
+    Ad = Q2 - noise * Q2 @ Q2 + noise * noise * Q2 @ Q2 @ Q2
+    rng = np.random.default_rng(3)
+    B = rng.normal(size=(Q2.shape[0], 12)).astype(np.float32)
+    ref = np.linalg.solve(Ad, B.astype(np.float64))
+    out = {}
+    try:
+        for series in (True, False):
+            nw._NEUMANN_FOR_CHAINS[0] = series
+            with mgp.settings.cg_tolerance(1e-6), mgp.settings.cg_stop_mode(1), mgp.settings.max_cg_iterations(20000):
+                out[series] = A.solve(T(B, dev)).cpu().numpy().astype(np.float64)
+    finally:
+        nw._NEUMANN_FOR_CHAINS[0] = True
+    for series, X in out.items():
+        res = np.linalg.norm(Ad @ X - B, axis=0) / np.linalg.norm(B, axis=0)
+        assert res.max() < 2e-5, (series, res.max())
+        assert np.abs(X - ref).max() < 5e-4 * np.abs(ref).max(), (series, np.abs(X - ref).max() / np.abs(ref).max())
+
+
 # ----------------------------------------------------------------------------- remaining section-8(a) rows
 @pytest.mark.parametrize("norm", NORMS)
 def test_operator_out_of_sample_vs_oracle(mgp, golden, dev, norm):
