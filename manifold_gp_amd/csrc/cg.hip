@@ -1400,6 +1400,8 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
     if (launched_first && g_cg_poll_spin > 0 && pl->last_solve_ns > 0) {
       const int64_t budget = 2 * pl->last_solve_ns + 20000;
       const auto t_spin = std::chrono::steady_clock::now();
+      // (not even one query every 20 us: two or three of them during a 55 us solve took the whole gain back.  A first
+      // graph that ends UNdecided costs this window once; the graph is then re-captured for the longer solve, below)
       while (!*flag) {
         for (int spin = 0; spin < g_cg_poll_spin && !*flag; ++spin) __builtin_ia32_pause();
         if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_spin).count() > budget) break;
@@ -1421,7 +1423,10 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
     if (guard == 0)      // decided inside the first chunk: how long such a solve takes (the next one's flag-only poll window)
       pl->last_solve_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
     const int need = pl->host_state[0];
-    if (pl->exec_first && need >= 1 && need <= 64 && need != pl->len_first && need == pl->last_need) {
+    // longer than the captured graph: re-capture at once (an undecided first graph costs the flag-only window above
+    // and a second launch); shorter: only when two solves in a row agree (the extra bodies of a graph that is one or
+    // two steps too long return at their first load)
+    if (pl->exec_first && need >= 1 && need <= 64 && (need > pl->len_first || (need < pl->len_first && need == pl->last_need))) {
       MGP_HIP_TRY(hipStreamSynchronize(st));   // the graph being replaced may still be draining
       capture_first(pl, need);
     }

@@ -833,6 +833,39 @@ def test_noise_wrapped_schur_solve_and_logdet(mgp, golden, dev):
     assert sign > 0 and abs(ld - want) < 0.03 * abs(want) + 0.02 * Ad.shape[0], (ld, want)
 
 
+@pytest.mark.parametrize("nu", [2, 3])
+@pytest.mark.parametrize("norm", NORMS)
+def test_factorised_chain_solve_vs_whole_chain_cg(mgp, golden, dev, norm, nu):
+    """Q = (tau I + L)^nu x D solved as nu sequential CG solves with B = tau I + L_sym (solvers._factorised_solve: the
+    default for unmasked form-0 chains) against CG on the whole chain and the dense float64 solve: true residual under
+    the tolerance, fewer operator applications, both stopping rules; a masked descriptor (Schur blocks) and the noise
+    forms are not factorised."""
+    from manifold_gp_amd import solvers
+    g = golden("dumbbell_k10_loop")              # eps = 0.05: the ill-conditioned regime, where it matters
+    lap = _operator(mgp, g, dev, norm)
+    Q = mgp.operators.PrecisionMaternOperator(lap, nu, torch.tensor([[float(g["kappa"])]], device=dev))
+    desc = Q._descriptor().with_(scale=0.7)
+    n = desc.n
+    assert solvers._factorisable(desc, {}) and not solvers._factorisable(desc.with_(form=2, noise=0.01), {})
+    mask = torch.ones(n, device=dev)
+    mask[::3] = 0.0
+    assert not solvers._factorisable(desc.masked(mask, mask), {})
+    rng = np.random.default_rng(nu)
+    B = T(rng.normal(size=(n, 5)).astype(np.float32), dev)
+    Ad = desc.apply(torch.eye(n, device=dev)).double().cpu().numpy()
+    ref = np.linalg.solve(Ad, B.cpu().numpy().astype(np.float64))
+    for stop_mode, tol in ((1, 1e-4), (0, 1e-2)):
+        Xf, itf, _ = solvers.cg_solve(desc, B, tol=tol, stop_mode=stop_mode, max_iter=20000)
+        Xw, itw, _ = solvers.cg_solve(desc, B, tol=tol, stop_mode=stop_mode, max_iter=20000, factorise=False)
+        rf = np.linalg.norm(Ad @ Xf.cpu().numpy().astype(np.float64) - B.cpu().numpy(), axis=0) / np.linalg.norm(B.cpu().numpy(), axis=0)
+        assert rf.max() < tol, (stop_mode, rf.max())
+        assert itf < itw * nu, (itf, itw)           # SpMMs: itf (one per iteration) against itw * nu
+        if stop_mode == 1:
+            ef = np.abs(Xf.cpu().numpy() - ref).max() / np.abs(ref).max()
+            ew = np.abs(Xw.cpu().numpy() - ref).max() / np.abs(ref).max()
+            assert ef < max(2.0 * ew, 50 * tol), (ef, ew)
+
+
 @pytest.mark.parametrize("tmax", [0.4, 2.0])
 @pytest.mark.parametrize("norm", NORMS)
 def test_noise_wrapped_chain_solve_series_and_cg(mgp, golden, dev, norm, tmax):
@@ -2014,7 +2047,7 @@ def test_pcg_single_rank_matches_cg(mgp, golden, dev, norm, form, nu, recurrence
     desc, dd, part = _padded_descriptor(mgp, g, dev, norm, nu, form, 1)
     n = desc.n
     y = part.pad(T(g["train_y"], dev))
-    xs, its, _ = cg_solve(desc, T(g["train_y"], dev), tol=1e-6, stop_mode=1, max_iter=20000)
+    xs, its, _ = cg_solve(desc, T(g["train_y"], dev), tol=1e-6, stop_mode=1, max_iter=20000, factorise=False)
     sols = {}
     for use_graph in (True, False):
         plan = PcgPlan(dd, part, 0, tol=1e-6, max_iter=20000, stop_mode=1, use_graph=use_graph, recurrence=recurrence)
@@ -2098,7 +2131,7 @@ def test_pcg_stagnation_guard_and_refinement_on_an_ill_conditioned_system(mgp, g
     n = desc.n
     yv = T(g["train_y"], dev)
     y = part.pad(yv)
-    xs, its, _ = cg_solve(desc, yv, tol=1e-6, stop_mode=1, max_iter=20000)
+    xs, its, _ = cg_solve(desc, yv, tol=1e-6, stop_mode=1, max_iter=20000, factorise=False)
     ref_true = float((desc.apply(xs) - yv).norm() / yv.norm())
     plan = PcgPlan(dd, part, 0, tol=1e-6, max_iter=20000, stop_mode=1)
     x = plan.solve(y).clone()[:n]
