@@ -149,6 +149,34 @@ def _lanczos_block_generic(operator, Z, steps):
     return A.double().cpu().numpy(), B.double().cpu().numpy()
 
 
+INVERSE_LANCZOS = [True]      # False: Lanczos over the Schur complement itself (nested solves), as in round 1
+
+
+class _InverseOperator:
+    """v -> op^-1 v as the `matmul` the generic block Lanczos calls."""
+
+    def __init__(self, op):
+        self.op = op
+        self.shape = op.shape
+
+    def matmul(self, V):
+        return self.op._solve(V)
+
+
+def _inverse_lanczos_target(target):
+    """target = [ScaleWrapper of] a SchurComplementOperator over a chain that factorises: its inverse is cheap."""
+    from .operators.scale_wrapper_operator import ScaleWrapperOperator
+    from .operators.schur_complement_operator import SchurComplementOperator
+    inner = target.operator if isinstance(target, ScaleWrapperOperator) else target
+    if not isinstance(inner, SchurComplementOperator):
+        return None
+    from .solvers import _factorisable
+    desc = getattr(inner.base, "_descriptor", lambda: None)()
+    if desc is None or not _factorisable(desc, {}):
+        return None
+    return _InverseOperator(target)
+
+
 def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
     desc = getattr(operator, "_descriptor", lambda: None)()
     if desc is None:
@@ -168,9 +196,19 @@ def slq_logdet(operator, num_probes=None, steps=None, seed=1337):
             sn = float(operator.noise.reshape(-1)[0].item()) if torch.is_tensor(operator.noise) else float(operator.noise)
             target = operator.operator
             fun = lambda th: th - sn * th * th + sn * sn * th * th * th     # noqa: E731
+        # A Schur complement underneath: every matvec S v hides a CG on Q_uu (not a product of sparse factors), while
+        # S^-1 v = [Q^-1 (v; 0)]_l is ONE solve with the full precision, which factorises (solvers._factorised_solve).
+        # tr log f(S) is just as much a spectral function of W = S^-1 (eigenvalues mu = 1 / theta), so the Lanczos runs
+        # go over W and the quadrature evaluates log f(1 / mu) at its Ritz values: half the SpMMs per step.
+        inv = _inverse_lanczos_target(target) if INVERSE_LANCZOS[0] else None
         with torch.no_grad():
-            a, b = _lanczos_block_generic(target, Z, steps)
-        total = _quadrature_log_sum(a, b, fun)
+            if inv is not None:
+                a, b = _lanczos_block_generic(inv, Z, steps)
+                f0 = fun if fun is not None else (lambda th: th)
+                total = _quadrature_log_sum(a, b, lambda mu: f0(1.0 / np.maximum(mu, 1e-30)))
+            else:
+                a, b = _lanczos_block_generic(target, Z, steps)
+                total = _quadrature_log_sum(a, b, fun)
         return torch.tensor(n * total / num_probes, dtype=torch.float32, device=Z.device)
     n = desc.n
     num_probes = settings.num_trace_samples.value() if num_probes is None else num_probes
