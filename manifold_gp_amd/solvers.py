@@ -174,7 +174,7 @@ def _factorised_solve(desc, B, kw):
     dinv = None if desc.pre is None else desc.data.dinvsqrt.view(-1, 1)
     bn = B.norm(dim=0).clamp_min(1e-30)
     X, R, its, rel = None, B, 0, None
-    want = tol
+    want, prev_worst = tol, float("inf")
     for rnd in range(3):
         kw["tol"] = max(want, 1e-7) / (2.0 * nu) / (1.0 if rnd == 0 else 4.0)
         Y = R if dinv is None else (R * dinv).contiguous()
@@ -194,8 +194,11 @@ def _factorised_solve(desc, B, kw):
         worst = float(rel.mean() if stop_mode == 0 else rel.max())
         if not (worst > tol) or not math.isfinite(worst):
             break
+        if rnd > 0 and worst > 0.5 * prev_worst:  # fp32 floor of the true residual (|A||x| eps32 / |b|): no point in going on
+            break
+        prev_worst = worst
         want = min(0.5, tol / worst)              # relative to the new right-hand side R
-    if worst > tol:
+    if worst > max(tol, 2e-5):
         warnings.warn("factorised CG solve: true residual %.3g above the tolerance %.3g after %d rounds" % (worst, tol, rnd + 1))
     return X, its, [float(v) for v in rel.tolist()]
 
