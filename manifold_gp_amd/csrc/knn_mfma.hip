@@ -256,6 +256,11 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
 // flop per byte copied -- and 1.19 ms per 4 096-row chunk against 0.94 ms for the kernel above: with one workgroup per
 // CU nothing covers a stage whose point tile misses L2 (half of those requests do: a point tile is shared by only
 // ny_per_xcd workgroups of an XCD at a time), and two stages of prefetch are shorter than that miss.
+// Also tried on THIS kernel: a second barrier right behind the fragment reads, which frees the stage's buffer early, so
+// that the copies of stage s + 2 go out before the MFMAs of stage s (two stages ahead with the same 64 KB; two arrays and
+// a 2x unrolled loop for the alias check; __launch_bounds__(256, 2), without which the accumulators moved between AGPRs
+// and VGPRs every stage): identical keys, 1.86 ms against 1.83 ms per 8 192-row chunk -- the wait for the copies is not
+// what the remaining 41 % of the MFMA pipes' time goes to.
 
 constexpr int kMaxPartialBlocks = 1024;
 
