@@ -180,7 +180,7 @@ def _factorised_solve(desc, B, kw):
         Y = R if dinv is None else (R * dinv).contiguous()
         for _ in range(nu):
             plan = _cached_plan(dB, Y.shape[1], kw)
-            Y = plan.solve(Y).clone()
+            Y = plan.solve(Y)                    # (a fresh tensor: copy=True)
             its += plan.iters
             if plan.status == 3:
                 raise RuntimeError("NaNs encountered in CG")
