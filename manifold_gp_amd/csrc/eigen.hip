@@ -816,13 +816,28 @@ __global__ __launch_bounds__(kBlock) void blz_dots_kernel(const float* __restric
   const int64_t stride = n * P;
   for (int i0 = 0; i0 < nq; i0 += 8) {          // 8 basis vectors per sweep over the chunk (registers)
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (on)
-      for (int64_t r = r0 + rl; r < r1; r += RL) {
-        const float w = W[r * P + p];
+    if (on) {
+      // two rows x (1 + 8) loads in flight per pass (clamped rows, masked products): with one row per pass the chunk was
+      // a chain of dependent round trips (34 us per launch at 60k x 12; the data is 3-60 MB)
+      const int nb = nq - i0 < 8 ? nq - i0 : 8;
+      for (int64_t rb = r0 + rl; rb < r1; rb += 2 * RL) {
+        float w[2], q[2][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (i0 + u < nq) acc[u] = fmaf(w, Q[(int64_t)(i0 + u) * stride + r * P + p], acc[u]);
+        for (int v = 0; v < 2; ++v) {
+          const int64_t r = rb + v * RL < r1 ? rb + v * RL : rb;
+          w[v] = W[r * P + p];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) q[v][u] = Q[(int64_t)(i0 + (u < nb ? u : 0)) * stride + r * P + p];
+        }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const float wv = rb + v * RL < r1 ? w[v] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (u < nb) acc[u] = fmaf(wv, q[v][u], acc[u]);
+        }
       }
+    }
     if (on)
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -837,21 +852,40 @@ __global__ __launch_bounds__(kBlock) void blz_dots_kernel(const float* __restric
   }
 }
 
-// h[i][p] = sum_blk partial; W -= sum_i h[i][p] Q_i; alpha[p] (+)= h[nq-1][p]; norm partials of the new W
+// out[e] = sum_blk partial[blk][e], e < count: four lanes per element (blocks part, part + 4, ...; eight loads in flight
+// each), quad xor-sum -- a fixed order.  Every workgroup of blz_update / blz_normalize used to re-reduce all nblk partials
+// itself, one serial chain of nblk loads per thread: 71 / 34 us per launch at 60k x 12.
+__global__ __launch_bounds__(kBlock) void blz_reduce_kernel(const float* __restrict__ partial, int nblk, int count,
+                                                            float* __restrict__ out) {
+  const int e = blockIdx.x * (kBlock / 4) + (threadIdx.x >> 2), part = threadIdx.x & 3;
+  const int ec = e < count ? e : count - 1;
+  float t = 0.f;
+  for (int b0 = part; b0 < nblk; b0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int b = b0 + 4 * k;
+      v[k] = partial[(int64_t)(b < nblk ? b : nblk - 1) * count + ec];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += (b0 + 4 * k < nblk) ? v[k] : 0.f;
+  }
+  t += __shfl_xor(t, 1, 64);
+  t += __shfl_xor(t, 2, 64);
+  if (part == 0 && e < count) out[e] = t;
+}
+
+// h[i][p] (reduced by blz_reduce_kernel); W -= sum_i h[i][p] Q_i; alpha[p] (+)= h[nq-1][p]; norm partials of the new W
 __global__ __launch_bounds__(kBlock) void blz_update_kernel(float* __restrict__ W, const float* __restrict__ Q, int64_t n,
                                                             int P, int nq, int64_t rows_per_block,
-                                                            const float* __restrict__ partial, int nblk,
+                                                            const float* __restrict__ hsum,
                                                             float* __restrict__ alpha_row, int accumulate,
                                                             float* __restrict__ norm_partial) {
   extern __shared__ float sh[];                 // h [nq][P], then reduction scratch [RL][P]
   float* h = sh;
   float* red = sh + nq * P;
   const int RL = kBlock / P;
-  for (int e = threadIdx.x; e < nq * P; e += kBlock) {
-    float t = 0.f;
-    for (int bI = 0; bI < nblk; ++bI) t += partial[(int64_t)bI * nq * P + e];
-    h[e] = t;
-  }
+  for (int e = threadIdx.x; e < nq * P; e += kBlock) h[e] = hsum[e];
   __syncthreads();
   if (blockIdx.x == 0 && (int)threadIdx.x < P) {
     const float a = h[(nq - 1) * P + threadIdx.x];
@@ -867,7 +901,15 @@ __global__ __launch_bounds__(kBlock) void blz_update_kernel(float* __restrict__ 
   if (on)
     for (int64_t r = r0 + rl; r < r1; r += RL) {
       float v = W[r * P + p];
-      for (int i = 0; i < nq; ++i) v = fmaf(-h[i * P + p], Q[(int64_t)i * stride + r * P + p], v);
+      // eight basis vectors' loads in flight per batch (one at a time: nq dependent round trips per row)
+      for (int i0 = 0; i0 < nq; i0 += 8) {
+        float q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = Q[(int64_t)(i0 + u < nq ? i0 + u : i0) * stride + r * P + p];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < nq) v = fmaf(-h[(i0 + u) * P + p], q[u], v);
+      }
       W[r * P + p] = v;
       nn = fmaf(v, v, nn);
     }
@@ -882,12 +924,11 @@ __global__ __launch_bounds__(kBlock) void blz_update_kernel(float* __restrict__ 
 
 // beta[p] = sqrt(sum_blk norm_partial[blk][p]); Qnext = W / beta  (a zero column stays zero)
 __global__ __launch_bounds__(kBlock) void blz_normalize_kernel(const float* __restrict__ W, float* __restrict__ Qnext,
-                                                               int64_t n, int P, const float* __restrict__ norm_partial,
-                                                               int nblk, float* __restrict__ beta_row) {
+                                                               int64_t n, int P, const float* __restrict__ norm_sum,
+                                                               float* __restrict__ beta_row) {
   __shared__ float inv[kBlzMaxP];
   if ((int)threadIdx.x < P) {
-    float t = 0.f;
-    for (int bI = 0; bI < nblk; ++bI) t += norm_partial[(int64_t)bI * P + threadIdx.x];
+    const float t = norm_sum[threadIdx.x];
     const float b = sqrtf(t);
     inv[threadIdx.x] = b > 0.f ? 1.0f / b : 0.f;
     if (blockIdx.x == 0) beta_row[threadIdx.x] = b;
@@ -909,6 +950,7 @@ extern "C" size_t mgp_lanczos_tridiag_block_workspace_bytes(const mgp_operator_t
   s += mgp_align((size_t)256 * (steps + 1) * P * sizeof(float));        // dot partials
   s += mgp_align((size_t)256 * P * sizeof(float));                      // norm partials
   s += 2 * mgp_align((size_t)(steps + 1) * P * sizeof(float));          // alpha, beta
+  s += mgp_align((size_t)(steps + 1) * P * sizeof(float)) + mgp_align(kBlzMaxP * sizeof(float));   // reduced dots / norms
   return s + 4096;
 }
 
@@ -927,6 +969,8 @@ extern "C" int mgp_lanczos_tridiag_block(const mgp_operator_t* op, const float* 
   void* ow = ar.take<char>(owb);
   float* dpart = ar.take<float>((size_t)256 * (steps + 1) * P);
   float* npart = ar.take<float>((size_t)256 * P);
+  float* hsum = ar.take<float>((size_t)(steps + 1) * P);
+  float* nsum = ar.take<float>((size_t)kBlzMaxP);
   float* d_alpha = ar.take<float>((size_t)(steps + 1) * P);
   float* d_beta = ar.take<float>((size_t)(steps + 1) * P);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
@@ -943,11 +987,16 @@ extern "C" int mgp_lanczos_tridiag_block(const mgp_operator_t* op, const float* 
   MGP_HIP_TRY(hipMemcpyAsync(Q, Q0, blockf * sizeof(float), hipMemcpyDeviceToDevice, st));
   MGP_HIP_TRY(hipMemsetAsync(dpart, 0, (size_t)256 * P * sizeof(float), st));
   MGP_HIP_TRY(hipMemsetAsync(d_alpha, 0, (size_t)(steps + 1) * P * sizeof(float), st));
+  auto reduce = [&](const float* part, int count, float* out) {
+    hipLaunchKernelGGL(blz_reduce_kernel, dim3((unsigned)mgp_cdiv(count, kBlock / 4)), dim3(kBlock), 0, st, part, (int)nblk, count, out);
+  };
+  MGP_HIP_TRY(hipMemsetAsync(hsum, 0, (size_t)P * sizeof(float), st));
   hipLaunchKernelGGL(blz_update_kernel, dim3((int)nblk), dim3(kBlock), (size_t)(P + RL * P) * sizeof(float), st, W, Q, n, P, 1,
-                     rpb, dpart, (int)nblk, d_alpha + (size_t)steps * P, 0, npart);
+                     rpb, hsum, d_alpha + (size_t)steps * P, 0, npart);
   MGP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(blz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, W, Q, n, P, npart, (int)nblk,
-                     d_beta + (size_t)steps * P);
+  reduce(npart, P, nsum);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(blz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, W, Q, n, P, nsum, d_beta + (size_t)steps * P);
   MGP_LAUNCH_CHECK();
   for (int j = 0; j < steps; ++j) {
     float* qj = Q + (int64_t)j * blockf;
@@ -957,12 +1006,16 @@ extern "C" int mgp_lanczos_tridiag_block(const mgp_operator_t* op, const float* 
       hipLaunchKernelGGL(blz_dots_kernel, dim3((int)nblk), dim3(kBlock), (size_t)nq * RL * P * sizeof(float), st, W, Q, n, P,
                          nq, rpb, dpart);
       MGP_LAUNCH_CHECK();
+      reduce(dpart, nq * P, hsum);
+      MGP_LAUNCH_CHECK();
       hipLaunchKernelGGL(blz_update_kernel, dim3((int)nblk), dim3(kBlock), (size_t)(nq * P + RL * P) * sizeof(float), st, W,
-                         Q, n, P, nq, rpb, dpart, (int)nblk, d_alpha + (size_t)j * P, pass, npart);
+                         Q, n, P, nq, rpb, hsum, d_alpha + (size_t)j * P, pass, npart);
       MGP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(blz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, W, Q + (int64_t)(j + 1) * blockf, n, P, npart,
-                       (int)nblk, d_beta + (size_t)j * P);
+    reduce(npart, P, nsum);
+    MGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(blz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, W, Q + (int64_t)(j + 1) * blockf, n, P, nsum,
+                       d_beta + (size_t)j * P);
     MGP_LAUNCH_CHECK();
   }
   MGP_HIP_TRY(hipMemcpyAsync(alpha, d_alpha, (size_t)steps * P * sizeof(float), hipMemcpyDeviceToHost, st));
