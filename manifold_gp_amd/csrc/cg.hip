@@ -603,6 +603,18 @@ __global__ __launch_bounds__(kBlock) void cg_decide_c1_kernel(CgArgs a) {
   a.host_state[1] = 1;
 }
 
+// ---- End-of-graph marker.  The host reads the stopping flag alone while the first graph of a solve runs (a stream query
+// during a ~55 us solve costs ~5 us of it); a first graph that ends UNdecided (the solve needs more steps than the graph
+// holds) must still be noticed at once: its last node counts the graphs that have run to their end in a host-mapped word
+// the host reads next to the flag.  When the decision has been taken the host has long seen the flag: this launch is
+// behind the critical path.
+__global__ void cg_marker_kernel(int* state, int* host_state) {
+  const int c = state[5] + 1;
+  state[5] = c;
+  __threadfence_system();
+  host_state[4] = c;
+}
+
 // ---- Fused CG step (C == 1, tile SpMV, single-chain operator with nu >= 2, no preconditioner).
 // update_k and the FIRST SpMV of apply_{k+1} in one launch: one launch floor (~2.7 us) and the update
 // kernel's own load chain less per step.  A workgroup owns the same 64-row tiles as spmv_tile_kernel.
@@ -993,6 +1005,7 @@ struct CgPlan {
   const float* patched_rhs;   // rhs the cg_init node currently points at
   int solves;                 // run_cg calls so far (graphs are captured at the second one)
   int64_t last_solve_ns;      // host time of the previous solve when it ended inside its first chunk (0: it did not)
+  int marker_seq;             // first graphs launched so far = what cg_marker_kernel will have counted when the newest ends
   bool graphs_tried;
   bool init_free;             // no cg_init launch: the first apply reads the rhs itself (CgArgs::pd_bb)
   float* pd_bb;               // [nbs] partials of ||b||^2 written by the first apply
@@ -1118,6 +1131,10 @@ void capture_first(CgPlan* pl, int len) {
     for (int i = done_bodies; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
     if (decide && rc == MGP_OK) {
       hipLaunchKernelGGL(cg_decide_c1_kernel, dim3(1), dim3(kBlock), 0, pl->cap_stream, pl->args);
+      rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
+    }
+    if (rc == MGP_OK) {
+      hipLaunchKernelGGL(cg_marker_kernel, dim3(1), dim3(1), 0, pl->cap_stream, pl->args.state, pl->args.host_state);
       rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
     }
     hipGraph_t graph = nullptr;
@@ -1257,6 +1274,7 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   a.bb = blk + 4 * (size_t)C;
   a.resid = blk + 5 * (size_t)C;
   a.state = reinterpret_cast<int*>(blk + 6 * (size_t)C);
+  (void)hipMemsetAsync(a.state, 0, 16 * sizeof(int), pl->stream);      // (state[5]: cg_marker_kernel's count)
   {
     float* tot = ar.take<float>(3 * (size_t)C);
     a.tot = reduce_once ? tot : nullptr;
@@ -1307,6 +1325,7 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_true_rel, (size_t)C * sizeof(float), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&pl->dev_true_rel, pl->host_true_rel, 0);
   if (e != hipSuccess) { delete pl; return (int)e; }
+  memset(pl->host_state, 0, 16 * sizeof(int32_t));
 
   *plan_out = pl;
   return MGP_OK;
@@ -1376,6 +1395,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   for (;;) {
     const bool launched_first = first && pl->has_first;
     if (launched_first) {
+      ++pl->marker_seq;
       MGP_HIP_TRY(hipGraphLaunch(pl->exec_first, st));
     } else if (pl->has_graph) {
       MGP_HIP_TRY(hipGraphLaunch(pl->exec, st));
@@ -1397,13 +1417,15 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
     // flag (measured: 60.5 -> 58.4 us per 60k solve with no query during the solve -- the queries themselves, a
     // runtime lock each, delay the launch's progress); continuation chunks poll as before.
     volatile int32_t* flag = pl->host_state + 1;
-    if (launched_first && g_cg_poll_spin > 0 && pl->last_solve_ns > 0) {
-      const int64_t budget = 2 * pl->last_solve_ns + 20000;
+    if (launched_first && g_cg_poll_spin > 0) {
+      // (not even one query every 20 us: two or three of them during a 55 us solve took the whole gain back.)  The
+      // graph's last node (cg_marker_kernel) reports a first graph that ran to its end undecided; the time budget --
+      // ten times the last decided solve, at least 2 ms -- is only the guard against a marker that never comes.
+      const int64_t budget = 10 * pl->last_solve_ns + 2000000;
       const auto t_spin = std::chrono::steady_clock::now();
-      // (not even one query every 20 us: two or three of them during a 55 us solve took the whole gain back.  A first
-      // graph that ends UNdecided costs this window once; the graph is then re-captured for the longer solve, below)
-      while (!*flag) {
-        for (int spin = 0; spin < g_cg_poll_spin && !*flag; ++spin) __builtin_ia32_pause();
+      volatile int32_t* marker = pl->host_state + 4;
+      while (!*flag && *marker != pl->marker_seq) {
+        for (int spin = 0; spin < g_cg_poll_spin && !*flag && *marker != pl->marker_seq; ++spin) __builtin_ia32_pause();
         if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_spin).count() > budget) break;
       }
     }
