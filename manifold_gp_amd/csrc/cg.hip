@@ -1184,9 +1184,9 @@ extern "C" size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C) {
   return cg_bytes(op, C);
 }
 
-// Graphs are captured at the SECOND solve of a plan: capture + instantiate cost ~20-30 ms, more than a
-// whole solve, and plans built for a one-off solve (every epoch of a training loop has new operator
-// values, hence a new plan) never earn it back.  The first solve runs the same launches eagerly.
+// Graphs are captured at the SECOND solve of a plan: capture + instantiate cost ~0.3 ms (7 ms the first time in a
+// process; tools/lab/time_capture.py), as much as a short solve, and plans built for a one-off solve never earn it
+// back.  The first solve runs the same launches eagerly.
 static void capture_graphs(CgPlan* pl) {
   pl->graphs_tried = true;
   if (!pl->prm.use_graph || pl->is_dist) return;   // collectives are enqueued eagerly (no capture)
