@@ -289,3 +289,58 @@ def test_operators_rebuild_from_their_constructor_record(monkeypatch):
         assert all(torch.is_tensor(t) for t in op.representation())
     assert lap._kwargs["normalization"] == "randomwalk" and "graph" not in lap._kwargs
     assert ops[1].transposed is True and ops[1]._kwargs["transposed"] is True
+
+
+def test_generic_block_lanczos_and_inverse_quadrature_on_cpu():
+    """slq._lanczos_block_generic (batched Gram-Schmidt, coefficients read back once) on a small dense SPD matrix on the
+    CPU: the tridiagonals' quadrature of log reproduces log det A to the stochastic error, and the same runs over A^-1
+    with log(1 / mu) at the Ritz values (what the Schur-complement log-determinant does) give the same number."""
+    import numpy as np
+    import torch
+    from manifold_gp_amd.slq import _lanczos_block_generic, _quadrature_log_sum
+    rng = np.random.default_rng(4)
+    n, P, steps = 160, 16, 40
+    M = rng.normal(size=(n, n))
+    A = torch.from_numpy((M @ M.T / n + 0.5 * np.eye(n)).astype(np.float32))
+    Ainv = torch.linalg.inv(A.double()).float()
+
+    class Op:
+        def __init__(self, mat):
+            self.mat, self.shape = mat, mat.shape
+
+        def matmul(self, V):
+            return self.mat @ V
+
+    Z = torch.from_numpy(rng.choice([-1.0, 1.0], size=(n, P)).astype(np.float32))
+    a, b = _lanczos_block_generic(Op(A), Z, steps)
+    ai, bi = _lanczos_block_generic(Op(Ainv), Z, steps)
+    want = float(torch.linalg.slogdet(A.double())[1])
+    direct = n * _quadrature_log_sum(a, b) / P
+    inverse = n * _quadrature_log_sum(ai, bi, lambda mu: 1.0 / np.maximum(mu, 1e-30)) / P
+    assert abs(direct - inverse) < 2e-3 * abs(want) + 1e-2, (direct, inverse)
+    assert abs(direct - want) < 0.05 * abs(want) + 0.5, (direct, want)
+
+
+def test_factorised_solve_is_chosen_only_for_unmasked_chains():
+    """solvers._factorisable: form 0, nu >= 2, pre / post absent (symmetric) or THE node scaling D^1/2 of the graph
+    (random walk); masks folded into pre / post, the noise forms, nu = 1 and refinement requests keep the whole-chain CG."""
+    import types
+    import torch
+    from manifold_gp_amd import solvers
+    from manifold_gp_amd.operators._descriptor import Descriptor
+    sq = torch.rand(10) + 0.5
+    data = types.SimpleNamespace(dsqrt=sq, dinvsqrt=1.0 / sq, graph=types.SimpleNamespace(n=10))
+    sym = Descriptor(data, 2, 1.3)
+    rw = Descriptor(data, 2, 1.3, pre=sq, post=sq)
+    assert solvers._factorisable(sym, {}) and solvers._factorisable(rw, {})
+    assert not solvers._factorisable(sym.with_(nu=1), {})
+    assert not solvers._factorisable(rw.with_(form=2, noise=0.1), {}) and not solvers._factorisable(rw.with_(form=1, noise=0.1), {})
+    mask = torch.ones(10)
+    mask[::2] = 0
+    assert not solvers._factorisable(rw.masked(mask, mask), {}) and not solvers._factorisable(sym.masked(mask, mask), {})
+    assert not solvers._factorisable(rw, {"refine": 2})
+    solvers.FACTORISED_SOLVES[0] = False
+    try:
+        assert not solvers._factorisable(rw, {})
+    finally:
+        solvers.FACTORISED_SOLVES[0] = True
