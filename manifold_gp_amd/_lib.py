@@ -150,6 +150,7 @@ SIGNATURES = {
     "mgp_features_oos": (c_int, [_P, _P, c_int64, c_int, c_int, c_float, c_float, c_int, _P, _P, _P, _P,
                                  c_int64, c_int, c_float, c_float, _P, _P]),
     "mgp_kernel_block": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, _P, _P]),
+    "mgp_kernel_block_set_pipe": (c_int, [c_int]),
     "mgp_kernel_diag": (c_int, [_P, _P, c_int64, c_int, c_float, _P, _P]),
     "mgp_lowrank_workspace_bytes": (c_size_t, [c_int, c_int]),
     "mgp_lowrank_apply": (c_int, [_P, c_int64, c_int, _P, c_int, c_float, c_float, _P, _P, c_size_t, _P]),

@@ -5,6 +5,7 @@
 // Reference: manifold_gp/kernels/riemann_kernel.py:79-149, riemann_matern_kernel.py:21-22,
 // manifold_gp/operators/graph_laplacian_operator.py:146-157, manifold_gp/utils/torch_utils.py:38-41.
 #include <math.h>
+#include <type_traits>
 #include "mgp_common.h"
 
 namespace {
@@ -156,13 +157,18 @@ __global__ __launch_bounds__(kBlock) void features_oos_kernel(
 // v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
 // C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int kKB = 128;   // workgroup tile (rows of Z1 x rows of Z2)
 constexpr int kKC = 16;    // modes per LDS stage (32 is no faster and wastes the tail stage at m = 100)
 
 // VEC (m % 4 == 0, 16-byte aligned rows): 16-byte global loads, and the next 16-mode stage is fetched
 // into registers while the MFMAs of the current one run -- with scalar staging and no prefetch every
 // stage exposed a full memory round trip (~1 us against ~0.85 us of MFMA work per stage).
-template <bool VEC>
+// X4 (n2 % 4 == 0, ldk % 4 == 0, K 16-byte aligned): the MFMA operands are swapped, so a lane's four consecutive accumulator
+// registers are four consecutive COLUMNS of one row of K and go out as one 16-byte store.  A vector store costs the CU about 64
+// cycles of its memory pipe whatever its width: with one dword per lane the 256 store instructions of a tile were 16k cycles
+// against 13k cycles of MFMA at m = 100, and the kernel ran at the rate of its stores (1.5 TB/s of K), not of the matrix pipe.
+template <bool VEC, bool X4>
 __global__ __launch_bounds__(kBlock) void kernel_block_mfma(const float* __restrict__ Z1, int64_t n1,
                                                             const float* __restrict__ Z2, int64_t n2, int m,
                                                             float scale, float* __restrict__ K, int64_t ldk) {
@@ -238,9 +244,28 @@ __global__ __launch_bounds__(kBlock) void kernel_block_mfma(const float* __restr
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = X4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+  }
+  if (X4) {
+    // transposed accumulators: K row = the MFMA column (lane & 31), K columns = 8 (r >> 2) + 4 (lane >> 5) + (r & 3)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t row = row0 + wr * 64 + i * 32 + (lane & 31);
+          const int64_t col = col0 + wc * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = scale * acc[i][j][4 * g + e];
+          // default cache policy: a non-temporal store of PART of a line (here 32 B of each of 32 rows) runs at a fifth of the rate
+          if (row < n1 && col < n2) *reinterpret_cast<f32x4*>(K + row * ldk + col) = v;
+        }
+    return;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -253,6 +278,228 @@ __global__ __launch_bounds__(kBlock) void kernel_block_mfma(const float* __restr
         // write-once output, larger than L2 at the shapes that matter: streaming (non-temporal) stores
         if (row < n1 && col < n2) __builtin_nontemporal_store(scale * acc[i][j][r], K + row * ldk + col);
       }
+}
+
+// The same product with the matrix pipe handed back and forth between TWO HALVES of one 512-thread workgroup per CU (X4 inputs
+// only).  What the stage stamps, the store-rate lab (tools/lab/storebw.hip) and a run with every store dropped showed about
+// kernel_block_mfma at two or three independent waves per SIMD:
+//  * K leaves the chip at 5-6 TB/s whatever a store instruction's width (144 MB: 24-28 us of a 103 us launch), as long as it is
+//    not a non-temporal store of PART of a line (32 rows x 32 B per instruction with nt: 1.0 TB/s): the stores are not the bound;
+//  * with no store at all the launch still takes 81 us for 54 us of MFMA: a wave's 32 MFMAs of a 16-mode stage are 2048 cycles
+//    of the pipe, and the pipe idles whenever both waves of a SIMD are between MFMA blocks at once (waiting for staging loads,
+//    writing LDS, at their workgroup's barrier, reading the first operands).  Independent workgroups drift into exactly that:
+//    measured stage cadence 5500 cycles for 2 x 2048 of MFMA.
+// So the alternation is made explicit.  Each half (4 waves, one per SIMD, 64 x 64 of a 128 x 128 tile each) walks its own tiles
+// t = 2 blockIdx.x + half, + 2 gridDim.x, ... and lives in two kinds of phase, a workgroup barrier after each:
+//     MFMA phase     issue the staging loads of the next stage (ONE instruction each: 32-bit lane offset fixed per tile + scalar
+//                    base that advances with the stage), then the stage's MFMAs from the half's LDS image;
+//     service phase  after a tile's last stage: scale the accumulators and store them (16 stores of 16 bytes per lane, see X4);
+//                    wait for the staging loads, write them to LDS (single buffer: the half's MFMAs are not running).
+// While one half is in its MFMA phase the other is in its service phase, so each SIMD always has exactly one wave feeding the
+// pipe and one wave doing everything else in its shadow.  One accumulator set, one LDS image per half.
+//  * no branch around a store or a load: the last row tile and the last column tile are moved back to end at n1 / n2, writing
+//    what they share with their neighbours twice with the same values.  Buffer stores: one VGPR of lane offset, the rest of the
+//    address scalar or constant (host side: 512 ldk < 2^31).
+//  * the ragged last stage (m not a multiple of 16) runs TS = 2, 4 or 6 two-mode steps: a template parameter, and the last
+//    stage is peeled out of the stage loop, so that no two alternative MFMA sequences meet in a join (where they did, the
+//    compiler copied accumulators between MFMAs).
+struct KbTile {
+  __amdgpu_buffer_rsrc_t rs;
+  int lane_off;
+};
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+// q = 0..15 -> accumulator (i, j) = (q >> 3, (q >> 2) & 1), registers 4 g .. 4 g + 3 with g = q & 3: with the operands swapped
+// (see kernel_block_mfma X4) these are columns j 32 + 8 g + 4 (lane >> 5) + 0..3 of row i 32 + (lane & 31) of the wave's 64 x 64
+// The data registers of these stores are the accumulators themselves and nothing writes them until kb_store_done: a 16-byte
+// buffer store reads its data over several cycles after issue, and with a REGISTER in the scalar-offset field the compiler does
+// not keep the next VALU write of those registers away from it (its hazard rule covers only the constant-offset form): with
+// scaled temporaries reused from store to store, lanes 12-15 of every 16 of the stores with a scalar row offset got the NEXT
+// store's first two values.
+template <int Q>
+__device__ __forceinline__ void kb_store_q(const f32x16 (&acc)[2][2], const KbTile& o, int ldk4) {
+  constexpr int i = Q >> 3, j = (Q >> 2) & 1, g = Q & 3;
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+  // the lane's part in the vector offset, the sub-tile's rows in the scalar offset, its columns as a constant
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o.rs, o.lane_off + (j * 32 + 8 * g) * 4, i * 32 * ldk4, 0);
+}
+
+template <int Q0, int N>
+__device__ __forceinline__ void kb_store_range(const f32x16 (&acc)[2][2], const KbTile& o, int ldk4) {
+  if constexpr (N > 0) {
+    kb_store_q<Q0>(acc, o, ldk4);
+    kb_store_range<Q0 + 1, N - 1>(acc, o, ldk4);
+  }
+}
+
+// between the last store and the first write of its data registers
+__device__ __forceinline__ void kb_store_done() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 4");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int kKS = kKC + 1;      // LDS row stride in floats: odd, so the 32 rows a half-wave reads fall in 32 banks
+
+// NS two-mode steps of one stage, straight-line
+template <int NS, int ST = 0>
+__device__ __forceinline__ void kb_steps(const float (*__restrict__ A)[kKS], const float (*__restrict__ B)[kKS], int arow, int brow,
+                                         int khalf, float a0, float a1, float b0, float b1, f32x16 (&acc)[2][2]) {
+  if constexpr (ST < NS) {
+    const float c0 = a0, c1 = a1, d0 = b0, d1 = b1;
+    if constexpr (ST + 1 < NS) {
+      const int ksel = 2 * (ST + 1) + khalf;
+      a0 = A[arow][ksel], a1 = A[arow + 32][ksel], b0 = B[brow][ksel], b1 = B[brow + 32][ksel];
+    }
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, c0, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, c0, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d0, c1, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d1, c1, acc[1][1], 0, 0, 0);
+    kb_steps<NS, ST + 1>(A, B, arow, brow, khalf, a0, a1, b0, b1, acc);
+  }
+}
+
+constexpr int kPpThreads = 2 * kBlock;
+
+template <int TS>
+__global__ __launch_bounds__(kPpThreads, 1) void kernel_block_pp(const float* __restrict__ Z1, int64_t n1,
+                                                                 const float* __restrict__ Z2, int64_t n2, int m, float scale,
+                                                                 float* __restrict__ K, int64_t ldk, int nrt, int ntiles,
+                                                                 int records) {
+  __shared__ float As[2][kKB][kKS];                     // [half]
+  __shared__ float Bs[2][kKB][kKS];
+  // wave-uniform by construction; said so, so that the tile walk and its branches are scalar
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;              // 2 x 2 waves per half, 64 x 64 each
+  const int arow = wr * 64 + (lane & 31), brow = wc * 64 + (lane & 31), khalf = lane >> 5;
+  const int ldk4 = (int)ldk * 4;
+  const int nst = (m + kKC - 1) / kKC;
+  const float (*A)[kKS] = As[half];
+  const float (*B)[kKS] = Bs[half];
+
+  constexpr int QPR = kKC / 4, NF = kKB * QPR / kBlock;
+  f32x4 ra[NF], rb[NF];
+  const int kq4 = 4 * (tid % QPR);                      // this lane's quad inside a stage (kBlock is a multiple of QPR)
+  int offa[NF], offb[NF];                               // byte offsets of this lane's rows in Z1 / Z2 (host side: both < 2^31)
+  auto aim = [&](int64_t row0, int64_t col0) {
+#pragma unroll
+    for (int h = 0; h < NF; ++h) {
+      const int r = (tid + h * kBlock) / QPR;
+      offa[h] = (int)(((row0 + r) * m + kq4) * 4);
+      offb[h] = (int)(((col0 + r) * m + kq4) * 4);
+    }
+  };
+  // The staging loads are inline asm and so is their wait.  As compiler-visible loads they were followed, a few instructions
+  // later, by `s_waitcnt vmcnt(1); v_mov` of two of the loaded dwords (live-range splitting: the registers were wanted for LDS
+  // addresses inside the MFMA block), a full memory round trip in front of every stage.  The compiler does not know these
+  // registers are in flight, so nothing may read them before kb_wait: the "+v" operands of kb_wait tie every later use to it
+  // (tests/test_host_cpu.py compiles this file and checks the instruction stream for exactly that).
+  // k0 past m - 16 (the ragged last stage): quads past m are aimed at the row's last quad instead; they are staged like the
+  // rest and never read (that stage runs TS steps).  One select, no second code path.
+  const int back_last = ((nst - 1) * kKC + kq4 < m) ? 0 : (m - 4 - (nst - 1) * kKC - kq4) * 4;
+  auto fetch = [&](int k0) {
+    const float* sa = Z1 + k0;
+    const float* sb = Z2 + k0;
+    const int back = (k0 + kKC > m) ? back_last : 0;
+#pragma unroll
+    for (int h = 0; h < NF; ++h) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[h]) : "v"(offa[h] + back), "s"(sa));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[h]) : "v"(offb[h] + back), "s"(sb));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // vmcnt counts loads and stores in issue order; the wait comes before the service phase's stores, so nothing issued after the
+  // staging loads may still be in flight: 0
+  auto kb_wait = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]));
+#pragma unroll
+    for (int h = 1; h < NF; ++h) asm volatile("" : "+v"(ra[h]), "+v"(rb[h]));
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int h = 0; h < NF; ++h) {
+      const int r = (tid + h * kBlock) / QPR;
+      float* a = &As[half][r][kq4];
+      float* b = &Bs[half][r][kq4];
+      a[0] = ra[h].x; a[1] = ra[h].y; a[2] = ra[h].z; a[3] = ra[h].w;
+      b[0] = rb[h].x; b[1] = rb[h].y; b[2] = rb[h].z; b[3] = rb[h].w;
+    }
+  };
+  auto describe = [&](int64_t row0, int64_t col0) {
+    KbTile o;
+    float* base = K + row0 * ldk + col0;
+    const uint64_t bits = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bits), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bits >> 32));
+    o.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, records, 0x00020000);
+    o.lane_off = ((wr * 64 + (lane & 31)) * (int)ldk + wc * 64 + 4 * (lane >> 5)) * 4;
+    return o;
+  };
+  auto zero = [](f32x16 (&x)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[i][j][r] = 0.f;
+  };
+  // the last row tile and the last column tile are moved back to end at n1 / n2 (host side: both >= 128, n2 a multiple of 4)
+  auto row_of = [&](int tt) { const int64_t r = (int64_t)(tt % nrt) * kKB; return r + kKB <= n1 ? r : n1 - kKB; };
+  auto col_of = [&](int tt) { const int64_t c = (int64_t)(tt / nrt) * kKB; return c + kKB <= n2 ? c : n2 - kKB; };
+
+  // tiles of this half, and of the half with more of them (half 0): every wave passes the same number of barriers
+  const int first = 2 * blockIdx.x + half, stride = 2 * gridDim.x;
+  const int mine = first < ntiles ? (ntiles - first + stride - 1) / stride : 0;
+  const int most = (ntiles - 2 * (int)blockIdx.x + stride - 1) / stride;     // half 0's count (blockIdx.x < ntiles / 2 rounded up)
+
+  f32x16 acc[2][2];
+  zero(acc);
+  if (mine > 0) {
+    aim(row_of(first), col_of(first));
+    fetch(0);
+    kb_wait();
+    stash();
+  }
+  __syncthreads();
+  if (half == 1) __syncthreads();          // half 1 runs one phase behind half 0
+
+  int t = first;
+  for (int it = 0; it < mine; ++it, t += stride) {
+    const KbTile out = describe(row_of(t), col_of(t));
+    const bool next_tile = it + 1 < mine;
+    // MFMA phases of the full stages, each followed by its service phase
+    for (int s = 0; s + 1 < nst; ++s) {
+      fetch((s + 1) * kKC);
+      kb_steps<kKC / 2>(A, B, arow, brow, khalf, A[arow][khalf], A[arow + 32][khalf], B[brow][khalf], B[brow + 32][khalf], acc);
+      __syncthreads();
+      kb_wait();
+      stash();
+      __syncthreads();
+    }
+    // the last stage: the next tile's first stage is what travels meanwhile, and the tile is written in the service phase
+    if (next_tile) {
+      aim(row_of(t + stride), col_of(t + stride));
+      fetch(0);
+    }
+    kb_steps<TS>(A, B, arow, brow, khalf, A[arow][khalf], A[arow + 32][khalf], B[brow][khalf], B[brow + 32][khalf], acc);
+    __syncthreads();
+    kb_wait();                     // unconditional: no branch between a staging load and its wait (tools/check_kblock_isa.py)
+    if (next_tile) stash();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] *= scale;
+    __builtin_amdgcn_sched_barrier(0);
+    kb_store_range<0, 16>(acc, out, ldk4);
+    kb_store_done();
+    zero(acc);
+    __syncthreads();
+  }
+  // the barriers of the phases this half does not have
+  const int pad = 2 * nst * (most - mine) + (half == 0 ? 1 : 0);
+  for (int i = 0; i < pad; ++i) __syncthreads();
 }
 
 __global__ void kernel_diag_kernel(const float* __restrict__ Z1, const float* __restrict__ Z2, int64_t n, int m,
@@ -379,14 +626,44 @@ extern "C" int mgp_features_oos(const float* evals_dev, const float* evecs, int6
   return MGP_OK;
 }
 
+constexpr int kPpBlocks = 256;     // one 512-thread workgroup per CU, two tile walks each
+// Measured (tools/lab/ab_kblock.py, tools/lab/clock_kblock.py; us, one tile per workgroup -> two-half walk):
+//   600 x 60000 x 100 (2345 tiles) 107 -> 111;  1000 x 50000 x 64 (3128) 83 -> 87;  8192 x 8192 x 256 (4096) 301 -> 297;
+//   4096 x 60000 x 100 (15008) 637 -> 568;  32768 x 60000 x 128 (120064) 4829 -> 4593 (104 -> 110 TFLOP/s; 127 with the stores
+//   dropped; clock 2.31 GHz on random operands, 2.39 on zeros: the chip does not hold its clock down here).
+// The walk pays from about 8 tiles per half: below that the tail of the walk (a half with 5 tiles beside halves with 4) costs
+// more than the idle matrix pipe it removes.
+constexpr int64_t kPpMinTiles = 4096;
+int g_kblock_pipe = 1;             // 0 = one tile per workgroup always, 1 = the two-half walk above kPpMinTiles tiles, 2 = always (tests)
+
 // K row stride ldk >= n2 (internal: the eigensolver rotates blocks in place of wider buffers)
 int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale, float* K,
                         int64_t ldk, void* stream) {
   if (!Z1 || !Z2 || !K || n1 <= 0 || n2 <= 0 || m <= 0 || ldk < n2) return MGP_ERR_ARG;
   dim3 grid((unsigned)mgp_cdiv(n2, kKB), (unsigned)mgp_cdiv(n1, kKB));
   const bool vec = (m % 4 == 0) && ((reinterpret_cast<uintptr_t>(Z1) | reinterpret_cast<uintptr_t>(Z2)) & 15) == 0;
-  if (vec) hipLaunchKernelGGL(kernel_block_mfma<true>, grid, dim3(kBlock), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, ldk);
-  else hipLaunchKernelGGL(kernel_block_mfma<false>, grid, dim3(kBlock), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, ldk);
+  const bool x4 = vec && n2 % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0;
+  const int64_t ntiles = (int64_t)grid.x * grid.y;
+  if (x4 && g_kblock_pipe && n1 >= kKB && n2 >= kKB && ldk * 512 < (int64_t(1) << 31) && ntiles < (int64_t(1) << 30) &&
+      n1 * m < (int64_t(1) << 29) && n2 * m < (int64_t(1) << 29) && (g_kblock_pipe >= 2 || ntiles > kPpMinTiles)) {
+    // tile id = column tile * row tiles + row tile, so the tiles in flight together share their Z2 rows
+    const int64_t nb = (ntiles + 1) / 2 < kPpBlocks ? (ntiles + 1) / 2 : kPpBlocks;
+    const int records = g_kblock_pipe == 3 ? 0 : 0x7fffffff;   // 3: a descriptor of zero bytes drops every store (timing only)
+    const int ts = (m - (m - 1) / kKC * kKC) / 2;      // 2-mode steps of the last 16-mode stage: 2, 4, 6 or 8
+#define MGP_KB_LAUNCH(TS)                                                                                                   \
+  hipLaunchKernelGGL(kernel_block_pp<TS>, dim3((unsigned)nb), dim3(kPpThreads), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, \
+                     ldk, (int)grid.y, (int)ntiles, records)
+    if (ts == 8) MGP_KB_LAUNCH(8);
+    else if (ts == 6) MGP_KB_LAUNCH(6);
+    else if (ts == 4) MGP_KB_LAUNCH(4);
+    else MGP_KB_LAUNCH(2);
+#undef MGP_KB_LAUNCH
+    MGP_LAUNCH_CHECK();
+    return MGP_OK;
+  }
+  if (x4) hipLaunchKernelGGL((kernel_block_mfma<true, true>), grid, dim3(kBlock), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, ldk);
+  else if (vec) hipLaunchKernelGGL((kernel_block_mfma<true, false>), grid, dim3(kBlock), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, ldk);
+  else hipLaunchKernelGGL((kernel_block_mfma<false, false>), grid, dim3(kBlock), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, ldk);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
@@ -394,6 +671,12 @@ int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2
 extern "C" int mgp_kernel_block(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale,
                                 float* K, void* stream) {
   return mgp_kernel_block_ld(Z1, n1, Z2, n2, m, scale, K, n2, stream);
+}
+
+extern "C" int mgp_kernel_block_set_pipe(int mode) {
+  if (mode < 0 || mode > 3) return MGP_ERR_ARG;    // 3 (lab): the pipelined walk with every store dropped by the hardware
+  g_kblock_pipe = mode;
+  return MGP_OK;
 }
 
 extern "C" int mgp_kernel_diag(const float* Z1, const float* Z2, int64_t n, int m, float scale, float* out,

@@ -485,6 +485,37 @@ def test_kernel_block_mfma_layout(mgp, dev):
     assert float((lowrank_apply(A, X, 0.3, 0.2).double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n1,n2,m", [(128, 256, 16), (131, 260, 8), (300, 1028, 36), (517, 388, 100), (256, 640, 48),
+                                     (200, 132, 60), (384, 384, 128), (129, 129 * 4, 12)])
+def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, m):
+    """mgp_kernel_block's two kernels on the same operands: one 128 x 128 tile per workgroup (knob 0) and the two-half tile walk
+    (knob 2: every ragged last stage m % 16 in {0, 4, 8, 12}, single-stage m, last row / column tiles moved back over their
+    neighbours, odd tile counts so that one half has a tile less).  Both against fp64, and bit-identical to each other (same
+    operands, same summation order); a NaN canary catches an entry nobody wrote."""
+    from manifold_gp_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(n1 * 7 + n2 * 3 + m)
+    Z1 = torch.randn(n1, m, generator=g).to(dev)
+    Z2 = torch.randn(n2, m, generator=g).to(dev)
+    ref = 1.7 * (Z1.double() @ Z2.double().t())
+    outs = []
+    try:
+        for knob in (0, 2):
+            assert lib.mgp_kernel_block_set_pipe(knob) == 0
+            K = torch.full((n1, n2), float("nan"), device=dev)
+            for _ in range(3):          # back to back: a launch must not depend on what the one before left in LDS / registers
+                assert lib.mgp_kernel_block(_lib.ptr(Z1), n1, _lib.ptr(Z2), n2, m, 1.7, _lib.ptr(K), _lib.stream()) == 0
+            torch.cuda.synchronize()
+            assert not torch.isnan(K).any(), knob
+            assert float((K.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max()) * max(1.0, m / 16) ** 0.5 + 1e-6, knob
+            outs.append(K)
+    finally:
+        lib.mgp_kernel_block_set_pipe(1)
+    assert torch.equal(outs[0], outs[1])
+    assert lib.mgp_kernel_block_set_pipe(7) != 0
+
+
 def test_spectral_posterior_vs_woodbury_fp64(mgp, golden, dev):
     """Posterior mean / variance with K = s Z Z^T + noise I: CG on device vs the fp64 Woodbury
     closed form (what gpytorch evaluates for the reference), 1e-4 relative."""

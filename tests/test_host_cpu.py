@@ -344,3 +344,38 @@ def test_factorised_solve_is_chosen_only_for_unmasked_chains():
         assert not solvers._factorisable(rw, {})
     finally:
         solvers.FACTORISED_SOLVES[0] = True
+
+
+def test_kernel_block_pp_instruction_stream_respects_its_own_waits():
+    """kernel_block_pp's staging loads are inline asm the compiler does not track (features.hip): tools/check_kblock_isa.py
+    compiles the file for gfx950 and verifies that nothing touches a destination register of such a load before the kernel's own
+    vmcnt wait, and that the tile's 16 stores keep their data registers until the s_nop.  The checker itself is exercised on a
+    doctored stream first."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_kblock_isa", os.path.join(root, "tools", "check_kblock_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    body = ["\tglobal_load_dwordx4 v[64:67], v5, s[20:21]", "\tv_mfma_f32_32x32x2_f32 v[0:15], v100, v101, v[0:15]",
+            "\ts_waitcnt vmcnt(0)", "\tds_write2_b32 v6, v64, v65 offset1:1"] + \
+           ["\tbuffer_store_dwordx4 v[%d:%d], v90, s[16:19], s56 offen" % (4 * q, 4 * q + 3) for q in range(16)] + ["\ts_nop 4", "\tv_mov_b32_e32 v0, 0"]
+    def kernels(lines):
+        out = []
+        for ts in (8, 6, 4, 2):
+            out += ["_ZN12_GLOBAL__N_115kernel_block_ppILi%dEEEvPKflS2_lifPfliii:" % ts] + lines + ["\t.end_amdhsa_kernel"]
+        return "\n".join(out)
+    assert chk.check(kernels(body)) == []
+    early_read = body[:1] + ["\tv_mov_b32_e32 v152, v65"] + body[1:]
+    assert any("in-flight" in p for p in chk.check(kernels(early_read)))
+    branch = body[:1] + ["\ts_cbranch_vccnz .LBB10_12"] + body[1:]
+    assert any("branch" in p for p in chk.check(kernels(branch)))
+    clobber = body[:-2] + ["\tv_pk_mul_f32 v[60:61], s[6:7], v[2:3]"] + body[-2:]
+    assert any("before the s_nop" in p for p in chk.check(kernels(clobber)))
+    assert any("expected the tile's 16" in p for p in chk.check(kernels(body[:10] + body[-2:])))
+    if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None:
+        pytest.skip("hipcc not found: only the checker's own logic was tested")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_kblock_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr

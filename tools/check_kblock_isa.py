@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""Static check of kernel_block_pp's instruction stream (manifold_gp_amd/csrc/features.hip).
+
+Its staging loads are inline asm (`global_load_dwordx4`) whose completion the compiler does not track: the kernel waits for
+them with its own `s_waitcnt vmcnt(0)`.  That is only sound if NO instruction touches a destination register of such a load
+between the load and the next vmcnt wait.  This script compiles features.hip to gfx950 assembly and walks every
+kernel_block_pp<TS> instantiation in text order, which is execution order here: between a load and its wait the kernel has no
+branch (the check fails if it finds one); a label there is where the path that skipped the loads joins.  It also checks that the tile's 16
+stores are the only VMEM stores, that each is a 16-byte buffer store, and that nothing writes their data registers before
+kb_store_done's s_nop (the compiler's own hazard rule does not cover the register-soffset form, see features.hip).
+Exit code 0 = clean.  Used by tests/test_host_cpu.py; needs hipcc, no GPU."""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def regs_of(text):
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
+        out |= set(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", text):
+        out.add(int(a))
+    return out
+
+
+def check(asm):
+    lines = asm.split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN\d+_GLOBAL__N_1\d+kernel_block_ppILi\d+EE.*:\s*(;.*)?$", l)]
+    problems, seen = [], 0
+    for a in starts:
+        b = next(i for i in range(a, len(lines)) if ".end_amdhsa_kernel" in lines[i])
+        name = lines[a].split(":")[0]
+        seen += 1
+        inflight, stores, store_regs, after_stores = set(), 0, set(), False
+        for l in lines[a + 1:b]:
+            t = l.strip()
+            if not t or t.startswith(";") or t.startswith("."):
+                continue        # a label inside the window is a join with a path that issued no load: the window stays open
+            op = t.split()[0]
+            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\]", t)
+            if m:
+                inflight |= set(range(int(m.group(1)), int(m.group(2)) + 1))
+                continue
+            if op.startswith("global_load") or op.startswith("buffer_load") or op.startswith("flat_load"):
+                problems.append("%s: a load the check does not know: %s" % (name, t))
+            if op == "s_waitcnt" and "vmcnt(0)" in t:
+                inflight = set()
+                continue
+            if inflight:
+                if op.startswith("s_cbranch") or op == "s_branch":
+                    problems.append("%s: branch between a staging load and its wait: %s" % (name, t))
+                if regs_of(t) & inflight:
+                    problems.append("%s: touches an in-flight staging register: %s" % (name, t))
+            if op.startswith("buffer_store") or op.startswith("global_store") or op.startswith("flat_store"):
+                if op != "buffer_store_dwordx4":
+                    problems.append("%s: unexpected store %s" % (name, t))
+                stores += 1
+                store_regs |= regs_of(t.split(",")[0])
+                after_stores = True
+                continue
+            if after_stores:
+                if op == "s_nop":
+                    after_stores, store_regs = False, set()
+                elif op.startswith("v_") and regs_of(t.split(",")[0]) & store_regs:
+                    problems.append("%s: writes a store's data register before the s_nop: %s" % (name, t))
+        if stores != 16:
+            problems.append("%s: %d stores, expected the tile's 16" % (name, stores))
+    if seen != 4:
+        problems.append("expected 4 instantiations of kernel_block_pp, found %d" % seen)
+    return problems
+
+
+def main():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(ROOT, "manifold_gp_amd", "csrc", "features.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "features.s")
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"),
+               "-I" + os.path.dirname(src), "--cuda-device-only", "-S", src, "-o", out]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr[-2000:])
+            return 2
+        problems = check(open(out).read())
+    for p in problems:
+        print(p)
+    print("kernel_block_pp instruction stream:", "clean" if not problems else "%d problem(s)" % len(problems))
+    return 1 if problems else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
