@@ -384,9 +384,10 @@ int mgp_features_oos(const float* evals_dev, const float* evecs, int64_t n, int 
                      int k, float bump_scale, float bump_decay, float* Z, void* stream);
 int mgp_kernel_block(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale,
                      float* K, void* stream);
-/* A/B and test knob: 0 = one 128x128 tile per workgroup, 1 (default) = above 4096 tiles one 512-thread workgroup per CU
- * whose two halves walk tiles and take turns on the matrix pipe, 2 = that walk whenever the operands allow it
- * (n1, n2 >= 128, m and n2 multiples of 4, 16-byte aligned), 3 = as 2 with every store dropped (timing only). */
+/* A/B and test knob: 0 / 1 (default) = one 128x128 tile per workgroup, by the lean kernel (single-instruction staging loads,
+ * 16-byte stores) where the operands allow it (n1, n2 >= 128, m and n2 multiples of 4, 16-byte aligned) and by the general
+ * one elsewhere; 2 = where they allow it, one 512-thread workgroup per CU whose two halves walk tiles and take turns on the
+ * matrix pipe; 3 = as 2 with every store dropped (timing only); 4 = the general kernel always. */
 int mgp_kernel_block_set_pipe(int mode);
 int mgp_kernel_diag(const float* Z1, const float* Z2, int64_t n, int m, float scale, float* out,
                     void* stream);

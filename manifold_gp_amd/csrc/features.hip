@@ -502,6 +502,108 @@ __global__ __launch_bounds__(kPpThreads, 1) void kernel_block_pp(const float* __
   for (int i = 0; i < pad; ++i) __syncthreads();
 }
 
+// One tile per workgroup with the same lean stage as kernel_block_pp (single-instruction staging loads, exact ragged last stage,
+// 16-byte stores, edge tiles moved back), LDS double buffered, one barrier per stage, 107 VGPRs = four workgroups per CU.
+// The default kernel wherever its conditions hold: 4096 x 60000 x 100 628 -> 493 us (78 -> 100 TFLOP/s), 8192 x 8192 x 256
+// 300 -> 280 (123 TFLOP/s = 78 % of peak) against kernel_block_mfma; the 600 x 60000 x 100 posterior block stays at 105 us:
+// 2345 tiles are 2.3 rounds of the 1024 resident workgroups, and each tile's first staging round trip and its final stores
+// are a third of its 5.3 us of MFMA.
+template <int TS>
+__global__ __launch_bounds__(kBlock, 4) void kernel_block_one(const float* __restrict__ Z1, int64_t n1,
+                                                              const float* __restrict__ Z2, int64_t n2, int m, float scale,
+                                                              float* __restrict__ K, int64_t ldk, int nrt, int records) {
+  __shared__ float As[2][kKB][kKS];                     // [buffer]
+  __shared__ float Bs[2][kKB][kKS];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wr = wave >> 1, wc = wave & 1;              // 2 x 2 waves, 64 x 64 each
+  const int arow = wr * 64 + (lane & 31), brow = wc * 64 + (lane & 31), khalf = lane >> 5;
+  const int ldk4 = (int)ldk * 4;
+  const int nst = (m + kKC - 1) / kKC;
+  const int t = blockIdx.x;
+  int64_t row0 = (int64_t)(t % nrt) * kKB, col0 = (int64_t)(t / nrt) * kKB;
+  if (row0 + kKB > n1) row0 = n1 - kKB;                 // edge tiles moved back to end at n1 / n2 (host side: both >= 128)
+  if (col0 + kKB > n2) col0 = n2 - kKB;
+
+  constexpr int QPR = kKC / 4, NF = kKB * QPR / kBlock;
+  f32x4 ra[NF], rb[NF];
+  const int kq4 = 4 * (tid % QPR);
+  int offa[NF], offb[NF];
+#pragma unroll
+  for (int h = 0; h < NF; ++h) {
+    const int r = (tid + h * kBlock) / QPR;
+    offa[h] = (int)(((row0 + r) * m + kq4) * 4);
+    offb[h] = (int)(((col0 + r) * m + kq4) * 4);
+  }
+  // inline-asm staging loads and their wait: see kernel_block_pp
+  const int back_last = ((nst - 1) * kKC + kq4 < m) ? 0 : (m - 4 - (nst - 1) * kKC - kq4) * 4;
+  auto fetch = [&](int k0) {
+    const float* sa = Z1 + k0;
+    const float* sb = Z2 + k0;
+    const int back = (k0 + kKC > m) ? back_last : 0;
+#pragma unroll
+    for (int h = 0; h < NF; ++h) {
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[h]) : "v"(offa[h] + back), "s"(sa));
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[h]) : "v"(offb[h] + back), "s"(sb));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto kb_wait = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0]), "+v"(rb[0]));
+#pragma unroll
+    for (int h = 1; h < NF; ++h) asm volatile("" : "+v"(ra[h]), "+v"(rb[h]));
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < NF; ++h) {
+      const int r = (tid + h * kBlock) / QPR;
+      float* a = &As[buf][r][kq4];
+      float* b = &Bs[buf][r][kq4];
+      a[0] = ra[h].x; a[1] = ra[h].y; a[2] = ra[h].z; a[3] = ra[h].w;
+      b[0] = rb[h].x; b[1] = rb[h].y; b[2] = rb[h].z; b[3] = rb[h].w;
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  fetch(0);
+  kb_wait();
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int s = 0; s + 1 < nst; ++s) {
+    fetch((s + 1) * kKC);
+    kb_steps<kKC / 2>(As[buf], Bs[buf], arow, brow, khalf, As[buf][arow][khalf], As[buf][arow + 32][khalf], Bs[buf][brow][khalf],
+                      Bs[buf][brow + 32][khalf], acc);
+    kb_wait();
+    stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  kb_steps<TS>(As[buf], Bs[buf], arow, brow, khalf, As[buf][arow][khalf], As[buf][arow + 32][khalf], Bs[buf][brow][khalf],
+               Bs[buf][brow + 32][khalf], acc);
+  KbTile out;
+  {
+    float* base = K + row0 * ldk + col0;
+    const uint64_t bits = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bits), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bits >> 32));
+    out.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, records, 0x00020000);
+    out.lane_off = ((wr * 64 + (lane & 31)) * (int)ldk + wc * 64 + 4 * (lane >> 5)) * 4;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] *= scale;
+  __builtin_amdgcn_sched_barrier(0);
+  kb_store_range<0, 16>(acc, out, ldk4);
+  kb_store_done();
+}
+
 __global__ void kernel_diag_kernel(const float* __restrict__ Z1, const float* __restrict__ Z2, int64_t n, int m,
                                    float scale, float* __restrict__ out) {
   // one 16-lane group per row
@@ -627,14 +729,16 @@ extern "C" int mgp_features_oos(const float* evals_dev, const float* evecs, int6
 }
 
 constexpr int kPpBlocks = 256;     // one 512-thread workgroup per CU, two tile walks each
-// Measured (tools/lab/ab_kblock.py, tools/lab/clock_kblock.py; us, one tile per workgroup -> two-half walk):
-//   600 x 60000 x 100 (2345 tiles) 107 -> 111;  1000 x 50000 x 64 (3128) 83 -> 87;  8192 x 8192 x 256 (4096) 301 -> 297;
-//   4096 x 60000 x 100 (15008) 637 -> 568;  32768 x 60000 x 128 (120064) 4829 -> 4593 (104 -> 110 TFLOP/s; 127 with the stores
-//   dropped; clock 2.31 GHz on random operands, 2.39 on zeros: the chip does not hold its clock down here).
-// The walk pays from about 8 tiles per half: below that the tail of the walk (a half with 5 tiles beside halves with 4) costs
-// more than the idle matrix pipe it removes.
-constexpr int64_t kPpMinTiles = 4096;
-int g_kblock_pipe = 1;             // 0 = one tile per workgroup always, 1 = the two-half walk above kPpMinTiles tiles, 2 = always (tests)
+// Measured (profiles/r02_kernel_block.txt; us: general kernel | lean one tile per workgroup | two-half walk):
+//   600 x 60000 x 100 (2345 tiles)   106 | 105 | 107      1000 x 50000 x 64 (3128)      83 |  79 |  90
+//   4096 x 60000 x 100 (15008)       628 | 493 | 544      8192 x 8192 x 256 (4096)     300 | 280 | 283
+//   600 x 60000 x 128                120 | 123 | 119      32768 x 60000 x 128 (120064) 4829 | 4761 | 4609
+// (clock 2.31 GHz on random operands, 2.39 on zeros: the chip does not hold its clock down here; with the stores dropped the
+// walk reaches 127-129 TFLOP/s.)  The lean one-tile kernel is the default wherever its conditions hold; the walk is a knob:
+// it wins a few per cent on the largest blocks only, its static split loses to the hardware's own dispatch of 2000-4000 tiles.
+// 0 / 1 = lean one tile per workgroup where the operands allow it (default), 2 = the two-half walk where they allow it,
+// 3 = as 2 with every store dropped (timing), 4 = the general kernel always (kernel_block_mfma: any shape, any alignment)
+int g_kblock_pipe = 1;
 
 // K row stride ldk >= n2 (internal: the eigensolver rotates blocks in place of wider buffers)
 int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale, float* K,
@@ -644,8 +748,11 @@ int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2
   const bool vec = (m % 4 == 0) && ((reinterpret_cast<uintptr_t>(Z1) | reinterpret_cast<uintptr_t>(Z2)) & 15) == 0;
   const bool x4 = vec && n2 % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0;
   const int64_t ntiles = (int64_t)grid.x * grid.y;
-  if (x4 && g_kblock_pipe && n1 >= kKB && n2 >= kKB && ldk * 512 < (int64_t(1) << 31) && ntiles < (int64_t(1) << 30) &&
-      n1 * m < (int64_t(1) << 29) && n2 * m < (int64_t(1) << 29) && (g_kblock_pipe >= 2 || ntiles > kPpMinTiles)) {
+  // the lean kernels: 16-byte stores, edge tiles moved back, 32-bit staging offsets, a 31-bit tile extent
+  const bool lean = x4 && g_kblock_pipe != 4 && n1 >= kKB && n2 >= kKB && ldk * 512 < (int64_t(1) << 31) &&
+                    ntiles < (int64_t(1) << 30) && n1 * m < (int64_t(1) << 29) && n2 * m < (int64_t(1) << 29);
+  const bool walk = g_kblock_pipe == 2 || g_kblock_pipe == 3;
+  if (lean && walk) {
     // tile id = column tile * row tiles + row tile, so the tiles in flight together share their Z2 rows
     const int64_t nb = (ntiles + 1) / 2 < kPpBlocks ? (ntiles + 1) / 2 : kPpBlocks;
     const int records = g_kblock_pipe == 3 ? 0 : 0x7fffffff;   // 3: a descriptor of zero bytes drops every store (timing only)
@@ -653,6 +760,20 @@ int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2
 #define MGP_KB_LAUNCH(TS)                                                                                                   \
   hipLaunchKernelGGL(kernel_block_pp<TS>, dim3((unsigned)nb), dim3(kPpThreads), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, \
                      ldk, (int)grid.y, (int)ntiles, records)
+    if (ts == 8) MGP_KB_LAUNCH(8);
+    else if (ts == 6) MGP_KB_LAUNCH(6);
+    else if (ts == 4) MGP_KB_LAUNCH(4);
+    else MGP_KB_LAUNCH(2);
+#undef MGP_KB_LAUNCH
+    MGP_LAUNCH_CHECK();
+    return MGP_OK;
+  }
+  if (lean) {
+    const int records = 0x7fffffff;
+    const int ts = (m - (m - 1) / kKC * kKC) / 2;
+#define MGP_KB_LAUNCH(TS)                                                                                                   \
+  hipLaunchKernelGGL(kernel_block_one<TS>, dim3((unsigned)ntiles), dim3(kBlock), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, \
+                     ldk, (int)grid.y, records)
     if (ts == 8) MGP_KB_LAUNCH(8);
     else if (ts == 6) MGP_KB_LAUNCH(6);
     else if (ts == 4) MGP_KB_LAUNCH(4);
@@ -674,7 +795,7 @@ extern "C" int mgp_kernel_block(const float* Z1, int64_t n1, const float* Z2, in
 }
 
 extern "C" int mgp_kernel_block_set_pipe(int mode) {
-  if (mode < 0 || mode > 3) return MGP_ERR_ARG;    // 3 (lab): the pipelined walk with every store dropped by the hardware
+  if (mode < 0 || mode > 4) return MGP_ERR_ARG;    // 3 (lab): the walk with every store dropped; 4: as 0 with the general kernel
   g_kblock_pipe = mode;
   return MGP_OK;
 }

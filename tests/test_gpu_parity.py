@@ -489,9 +489,9 @@ def test_kernel_block_mfma_layout(mgp, dev):
 @pytest.mark.parametrize("n1,n2,m", [(128, 256, 16), (131, 260, 8), (300, 1028, 36), (517, 388, 100), (256, 640, 48),
                                      (200, 132, 60), (384, 384, 128), (129, 129 * 4, 12)])
 def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, m):
-    """mgp_kernel_block's two kernels on the same operands: one 128 x 128 tile per workgroup (knob 0) and the two-half tile walk
-    (knob 2: every ragged last stage m % 16 in {0, 4, 8, 12}, single-stage m, last row / column tiles moved back over their
-    neighbours, odd tile counts so that one half has a tile less).  Both against fp64, and bit-identical to each other (same
+    """mgp_kernel_block's three kernels on the same operands: the general one (knob 4), the lean one-tile-per-workgroup one (0)
+    and the two-half tile walk (2): every ragged last stage m % 16 in {0, 4, 8, 12}, single-stage m, last row / column tiles
+    moved back over their neighbours, odd tile counts so that one half has a tile less.  Both against fp64, and bit-identical to each other (same
     operands, same summation order); a NaN canary catches an entry nobody wrote."""
     from manifold_gp_amd import _lib
     lib = _lib.lib()
@@ -501,7 +501,7 @@ def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, 
     ref = 1.7 * (Z1.double() @ Z2.double().t())
     outs = []
     try:
-        for knob in (0, 2):
+        for knob in (4, 0, 2):
             assert lib.mgp_kernel_block_set_pipe(knob) == 0
             K = torch.full((n1, n2), float("nan"), device=dev)
             for _ in range(3):          # back to back: a launch must not depend on what the one before left in LDS / registers
@@ -512,7 +512,7 @@ def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, 
             outs.append(K)
     finally:
         lib.mgp_kernel_block_set_pipe(1)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert lib.mgp_kernel_block_set_pipe(7) != 0
 
 

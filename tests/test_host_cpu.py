@@ -366,6 +366,7 @@ def test_kernel_block_pp_instruction_stream_respects_its_own_waits():
         out = []
         for ts in (8, 6, 4, 2):
             out += ["_ZN12_GLOBAL__N_115kernel_block_ppILi%dEEEvPKflS2_lifPfliii:" % ts] + lines + ["\t.end_amdhsa_kernel"]
+            out += ["_ZN12_GLOBAL__N_116kernel_block_oneILi%dEEEvPKflS2_lifPflii:" % ts] + lines + ["\t.end_amdhsa_kernel"]
         return "\n".join(out)
     assert chk.check(kernels(body)) == []
     early_read = body[:1] + ["\tv_mov_b32_e32 v152, v65"] + body[1:]

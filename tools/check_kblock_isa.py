@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Static check of kernel_block_pp's instruction stream (manifold_gp_amd/csrc/features.hip).
+"""Static check of the instruction streams of kernel_block_pp and kernel_block_one (manifold_gp_amd/csrc/features.hip).
 
 Its staging loads are inline asm (`global_load_dwordx4`) whose completion the compiler does not track: the kernel waits for
 them with its own `s_waitcnt vmcnt(0)`.  That is only sound if NO instruction touches a destination register of such a load
@@ -25,7 +25,7 @@ def regs_of(text):
 
 def check(asm):
     lines = asm.split("\n")
-    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN\d+_GLOBAL__N_1\d+kernel_block_ppILi\d+EE.*:\s*(;.*)?$", l)]
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN\d+_GLOBAL__N_1\d+kernel_block_(pp|one)ILi\d+EE.*:\s*(;.*)?$", l)]
     problems, seen = [], 0
     for a in starts:
         b = next(i for i in range(a, len(lines)) if ".end_amdhsa_kernel" in lines[i])
@@ -65,8 +65,8 @@ def check(asm):
                     problems.append("%s: writes a store's data register before the s_nop: %s" % (name, t))
         if stores != 16:
             problems.append("%s: %d stores, expected the tile's 16" % (name, stores))
-    if seen != 4:
-        problems.append("expected 4 instantiations of kernel_block_pp, found %d" % seen)
+    if seen != 8:
+        problems.append("expected 4 instantiations each of kernel_block_pp and kernel_block_one, found %d in all" % seen)
     return problems
 
 
@@ -84,7 +84,7 @@ def main():
         problems = check(open(out).read())
     for p in problems:
         print(p)
-    print("kernel_block_pp instruction stream:", "clean" if not problems else "%d problem(s)" % len(problems))
+    print("kernel_block_pp / kernel_block_one instruction streams:", "clean" if not problems else "%d problem(s)" % len(problems))
     return 1 if problems else 0
 
 
