@@ -364,7 +364,7 @@ def _main(quiet):
     line = dict(metric="CG-solve wall-time + SpMV HBM GB/s, N=60k RMNIST graph", value=round(value, 2),
                 unit="GB/s (algorithmic SpMV bytes inside the CG solve)", n_gpus=1, steps=args.steps,
                 warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
-                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                scaling=args.scaling, vs_baseline=None, dtype="f32", data="synthetic",
                 config=dict(workload=wl["name"], nodes=g.n, edges=g.M, nnz_padded=g.nnz, rhs_columns=1,
                             system="A = I + noise*outputscale*Q, Q=(2nu/kappa^2 I + L)^nu x D",
                             cg_tol=args.tol, cg_iters=its, cg_rel_residual=resid, cg_true_residual_fp32_apply=true_res,

@@ -514,6 +514,15 @@ def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, 
         lib.mgp_kernel_block_set_pipe(1)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert lib.mgp_kernel_block_set_pipe(7) != 0
+    if n2 % 4 == 0:                     # knob 3 (timing arm): the walk with a zero-byte descriptor writes nothing
+        try:
+            assert lib.mgp_kernel_block_set_pipe(3) == 0
+            K = torch.full((n1, n2), float("nan"), device=dev)
+            assert lib.mgp_kernel_block(_lib.ptr(Z1), n1, _lib.ptr(Z2), n2, m, 1.7, _lib.ptr(K), _lib.stream()) == 0
+            torch.cuda.synchronize()
+            assert bool(torch.isnan(K).all())
+        finally:
+            lib.mgp_kernel_block_set_pipe(1)
 
 
 def test_spectral_posterior_vs_woodbury_fp64(mgp, golden, dev):
