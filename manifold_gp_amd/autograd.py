@@ -71,8 +71,20 @@ def node_vector(eps, data, name):
     return _NodeVector.apply(eps, data, name)
 
 
-def _as0(t, like):
-    return t if torch.is_tensor(t) else torch.tensor(float(t), device=like.device)
+def _as0(t, like=None):
+    # a python scalar becomes a CPU tensor: no host-to-device copy, and reading it back is free (the kernels take their
+    # coefficients by value; a device tensor here would be copied up only to be synchronised down again)
+    return t if torch.is_tensor(t) else torch.tensor(float(t))
+
+
+def _host_values(*ts):
+    """Python floats of 0-d tensors with at most ONE device synchronisation (for those that live on the GPU)."""
+    dev = [t for t in ts if t.device.type != "cpu"]
+    if len(dev) > 1:
+        vals = iter(torch.stack([t.detach().reshape(()).float() for t in dev]).tolist())
+    else:
+        vals = iter([t.item() for t in dev])
+    return [float(next(vals)) if t.device.type != "cpu" else float(t) for t in ts]
 
 
 class _FusedSpmm(torch.autograd.Function):
@@ -83,7 +95,8 @@ class _FusedSpmm(torch.autograd.Function):
                               pre if pre is not None else torch.empty(0), post if post is not None else torch.empty(0),
                               base if base is not None else torch.empty(0))
         ctx.has = (pre is not None, post is not None, base is not None)
-        return _spmm(data, X, a.item(), b.item(), pre, post, base, cb.item(), co.item())
+        av, bv, cov, cbv = ctx.vals = _host_values(a, b, co, cb)       # read once, reused by backward
+        return _spmm(data, X, av, bv, pre, post, base, cbv, cov)
 
     @staticmethod
     def backward(ctx, g):
@@ -94,7 +107,7 @@ class _FusedSpmm(torch.autograd.Function):
         post = post if has_post else None
         base = base if has_base else None
         g = _lib.f32c(g)
-        av, bv, cov, cbv = a.item(), b.item(), co.item(), cb.item()
+        av, bv, cov, cbv = ctx.vals
         need = ctx.needs_input_grad
         xs = X * pre.view(-1, 1) if pre is not None else X
         h = g * cov
@@ -114,17 +127,17 @@ class _FusedSpmm(torch.autograd.Function):
             dlx = _spmm(data, xs, 0.0, 1.0, None, None, None, 0.0, 1.0, tangent=True)   # L' xs
             geps = (bv * (h * dlx).sum()).reshape(eps.shape)
         if need[2]:
-            ga = (h * xs).sum().reshape(a.shape)
+            ga = (h * xs).sum().reshape(a.shape).to(a.device)
         if need[3]:
-            gb = (h * lx).sum().reshape(b.shape)
+            gb = (h * lx).sum().reshape(b.shape).to(b.device)
         if need[4] or need[7]:
             t = av * xs + bv * lx
             if need[4]:
-                gco = ((g * t * post.view(-1, 1)).sum() if post is not None else (g * t).sum()).reshape(co.shape)
+                gco = ((g * t * post.view(-1, 1)).sum() if post is not None else (g * t).sum()).reshape(co.shape).to(co.device)
             if need[7] and post is not None:
                 gpost = (g * t).sum(1) * cov
         if need[5]:
-            gcb = ((g * base).sum() if base is not None else torch.zeros((), device=g.device)).reshape(cb.shape)
+            gcb = ((g * base).sum() if base is not None else torch.zeros((), device=g.device)).reshape(cb.shape).to(cb.device)
         if need[8] and base is not None:
             gbase = g * cbv
         return gX, geps, ga, gb, gco, gcb, gpre, gpost, gbase, None
