@@ -352,3 +352,35 @@ def test_c5_swiss_roll_1m_pipeline(mgp, dev):
     assert true_rel <= 3e-6, true_rel
     assert rel_oracle <= 1e-3                     # fp32 storage of the matrix: ~1e-7 |A| |x| / |y|
     plan.close()
+
+
+@pytest.mark.gpu
+def test_bench_line_contract(dev):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline and cpu_baseline objects and a solution that
+    matches the CPU baseline's (a reduced node count keeps the CPU leg to a second; the full-size line is the driver's)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--nodes", "8000"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["higher_is_better"] is True
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and line["vs_baseline"] is None
+    assert line["scaling"] in ("strong", "weak") and "workload" in line["config"] and "model" not in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    cb = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1
+    assert line["value"] > 0 and line["ms_per_step"] > 0
+    assert line["config"]["cg_true_residual_fp32_apply"] < 1e-5 and line["config"]["max_rel_diff_vs_cpu_solution"] < 1e-4

@@ -1,4 +1,4 @@
-"""Lab: host-side profile (cProfile) of supervised training epochs at C3 size, after two warm epochs."""
+"""Lab: host-side profile (cProfile) of training epochs at C3 / C4 size after warm epochs.  `semisup` as first argument: 10 % labelled."""
 import cProfile, json, os, pstats, sys, time, io
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
@@ -13,14 +13,22 @@ kern = mgp.kernels.RiemannMaternKernel(nu=2, x=x, nearest_neighbors=50, laplacia
 D1, _ = kern.knn.search(x[:20000], 2)
 eps, _ = synth.bandwidth_rule(D1[:, 1].cpu().numpy(), hp["graphbandwidth"])
 kern.initialize(graphbandwidth=eps, lengthscale=hp["lengthscale"])
-model = RiemannGP(x, y, GaussianLikelihood(hp["noise"]).to(dev), ScaleKernel(kern, hp["outputscale"]).to(dev)).to(dev)
+SEMI = len(sys.argv) > 1 and sys.argv[1] == "semisup"
+if SEMI:
+    torch.manual_seed(1337)
+    labeled = torch.zeros(x.shape[0], dtype=torch.bool, device=dev)
+    labeled[torch.randperm(x.shape[0], device=dev)[: x.shape[0] // 10]] = True
+    model = RiemannGP(x[labeled], y[labeled], GaussianLikelihood(hp["noise"]).to(dev), ScaleKernel(kern, hp["outputscale"]).to(dev), labeled=labeled).to(dev)
+else:
+    model = RiemannGP(x, y, GaussianLikelihood(hp["noise"]).to(dev), ScaleKernel(kern, hp["outputscale"]).to(dev)).to(dev)
 opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-2)
 def run(n):
-    manifold_informed_train(model, opt, max_iter=n, tolerance=0.0, num_rand_vec=100, max_cholesky=800, cg_tolerance=1e-2, cg_max_iter=1000)
+    manifold_informed_train(model, opt, max_iter=n, tolerance=0.0, num_rand_vec=32 if SEMI else 100, max_cholesky=800, cg_tolerance=1e-2, cg_max_iter=1000)
     torch.cuda.synchronize()
-run(3)
-t0 = time.perf_counter(); run(10); print("epoch ms (no profiler): %.2f" % ((time.perf_counter() - t0) / 10 * 1e3))
-pr = cProfile.Profile(); pr.enable(); run(10); pr.disable()
+NE = 4 if SEMI else 10
+run(2 if SEMI else 3)
+t0 = time.perf_counter(); run(NE); print("epoch ms (no profiler): %.2f" % ((time.perf_counter() - t0) / NE * 1e3))
+pr = cProfile.Profile(); pr.enable(); run(NE); pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(34); print(s.getvalue()[:7000])
 s = io.StringIO(); st = pstats.Stats(pr, stream=s); st.print_callers("method 'item'"); st.print_callers("built-in method torch.tensor"); st.print_callers("solvers.py:99"); print(s.getvalue()[:9000])
