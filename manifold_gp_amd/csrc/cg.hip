@@ -21,7 +21,9 @@
 //     residual (stop_mode 1).
 #include <math.h>
 #include <chrono>
+#include <mutex>
 #include <new>
+#include <vector>
 #include <string.h>
 #include "mgp_common.h"
 #include "mgp_internal.h"
@@ -1031,7 +1033,56 @@ __global__ void refine_publish64_kernel(const double* __restrict__ xacc, float* 
   }
 }
 
+// Host-mapped blocks of the plans (solve state, residuals), pooled: hipHostMalloc costs ~0.1 ms and hipHostFree waits for the
+// device to go idle, and a training epoch creates and retires a dozen plans (every hyper-parameter step changes the operator).
+// A retired plan's block goes back behind an event recorded on the plan's stream (its last graph's end-of-graph marker may
+// still be on its way); it is handed out again only once that event has completed.
+struct HostBlock {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipEvent_t ev = nullptr;
+  bool pending = false;
+};
+std::mutex g_host_pool_mu;
+std::vector<HostBlock> g_host_pool;
+
+bool host_block_acquire(size_t bytes, HostBlock* out) {
+  {
+    std::lock_guard<std::mutex> lk(g_host_pool_mu);
+    for (size_t i = 0; i < g_host_pool.size(); ++i) {
+      HostBlock& b = g_host_pool[i];
+      if (b.bytes < bytes || b.bytes > 4 * bytes + 4096) continue;
+      if (b.pending && hipEventQuery(b.ev) != hipSuccess) continue;
+      *out = b;
+      out->pending = false;
+      g_host_pool.erase(g_host_pool.begin() + (long)i);
+      return true;
+    }
+  }
+  HostBlock b;
+  b.bytes = (bytes + 4095) & ~size_t(4095);
+  if (hipHostMalloc(&b.p, b.bytes, hipHostMallocMapped) != hipSuccess) return false;
+  if (hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(b.p); return false; }
+  *out = b;
+  return true;
+}
+
+void host_block_release(HostBlock b, hipStream_t stream) {
+  if (!b.p) return;
+  if (hipEventRecord(b.ev, stream) != hipSuccess) {          // cannot tell when its last writer ends: do not reuse it
+    (void)hipEventDestroy(b.ev);
+    (void)hipHostFree(b.p);
+    return;
+  }
+  b.pending = true;
+  std::lock_guard<std::mutex> lk(g_host_pool_mu);
+  if (g_host_pool.size() < 64) { g_host_pool.push_back(b); return; }
+  (void)hipEventDestroy(b.ev);
+  (void)hipHostFree(b.p);
+}
+
 struct CgPlan {
+  HostBlock host_block;
   mgp_operator_t op;
   MgpDist dist;             // row partition (is_dist): op.L holds the local rows only
   bool is_dist;
@@ -1367,14 +1418,18 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
     a.pd_bb = pl->pd_bb;
   }
   if (!ar.ok()) { delete pl; return MGP_ERR_WORKSPACE; }
-  hipError_t e = hipHostMalloc((void**)&pl->host_state, 16 * sizeof(int32_t), hipHostMallocMapped);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_resid, (size_t)C * sizeof(float), hipHostMallocMapped);
-  if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&a.host_state, pl->host_state, 0);
+  // one pooled host-mapped block: [16 int32 state | C resid | C true_rel], each part on its own 64-byte line
+  const size_t rbytes = (((size_t)C * sizeof(float)) + 63) & ~size_t(63);
+  if (!host_block_acquire(64 + 2 * rbytes, &pl->host_block)) { delete pl; return (int)hipErrorOutOfMemory; }
+  char* hb = static_cast<char*>(pl->host_block.p);
+  pl->host_state = reinterpret_cast<int32_t*>(hb);
+  pl->host_resid = reinterpret_cast<float*>(hb + 64);
+  pl->host_true_rel = reinterpret_cast<float*>(hb + 64 + rbytes);
+  hipError_t e = hipHostGetDevicePointer((void**)&a.host_state, pl->host_state, 0);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&a.host_resid, pl->host_resid, 0);
-  if (e == hipSuccess) e = hipHostMalloc((void**)&pl->host_true_rel, (size_t)C * sizeof(float), hipHostMallocMapped);
   if (e == hipSuccess) e = hipHostGetDevicePointer((void**)&pl->dev_true_rel, pl->host_true_rel, 0);
-  if (e != hipSuccess) { delete pl; return (int)e; }
-  memset(pl->host_state, 0, 16 * sizeof(int32_t));
+  if (e != hipSuccess) { host_block_release(pl->host_block, pl->stream); delete pl; return (int)e; }
+  memset(hb, 0, 64 + 2 * rbytes);
 
   *plan_out = pl;
   return MGP_OK;
@@ -1619,9 +1674,7 @@ extern "C" int mgp_cg_plan_destroy(void* plan) {
   if (pl->exec_first) (void)hipGraphExecDestroy(pl->exec_first);
   if (pl->graph_first) (void)hipGraphDestroy(pl->graph_first);
   if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
-  if (pl->host_state) (void)hipHostFree(pl->host_state);
-  if (pl->host_resid) (void)hipHostFree(pl->host_resid);
-  if (pl->host_true_rel) (void)hipHostFree(pl->host_true_rel);
+  host_block_release(pl->host_block, pl->stream);
   delete pl;
   return MGP_OK;
 }
