@@ -137,6 +137,15 @@ def clear_plan_cache():
 
 
 FACTORISED_SOLVES = [True]      # lab / test switch: False = CG on the whole chain Q = (tau I + L)^nu even when it factorises
+# Each factor of the first round is solved to tol / (divisor * nu).  divisor 2 leaves the whole system under tol when the
+# later factors' residuals are not amplified (direct solves with Q in supervised training, the 100 one-hot columns of
+# _average_variance: one round, worst true residual 0.3-0.6 tol); the Schur complement's solves (right-hand sides padded with
+# zeros on the unlabelled rows) needed a second round 53 times out of 65 per epoch at 2 and never at 4: 42 -> 29 iterations
+# per solve, semi-supervised epoch 92 -> 80 ms on one box (tools/lab/prof_training.py).  So the divisor starts at
+# FACTOR_TOL_DIVISOR and a (graph, column count) whose solve needed a second round is solved with twice that from then on.
+FACTOR_TOL_DIVISOR = [2.0]
+_FACTOR_DIVISOR_OF = {}
+FACTOR_ROUNDS_LOG = None        # lab: a list here collects (rounds, iterations, worst true residual / tol) per factorised solve
 
 
 def _factorisable(desc, kw):
@@ -161,7 +170,8 @@ def _factorised_solve(desc, B, kw):
     to tol / (2 nu), which leaves the whole under tol / 2 on well conditioned graphs, but B amplifies the later factors'
     residuals by up to cond(B)^(k-1) (dumbbell, eps = 0.05, nu = 3: 5 tol).  So the TRUE residual b - Q x is formed (one
     apply) and, while it is above tol, a correction Q d = r is solved the same way (to the looser tolerance that remains)
-    and added: at most three rounds, usually one, and `resid` is the true relative residual."""
+    and added: at most three rounds, usually one, and `resid` is the true relative residual.  A (graph, column count) that
+    needed a second round starts tighter the next time (FACTOR_TOL_DIVISOR above)."""
     import math
     nu = int(desc.nu)
     dB = desc.with_(nu=1, kappa=desc.kappa / math.sqrt(nu), scale=1.0, pre=None, post=None)
@@ -175,8 +185,10 @@ def _factorised_solve(desc, B, kw):
     bn = B.norm(dim=0).clamp_min(1e-30)
     X, R, its, rel = None, B, 0, None
     want, prev_worst = tol, float("inf")
+    hint = (id(getattr(desc.data, "graph", None)), int(B.shape[1]))
+    div0 = _FACTOR_DIVISOR_OF.get(hint, FACTOR_TOL_DIVISOR[0])
     for rnd in range(3):
-        kw["tol"] = max(want, 1e-7) / (2.0 * nu) / (1.0 if rnd == 0 else 4.0)
+        kw["tol"] = max(want, 1e-7) / ((div0 if rnd == 0 else 8.0) * nu)
         Y = R if dinv is None else (R * dinv).contiguous()
         for _ in range(nu):
             plan = _cached_plan(dB, Y.shape[1], kw)
@@ -198,6 +210,12 @@ def _factorised_solve(desc, B, kw):
             break
         prev_worst = worst
         want = min(0.5, tol / worst)              # relative to the new right-hand side R
+    if rnd > 0 and div0 < 4.0 * FACTOR_TOL_DIVISOR[0]:
+        if len(_FACTOR_DIVISOR_OF) > 256:
+            _FACTOR_DIVISOR_OF.clear()
+        _FACTOR_DIVISOR_OF[hint] = 2.0 * div0
+    if FACTOR_ROUNDS_LOG is not None:
+        FACTOR_ROUNDS_LOG.append((rnd + 1, its, worst / tol))
     if worst > max(tol, 2e-5):
         warnings.warn("factorised CG solve: true residual %.3g above the tolerance %.3g after %d rounds" % (worst, tol, rnd + 1))
     return X, its, [float(v) for v in rel.tolist()]

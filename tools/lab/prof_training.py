@@ -26,8 +26,18 @@ def run(n):
     manifold_informed_train(model, opt, max_iter=n, tolerance=0.0, num_rand_vec=32 if SEMI else 100, max_cholesky=800, cg_tolerance=1e-2, cg_max_iter=1000)
     torch.cuda.synchronize()
 NE = 4 if SEMI else 10
+from manifold_gp_amd import solvers as _sv
+if os.environ.get("FACTOR_DIV"):
+    _sv.FACTOR_TOL_DIVISOR[0] = float(os.environ["FACTOR_DIV"])
 run(2 if SEMI else 3)
 t0 = time.perf_counter(); run(NE); print("epoch ms (no profiler): %.2f" % ((time.perf_counter() - t0) / NE * 1e3))
+_sv.FACTOR_ROUNDS_LOG = []
+run(2)
+log = _sv.FACTOR_ROUNDS_LOG; _sv.FACTOR_ROUNDS_LOG = None
+import collections
+print("factorised solves per epoch %.1f, rounds histogram %s, mean iterations %.1f, mean worst/tol %.2f" % (len(log) / 2, dict(collections.Counter(r for r, _, _ in log)), sum(i for _, i, _ in log) / max(1, len(log)), sum(w for _, _, w in log) / max(1, len(log))))
+if os.environ.get("NO_PROFILE"):
+    sys.exit(0)
 pr = cProfile.Profile(); pr.enable(); run(NE); pr.disable()
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
 s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(34); print(s.getvalue()[:7000])
