@@ -1,0 +1,16 @@
+"""Lab: one SpMM configuration on the C3 graph, 40 launches (for PMC passes): spmm_one.py <C> <v4 mode 0/2> [wide 0/2]"""
+import ctypes, os, sys, argparse
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+import torch
+import bench
+from manifold_gp_amd import _lib
+dev = torch.device("cuda:0")
+wl = bench.build_workload(argparse.Namespace(workload="c3", nodes=0, s5_order="morton"), dev, 0, 1)
+g, lap = wl["graph"], wl["lap"]
+lib = _lib.lib(); lib.mgp_spmm_set_group_hint(g.spmv_lanes)
+csr = lap.data.csr()
+C = int(sys.argv[1]); lib.mgp_spmm_set_v4_mode(int(sys.argv[2])); lib.mgp_spmm_set_tile_wide_mode(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
+X = torch.randn(g.n, C, device=dev); Y = torch.empty_like(X)
+ms = ctypes.c_float(0.0)
+_lib.check(lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y), 40, ctypes.byref(ms), _lib.stream()), "repeat")
+print("C", C, "us per launch", ms.value / 40 * 1e3)
