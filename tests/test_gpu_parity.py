@@ -906,6 +906,40 @@ def test_factorised_chain_solve_vs_whole_chain_cg(mgp, golden, dev, norm, nu):
             assert ef < max(2.0 * ew, 50 * tol), (ef, ew)
 
 
+def test_factorised_solve_tightens_its_first_round_after_a_correction(mgp, golden, dev):
+    """A factorised solve that needed a correction round makes the next solve with the same graph and column count start
+    tighter (solvers.FACTOR_TOL_DIVISOR / _FACTOR_DIVISOR_OF): forced here by a first round that is too loose on purpose.
+    Every solve still ends under the tolerance (true residual, dense float64 operator)."""
+    from manifold_gp_amd import solvers
+    g = golden("dumbbell_k10_loop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[float(g["kappa"])]], device=dev))
+    desc = Q._descriptor()
+    n = desc.n
+    rng = np.random.default_rng(7)
+    b = np.zeros((n, 3), np.float32)
+    b[: n // 10] = rng.normal(size=(n // 10, 3)).astype(np.float32)          # zero-padded like the Schur complement's
+    B = T(b, dev)
+    Ad = desc.apply(torch.eye(n, device=dev)).double().cpu().numpy()
+    hint = (id(desc.data.graph), 3)
+    old_div, old_log = solvers.FACTOR_TOL_DIVISOR[0], solvers.FACTOR_ROUNDS_LOG
+    solvers._FACTOR_DIVISOR_OF.pop(hint, None)
+    try:
+        solvers.FACTOR_TOL_DIVISOR[0] = 0.02                               # first round at 25 tol per factor: cannot do
+        solvers.FACTOR_ROUNDS_LOG = log = []
+        divs = []
+        for _ in range(4):
+            X, _, res = solvers.cg_solve(desc, B, tol=1e-3, stop_mode=1, max_iter=20000)
+            r = np.linalg.norm(Ad @ X.cpu().numpy().astype(np.float64) - b, axis=0) / np.linalg.norm(b, axis=0)
+            assert r.max() < 1e-3 and max(res) < 1e-3, (r.max(), res)
+            divs.append(solvers._FACTOR_DIVISOR_OF.get(hint, solvers.FACTOR_TOL_DIVISOR[0]))
+        assert log[0][0] >= 2                                              # the loose first round needed a correction ...
+        assert divs[0] == 2 * 0.02 and divs[-1] <= 4 * 0.02 and divs == sorted(divs)   # ... and the divisor doubled, at most twice
+    finally:
+        solvers.FACTOR_TOL_DIVISOR[0], solvers.FACTOR_ROUNDS_LOG = old_div, old_log
+        solvers._FACTOR_DIVISOR_OF.pop(hint, None)
+
+
 @pytest.mark.parametrize("tmax", [0.4, 2.0])
 @pytest.mark.parametrize("norm", NORMS)
 def test_noise_wrapped_chain_solve_series_and_cg(mgp, golden, dev, norm, tmax):
