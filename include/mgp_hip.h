@@ -179,7 +179,8 @@ typedef struct {
 /* workgroups that write dot partials for this CSR (format aware; use this one to size dot_partials) */
 int mgp_spmm_dot_blocks_csr(const mgp_csr_t* L, int C);
 int mgp_spmm_set_tile_mode(int on);          /* C == 1: use the tile dictionaries when present (default 1) */
-int mgp_spmm_set_tile_small_mode(int on);
+int mgp_spmm_set_tile_small_mode(int on);    /* C in {4,8,12,16}: LDS-dictionary multi-column kernel on 64-row tiles
+                                                (default 1; 0 = the per-entry gather kernel) */
 /* 16 < C <= 256 with C % 4 == 0 on 64-row tiles: LDS-dictionary kernel in 16-column chunks where it wins (C <= 32, or
  * an X block of 96 MB and more: default 1); 0 = always the per-entry X-row gather kernel; 2 = always the dictionary
  * kernel (tests, A/B runs). */
@@ -187,8 +188,7 @@ int mgp_spmm_set_tile_wide_mode(int on);
 /* 16 < C <= 256 with C % 4 == 0 on a quad-padded CSR (what the graph builder produces), 16-byte aligned operands: a
  * lane owns one float4 of the row instead of one column; used where it wins (C <= 64, or an X block of 96 MB and more:
  * default 1); 0 = never (the per-column gather kernel); 2 = always (tests, A/B runs). */
-int mgp_spmm_set_v4_mode(int on);    /* C in {4,8,12,16}: LDS-dictionary multi-column kernel on 64-row tiles
-                                                (default 1; 0 = the per-entry gather kernel) */
+int mgp_spmm_set_v4_mode(int on);
 
 int mgp_spmm_dot_blocks(int64_t n, int C);   /* workgroups that write dot partials */
 int mgp_spmm_set_group_hint(int lanes);      /* C == 1: lanes per row, one of 4,8,16,32,64 */
