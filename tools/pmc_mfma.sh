@@ -15,7 +15,7 @@ for d in sorted(glob.glob("gpurun_out/pmc_mfma/p*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if "kernel_block_mfma" in r["Kernel_Name"]:
+            if "kernel_block" in r["Kernel_Name"]:
                 acc[(r["Counter_Name"], r["Grid_Size"] if "Grid_Size" in r else "")].append(float(r["Counter_Value"]))
         for k, v in sorted(acc.items()):
             print(k[0], "grid", k[1], "launches", len(v), "mean", sum(v) / len(v))
