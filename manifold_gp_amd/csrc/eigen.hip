@@ -687,7 +687,10 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
       if (getenv("MGP_EIG_TIMING")) {
         int lead = 0;
         while (lead < m && res[lead] <= tol * ub) ++lead;
-        fprintf(stderr, "[eig] round %d: deg %d, converged %d of %d (leading run %d)\n", outer, deg, nconv, m, lead);
+        double rmx = 0.0;
+        for (int j = 0; j < m; ++j) rmx = std::max(rmx, res[j]);
+        fprintf(stderr, "[eig] round %d: deg %d, converged %d of %d (leading run %d), max resid %.3e (tol*ub %.3e)\n", outer,
+                deg, nconv, m, lead, rmx, tol * ub);
       }
       if (nconv == m) { ++outer; break; }
       {

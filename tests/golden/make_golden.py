@@ -42,6 +42,92 @@ def _load(name, path):
     return m
 
 
+def reference_posterior(dense, tu, train_x, train_y, post_x, k, eps, kappa, nu, modes, bump, norm, outputscale, noise):
+    """The reference's whole prediction pipeline in float64 on the imported reference functions, dense and without any
+    low-rank shortcut: dense Laplacian (test/_dense_operators.py:7-24, self loops as riemann_kernel.py:115 builds it)
+    -> torch.linalg.eigh, first `modes` pairs, eigval[0] = 0, D^-1/2 scaling + column normalisation
+    (riemann_kernel.py:121-128) -> in-sample features (:134-136) / out-of-sample features with the support mask and
+    the bump (:138-147, dense extension matrix of test/_test_functions.py:134-150) -> ExactGP prediction with a
+    zero ConstantMean, ScaleKernel(outputscale) and Gaussian noise (riemann_gp.py:16-30,45-46):
+        mean = K*t (K + noise I)^-1 y,   cov = K** - K*t (K + noise I)^-1 K*t^T,   K = outputscale Z Z^T.
+    Returns numpy float64 (mean [T], cov [T,T], alpha = (K + noise I)^-1 y [n], Z* Z^T of the first 64 nodes)."""
+    n = train_x.shape[0]
+    D, I = oknn.knn_search(train_x.numpy(), train_x.numpy(), k)
+    idx_np, val_np = oknn.knn_graph_from_search(D, I, n)
+    Dt, It = oknn.knn_search(train_x.numpy(), post_x.numpy(), k)
+    idx, val = torch.from_numpy(idx_np), torch.from_numpy(val_np).double()
+    gb = torch.tensor([[eps]], dtype=torch.float64)
+    ls = torch.tensor([[kappa]], dtype=torch.float64)
+    # eval() always diagonalises the SYMMETRIC matrix (riemann_kernel.py:121-124 assembles diag / -triu, which are
+    # the symmetric-normalised pieces for both settings) and always rescales by D^-1/2
+    Lsym, _, deg_un, _, deg = dense.graph_laplacian(idx, val, gb, n, normalization="symmetric", self_loops=True)
+    ev, U = torch.linalg.eigh(Lsym)
+    gap = (ev[modes] - ev[modes - 1]).item()
+    ev, U = ev[:modes].clone(), U[:, :modes].clone()
+    ev[0] = 0.0
+    U = U * deg.pow(-0.5).view(-1, 1)
+    U = torch.nn.functional.normalize(U, p=2, dim=0)
+    sd = (2 * nu / ls.square() + ev).pow(-nu)                  # riemann_matern_kernel.py:21-22
+    sd = sd / sd.sum()
+    Z = (sd * n).sqrt() * U                                     # riemann_kernel.py:134-136
+    dv, di = torch.from_numpy(Dt).double(), torch.from_numpy(It)
+    T = di.shape[0]
+    within = dv[:, 0].sqrt() < bump[0] * eps                    # :140
+    Zt = torch.zeros(T, modes, dtype=torch.float64)
+    if within.sum() != 0:                                       # :142 -- only the rows inside the support are extended
+        wv, wi = dv[within], di[within]
+        Tw = wi.shape[0]
+        rows = torch.arange(Tw).repeat_interleave(wi.shape[1])
+        aeu = torch.sparse_coo_tensor(torch.stack([rows, wi.reshape(-1)]), wv.reshape(-1).div(-4 * gb.square()).exp().squeeze(),
+                                      (Tw, n)).to_dense()
+        deu = aeu.sum(dim=1)
+        ae = torch.mm(deu.pow(-1).diag(), torch.mm(aeu, deg_un.pow(-1).diag()))
+        de = ae.sum(dim=1)
+        if norm == "symmetric":
+            ext = torch.mm(de.pow(-0.5).diag(), torch.mm(ae, deg.pow(-0.5).diag()))
+        else:
+            ext = torch.mm(de.pow(-1.0).diag(), ae)
+        sd2 = (2 * nu / ls.square() + ev).pow(-nu) / (1 - ev * gb.square()).square()    # :144
+        sd2 = sd2 / sd2.sum() * n
+        b = tu.bump_function(wv[:, 0].sqrt(), torch.tensor(bump[0] * eps, dtype=torch.float64), bump[1])
+        Zt[within] = sd2.sqrt() * torch.mm(ext, U) * b.unsqueeze(-1)                    # :146-147
+    y = train_y.double()
+    K = outputscale * (Z @ Z.T) + noise * torch.eye(n, dtype=torch.float64)
+    Ks = outputscale * (Zt @ Z.T)
+    alpha = torch.linalg.solve(K, y)
+    mean = Ks @ alpha
+    cov = outputscale * (Zt @ Zt.T) - Ks @ torch.linalg.solve(K, Ks.T)
+    return dict(mean=mean.numpy(), cov=cov.numpy(), alpha=alpha.numpy(), cross64=(Zt @ Z[:64].T).numpy(),
+                within=within.numpy(), gap=np.float64(gap), evals=ev.numpy(), knn_D=Dt, knn_I=It.astype(np.int32))
+
+
+def posterior_goldens(dense, tu, train_x, train_y, test_x):
+    """tests/golden/dumbbell_posterior.npz: the end-to-end posterior of the reference pipeline (float64) for the two
+    dumbbell configurations, both normalisations, nu in {1, 2}; test inputs = the 10 held-out nodes, 40 jittered
+    training points and 5 points far outside the bump support."""
+    rng = np.random.default_rng(3)
+    n = train_x.shape[0]
+    jit = train_x.numpy()[rng.choice(n, 40, replace=False)] + rng.normal(scale=0.02, size=(40, train_x.shape[1])).astype(np.float32)
+    far = train_x.numpy()[:5] + 5.0
+    post_x = torch.from_numpy(np.concatenate([test_x.numpy(), jit, far]).astype(np.float32))
+    out = dict(post_x=post_x.numpy(), outputscale=np.float64(0.7), noise=np.float64(1e-2))
+    for tag, k, eps, kappa, modes, bump in [("k10", 10, 0.05, 0.5, 50, (1.0, 0.01)), ("k50", 50, 0.5, 0.5, 20, (3.0, 1.0))]:
+        out[tag + "_cfg"] = np.array([k, eps, kappa, modes, bump[0], bump[1]], np.float64)
+        for norm in ("symmetric", "randomwalk"):
+            for nu in (1, 2):
+                torch.set_default_dtype(torch.float64)
+                r = reference_posterior(dense, tu, train_x, train_y, post_x, k, eps, kappa, nu, modes, bump, norm, 0.7, 1e-2)
+                torch.set_default_dtype(torch.float32)
+                for key, v in r.items():
+                    if key in ("knn_D", "knn_I", "within", "gap", "evals") and not (norm == "symmetric" and nu == 1):
+                        continue
+                    name = f"{tag}_{key}" if key in ("knn_D", "knn_I", "within", "gap", "evals") else f"{tag}_{norm}_nu{nu}_{key}"
+                    out[name] = v
+                print(tag, norm, nu, "gap behind the kept block %.3e" % r["gap"], "|mean| %.3f" % np.abs(r["mean"]).max(),
+                      "within", int(r["within"].sum()))
+    np.savez_compressed(os.path.join(HERE, "dumbbell_posterior.npz"), **out)
+
+
 def main():
     dense = _load("ref_dense_operators", f"{REF}/test/_dense_operators.py")
     tu = _load("ref_torch_utils", f"{REF}/manifold_gp/utils/torch_utils.py")
@@ -54,8 +140,9 @@ def main():
     truth, _ = ld.groundtruth_from_samples(vertices, edges)
     sampled_x = torch.from_numpy(vertices).float()
     sampled_y = torch.from_numpy(truth).float()
-    np.savez_compressed(os.path.join(HERE, "dumbbell.npz"),
-                        x=sampled_x.numpy(), y=sampled_y.numpy(), segments=edges.astype(np.int32))
+    if "--only-posterior" not in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "dumbbell.npz"),
+                            x=sampled_x.numpy(), y=sampled_y.numpy(), segments=edges.astype(np.int32))
 
     # ---- split (test_laplacian.py:20-23) ----
     torch.manual_seed(1337)
@@ -66,6 +153,10 @@ def main():
     n = train_x.shape[0]
     torch.manual_seed(7)
     probes = torch.randn(n, 4)
+
+    posterior_goldens(dense, tu, train_x, train_y, test_x)
+    if "--only-posterior" in sys.argv:
+        return
 
     for tag, k, self_loops, eps, kappa, nu_list, modes, bump in [
         ("k50_noloop", 50, False, 0.5, 0.5, (1, 2, 3), 20, (3.0, 1.0)),   # test_laplacian.py:31-50

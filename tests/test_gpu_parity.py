@@ -381,6 +381,57 @@ def test_kernel_eval_features_oos(mgp, golden, dev, case, norm):
     assert e_val < 5e-8 and e_gram < 5e-6 and e_diag < 1e-5 and e_oos < 5e-6, (e_val, e_gram, e_diag, e_oos)
 
 
+def _end_to_end_posterior_errors(mgp, golden, dev, tag, norm, nu, eigen_tol=None):
+    """RiemannGP through the HIP path only (k-NN -> graph -> Laplacian -> eigensolve -> in-sample / out-of-sample
+    features -> Woodbury posterior, MFMA covariance block) against tests/golden/dumbbell_posterior.npz = the
+    reference's pipeline in float64 (dense eigh, dense (K + noise I)^-1; make_golden.py::reference_posterior).
+    Nothing of the HIP path is fed to the checker.  Errors are relative to the largest entry of each quantity."""
+    from manifold_gp_amd.models import GaussianLikelihood, RiemannGP, ScaleKernel
+    from manifold_gp_amd.solvers import lowrank_solve
+    gp, g = golden("dumbbell_posterior"), golden("dumbbell_k10_loop")
+    k, eps, kappa, modes, bs, bd = gp[tag + "_cfg"]
+    x, y, xt = T(g["train_x"], dev), T(g["train_y"], dev), T(gp["post_x"], dev)
+    s, noise = float(gp["outputscale"]), float(gp["noise"])
+    kern = mgp.kernels.RiemannMaternKernel(nu=nu, x=x, nearest_neighbors=int(k), laplacian_normalization=norm,
+                                           num_modes=int(modes), bump_scale=float(bs), bump_decay=float(bd)).to(dev)
+    kern.initialize(graphbandwidth=float(eps), lengthscale=float(kappa))
+    if eigen_tol is not None:
+        kern.eigen_tol = eigen_tol
+    model = RiemannGP(x, y, GaussianLikelihood(noise).to(dev), ScaleKernel(kern, s).to(dev)).to(dev)
+    model.eval()
+    model.posterior(xt)
+    p = f"{tag}_{norm}_nu{nu}_"
+    mean, cov = model.posterior_mean.double().cpu().numpy(), model.posterior_covar.double().cpu().numpy()
+    Z = kern.features(x)
+    alpha = lowrank_solve(Z, y, s, noise).double().cpu().numpy()              # (K + noise I)^-1 y at the nodes
+    cross = (kern.features(xt).double() @ Z[:64].double().t()).cpu().numpy()   # kernel entries k(x*, x_i) / s
+    within = gp[tag + "_within"]
+    # outside the bump support (riemann_kernel.py:140-142) the features are exactly zero; inside, a bump that is
+    # positive in float64 may underflow in float32 right at the edge of the support, so only this direction is exact
+    assert np.abs(cross[~within]).max(initial=0.0) == 0.0 and (np.abs(cross).sum(1) > 0).sum() >= within.sum() - 2
+    assert np.abs(mean[~within]).max(initial=0.0) == 0.0 and np.abs(cov[~within]).max(initial=0.0) == 0.0
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / np.abs(b).max())
+
+    return dict(mean=rel(mean, gp[p + "mean"]), cov=rel(cov, gp[p + "cov"]), var=rel(np.diag(cov), np.diag(gp[p + "cov"])),
+                alpha=rel(alpha, gp[p + "alpha"]), kernel=rel(cross, gp[p + "cross64"]),
+                evals=float(np.abs(kern.eigval.cpu().numpy() - gp[tag + "_evals"]).max()), gap=float(gp[tag + "_gap"]),
+                resid=float(max(kern.eigen_residuals)))
+
+
+@pytest.mark.parametrize("tag", ["k10", "k50"])
+@pytest.mark.parametrize("norm", NORMS)
+@pytest.mark.parametrize("nu", [1, 2])
+def test_posterior_end_to_end_vs_reference_pipeline(mgp, golden, dev, tag, norm, nu):
+    """North-star target, end to end: posterior mean / variance / covariance, (K + noise I)^-1 y and kernel entries
+    of the HIP pipeline within 1e-4 of the REFERENCE pipeline's float64 values (riemann_kernel.py:117-149,
+    riemann_gp.py:45-75), with the package's default eigensolver tolerance."""
+    e = _end_to_end_posterior_errors(mgp, golden, dev, tag, norm, nu)
+    print("end-to-end posterior %s %s nu=%d: %s" % (tag, norm, nu, " ".join("%s %.2e" % kv for kv in e.items())))
+    assert e["mean"] < 1e-4 and e["var"] < 1e-4 and e["cov"] < 1e-4 and e["alpha"] < 1e-4 and e["kernel"] < 1e-4, e
+
+
 def test_eigensolver_vs_dense_eigh_k50(mgp, golden, dev):
     """test/_test_functions.py:107-131 `test_eigen` for the symmetric operator: eigenvalues[1:10]."""
     g = golden("dumbbell_k50_noloop")

@@ -259,3 +259,37 @@ def test_dense_differentiable_precision_oracle_matches_reference_autograd(golden
     assert abs(quad.item() - float(g[p + "ml_quad"])) < 1e-9 * abs(float(g[p + "ml_quad"]))
     assert abs(logdet.item() - float(g[p + "ml_logdet"])) < 1e-9 * abs(float(g[p + "ml_logdet"]))
     np.testing.assert_allclose([t.grad.item() for t in th], g[p + "ml_grads"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("tag", ["k10", "k50"])
+@pytest.mark.parametrize("norm", NORMS)
+@pytest.mark.parametrize("nu", [1, 2])
+def test_posterior_oracle_against_reference_pipeline(golden, tag, norm, nu):
+    """tests/golden/dumbbell_posterior.npz holds the posterior of the reference's own pipeline (dense float64 eigh ->
+    features -> dense (K + noise I)^-1, make_golden.py::reference_posterior).  The oracle's chain -- k-NN, Laplacian,
+    eval_eigenpairs, features_insample / features_oos, Woodbury gp_posterior_lowrank -- must reproduce it: this pins
+    the posterior oracle the GPU tests use at sizes where no reference run exists."""
+    from oracle.solvers import gp_posterior_lowrank
+    gp = golden("dumbbell_posterior")
+    g = golden("dumbbell_k10_loop")                      # same seed-1337 split: train_x / train_y
+    k, eps, kappa, modes, bs, bd = gp[tag + "_cfg"]
+    k, modes = int(k), int(modes)
+    x, y, xt = g["train_x"], g["train_y"], gp["post_x"]
+    n = x.shape[0]
+    D, I = oknn.knn_search(x, x, k)
+    idx, val = oknn.knn_graph_from_search(D, I, n)
+    Dt, It = oknn.knn_search(x, xt, k)
+    assert np.array_equal(It, gp[tag + "_knn_I"]) and np.array_equal(Dt, gp[tag + "_knn_D"])
+    lap = LaplacianOracle(val, idx, n, eps, norm, True, dtype=np.float64)
+    lam, phi = osp.eval_eigenpairs(lap, modes)
+    np.testing.assert_allclose(lam, gp[tag + "_evals"], rtol=0, atol=1e-10)
+    Z = osp.features_insample(lam, phi, nu, kappa)
+    Zt = osp.features_oos(lap, lam, phi, nu, kappa, Dt.astype(np.float64), It, bs, bd)
+    assert np.array_equal(np.abs(Zt).sum(1) > 0, gp[tag + "_within"])
+    s, noise = float(gp["outputscale"]), float(gp["noise"])
+    mean, cov, alpha = gp_posterior_lowrank(Z, y, Zt, s, noise)
+    p = f"{tag}_{norm}_nu{nu}_"
+    np.testing.assert_allclose(mean, gp[p + "mean"], rtol=0, atol=1e-9 * np.abs(gp[p + "mean"]).max())
+    np.testing.assert_allclose(cov, gp[p + "cov"], rtol=0, atol=1e-7 * np.abs(gp[p + "cov"]).max())     # cancellation: the prior is ~1e3 x larger
+    np.testing.assert_allclose(alpha, gp[p + "alpha"], rtol=0, atol=1e-8 * np.abs(gp[p + "alpha"]).max())
+    np.testing.assert_allclose(Zt @ Z[:64].T, gp[p + "cross64"], rtol=0, atol=1e-9 * np.abs(gp[p + "cross64"]).max())

@@ -8,8 +8,10 @@ class A: workload, nodes, gpus, s5_order = "c3", 0, 1, "morton"
 wl = bench.build_workload(A(), torch.device("cuda:0"), 0, 1)
 data = wl["lap"].data
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-for rep in range(3):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    ev, V, res = lanczos_smallest(data, m, tol=1e-5)
-    torch.cuda.synchronize()
-    print("eigensolve ms %.1f info %s max resid %.2e" % ((time.perf_counter() - t0) * 1e3, lanczos_smallest.last_info, max(res)), flush=True)
+tols = [float(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1e-5]
+for tol in tols:
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ev, V, res = lanczos_smallest(data, m, tol=tol)
+        torch.cuda.synchronize()
+        print("tol %.0e eigensolve ms %.1f info %s max resid %.2e" % (tol, (time.perf_counter() - t0) * 1e3, lanczos_smallest.last_info, max(res)), flush=True)
