@@ -185,6 +185,14 @@ int mgp_spmm_set_tile_small_mode(int on);    /* C in {4,8,12,16}: LDS-dictionary
  * an X block of 96 MB and more: default 1); 0 = always the per-entry X-row gather kernel; 2 = always the dictionary
  * kernel (tests, A/B runs). */
 int mgp_spmm_set_tile_wide_mode(int on);
+/* 16 < C <= 256 with C % 4 == 0 on 64-row tiles (round 3): the dictionary kernel with LANES OVER COLUMNS
+ * (csrc/spmm.hip spmm_dict_kernel) -- a tile's distinct X rows cross the vector memory path once per tile, staged in
+ * double-buffered slices of 256-byte-aligned LDS slots that every entry then reads conflict-free.  Default 1: taken
+ * wherever the shape allows (it takes precedence over the two kernels above); 0 = never.  Requires what the graph
+ * builders guarantee: within a row the entries' columns ascend (padding entries, value 0, at the row's end).
+ * Replaces torch_sparse.spmm at manifold_gp/operators/graph_laplacian_operator.py:118-119 for the [N, 100] right-hand
+ * sides of precision_matern_operator.py:50-53 and the eigensolver's blocks. */
+int mgp_spmm_set_dict_mode(int on);
 /* 16 < C <= 256 with C % 4 == 0 on a quad-padded CSR (what the graph builder produces), 16-byte aligned operands: a
  * lane owns one float4 of the row instead of one column; used where it wins (C <= 64, or an X block of 96 MB and more:
  * default 1); 0 = never (the per-column gather kernel); 2 = always (tests, A/B runs). */

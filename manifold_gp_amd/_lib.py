@@ -80,6 +80,7 @@ SIGNATURES = {
     "mgp_spmm_set_tile_mode": (c_int, [c_int]),
     "mgp_spmm_set_tile_small_mode": (c_int, [c_int]),
     "mgp_spmm_set_tile_wide_mode": (c_int, [c_int]),
+    "mgp_spmm_set_dict_mode": (c_int, [c_int]),
     "mgp_spmm_set_v4_mode": (c_int, [c_int]),
     "mgp_cg_set_fuse": (c_int, [c_int]),
     "mgp_cg_set_reduce_once": (c_int, [c_int]),

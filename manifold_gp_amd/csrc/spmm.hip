@@ -1082,6 +1082,237 @@ __global__ __launch_bounds__(256, 2) void spmm_tile_wide_kernel(SpmmArgs p, Tile
   if (p.tick && blockIdx.x == 0 && tid == 0) *p.tick = tickv + 1;
 }
 
+// ---------------------------------------------------------------- 16 < C <= 256 on tile dictionaries, LANES OVER COLUMNS
+// (round 3).  What the counters said about the per-entry gather kernels at C = 128 on the 60k graph
+// (profiles/r02_pmc_spmm_wide_kernel_block.txt): 33.8 M 64-byte L1 accesses = 2.16 GB per launch, 24x the algorithmic
+// bytes -- every ENTRY fetches its 512-byte X row through the vector memory path (64 B/clk/CU: 48 us of a 91 us launch).
+// A 64-row tile references only ~486 distinct X rows for its ~3 900 entries, so here an X row crosses the vector memory
+// path once per TILE (233 MB per launch instead of 1.9 GB) and every entry reads it from LDS.  The two earlier
+// dictionary kernels did that too and lost to LDS bank conflicts: they laid lanes over ENTRIES (each lane a 16-byte piece
+// of a different dictionary slot: random 16- and 32-byte reads collide about three deep).  Here the 16 lanes of a group
+// lie over the COLUMNS of one dictionary slot: a slot is NV x 256 bytes, 256-byte aligned, lane l reads bytes
+// [16 l, 16 l + 16) of each 256-byte piece.  Whatever slots the four groups of a wave address, every lane group of a
+// ds_read_b128 (MI355X_MICROARCH.md, LDS table) then covers all 64 banks exactly once: conflict-free at 256 B/clk/CU.
+//   * one 1024-thread workgroup per tile: group g (16 lanes) owns row g of the tile, its accumulators (NV float4 per
+//     lane) stay in registers over the whole tile;
+//   * the tile's matrix stream (values + 16-bit dictionary ids, 6 B per entry) is copied to LDS once, coalesced; a group
+//     reads its row's quads from there (same address in all 16 lanes: a broadcast);
+//   * the dictionary does not fit LDS at these widths (486 x 512 B), so it is staged in SLICES of S slots, double
+//     buffered: the X rows of slice k + 1 are in flight (registers) while slice k is walked, their column ids one slice
+//     further ahead; one barrier per slice.  A row's entries are sorted by column, hence by dictionary id: per slice a
+//     row contributes one contiguous run of entries, found by a per-row cursor.  Quads that straddle a slice boundary are
+//     visited in both slices with the out-of-slice entries masked (value 0, clamped slot); the padding entries at a
+//     row's end (value 0, id = the row's own slot) are masked the same way and never stall anything but their own row.
+// Summation order per row: entries in storage order within a slice, slices ascending -- fixed, independent of the grid.
+constexpr int kDictThreads = 1024;
+constexpr int kDictLdsBudget = 160 * 1024 - 2048;   // bytes of LDS a workgroup may carve (160 KiB per CU)
+// staged float4 per thread and slice (their registers are live across the walk: what the 128-VGPR budget of a
+// 16-wave workgroup leaves)
+constexpr int dict_max_u(int nv) { return nv == 1 ? 7 : (nv == 2 ? 5 : 4); }
+
+// acc += v_e * a_e for the four entries of a quad, two floats at a time (v_pk_fma_f32 with the op_sel broadcast of one
+// half of the (x, y) / (z, w) value pair; entry order 0, 1, 2, 3)
+__device__ __forceinline__ void quad_fma(mgp_v4f& acc, mgp_v4f vv, mgp_v4f a0, mgp_v4f a1, mgp_v4f a2, mgp_v4f a3) {
+  const mgp_v2f vlo = mgp_v2f{vv.x, vv.y}, vhi = mgp_v2f{vv.z, vv.w};
+  mgp_v2f lo = mgp_v2f{acc.x, acc.y}, hi = mgp_v2f{acc.z, acc.w};
+  lo = pk_fma_lo(vlo, mgp_v2f{a0.x, a0.y}, lo); hi = pk_fma_lo(vlo, mgp_v2f{a0.z, a0.w}, hi);
+  lo = pk_fma_hi(vlo, mgp_v2f{a1.x, a1.y}, lo); hi = pk_fma_hi(vlo, mgp_v2f{a1.z, a1.w}, hi);
+  lo = pk_fma_lo(vhi, mgp_v2f{a2.x, a2.y}, lo); hi = pk_fma_lo(vhi, mgp_v2f{a2.z, a2.w}, hi);
+  lo = pk_fma_hi(vhi, mgp_v2f{a3.x, a3.y}, lo); hi = pk_fma_hi(vhi, mgp_v2f{a3.z, a3.w}, hi);
+  acc = mgp_v4f{lo.x, lo.y, hi.x, hi.y};
+}
+
+template <int NV, bool PRE>
+__global__ __launch_bounds__(kDictThreads) void spmm_dict_kernel(SpmmArgs p, TileArgs t, int S, int stream_cap) {
+  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+  constexpr int TR = 64, SLOT4 = 16 * NV;            // float4 per dictionary slot
+  constexpr int kDictMaxU = dict_max_u(NV);
+  mgp_v4f* __restrict__ dict = reinterpret_cast<mgp_v4f*>(tile_lds);                       // [S + 1][SLOT4]; slot S = zeros
+  mgp_v4f* __restrict__ svals = dict + (size_t)(S + 1) * SLOT4;                            // [stream_cap / 4]
+  mgp_v4h* __restrict__ slid = reinterpret_cast<mgp_v4h*>(svals + (stream_cap >> 2));      // [stream_cap / 4]
+  const int skipv = p.skip ? *p.skip : 0;
+  const int tickv = (p.tick && blockIdx.x == 0) ? *p.tick : 0;
+  if (skipv) return;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int tid = threadIdx.x, grp = tid >> 4, gl = tid & 15;
+  const int C = p.C, C4 = C >> 2;
+  const mgp_v4f* __restrict__ X4 = reinterpret_cast<const mgp_v4f*>(p.X);
+  const int32_t* __restrict__ rowptr = t.rowptr_t ? t.rowptr_t : p.rowptr;
+  const float* __restrict__ vals = t.vals_t ? t.vals_t : p.vals;
+  const uint32_t* __restrict__ tile_cols = reinterpret_cast<const uint32_t*>(t.tile_cols);
+  const int total4 = S * SLOT4;                       // float4 per staged slice
+  // the zero slot: entries outside the staged slice are redirected here (value x 0) instead of being masked one by one
+  if (tid < SLOT4) dict[total4 + tid] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+  mgp_v4f dsum[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) dsum[v] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+
+  // workgroup lb walks the contiguous tile range [lb T / G, (lb + 1) T / G): any grid; one tile per workgroup up to
+  // kMaxGrid tiles.  (A persistent grid of one workgroup per CU was measured too: the launch of a 1024-thread workgroup
+  // with ~150 KB of LDS costs ~5 us per round of the grid, but a persistent workgroup serialises its tiles' prologues
+  // completely: 115 against 90 us at C = 128 on the 60k graph.)
+  const int64_t t0 = (int64_t)lb * t.ntiles / gridDim.x;
+  const int64_t t1 = ((int64_t)lb + 1) * t.ntiles / gridDim.x;
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const int64_t r0 = tile * TR;
+    const int64_t r1 = r0 + TR < p.n ? r0 + TR : p.n;
+    const int dp = t.tile_ptr[tile];
+    const int D = t.tile_ptr[tile + 1] - dp;
+    const int e0 = rowptr[r0], e1 = rowptr[r1];
+    const int nq = (e1 - e0) >> 2;                     // quads of the tile (rows are padded to quads)
+    const int nsl = (D + S - 1) / S;
+    // ---- this group's row
+    const int64_t prow = r0 + grp;
+    const bool valid = prow < r1;
+    const int64_t pr = valid ? prow : r0;
+    const int64_t rr = t.rowid ? (int64_t)t.rowid[pr] : pr;
+    const int64_t grr = rr + p.goff;
+    int cur = (rowptr[pr] - e0) >> 2;                  // in quads, relative to the tile's stream
+    const int end = valid ? (rowptr[pr + 1] - e0) >> 2 : cur;
+    // ---- staging helpers: thread -> float4 j = tid + 1024 u of the slice image, slot j / SLOT4, piece j % SLOT4
+    unsigned ids[kDictMaxU];
+    mgp_v4f xr[kDictMaxU];
+    float sc[PRE ? kDictMaxU : 1];
+    auto load_ids = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < kDictMaxU; ++u) {
+        const int j = tid + kDictThreads * u;
+        const int slot = k * S + j / SLOT4;
+        ids[u] = tile_cols[dp + ((j < total4 && slot < D) ? slot : 0)];
+      }
+    };
+    auto load_rows = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < kDictMaxU; ++u) {
+        const int j = tid + kDictThreads * u;
+        const int f = j % SLOT4;
+        xr[u] = X4[(int64_t)ids[u] * C4 + (f < C4 ? f : 0)];
+        if (PRE) sc[u] = p.pre[ids[u]];
+      }
+    };
+    // slots past the dictionary's end (last slice) and pieces past the row's end hold zeros
+    auto write_rows = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < kDictMaxU; ++u) {
+        const int j = tid + kDictThreads * u;
+        if (j < total4) {
+          const bool on = k * S + j / SLOT4 < D && j % SLOT4 < C4;
+          mgp_v4f v = xr[u];
+          if (PRE) { v.x *= sc[u]; v.y *= sc[u]; v.z *= sc[u]; v.w *= sc[u]; }
+          dict[j] = on ? v : mgp_v4f{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    };
+    // ---- prologue: ids of slice 0 -> rows of slice 0 + ids of slice 1 + the matrix stream, all in flight
+    if (nsl > 0) load_ids(0);
+    const float e_pre = PRE ? p.pre[grr] : 1.f;
+    const float e_diag = p.diag[rr];
+    const float l_post = p.post ? p.post[grr] : 1.f;
+    for (int i = tid; i < nq; i += kDictThreads) {
+      svals[i] = *reinterpret_cast<const mgp_v4f*>(vals + (int64_t)e0 + 4 * (int64_t)i);
+      slid[i] = *reinterpret_cast<const mgp_v4h*>(t.lid + (int64_t)e0 + 4 * (int64_t)i);
+    }
+    if (nsl > 0) {
+      load_rows();
+      write_rows(0);
+      if (nsl > 1) load_ids(1);
+    }
+    __syncthreads();
+    mgp_v4f acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsl; ++k) {
+      if (k + 1 < nsl) {
+        load_rows();                                   // X rows of slice k + 1: in flight (registers) during the walk below
+        if (k + 2 < nsl) load_ids(k + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- walk this row's run of slice k
+      const unsigned lo = (unsigned)(k * S);
+      const int Sk = D - k * S < S ? D - k * S : S;
+      const mgp_v4f* __restrict__ db = dict + gl;
+      while (cur < end) {
+        const mgp_v4f vq = svals[cur];
+        const mgp_v4h lq = slid[cur];
+        const unsigned i0 = (unsigned)lq.x - lo, i1 = (unsigned)lq.y - lo, i2 = (unsigned)lq.z - lo, i3 = (unsigned)lq.w - lo;
+        // the first entry of a quad is never padding: a quad that starts behind this slice ends the run
+        if ((int)i0 >= Sk) break;
+        // outside the slice (already done, still to come, or padding): the zero slot
+        const unsigned s0 = min(i0, (unsigned)S), s1 = min(i1, (unsigned)S), s2 = min(i2, (unsigned)S), s3 = min(i3, (unsigned)S);
+        const mgp_v4f* __restrict__ b0 = db + s0 * SLOT4;
+        const mgp_v4f* __restrict__ b1 = db + s1 * SLOT4;
+        const mgp_v4f* __restrict__ b2 = db + s2 * SLOT4;
+        const mgp_v4f* __restrict__ b3 = db + s3 * SLOT4;
+        // two 256-byte pieces of the four slots at a time (32 VGPRs of operands whatever NV is)
+#pragma unroll
+        for (int v0 = 0; v0 < NV; v0 += 2) {
+          constexpr int kTwo = 2;
+          mgp_v4f a0[kTwo], a1[kTwo], a2[kTwo], a3[kTwo];
+#pragma unroll
+          for (int w = 0; w < kTwo; ++w)
+            if (v0 + w < NV) {
+              a0[w] = b0[16 * (v0 + w)];
+              a1[w] = b1[16 * (v0 + w)];
+              a2[w] = b2[16 * (v0 + w)];
+              a3[w] = b3[16 * (v0 + w)];
+            }
+#pragma unroll
+          for (int w = 0; w < kTwo; ++w)
+            if (v0 + w < NV) quad_fma(acc[v0 + w], vq, a0[w], a1[w], a2[w], a3[w]);
+        }
+        // entries behind this slice (or padding whose own slot lies there) keep the cursor on this quad
+        const int mx = max(max((int)i1, (int)i2), (int)i3);
+        if (mx >= Sk) break;
+        ++cur;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < nsl) {
+        __syncthreads();                               // every group is done with slice k: the buffer may be overwritten
+            write_rows(k + 1);
+      }
+      __syncthreads();
+      }
+    // ---- epilogue of this lane's 4 NV columns
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int f = gl + 16 * v;
+      if (valid && f < C4) {
+        const mgp_v4f ex = X4[grr * C4 + f];
+        const mgp_v4f lb4 = *reinterpret_cast<const mgp_v4f*>((p.base ? p.base : p.X) + grr * C + 4 * f);
+        const mgp_v4f ld4 = *reinterpret_cast<const mgp_v4f*>((p.dotw ? p.dotw : p.X) + grr * C + 4 * f);
+        const float xs0 = ex.x * e_pre, xs1 = ex.y * e_pre, xs2 = ex.z * e_pre, xs3 = ex.w * e_pre;
+        mgp_v4f y;
+        y.x = p.co * ((p.a * xs0 + p.b * (e_diag * xs0 - acc[v].x)) * l_post) + (p.base ? p.cb * lb4.x : 0.f);
+        y.y = p.co * ((p.a * xs1 + p.b * (e_diag * xs1 - acc[v].y)) * l_post) + (p.base ? p.cb * lb4.y : 0.f);
+        y.z = p.co * ((p.a * xs2 + p.b * (e_diag * xs2 - acc[v].z)) * l_post) + (p.base ? p.cb * lb4.z : 0.f);
+        y.w = p.co * ((p.a * xs3 + p.b * (e_diag * xs3 - acc[v].w)) * l_post) + (p.base ? p.cb * lb4.w : 0.f);
+        *reinterpret_cast<mgp_v4f*>(p.Y + grr * C + 4 * f) = y;
+        if (p.dotw) {
+          dsum[v].x = fmaf(ld4.x, y.x, dsum[v].x); dsum[v].y = fmaf(ld4.y, y.y, dsum[v].y);
+          dsum[v].z = fmaf(ld4.z, y.z, dsum[v].z); dsum[v].w = fmaf(ld4.w, y.w, dsum[v].w);
+        }
+      }
+    }
+    // (the next tile's prologue overwrites the stream and the dictionary: every group is past its last read of both at
+    // the slice loop's final barrier; a tile without slices has read neither)
+  }
+  if (p.dot_partials) {
+    // red[group][SLOT4] float4: the workgroup's 64 rows (x its tiles) per column, added in group order
+    mgp_v4f* red = dict;
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[grp * SLOT4 + gl + 16 * v] = dsum[v];
+    __syncthreads();
+    if (tid < C) {
+      const float* rf = reinterpret_cast<const float*>(red);
+      float sacc = 0.f;
+      for (int g = 0; g < TR; ++g) sacc += rf[g * (SLOT4 * 4) + tid];
+      p.dot_partials[(int64_t)lb * C + tid] = sacc;
+    }
+  }
+  if (p.tick && blockIdx.x == 0 && tid == 0) *p.tick = tickv + 1;
+}
+
 struct Plan {
   int grid;
   int64_t rows_per_block;
@@ -1244,9 +1475,64 @@ extern "C" int mgp_spmm_set_tile_small_mode(int on) {
   return MGP_OK;
 }
 
+// 16 < C <= 256 on 64-row tiles with lanes over columns (spmm_dict_kernel): slots per slice from what the stream leaves
+// of the CU's LDS.  mgp_spmm_set_dict_mode: 0 never, 1 (default) where it was measured to win, 2 wherever the shape allows.
+// Measured (tools/lab/time_spmm_wide.py, round 3; us: this kernel | chunked dictionary kernel | float4 gather | per-column
+// gather):  60k graph  C = 64: 52 | 84 | 54 | 63   C = 128: 90 | 160 | 101 | 91   C = 256: 176 | 319 | 204 | 186
+//           1M graph   C = 64: 704 | 777 | 1020 | 1188   C = 128: 1201 | 1458 | 2084 | 3037   C = 256: 2380 | 2871 | 6515 | 6828
+// -> taken from 64 columns up when the X block (n x C floats) is 96 MB or more, i.e. does not sit in the caches.
+int g_dict_mode = 1;
+static int dict_nv(int C) { return (C + 63) / 64; }
+static int dict_stream_cap(const mgp_csr_t* L) { return (L->tile_max_entries + 7) / 8 * 8; }
+static int dict_slots(const mgp_csr_t* L, int C) {
+  const int nv = dict_nv(C);
+  const long left = (long)kDictLdsBudget - (long)dict_stream_cap(L) * 6 - (long)nv * 256;      // (the zero slot)
+  long s = left / (nv * 256L);
+  const long cap = (long)dict_max_u(nv) * kDictThreads / (16 * nv);      // staged float4 per thread <= dict_max_u
+  if (s > cap) s = cap;
+  s = s / 16 * 16;
+  // no point in slices larger than the largest dictionary
+  const long need = ((long)L->tile_max_cols + 15) / 16 * 16;
+  if (s > need) s = need;
+  return (int)s;
+}
+static size_t dict_lds_bytes(const mgp_csr_t* L, int C) {
+  const size_t d = (size_t)(dict_slots(L, C) + 1) * dict_nv(C) * 256 + (size_t)dict_stream_cap(L) * 6;
+  const size_t red = (size_t)64 * dict_nv(C) * 256;
+  return d > red ? d : red;
+}
+static int dict_grid(const mgp_csr_t* L) {
+  const int64_t ntiles = mgp_cdiv(L->n, L->tile_rows);
+  return (int)(ntiles < kMaxGrid ? ntiles : kMaxGrid);
+}
+static bool dict_shape_ok(const mgp_csr_t* L, int C) {
+  const int ord = (L->tile_rowptr != nullptr) + (L->tile_vals != nullptr) + (L->tile_rowid != nullptr);
+  if (ord != 0 && ord != 3) return false;
+  if (C <= 16 || C > 256 || (C & 3) != 0 || !g_tile_mode || !g_dict_mode) return false;
+  if (!L->lid || !L->tile_ptr || !L->tile_cols || L->tile_rows != 64) return false;
+  if ((L->tile_max_entries & 3) != 0) return false;
+  if (dict_slots(L, C) < 32) return false;
+  if (g_dict_mode == 2) return true;
+  return C >= 64 && (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20);
+}
+// the kernel moves 16 bytes per lane: X, Y, base and dotw rows must be 16-byte aligned (C % 4 == 0 makes every row so
+// once the block is); the planned kernel (dot-partial blocks) and the launched one must never disagree, so a
+// misaligned operand is an argument error at launch instead of a silent fall-through to another kernel
+static bool aligned16(const void* a, const void* b, const void* c, const void* d) {
+  return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+           reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
+
+extern "C" int mgp_spmm_set_dict_mode(int on) {
+  g_dict_mode = on == 2 ? 2 : (on ? 1 : 0);
+  return MGP_OK;
+}
+
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (!L) return MGP_ERR_ARG;
-  if (use_tiles(L, C) || use_tiles_small(L, C) || use_tiles_wide(L, C)) return tile_grid(L, nullptr);
+  if (use_tiles(L, C) || use_tiles_small(L, C)) return tile_grid(L, nullptr);
+  if (dict_shape_ok(L, C)) return dict_grid(L);
+  if (use_tiles_wide(L, C)) return tile_grid(L, nullptr);
   return mgp_spmm_dot_blocks(L->n, C);
 }
 
@@ -1395,9 +1681,41 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     else if (C == 12) MGP_TILE_SMALL_LAUNCH(3);
     else MGP_TILE_SMALL_LAUNCH(4);
 #undef MGP_TILE_SMALL_LAUNCH
-  } else if (use_tiles_wide(L, C) &&
-             ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(base) |
-               reinterpret_cast<uintptr_t>(dotw)) & 15) == 0) {
+  } else if (dict_shape_ok(L, C)) {
+    if (!aligned16(X, Y, base, dotw)) return MGP_ERR_ARG;   // (the plan counted this kernel's dot-partial blocks)
+    TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
+                L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries, 0};
+    const int grid = dict_grid(L);
+    const size_t lds = dict_lds_bytes(L, C);
+    const int S = dict_slots(L, C), cap = dict_stream_cap(L);
+#define MGP_DICT_LAUNCH(NV)                                                                                         \
+  do {                                                                                                              \
+    static bool attr_set[2] = {false, false};                                                                       \
+    if (pre) {                                                                                                      \
+      if (!attr_set[1]) {                                                                                           \
+        MGP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_dict_kernel<NV, true>),                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kDictLdsBudget));               \
+        attr_set[1] = true;                                                                                         \
+      }                                                                                                             \
+      hipLaunchKernelGGL((spmm_dict_kernel<NV, true>), dim3(grid), dim3(kDictThreads), lds, st, p, ta, S, cap);     \
+    } else {                                                                                                        \
+      if (!attr_set[0]) {                                                                                           \
+        MGP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_dict_kernel<NV, false>),                \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kDictLdsBudget));               \
+        attr_set[0] = true;                                                                                         \
+      }                                                                                                             \
+      hipLaunchKernelGGL((spmm_dict_kernel<NV, false>), dim3(grid), dim3(kDictThreads), lds, st, p, ta, S, cap);    \
+    }                                                                                                               \
+  } while (0)
+    switch (dict_nv(C)) {
+      case 1: MGP_DICT_LAUNCH(1); break;
+      case 2: MGP_DICT_LAUNCH(2); break;
+      case 3: MGP_DICT_LAUNCH(3); break;
+      default: MGP_DICT_LAUNCH(4); break;
+    }
+#undef MGP_DICT_LAUNCH
+  } else if (use_tiles_wide(L, C)) {
+    if (!aligned16(X, Y, base, dotw)) return MGP_ERR_ARG;   // planned and launched kernel must not disagree
     TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
                 L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries, 0};
     const int grid = tile_grid(L, &ta.tiles_per_block);

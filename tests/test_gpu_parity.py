@@ -1953,8 +1953,12 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
         try:
             # 0: no tile kernels (C > 16: the float4-lane gather kernel); 1: kernels picked as in production; 2: the wide
             # dictionary kernel forced; 3: no tile kernels, per-column gather kernel
-            for mode in (0, 1, 2, 3):
-                lib.mgp_spmm_set_tile_mode(1 if mode in (1, 2) else 0)
+            # (round 3: mode 1 forces the lanes-over-columns dictionary kernel for C > 16 -- production takes it only for
+            # X blocks that do not sit in the caches; mode 2 turns it off so that the older chunked dictionary kernel runs;
+            # mode 4 is production's own choice)
+            for mode in (0, 1, 2, 3, 4):
+                lib.mgp_spmm_set_tile_mode(1 if mode in (1, 2, 4) else 0)
+                lib.mgp_spmm_set_dict_mode(0 if mode == 2 else (2 if mode == 1 else 1))
                 lib.mgp_spmm_set_tile_wide_mode(2 if mode == 2 else 1)
                 lib.mgp_spmm_set_v4_mode(0 if mode == 3 else (2 if mode == 0 else 1))
                 csr = data.csr()
@@ -1967,6 +1971,7 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
                 outs.append((Y.cpu().double().numpy(), part.double().sum(0).cpu().numpy(), nb))
         finally:
             lib.mgp_spmm_set_tile_mode(1)
+            lib.mgp_spmm_set_dict_mode(1)
             lib.mgp_spmm_set_tile_wide_mode(1)
             lib.mgp_spmm_set_v4_mode(1)
         Xs = (pre.cpu().double().view(-1, 1) * X.cpu().double()).numpy()

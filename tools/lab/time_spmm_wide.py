@@ -11,10 +11,11 @@ wl = bench.build_workload(argparse.Namespace(workload=sys.argv[1] if len(sys.arg
 g, lap = wl["graph"], wl["lap"]
 lib = _lib.lib(); lib.mgp_spmm_set_group_hint(g.spmv_lanes)
 csr = lap.data.csr()
-for C in (20, 32, 64, 100, 128, 256):
+for C in (20, 32, 64, 84, 100, 128, 192, 256):
     X = torch.randn(g.n, C, device=dev); Y = torch.empty_like(X)
     out = []
-    for mode in (2, 0, 3):
+    for mode in (1, 2, 0, 3):
+        lib.mgp_spmm_set_dict_mode(1 if mode == 1 else 0)
         lib.mgp_spmm_set_tile_wide_mode(2 if mode == 2 else 0)
         lib.mgp_spmm_set_v4_mode(0 if mode == 3 else 2)
         ms = ctypes.c_float(0.0)
@@ -25,5 +26,6 @@ for C in (20, 32, 64, 100, 128, 256):
             best = min(best, ms.value)
         out.append(best / 30 * 1e3)
     B = bench.spmm_bytes(g.n, g.M, C)
-    print("C %3d  wide tile %.1f us   float4 gather %.1f us (%.0f GB/s algorithmic)   per-column gather %.1f us" % (C, out[0], out[1], B / out[1] / 1e3, out[2]))
-lib.mgp_spmm_set_tile_wide_mode(1); lib.mgp_spmm_set_v4_mode(1)
+    print("C %3d  dict (lanes over columns) %.1f us (%.0f GB/s algorithmic)   wide tile %.1f us   float4 gather %.1f us   per-column gather %.1f us"
+          % (C, out[0], B / out[0] / 1e3, out[1], out[2], out[3]), flush=True)
+lib.mgp_spmm_set_tile_wide_mode(1); lib.mgp_spmm_set_v4_mode(1); lib.mgp_spmm_set_dict_mode(1)
