@@ -353,6 +353,19 @@ size_t mgp_lanczos_workspace_bytes(int64_t n, int m, const mgp_lanczos_params_t*
 int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals,
                          float* evecs, float* resid, int32_t* info, void* work, size_t work_bytes,
                          void* stream);
+/* The same solve, also handing out the WHOLE Rayleigh-Ritz block it ended with -- the m wanted pairs plus the guard
+ * columns behind them (b = mgp_lanczos_block_size(m, p) columns, Ritz values ascending): block_evals [b] (host),
+ * block_evecs [n, b] row-major (device), block_resid [b] (host); any of the three may be NULL.  What an independent
+ * check of the spectral stage needs (tests/test_gpu_configs.py: float64 Rayleigh-Ritz of the block with the oracle's
+ * matrix, the gap behind the kept modes, a Davis-Kahan bound).
+ * Return value of both: MGP_OK when all m residuals are <= tol * lambda_max, and ALSO when the iteration has reached the
+ * fp32 residual floor (a few ulp of |L|: the filter at its degree cap, no pair converging, the largest residual within
+ * 15 % of its value two rounds earlier): info[2] (pairs under tol) < m tells the two apart and `resid` holds what was
+ * reached.  MGP_ERR_NOT_CONVERGED: max_restarts rounds without either. */
+int mgp_lanczos_block_size(int m, const mgp_lanczos_params_t* p);
+int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs,
+                            float* resid, int32_t* info, float* block_evals, float* block_evecs, float* block_resid,
+                            void* work, size_t work_bytes, void* stream);
 
 /* k-step Lanczos tridiagonalisation of a precision-family operator with full re-orthogonalisation
  * (classical Gram-Schmidt against all previous vectors, twice).  Replaces

@@ -492,9 +492,17 @@ extern "C" size_t mgp_lanczos_workspace_bytes(int64_t n, int m, const mgp_lanczo
   return eig_bytes(n, m, p);
 }
 
+extern "C" int mgp_lanczos_block_size(int m, const mgp_lanczos_params_t* p) { return m > 0 ? block_size_for(m, p) : 0; }
+
 extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals,
                                     float* evecs, float* resid, int32_t* info, void* work, size_t work_bytes,
                                     void* stream) {
+  return mgp_lanczos_smallest_ex(L, m, p, evals, evecs, resid, info, nullptr, nullptr, nullptr, work, work_bytes, stream);
+}
+
+extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals,
+                                       float* evecs, float* resid, int32_t* info, float* block_evals, float* block_evecs,
+                                       float* block_resid, void* work, size_t work_bytes, void* stream) {
   if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !evals || !evecs || !work) return MGP_ERR_ARG;
   const int64_t n = L->n;
   if (n <= 0 || m <= 0 || m > n) return MGP_ERR_ARG;
@@ -549,6 +557,9 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
   std::vector<float> wt((size_t)b * b), thf(b);
   std::vector<double> rp((size_t)w.rchunks * b), res(b, 1e300);
   int outer = 0, nspmm = 0, nconv = 0, kept = b;
+  double rmax_prev1 = 1e300;
+  int nconv_prev1 = 0, deg_used = 0;
+  bool floor_hit = false;
   auto move_cols = [&](const float* src, int sld, int sc0, int mcols, float* dst, int dld, int dc0) {
     const int grid = (int)std::min<int64_t>(4096, mgp_cdiv(n * mcols, kBlock));
     hipLaunchKernelGGL(move_cols_kernel, dim3(grid), dim3(kBlock), 0, st, src, n, sld, sc0, mcols, dst, dld, dc0);
@@ -556,6 +567,7 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
   for (outer = 0; outer < max_outer; ++outer) {
     // ---- scaled Chebyshev filter of degree `deg` damping [a, ub], normalised at a0, on the active columns
     const int ba = b - nlock;
+    deg_used = deg;
     const double e = (ub - a) / 2.0, c = (ub + a) / 2.0;
     double sig = e / (a0 - c);
     const double tau = 2.0 / sig;
@@ -693,6 +705,20 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
                 deg, nconv, m, lead, rmx, tol * ub);
       }
       if (nconv == m) { ++outer; break; }
+      // The attainable residual of an fp32 iteration is a few ulp of |L| (the SpMM's own rounding: measured 1.8e-6 ub on
+      // the 60k RMNIST-like graph, 7e-8 ub on the smooth modes of the dumbbell): a tolerance under that floor can never
+      // be met, and the rounds past it only shuffle round-off (60 rounds / 1.3 s where 5 reach the floor).  With the
+      // filter at its degree cap a round multiplies the error of the slowest wanted pair by <= e^-3 unless the gap
+      // behind the block is tiny; a round at the cap that does not even halve the largest residual, with no further
+      // pair converging, is therefore taken as the floor: the caller gets the block as it stands, the true residuals in
+      // `resid`, info[2] = pairs under tol (< m) and MGP_OK.
+      {
+        double rmx = 0.0;
+        for (int j = 0; j < m; ++j) rmx = std::max(rmx, res[j]);
+        if (deg_used >= 200 && rmx > 0.5 * rmax_prev1 && nconv <= nconv_prev1 && rmx <= 1e-3 * ub) { floor_hit = true; ++outer; break; }
+        rmax_prev1 = rmx;
+        nconv_prev1 = nconv;
+      }
       {
         int lead = 0;
         while (lead < m && res[lead] <= tol * ub) ++lead;
@@ -712,13 +738,23 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
   const int cgrid = (int)std::min<int64_t>(4096, mgp_cdiv(n * m, kBlock));
   hipLaunchKernelGGL(copy_cols_kernel, dim3(cgrid), dim3(kBlock), 0, st, w.buf[bV], n, b, m, evecs);
   MGP_LAUNCH_CHECK();
+  if (block_evecs) {     // the whole Rayleigh-Ritz block, guard columns included: [n, b] row-major
+    const int bgrid = (int)std::min<int64_t>(4096, mgp_cdiv(n * b, kBlock));
+    hipLaunchKernelGGL(copy_cols_kernel, dim3(bgrid), dim3(kBlock), 0, st, w.buf[bV], n, b, b, block_evecs);
+    MGP_LAUNCH_CHECK();
+  }
   MGP_HIP_TRY(hipStreamSynchronize(st));
   for (int j = 0; j < m; ++j) {
     evals[j] = (kept >= m) ? (float)th[j] : 0.f;
     if (resid) resid[j] = (float)res[j];
   }
+  for (int j = 0; j < b; ++j) {
+    if (block_evals) block_evals[j] = j < kept ? (float)th[j] : 0.f;
+    if (block_resid) block_resid[j] = (float)res[j];
+  }
   if (info) { info[0] = outer; info[1] = nspmm; info[2] = nconv; info[3] = b; }
-  return nconv == m ? MGP_OK : MGP_ERR_NOT_CONVERGED;
+  if (nconv == m) return MGP_OK;
+  return floor_hit ? MGP_OK : MGP_ERR_NOT_CONVERGED;
 }
 
 // ================================================================= Lanczos tridiagonalisation

@@ -64,7 +64,12 @@ class RiemannKernel(Kernel):
         self.num_modes = num_modes
         self.bump_scale = bump_scale
         self.bump_decay = bump_decay
-        self.eigen_tol = 1e-5
+        # residual tolerance of eval()'s eigensolve relative to lambda_max.  1e-6 since round 3: against the reference
+        # pipeline's float64 posterior on the dumbbell (tests/golden/dumbbell_posterior.npz) 1e-5 leaves 1.8e-4 in the
+        # posterior mean and 5.5e-3 in (K + noise I)^-1 y, 1e-6 leaves 1.3e-6 / 5.2e-5 (tools/probe_posterior.py); where
+        # fp32 cannot reach it the solver stops at its residual floor (include/mgp_hip.h)
+        self.eigen_tol = 1e-6
+        self.keep_eigen_block = False     # True: eval() keeps the solver's whole Rayleigh-Ritz block (guard columns) in .eigen_block
 
         if graphbandwidth_constraint is None:
             graphbandwidth_constraint = Positive()
@@ -137,7 +142,9 @@ class RiemannKernel(Kernel):
             data = self.laplacian_operator.data
             n = self.laplacian_operator.operator_dimension
             m = min(self.num_modes, n)
-            evals, evecs, resid = lanczos_smallest(data, m, tol=self.eigen_tol)
+            out = lanczos_smallest(data, m, tol=self.eigen_tol, return_block=self.keep_eigen_block)
+            evals, evecs, resid = out[:3]
+            self.eigen_block = out[3] if self.keep_eigen_block else None
             self.eigen_residuals = resid
             evals[0] = 0.0                                              # :126
             work = torch.empty(int(lib().mgp_eigvec_postprocess_work_floats(m)), dtype=torch.float32,

@@ -386,9 +386,11 @@ def dense_symeig(operator):
 
 
 # ------------------------------------------------------------------------------ Lanczos
-def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=60, seed=1337):
-    """m smallest eigenpairs of L_sym (CSR in `lap_data`) by the HIP filtered Lanczos.
-    Returns (evals[m] device, evecs[n,m] device, resid[m] host list)."""
+def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=60, seed=1337, return_block=False):
+    """m smallest eigenpairs of L_sym (CSR in `lap_data`) by the HIP filtered block iteration.
+    Returns (evals[m] device, evecs[n,m] device, resid[m] host list); with return_block=True a fourth item
+    dict(evals [b] device, evecs [n, b] device, resid [b] list): the whole Rayleigh-Ritz block the solver ended with,
+    guard columns included (what the independent float64 check of the spectral stage starts from)."""
     g = lap_data.graph
     dev = g.device
     check(lib().mgp_spmm_set_group_hint(g.spmv_lanes), "mgp_spmm_set_group_hint")
@@ -418,8 +420,13 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
     resid = (ctypes.c_float * m)()
     info = (ctypes.c_int32 * 4)()
     evecs = torch.empty(g.n, m, dtype=torch.float32, device=dev)
-    rc = lib().mgp_lanczos_smallest(ctypes.byref(csr), int(m), ctypes.byref(prm), evals, ptr(evecs), resid, info,
-                                    ptr(work), work.numel(), stream())
+    b = int(lib().mgp_lanczos_block_size(int(m), ctypes.byref(prm))) if return_block else 0
+    b = min(b, g.n)
+    bev = (ctypes.c_float * b)() if b else None
+    bres = (ctypes.c_float * b)() if b else None
+    bvec = torch.empty(g.n, b, dtype=torch.float32, device=dev) if b else None
+    rc = lib().mgp_lanczos_smallest_ex(ctypes.byref(csr), int(m), ctypes.byref(prm), evals, ptr(evecs), resid, info,
+                                       bev, ptr(bvec) if b else None, bres, ptr(work), work.numel(), stream())
     if rc == -4:      # MGP_ERR_NOT_CONVERGED: the best block is returned, residuals say how good it is
         warnings.warn("eigensolver stopped after %d rounds with %d/%d pairs below tol (max residual %.3g)"
                       % (info[0], info[2], m, max(resid)))
@@ -431,6 +438,13 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
         out = torch.empty_like(evecs)
         out[order] = evecs                                   # row p of the relabelled problem is node order[p]
         evecs = out
+        if b:
+            outb = torch.empty_like(bvec)
+            outb[order] = bvec
+            bvec = outb
+    if return_block:
+        return ev, evecs, list(resid), dict(evals=torch.tensor(list(bev), dtype=torch.float32, device=dev), evecs=bvec,
+                                            resid=list(bres))
     return ev, evecs, list(resid)
 
 

@@ -120,6 +120,71 @@ def test_c2_dumbbell_10k_spmv_and_eigensolve(mgp, dev, eps_rule):
         assert np.abs(sol - refs).max() < 1e-4 * np.abs(refs).max(), np.abs(sol - refs).max() / np.abs(refs).max()
 
 
+def test_c2_dumbbell_10k_posterior_vs_dense_float64_pipeline(mgp, dev):
+    """The north-star target end to end at a size where an INDEPENDENT float64 reference exists: the dumbbell resampled
+    to 10 000 points, 300 of them held out.  Checker = the reference's pipeline restated in float64 and evaluated densely
+    (oracle Laplacian -> dense float64 eigh of the 9 700 x 9 700 L_sym, riemann_kernel.py:121-128 -> features :134-147 ->
+    Woodbury posterior, riemann_gp.py:45-75); nothing of the HIP path is fed to it except the k-NN lists, which are
+    bit-exact against the C oracle (sampled rows).  HIP: k-NN -> graph -> Laplacian -> block eigensolve -> features ->
+    posterior.  99 modes: on a closed curve the eigenvalues come in near-pairs (1,2), (3,4), ...; 99 keeps whole pairs,
+    the gap behind the kept block is printed and asserted against the residual (Davis-Kahan)."""
+    from manifold_gp_amd.models import GaussianLikelihood, RiemannGP, ScaleKernel
+    from oracle import spectral as osp
+    from oracle.solvers import gp_posterior_lowrank
+    from oracle.sparse import laplacian_sym_csr
+    from tools import synth
+    n_all, k, m, nu = 10000, 50, 99, 2
+    eps, kappa, s, noise, bump = 0.02, 0.5, 0.7, 1e-2, (3.0, 0.01)
+    x_np, y_np, _ = synth.dumbbell_resampled(n_all)
+    rng = np.random.default_rng(11)
+    perm = rng.permutation(n_all)
+    te, tr = np.sort(perm[:300]), np.sort(perm[300:])
+    x, y, xt = T(x_np[tr], dev), T(y_np[tr], dev), T(x_np[te], dev)
+    n = x.shape[0]
+    kern = mgp.kernels.RiemannMaternKernel(nu=nu, x=x, nearest_neighbors=k, laplacian_normalization="symmetric", num_modes=m,
+                                           bump_scale=bump[0], bump_decay=bump[1]).to(dev)
+    kern.initialize(graphbandwidth=eps, lengthscale=kappa)
+    D, I = kern.knn.search(x, k)
+    _knn_rows_bit_exact(x_np[tr], D, I, k, rng.choice(n, 200, replace=False))
+    Dt, It = kern.knn.search(xt, k)
+    from oracle import knn as oknn
+    Dr, Ir = oknn.knn_search(x_np[tr], x_np[te][:50], k)
+    assert np.array_equal(It[:50].cpu().numpy(), Ir) and np.array_equal(Dt[:50].cpu().numpy(), Dr)
+    model = RiemannGP(x, y, GaussianLikelihood(noise).to(dev), ScaleKernel(kern, s).to(dev)).to(dev)
+    model.eval()
+    model.posterior(xt)
+    # ---- the float64 reference pipeline (dense eigh on the device through torch: the checker, 750 MB)
+    lo = _oracle_lap(kern.knn.knn_graph, eps, "symmetric")
+    w, Uw = torch.linalg.eigh(T(laplacian_sym_csr(lo).toarray(), dev))
+    w, Uw = w[:m + 2].cpu().numpy(), Uw[:, :m].cpu().numpy()
+    gap = float(w[m] - w[m - 1])
+    lam = w[:m].copy()
+    lam[0] = 0.0
+    Phi = Uw * (lo.degree ** -0.5)[:, None]
+    Phi /= np.linalg.norm(Phi, axis=0, keepdims=True)
+    Z64 = osp.features_insample(lam, Phi, nu, kappa)
+    Zt64 = osp.features_oos(lo, lam, Phi, nu, kappa, Dt.double().cpu().numpy(), It.cpu().numpy(), bump[0], bump[1])
+    mean_o, cov_o, alpha_o = gp_posterior_lowrank(Z64, y_np[tr], Zt64, s, noise)
+    lmax = 2.0 * float(np.abs(lo.diag).max())
+    res = max(kern.eigen_residuals)
+    mean, cov = model.posterior_mean.double().cpu().numpy(), model.posterior_covar.double().cpu().numpy()
+    Z = kern.features(x).double().cpu().numpy()
+    Zt = kern.features(xt).double().cpu().numpy()
+    rows = rng.choice(n, 256, replace=False)
+    e = dict(evals=float(np.abs(kern.eigval.cpu().numpy()[1:] - lam[1:]).max() / lmax),
+             kernel=float(np.abs(Z[rows] @ Z.T - Z64[rows] @ Z64.T).max() / np.abs(Z64[rows] @ Z64.T).max()),
+             cross=float(np.abs(Zt @ Z.T - Zt64 @ Z64.T).max() / np.abs(Zt64 @ Z64.T).max()),
+             mean=float(np.abs(mean - mean_o).max() / np.abs(mean_o).max()),
+             var=float(np.abs(np.diag(cov) - np.diag(cov_o)).max() / np.abs(np.diag(cov_o)).max()),
+             cov=float(np.abs(cov - cov_o).max() / np.abs(cov_o).max()))
+    print("C2 end to end vs dense float64 pipeline: gap behind the kept block %.3e, eigensolver residual %.2e (|R| / gap = %.1e); %s"
+          % (gap, res, res * np.sqrt(m) / gap, " ".join("%s %.2e" % kv for kv in e.items())))
+    assert (np.abs(Zt64).sum(1) > 0).mean() > 0.9                           # the held-out points lie in the bump support
+    assert res * np.sqrt(m) / gap < 0.1                                      # a conditioned cut (Davis-Kahan)
+    assert e["evals"] < 1e-6 and e["kernel"] < 1e-4 and e["cross"] < 1e-4, e
+    assert e["mean"] < 1e-4 and e["var"] < 1e-4 and e["cov"] < 1e-4, e
+
+
 # ============================================================================= C3 / C4 (shared 60k graph)
 @pytest.fixture(scope="module")
 def rmnist60k(mgp, dev):
@@ -176,6 +241,7 @@ def test_c3_rmnist_60k_knn_spectrum_posterior(mgp, dev, rmnist60k):
             out = op.matmul(v.to(dev)).cpu().numpy()
             assert np.abs(out - ref).max() < 4e-6 * lmax * float(v.abs().max()), tr
     # ---- eval(): eigenpairs of L_sym (riemann_kernel.py:117-130); phi = normalise(D^-1/2 u)
+    kern.keep_eigen_block = True
     kern.eval()
     assert float(kern.eigval[0]) == 0.0 and kern.eigvec.shape == (n, 100)
     assert max(kern.eigen_residuals) <= 2e-5 * lmax
@@ -187,6 +253,54 @@ def test_c3_rmnist_60k_knn_spectrum_posterior(mgp, dev, rmnist60k):
     lam[0] = float(U[:, 0] @ (sq.L @ U[:, 0]))                              # eigval[0] is SET to 0 (:126)
     R = sq.L @ U - U * lam[None, :]
     assert np.linalg.norm(R, axis=0).max() <= 3e-5 * lmax, np.linalg.norm(R, axis=0) / lmax
+    # ---- an INDEPENDENT float64 look at the spectral stage: Rayleigh-Ritz of the solver's whole block (the 100 kept
+    # columns + 28 guard columns) with the oracle's float64 CSR
+    m = 100
+    blk = kern.eigen_block
+    V = blk["evecs"].double().cpu().numpy()
+    assert V.shape == (n, 128)
+    assert np.abs(V.T @ V - np.eye(128)).max() < 5e-5                        # the block is orthonormal
+    Qb, _ = np.linalg.qr(V)
+    LQ = sq.L @ Qb
+    Hb = Qb.T @ LQ
+    th, Sb = np.linalg.eigh(0.5 * (Hb + Hb.T))
+    Rb = LQ @ Sb - (Qb @ Sb) * th[None, :]
+    rn = np.linalg.norm(Rb, axis=0)
+    gap = float(th[m] - th[m - 1])
+    dk = float(np.linalg.norm(Rb[:, :m])) / max(gap, 1e-300)
+    e_ritz = float(np.abs(blk["evals"].cpu().numpy() - th).max())
+    print("C3 spectral stage in float64: Ritz values theta[0, 1, 99, 100, 127] = %s; HIP Ritz values differ by %.1e; "
+          "residuals of the kept pairs <= %.2e (%.1e lambda_max); gap theta_100 - theta_99 = %.2e; Davis-Kahan "
+          "sin(angle) <= |R| / gap = %.1e" % (np.array2string(th[[0, 1, 99, 100, 127]], precision=3), e_ritz, rn[:m].max(),
+                                               rn[:m].max() / lmax, gap, dk))
+    assert e_ritz <= 1e-6 * lmax                                              # the Ritz values are float64's (measured 1.6e-7)
+    assert rn[:m].max() <= 2e-5 * lmax                                        # backward error of every kept pair (measured 8e-6)
+    assert th[0] > -1e-6 * lmax and np.all(np.diff(th) >= 0)
+    # What this says about "within 1e-4 of the reference" at this size.  By Cauchy interlacing lambda_i <= theta_i: the
+    # graph has at least 128 eigenvalues below theta_127 (measured 5e-5, i.e. 1.7e-6 lambda_max) -- its ~600 rotation orbits
+    # are nearly disconnected clusters at the notebooks' bandwidth rule -- and neighbouring eigenvalues at the m = 100
+    # cut are ~2e-6 apart, below the float32 rounding of the matrix entries themselves (ulp(lambda_max) = 3.5e-6 per
+    # entry) and far below any float32 eigensolver's resolution: the reference's own float32 dense eigh (riemann_kernel.py:
+    # 124; 14.4 GB at this size, it cannot run) would return an equally arbitrary basis of that cluster, so the 100-mode
+    # kernel is NOT a well-defined function of the data here and no independent float64 value exists to be within 1e-4
+    # of.  The test therefore asserts (a) above: every returned pair is an exact eigenpair of a matrix within 2e-5
+    # lambda_max of L; (b) below: everything DOWNSTREAM of the eigenvectors -- post-processing, in- and out-of-sample
+    # features, kernel entries, Woodbury posterior -- within 1e-4 of a float64 evaluation by the oracle that is handed
+    # ONLY the solver's raw block (not the HIP features); and (c) the end-to-end 1e-4 check against an independent
+    # float64 eigendecomposition where one is well defined: tests/golden/dumbbell_posterior.npz (reference pipeline)
+    # and test_c2_dumbbell_10k_posterior_vs_dense_float64_pipeline (N = 10k).
+    ill_conditioned = rn[:m].max() > 0.1 * gap
+    assert ill_conditioned, "the cut became well conditioned: tighten this test to the Davis-Kahan bound"
+    # (b) float64 pipeline from the solver's raw Ritz block: riemann_kernel.py:126-128 (lambda_0 = 0, D^-1/2, normalise),
+    # :134-136 (in-sample features), :138-147 + graph_laplacian_operator.py:146-157 (out-of-sample features)
+    from oracle import spectral as osp
+    lam64 = blk["evals"].double().cpu().numpy()[:m].copy()
+    lam64[0] = 0.0
+    Phi64 = V[:, :m] * (lo.degree ** -0.5)[:, None]
+    Phi64 /= np.linalg.norm(Phi64, axis=0, keepdims=True)
+    Z64 = osp.features_insample(lam64, Phi64, 2, hp["lengthscale"])
+    Dt, It = kern.knn.search(xt, 50)
+    Zt64 = osp.features_oos(lo, lam64, Phi64, 2, hp["lengthscale"], Dt.double().cpu().numpy(), It.cpu().numpy(), 3.0, 0.01)
     # ---- spectral posterior at 600 held-out points
     s, noise = hp["outputscale"], hp["noise"]
     model = RiemannGP(x, y, GaussianLikelihood(noise).to(dev), ScaleKernel(kern, s).to(dev)).to(dev)
@@ -194,21 +308,25 @@ def test_c3_rmnist_60k_knn_spectrum_posterior(mgp, dev, rmnist60k):
     model.posterior(xt)
     Z, Zt = kern.features(x), kern.features(xt)
     assert float((Zt.abs().sum(1) > 0).float().mean()) > 0.9                 # the held-out points lie in the bump support
-    mean_o, cov_o, alpha_o = gp_posterior_lowrank(Z.cpu().numpy(), y.cpu().numpy(), Zt.cpu().numpy(), s, noise)
+    mean_o, cov_o, alpha_o = gp_posterior_lowrank(Z64, y.cpu().numpy(), Zt64, s, noise)
     mean, cov = model.posterior_mean.cpu().numpy(), model.posterior_covar.cpu().numpy()
     e_mean = np.abs(mean - mean_o).max() / np.abs(mean_o).max()
     e_cov = np.abs(cov - cov_o).max() / np.abs(cov_o).max()
     e_var = np.abs(np.diag(cov) - np.diag(cov_o)).max() / np.abs(np.diag(cov_o)).max()
-    print("C3 posterior: mean %.2e cov %.2e var %.2e" % (e_mean, e_cov, e_var))
+    e_z = np.abs(Z.double().cpu().numpy() - Z64).max() / np.abs(Z64).max()
+    e_zt = np.abs(Zt.double().cpu().numpy() - Zt64).max() / np.abs(Zt64).max()
+    print("C3 downstream of the eigenvectors vs float64: features %.2e / %.2e, posterior mean %.2e cov %.2e var %.2e"
+          % (e_z, e_zt, e_mean, e_cov, e_var))
+    assert e_z < 1e-5 and e_zt < 1e-4
     assert e_mean < 1e-4 and e_cov < 1e-4 and e_var < 1e-4, (e_mean, e_cov, e_var)
     alpha = lowrank_solve(Z, y, s, noise).cpu().numpy()                      # (K + noise I)^-1 y at the nodes
     assert np.abs(alpha - alpha_o).max() < 1e-4 * np.abs(alpha_o).max()
-    # kernel entries: 256 x 60000 and 600 x 60000 blocks of s Z1 Z2^T on the fp32 MFMA against float64 (riemann_kernel.py:92-100)
-    Zd = Z.double()
-    for Z1 in (Z[T(rows, dev)].contiguous(), Zt):
-        Kb = kernel_block(Z1, Z, s).double()
-        Kr = s * (Z1.double() @ Zd.t())
-        assert float((Kb - Kr).abs().max()) < 2e-6 * float(Kr.abs().max())
+    # kernel entries: 256 x 60000 and 600 x 60000 blocks of s Z1 Z2^T on the fp32 MFMA against the float64 features' products
+    # (riemann_kernel.py:92-100)
+    for Z1, Z1o in ((Z[T(rows, dev)].contiguous(), Z64[rows]), (Zt, Zt64)):
+        Kb = kernel_block(Z1, Z, s).double().cpu().numpy()
+        Kr = s * (Z1o @ Z64.T)
+        assert np.abs(Kb - Kr).max() < 1e-4 * np.abs(Kr).max(), np.abs(Kb - Kr).max() / np.abs(Kr).max()
     # ---- precision form: (I + noise s Q) x = y by the HIP CG vs float64 CG on the oracle's operator
     with torch.no_grad():
         desc = kern.precision()._descriptor().with_(scale=s, form=2, noise=noise)
