@@ -193,6 +193,11 @@ int mgp_spmm_set_tile_wide_mode(int on);
  * Replaces torch_sparse.spmm at manifold_gp/operators/graph_laplacian_operator.py:118-119 for the [N, 100] right-hand
  * sides of precision_matern_operator.py:50-53 and the eigensolver's blocks. */
 int mgp_spmm_set_dict_mode(int on);
+/* Measurement hook (bench.py `roofline`): between begin and end every EAGER launch of the C == 1 tile kernel carries
+ * its own start / stop event pair (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps); end returns the sum of
+ * the kernel durations and the number of launches timed (at most max_launches).  No effect on results. */
+int mgp_spmm_timing_begin(int max_launches);
+int mgp_spmm_timing_end(float* total_ms, int* launches);
 /* 16 < C <= 256 with C % 4 == 0 on a quad-padded CSR (what the graph builder produces), 16-byte aligned operands: a
  * lane owns one float4 of the row instead of one column; used where it wins (C <= 64, or an X block of 96 MB and more:
  * default 1); 0 = never (the per-column gather kernel); 2 = always (tests, A/B runs). */

@@ -24,6 +24,8 @@
 #include <string.h>
 #include "mgp_common.h"
 #include "mgp_internal.h"
+#include <hip/hip_ext.h>
+#include <vector>
 
 namespace {
 
@@ -1313,6 +1315,18 @@ __global__ __launch_bounds__(kDictThreads) void spmm_dict_kernel(SpmmArgs p, Til
   if (p.tick && blockIdx.x == 0 && tid == 0) *p.tick = tickv + 1;
 }
 
+// In-solve duration of the C = 1 tile kernel, measured live (bench.py `roofline`): between mgp_spmm_timing_begin and
+// mgp_spmm_timing_end every launch of spmv_tile_kernel is made with hipExtLaunchKernelGGL and its own start / stop event
+// pair -- the events take the dispatch's begin / end timestamps (what rocprofv3 --kernel-trace reports), not the gaps
+// between launches.  Eager launches only (the events of a captured launch belong to the graph node): bench.py times a
+// plan created with use_graph = 0.
+struct SpmvTimer {
+  std::vector<hipEvent_t> ev;
+  int used = 0;
+  bool on = false;
+};
+SpmvTimer g_spmv_timer;
+
 struct Plan {
   int grid;
   int64_t rows_per_block;
@@ -1656,7 +1670,12 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     }
 #define MGP_TILE_LAUNCH(BS)                                                                              \
   do {                                                                                                   \
-    if (pre) hipLaunchKernelGGL((spmv_tile_kernel<true, BS>), dim3(grid), dim3(BS), lds, st, p, ta);      \
+    if (g_spmv_timer.on && 2 * g_spmv_timer.used + 1 < (int)g_spmv_timer.ev.size()) {                    \
+      hipEvent_t e0 = g_spmv_timer.ev[2 * g_spmv_timer.used], e1 = g_spmv_timer.ev[2 * g_spmv_timer.used + 1]; \
+      ++g_spmv_timer.used;                                                                               \
+      if (pre) hipExtLaunchKernelGGL((spmv_tile_kernel<true, BS>), dim3(grid), dim3(BS), lds, st, e0, e1, 0, p, ta);  \
+      else hipExtLaunchKernelGGL((spmv_tile_kernel<false, BS>), dim3(grid), dim3(BS), lds, st, e0, e1, 0, p, ta);     \
+    } else if (pre) hipLaunchKernelGGL((spmv_tile_kernel<true, BS>), dim3(grid), dim3(BS), lds, st, p, ta);      \
     else hipLaunchKernelGGL((spmv_tile_kernel<false, BS>), dim3(grid), dim3(BS), lds, st, p, ta);         \
   } while (0)
     if (L->tile_rows == 32) MGP_TILE_LAUNCH(128);
@@ -1840,6 +1859,35 @@ extern "C" int mgp_spmm_fused_rows(const mgp_csr_t* L_local, int64_t row_offset,
 // eager launch path (~2.7 us per launch, host-bound) paces the kernels -- the same way the CG
 // iteration graph issues them.  Falls back to eager launches if the capture fails.
 // elapsed_ms (nullable): HIP-event time of the `reps` launches on `stream` (graph build excluded).
+extern "C" int mgp_spmm_timing_begin(int max_launches) {
+  if (max_launches <= 0 || max_launches > 65536 || g_spmv_timer.on) return MGP_ERR_ARG;
+  g_spmv_timer.ev.assign((size_t)2 * max_launches, nullptr);
+  for (auto& e : g_spmv_timer.ev) MGP_HIP_TRY(hipEventCreate(&e));
+  g_spmv_timer.used = 0;
+  g_spmv_timer.on = true;
+  return MGP_OK;
+}
+
+extern "C" int mgp_spmm_timing_end(float* total_ms, int* launches) {
+  if (!g_spmv_timer.on) return MGP_ERR_ARG;
+  g_spmv_timer.on = false;
+  double sum = 0.0;
+  int rc = MGP_OK;
+  for (int i = 0; i < g_spmv_timer.used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_spmv_timer.ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, g_spmv_timer.ev[2 * i], g_spmv_timer.ev[2 * i + 1]) != hipSuccess)
+      rc = MGP_ERR_ARG;
+    sum += ms;
+  }
+  if (total_ms) *total_ms = (float)sum;
+  if (launches) *launches = g_spmv_timer.used;
+  for (auto e : g_spmv_timer.ev) (void)hipEventDestroy(e);
+  g_spmv_timer.ev.clear();
+  g_spmv_timer.used = 0;
+  return rc;
+}
+
 extern "C" int mgp_spmm_repeat(const mgp_csr_t* L, const float* X, int C, float* Y, int reps, float* elapsed_ms,
                                void* stream) {
   hipStream_t cap = nullptr;

@@ -496,6 +496,12 @@ def test_bench_line_contract(dev):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in roof, key
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # what actually ran is in the line: the untimed pre-heat, the step with an alternating right-hand side (graph node
+    # re-pointed every solve), and the two live timings of the dominant kernel that bracket its in-solve duration
+    assert "preheat_solves" in line and line["ms_per_step_alternating_rhs"] > 0
+    b2b, eag = roof["live_back_to_back"], roof["live_eager_in_solve"]
+    assert b2b["avg_launch_us"] > 0 and eag["avg_launch_us"] > 0 and "measured" in roof
+    assert 0.5 * b2b["avg_launch_us"] < eag["avg_launch_us"] < 4 * b2b["avg_launch_us"]
     cb = line["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key

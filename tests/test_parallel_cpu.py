@@ -238,3 +238,84 @@ def test_ghost_layers_and_rank_order_on_cpu_tensors():
     l1, l2 = ghost_layers(g, 0, 4, 2)
     assert l1.tolist() == [4, 9, 11]                       # neighbours of {0,1,2,3}: 11, 4 and the chord 2-9
     assert l2.tolist() == [5, 8, 10]
+
+
+def _small_problem():
+    """100 nodes on a ring with chords (float64 oracle operator A = I + noise s Q): with 4 ranks and 64-row blocks the
+    partition is [0, 64), [64, 100) + padding, and TWO ranks that own nothing but padding rows."""
+    from oracle.laplacian import LaplacianOracle
+    from oracle.sparse import SparsePrecision
+    n = 100
+    rng = np.random.default_rng(2)
+    pairs = {(i, (i + 1) % n) for i in range(n)} | {(int(a), int(b)) for a, b in rng.integers(0, n, (60, 2)) if a != b}
+    pairs = np.array(sorted({(min(a, b), max(a, b)) for a, b in pairs}), dtype=np.int64).T
+    val = (rng.random(pairs.shape[1]) * 0.02).astype(np.float64)
+    lap = LaplacianOracle(val, pairs, n, 0.1, "randomwalk", True, dtype=np.float64)
+    return n, SparsePrecision(lap, 2, 0.8, 0.7), 1e-2, rng.normal(size=n)
+
+
+def _worker_small(rank, world, port, q, algo):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        from manifold_gp_amd.parallel import RowPartition, distributed_cg_reference, distributed_pcg_reference
+        n, sq, noise, b_np = _small_problem()
+        part = RowPartition(n, world)
+        r0, r1 = part.range(rank)
+
+        def rows_of_A(v_full):             # padding rows: identity
+            out = v_full.clone()
+            out[:n] = torch.from_numpy(sq.posterior_system(v_full[:n].numpy(), noise)).to(out.dtype).reshape(out[:n].shape)
+            return out[r0:r1]
+
+        b = torch.zeros(part.n_pad, dtype=torch.float64)
+        b[:n] = torch.from_numpy(b_np)
+        if algo == "pcg":
+            x_loc, its = distributed_pcg_reference(rows_of_A, b[r0:r1].clone(), part, rank, tol=1e-12, max_iter=500)
+            xs = [torch.empty_like(x_loc) for _ in range(world)]
+            dist.all_gather(xs, x_loc)
+            x = torch.cat(xs)
+        else:
+            def local_matvec(u):           # [n_pad, C] replicated vectors, this rank's rows
+                out = u.clone()
+                out[:n] = torch.from_numpy(sq.posterior_system(u[:n].numpy(), noise))
+                return out[r0:r1]
+            xr, its = distributed_cg_reference(local_matvec, b.view(-1, 1), part, rank, tol=1e-12, max_iter=500)
+            x = xr[:, 0]
+        if rank == 0:
+            q.put(dict(ok=True, its=its, x=x[:n].numpy(), pad=float(x[n:].abs().max()), owned=[part.owned(r) for r in range(world)]))
+    except Exception as e:  # pragma: no cover
+        if rank == 0:
+            q.put(dict(ok=False, err=repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo", ["pcg", "cg"])
+def test_world4_gloo_with_ranks_that_own_only_padding(algo):
+    """Four processes, 100 nodes: ranks 2 and 3 own no real row (RowPartition pads to whole 64-row blocks).  Both
+    distributed recurrences (the partitioned pipelined CG of csrc/pcg.hip and round 1's replicated-vector CG) must still
+    take identical decisions on every rank -- the padding ranks contribute zeros to every gathered dot product and must
+    issue the same collectives -- and reproduce the dense float64 solve."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_small, args=(r, 4, port, q, algo)) for r in range(4)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out["ok"], out.get("err")
+    assert out["owned"][2] == (128, 128) and out["owned"][3] == (192, 192)
+    n, sq, noise, b = _small_problem()
+    A = np.stack([sq.posterior_system(e, noise) for e in np.eye(n)], 1)
+    ref = np.linalg.solve(A, b)
+    assert out["pad"] == 0.0 and out["its"] < 200
+    assert np.abs(out["x"] - ref).max() < 1e-9 * np.abs(ref).max(), np.abs(out["x"] - ref).max() / np.abs(ref).max()

@@ -17,7 +17,7 @@ def newest(pattern):
 
 def main(tag):
     base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-    out = os.path.join(ROOT, "profiles")
+    out = os.environ.get("MGP_PROFILE_OUT") or os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     stats = list(csv.DictReader(open(newest(base + "/trace/*/*_kernel_stats.csv"))))
     with open(os.path.join(out, tag + "_kernel_stats.csv"), "w") as f:
@@ -57,6 +57,11 @@ def main(tag):
     res["note"] = ("FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); "
                    "WRITE_SIZE as is; durations: non-skipped launches (> 2.5 us) from rocprofv3 --kernel-trace")
     res["spmv_hbm_bytes_per_launch"] = res["spmv_kernel (no pre-scaling)"]["hbm_bytes_per_launch_corrected"]
+    # mean duration of the dominant kernel over every non-skipped launch of the profiled command (the solves' graph
+    # launches outnumber everything else): the figure bench.py's roofline quotes as "in_graph_profile"
+    d = durs(pats["spmv_kernel (no pre-scaling)"])
+    res["spmv_kernel_trace_mean_ns"] = (sum(d) / len(d)) if d else None
+    res["spmv_kernel_trace_launches"] = len(d)
     json.dump(res, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
     for name in ("bench_trace.json", "bench_fetch.json"):
         src = os.path.join(base, name)
