@@ -334,7 +334,15 @@ __device__ __forceinline__ void kb_store_range(const f32x16 (&acc)[2][2], const 
   }
 }
 
-// between the last store and the first write of its data registers
+// between the last store and the first write of its data registers.  Where the 5 wait states come from: the ISA's
+// manually-inserted-wait table (and LLVM's GCNHazardRecognizer, "VMEM store of more than 8 bytes followed by a VALU write
+// of its data VGPRs": VmemStoreHazardWaitStates = 1) asks for 1 wait state, and the compiler inserts it -- but only for
+// stores WITHOUT an SGPR in the soffset field (its createsVALUHazard returns "no hazard" when soffset is a register,
+// as the hardware documentation words the rule).  Round 2's parity test showed the rule does not hold on gfx950 for
+// this form (lanes 12-15 of every 16 took the next store's first two values).  A 16-byte store reads its four data
+// registers over at most four issue cycles after the address cycle; `s_nop 4` (5 wait states) covers that with one to
+// spare, and it is needed once per tile: only the LAST store is followed by a write of accumulator registers (the
+// earlier ones are followed by further stores, which read other registers).
 __device__ __forceinline__ void kb_store_done() {
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_nop 4");
@@ -399,15 +407,19 @@ __global__ __launch_bounds__(kPpThreads, 1) void kernel_block_pp(const float* __
   // (tests/test_host_cpu.py compiles this file and checks the instruction stream for exactly that).
   // k0 past m - 16 (the ragged last stage): quads past m are aimed at the row's last quad instead; they are staged like the
   // rest and never read (that stage runs TS steps).  One select, no second code path.
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z1), (short)0, (int)(n1 * m * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z2), (short)0, (int)(n2 * m * 4), 0x00020000);
   const int back_last = ((nst - 1) * kKC + kq4 < m) ? 0 : (m - 4 - (nst - 1) * kKC - kq4) * 4;
+  // buffer loads through descriptors of EXACTLY the operands' extents (n1 m and n2 m floats; host side: both < 2^29):
+  // a stray staging address returns zeros instead of faulting (a GPU memory fault can reset every GPU of the host).  The
+  // lane's row / quad offset is the vector offset, the stage's k0 the scalar offset.
   auto fetch = [&](int k0) {
-    const float* sa = Z1 + k0;
-    const float* sb = Z2 + k0;
+    const int so = k0 * 4;
     const int back = (k0 + kKC > m) ? back_last : 0;
 #pragma unroll
     for (int h = 0; h < NF; ++h) {
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[h]) : "v"(offa[h] + back), "s"(sa));
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[h]) : "v"(offb[h] + back), "s"(sb));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[h]) : "v"(offa[h] + back), "s"(rs1), "s"(so));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[h]) : "v"(offb[h] + back), "s"(rs2), "s"(so));
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -433,7 +445,11 @@ __global__ __launch_bounds__(kPpThreads, 1) void kernel_block_pp(const float* __
     float* base = K + row0 * ldk + col0;
     const uint64_t bits = reinterpret_cast<uint64_t>(base);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bits), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bits >> 32));
-    o.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, records, 0x00020000);
+    // num_records = the bytes from the tile's first element to the end of its LAST row inside K (the tile's 128 rows x the
+    // row stride, cut at column n2): a store that strays past the tile's rows is dropped by the hardware's range check
+    // instead of landing in another allocation (records = 0 drops every store: the timing knob)
+    const int extent = records == 0 ? 0 : (int)(((int64_t)(kKB - 1) * ldk + (n2 - col0)) * 4);
+    o.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, extent, 0x00020000);
     o.lane_off = ((wr * 64 + (lane & 31)) * (int)ldk + wc * 64 + 4 * (lane >> 5)) * 4;
     return o;
   };
@@ -536,15 +552,19 @@ __global__ __launch_bounds__(kBlock, 4) void kernel_block_one(const float* __res
     offb[h] = (int)(((col0 + r) * m + kq4) * 4);
   }
   // inline-asm staging loads and their wait: see kernel_block_pp
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z1), (short)0, (int)(n1 * m * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z2), (short)0, (int)(n2 * m * 4), 0x00020000);
   const int back_last = ((nst - 1) * kKC + kq4 < m) ? 0 : (m - 4 - (nst - 1) * kKC - kq4) * 4;
+  // buffer loads through descriptors of EXACTLY the operands' extents (n1 m and n2 m floats; host side: both < 2^29):
+  // a stray staging address returns zeros instead of faulting (a GPU memory fault can reset every GPU of the host).  The
+  // lane's row / quad offset is the vector offset, the stage's k0 the scalar offset.
   auto fetch = [&](int k0) {
-    const float* sa = Z1 + k0;
-    const float* sb = Z2 + k0;
+    const int so = k0 * 4;
     const int back = (k0 + kKC > m) ? back_last : 0;
 #pragma unroll
     for (int h = 0; h < NF; ++h) {
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(ra[h]) : "v"(offa[h] + back), "s"(sa));
-      asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rb[h]) : "v"(offb[h] + back), "s"(sb));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ra[h]) : "v"(offa[h] + back), "s"(rs1), "s"(so));
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(rb[h]) : "v"(offb[h] + back), "s"(rs2), "s"(so));
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -592,7 +612,9 @@ __global__ __launch_bounds__(kBlock, 4) void kernel_block_one(const float* __res
     float* base = K + row0 * ldk + col0;
     const uint64_t bits = reinterpret_cast<uint64_t>(base);
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)bits), hi = __builtin_amdgcn_readfirstlane((uint32_t)(bits >> 32));
-    out.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, records, 0x00020000);
+    // exact extent of the tile inside K (see kernel_block_pp::describe)
+    const int extent = records == 0 ? 0 : (int)(((int64_t)(kKB - 1) * ldk + (n2 - col0)) * 4);
+    out.rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), (short)0, extent, 0x00020000);
     out.lane_off = ((wr * 64 + (lane & 31)) * (int)ldk + wc * 64 + 4 * (lane >> 5)) * 4;
   }
 #pragma unroll

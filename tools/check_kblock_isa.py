@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Static check of the instruction streams of kernel_block_pp and kernel_block_one (manifold_gp_amd/csrc/features.hip).
 
-Its staging loads are inline asm (`global_load_dwordx4`) whose completion the compiler does not track: the kernel waits for
+Its staging loads are inline asm (`buffer_load_dwordx4 ... offen` through descriptors of the operands' exact extents) whose completion the compiler does not track: the kernel waits for
 them with its own `s_waitcnt vmcnt(0)`.  That is only sound if NO instruction touches a destination register of such a load
 between the load and the next vmcnt wait.  This script compiles features.hip to gfx950 assembly and walks every
 kernel_block_pp<TS> instantiation in text order, which is execution order here: between a load and its wait the kernel has no
@@ -37,7 +37,7 @@ def check(asm):
             if not t or t.startswith(";") or t.startswith("."):
                 continue        # a label inside the window is a join with a path that issued no load: the window stays open
             op = t.split()[0]
-            m = re.match(r"global_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\]", t)
+            m = re.match(r"buffer_load_dwordx4 v\[(\d+):(\d+)\], v\d+, s\[\d+:\d+\], s\d+ offen", t)
             if m:
                 inflight |= set(range(int(m.group(1)), int(m.group(2)) + 1))
                 continue

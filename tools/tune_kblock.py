@@ -4,6 +4,8 @@ import ctypes, json, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from manifold_gp_amd import _lib
+if len(sys.argv) > 1:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])      # A/B: another build of the library
 lib = _lib.lib()
 res = []
 for (n1, n2, m) in ((600, 60000, 100), (4096, 60000, 100), (60000, 128, 128), (8192, 8192, 256), (600, 60000, 125)):
