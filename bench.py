@@ -321,7 +321,15 @@ def _main(quiet):
 
     if world > 1 or os.environ.get("MGP_FORCE_DIST") == "1":
         from manifold_gp_amd import parallel
-        return parallel.bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, HBM_PEAK_GBS, quiet.emit)
+        try:
+            return parallel.bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, HBM_PEAK_GBS, quiet.emit)
+        except BaseException as e:      # a failed or timed-out collective (MGP_ERR_TIMEOUT) must end THIS process with a
+            # non-zero code at once -- no communicator teardown (it can hang on a dead peer), never a re-exec
+            import traceback
+            traceback.print_exc()
+            log("[bench] rank %d: distributed run failed (%r): exiting 3" % (rank, e))
+            sys.stderr.flush()
+            os._exit(3)
 
     wl = build_workload(args, dev, rank, world)
     from manifold_gp_amd.solvers import CgPlan

@@ -31,6 +31,8 @@ extern "C" {
 #define MGP_ERR_UNSUPPORTED (-3)
 #define MGP_ERR_NOT_CONVERGED (-4)
 #define MGP_ERR_KNN_AMBIGUOUS (-5)
+#define MGP_ERR_TIMEOUT (-6)      /* a multi-rank solve's stream did not drain within MGP_DIST_TIMEOUT_S seconds (default 300):
+                                      a peer rank is gone or a collective hangs; the caller must exit, not retry */
 
 #define MGP_PAD 4 /* CSR rows are padded to a multiple of 4 entries (16-byte vector loads) */
 

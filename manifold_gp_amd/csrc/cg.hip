@@ -1533,6 +1533,9 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
         if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_spin).count() > budget) break;
       }
     }
+    if (!*flag && pl->is_dist && pl->dist.world > 1) {
+      MGP_TRY(mgp_stream_wait_bounded(st));      // collectives on the stream: a dead peer must not hang this rank
+    }
     while (!*flag) {
       const hipError_t q = hipStreamQuery(st);
       if (q == hipSuccess) break;
@@ -1607,7 +1610,7 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
       hipLaunchKernelGGL(refine_finalize_kernel, dim3(1), dim3(kBlock), 0, st, pl->rpart, rgrid, pl->C, pl->dev_true_rel);
       MGP_LAUNCH_CHECK();
     }
-    MGP_HIP_TRY(hipStreamSynchronize(st));
+    MGP_STREAM_WAIT(st, pl->is_dist && pl->dist.world > 1);
     bool ok = true;
     for (int c = 0; c < pl->C; ++c) ok = ok && (pl->host_true_rel[c] <= 2.0f * pl->prm.tol);
     if (ok || ref == max_refine || last_status == 3) break;
@@ -1621,7 +1624,7 @@ extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* 
     MGP_HIP_TRY(hipMemcpyAsync(pl->args.x, pl->xacc, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (X) MGP_HIP_TRY(hipMemcpyAsync(X, pl->xacc, nc * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  MGP_HIP_TRY(hipStreamSynchronize(st));
+  MGP_STREAM_WAIT(st, pl->is_dist && pl->dist.world > 1);
   if (iters) *iters = total_iters;
   if (status) *status = last_status;
   if (resid) memcpy(resid, pl->host_true_rel, (size_t)pl->C * sizeof(float));   // TRUE relative residuals

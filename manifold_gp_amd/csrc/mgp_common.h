@@ -23,6 +23,35 @@
 #define MGP_LAUNCH_CHECK() MGP_HIP_TRY(hipGetLastError())
 
 static inline hipStream_t mgp_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Wait for a stream that carries RCCL collectives of a job with more than one rank: hipStreamSynchronize never returns
+// when a peer rank has died or a collective hangs.  Polls hipStreamQuery (sleeping 50 us between polls after the first
+// millisecond) for at most MGP_DIST_TIMEOUT_S seconds (default 300), then returns MGP_ERR_TIMEOUT: the process is expected
+// to exit non-zero (a fresh launch of the job, never a re-exec).  Single-rank callers keep hipStreamSynchronize.
+#include <chrono>
+#include <cstdlib>
+#include <thread>
+static inline int mgp_stream_wait_bounded(hipStream_t st) {
+  static const double limit_s = [] {
+    const char* e = getenv("MGP_DIST_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 300.0;
+  }();
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return MGP_OK;
+    if (q != hipErrorNotReady) return (int)q;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (dt > limit_s) return MGP_ERR_TIMEOUT;
+    if (dt > 1e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+#define MGP_STREAM_WAIT(st, multi_rank)                                   \
+  do {                                                                    \
+    if (multi_rank) { MGP_TRY(mgp_stream_wait_bounded(st)); }             \
+    else { MGP_HIP_TRY(hipStreamSynchronize(st)); }                       \
+  } while (0)
 static inline int64_t mgp_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t mgp_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 

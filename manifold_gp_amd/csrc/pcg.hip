@@ -841,6 +841,7 @@ extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int3
   if (!pl || !B) return MGP_ERR_ARG;
   if (pl->virt) return MGP_ERR_UNSUPPORTED;               // virtual ranks are driven by mgp_pcg_plan_enqueue
   hipStream_t st = pl->stream;
+  const bool multi = pl->comm && pl->world > 1;     // waits are bounded (MGP_ERR_TIMEOUT): a dead peer must not hang this rank
   if (pl->solves++ >= 1 && !pl->graphs_tried) try_capture(pl);
   const int max_refine = pl->prm.max_refine > 0 ? pl->prm.max_refine : 0;
   const PcgArgs& a = pl->args;
@@ -872,7 +873,7 @@ extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int3
           if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_spin).count() > budget) break;
         }
       }
-      if (!*flag) MGP_HIP_TRY(hipStreamSynchronize(st));
+      if (!*flag) MGP_STREAM_WAIT(st, multi);
       if (*flag) {
         if (guard == 0 && round == 0)
           pl->last_solve_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
@@ -895,7 +896,7 @@ extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int3
     MGP_TRY(enqueue_gather_vec(pl, pl->rfull, true, st));
     hipLaunchKernelGGL(pcg_refine_finalize_kernel, dim3(1), dim3(kBlock), 0, st, pl->args, pl->dev_true_rel);
     MGP_LAUNCH_CHECK();
-    MGP_HIP_TRY(hipStreamSynchronize(st));
+    MGP_STREAM_WAIT(st, multi);
     pl->host_resid[0] = pl->host_true_rel[0];                         // `resid` reports the TRUE relative residual
     if (pl->host_true_rel[0] <= 2.0f * pl->prm.tol) { last_status = 1; break; }
     if (round == max_refine || last_status == 3) { if (last_status == 1) last_status = 2; break; }
@@ -904,14 +905,14 @@ extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int3
   if (max_refine > 0) {
     hipLaunchKernelGGL(pcg_publish_kernel, dim3(egrid), dim3(kBlock), 0, st, pl->args, pl->xacc);
     MGP_LAUNCH_CHECK();
-    MGP_HIP_TRY(hipStreamSynchronize(st));
+    MGP_STREAM_WAIT(st, multi);
     pl->host_state[0] = total_iters;
     pl->host_state[2] = last_status;
   }
   if (X_loc) {
     MGP_HIP_TRY(hipMemcpyAsync(X_loc, pl->args.x + pl->args.row0, (size_t)pl->args.n_loc * sizeof(float),
                                hipMemcpyDeviceToDevice, st));
-    MGP_HIP_TRY(hipStreamSynchronize(st));
+    MGP_STREAM_WAIT(st, multi);
   }
   if (iters) *iters = pl->host_state[0];
   if (status) *status = pl->host_state[2];

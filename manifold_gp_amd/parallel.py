@@ -569,6 +569,40 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
         xg = out.contiguous()
     r = apply_partitioned(desc, part, rank, comm, xg) - y
     true_res = float(r.norm() / y.norm())
+    # ---- the workload of this graph that CAN use several GPUs: the 100 one-hot right-hand sides of `_average_variance`
+    # (precision_matern_operator.py:45-53), columns dealt to the ranks, every rank solving its share with the single-GPU
+    # plan on the whole (replicated) graph, one all-gather of the solutions at the end -- no collective inside the solves
+    sharded = None
+    if args.workload == "c3" and not getattr(args, "no_extras", False):
+        columns, tol_mr = 100, 1e-2
+        desc_q = wl["desc"].with_(scale=1.0, form=0, noise=0.0)
+        torch.manual_seed(1337)
+        idxc = torch.randint(0, g.n - 1, (1, columns), device=dev)
+        Bm = torch.zeros(g.n, columns, device=dev).scatter_(0, idxc, 1.0)
+        for _ in range(2):
+            Xs, its_s = solve_columns_sharded(desc_q, Bm, rank, world, tol=tol_mr, max_iter=1000, stop_mode=0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            Xs, its_s = solve_columns_sharded(desc_q, Bm, rank, world, tol=tol_mr, max_iter=1000, stop_mode=0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ts = torch.tensor([(time.perf_counter() - t0s) / reps], device=dev)
+        if world > 1:
+            dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        rs = desc_q.apply(Xs) - Bm
+        sharded = dict(columns=columns, columns_per_rank=-(-columns // world), solve_ms=round(float(ts.item()) * 1e3, 3),
+                       iterations_rank0=its_s, stop="linear_cg rule, tol %g" % tol_mr,
+                       true_mean_rel_residual=float((rs.norm(dim=0) / Bm.norm(dim=0)).mean()),
+                       average_variance=float((Xs * Bm).sum() / columns),
+                       how="columns [rank::world] solved with the single-GPU plan on the replicated graph, one all-gather of "
+                           "the solutions; time = max over ranks, barriers on both sides")
     if rank == 0:
         how = ("rows AND vectors partitioned over %d ranks, %s, %d ghost rows on rank 0"
                % (world, "Chronopoulos-Gear recurrence: two RCCL collectives per iteration (gathered vector + gamma partials; "
@@ -593,6 +627,10 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
                                   frac=round(value / world / hbm_peak, 4), traffic=None,
                                   note="per-GPU share of the whole-job rate (includes collectives and vector "
                                        "kernels); the kernel-only figure is the N=1 line"))
+        if sharded is not None:
+            line["cg_multi_rhs_sharded"] = sharded
+        line["unmeasured_note"] = ("the partitioned solver has run with more than one RCCL rank only in the driver's scale "
+                                   "record; `--scaling weak` (round 1's replicated-vector plan) is the fallback form")
         emit(json.dumps(line))
     plan.close()
     if world > 1:
