@@ -229,19 +229,34 @@ template <class F>
 __device__ __forceinline__ void for_each_key(const uint32_t* __restrict__ keys, int64_t N, int tid, F f) {
   const int64_t nq = N >> 2;
   const uint4* __restrict__ k4 = reinterpret_cast<const uint4*>(keys);
-  for (int64_t b0 = 0; b0 < nq; b0 += 4 * kBlock) {
-    uint4 v[4];
+  // software pipelined (round 3): the next batch of 4 x 16 bytes per lane is requested before the current one is
+  // consumed -- the consumer's LDS atomics otherwise sit between two memory round trips with nothing in flight (a
+  // 240 KB row was 15 dependent HBM round trips, 25 us; the slab does not fit the Infinity Cache)
+  uint4 v[4], w[4];
+  auto load = [&](uint4 (&dst)[4], int64_t b0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t qi = b0 + tid + u * kBlock;
-      v[u] = k4[qi < nq ? qi : nq - 1];
+      dst[u] = k4[qi < nq ? qi : (nq > 0 ? nq - 1 : 0)];
     }
+  };
+  auto use = [&](const uint4 (&src)[4], int64_t b0) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t qi = b0 + tid + u * kBlock;
       if (qi < nq) {
-        f(v[u].x, 4 * qi); f(v[u].y, 4 * qi + 1); f(v[u].z, 4 * qi + 2); f(v[u].w, 4 * qi + 3);
+        f(src[u].x, 4 * qi); f(src[u].y, 4 * qi + 1); f(src[u].z, 4 * qi + 2); f(src[u].w, 4 * qi + 3);
       }
+    }
+  };
+  if (nq > 0) load(v, 0);
+  for (int64_t b0 = 0; b0 < nq; b0 += 8 * kBlock) {
+    const int64_t b1 = b0 + 4 * kBlock;
+    if (b1 < nq) load(w, b1);
+    use(v, b0);
+    if (b1 < nq) {
+      if (b1 + 4 * kBlock < nq) load(v, b1 + 4 * kBlock);
+      use(w, b1);
     }
   }
   for (int64_t i = (nq << 2) + tid; i < N; i += kBlock) f(keys[i], i);
@@ -251,6 +266,12 @@ __device__ __forceinline__ void for_each_key(const uint32_t* __restrict__ keys, 
 constexpr int kListCap = 3840;      // LDS list of the keys under the sampled threshold (with the 24 KB of candidate
                                     // arrays of the widest retry the kernel stays under 64 KB of LDS)
 constexpr int kSampleBlock = 64;    // sampled keys come in runs of 64 (256-byte loads)
+// fp64 re-rank with staged products (select_kernel): candidates x (F + 1) doubles share the dead key list's storage
+// (30 720 bytes) with the query row (d <= kMaxDimLds floats): up to kRerankWide candidates at 32 features per chunk, up
+// to kRerankMax at 16; kRerankItems = float4 loads per thread and chunk (kRerankMax * 4 / 256, rounded up)
+constexpr int kRerankWide = 96;
+constexpr int kRerankMax = 192;
+constexpr int kRerankItems = 3;
 
 // rank-th smallest (1-based) of the keys `scan` visits: 3-pass radix select (11 / 11 / 10 bits) with an LDS
 // histogram.  Returns the key; *rank_eq = how many of the keys equal to it are among the `rank` smallest.
@@ -405,9 +426,66 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   __syncthreads();
 
   // ---- fp64 re-evaluation in the oracle's operation order
-  for (int c = tid; c < want; c += kBlock) {
-    const int idx = cand_idx[c];
-    cand_d[c] = oracle_d2(q_lds ? qrow_s : qrow, a.db + (int64_t)idx * a.d, a.d);
+  // One thread per candidate running oracle_d2 (below, kept for wide retry sets and odd shapes) leaves 3/4 of the
+  // workgroup idle and makes every load instruction touch 64 different rows.  (Measured, round 3: 22.3 -> 21.6 ms per
+  // 60k x 784 search, no more -- with three rows per CU in flight the kernel is bound by its TRAFFIC, not by a row's
+  // latency: per 7 500-row chunk it reads the 1.8 GB key slab once and 75 candidate rows of 3 136 bytes per query,
+  // another 1.76 GB, in 0.77 ms = 4.7 TB/s of the ~6.3 TB/s the memory system delivers.)  The SUM of a
+  // candidate must run in ascending feature order (the oracle's rounding), the PRODUCTS (q_j - x_j)^2 need not: per
+  // chunk of F features all 256 threads form the products of all candidates -- 8 consecutive lanes read one
+  // candidate's 128 bytes, coalesced -- and leave them in LDS as doubles; thread c then adds candidate c's F products in
+  // order.  Same operations, same order, same bits; the next chunk's loads are in flight during the adds.
+  const int q_floats = ((a.d + 3) & ~3) + 4;
+  auto fits = [&](int f) { return (size_t)q_floats * 4 + (size_t)want * (f + 1) * 8 <= sizeof(list_mem) && want * (f >> 2) <= kRerankItems * kBlock; };
+  const int F = (want <= kRerankWide && fits(32)) ? 32 : 16;   // products staged per candidate and chunk
+  const bool staged = q_lds && want <= kRerankMax && fits(F) && (a.d & 3) == 0 && (reinterpret_cast<uintptr_t>(a.db) & 15) == 0;
+  if (staged) {
+    double* prod = reinterpret_cast<double*>(list_mem + q_floats);     // behind the query row; [want][F + 1]
+    const int PS = F + 1, F4 = F >> 2;
+    const int items = want * F4;                                // (candidate, float4) pairs per chunk
+    double acc = 0.0;
+    float4 xv[kRerankItems];
+    auto fetch = [&](int j0) {
+#pragma unroll
+      for (int u = 0; u < kRerankItems; ++u) {
+        const int it = tid + u * kBlock;
+        const int c = it / F4, q4 = it - c * F4;
+        const bool on = it < items && j0 + 4 * q4 < a.d;
+        const int idx = cand_idx[on ? c : 0];
+        xv[u] = *reinterpret_cast<const float4*>(a.db + (int64_t)idx * a.d + (on ? j0 + 4 * q4 : 0));
+      }
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < a.d; j0 += F) {
+#pragma unroll
+      for (int u = 0; u < kRerankItems; ++u) {
+        const int it = tid + u * kBlock;
+        const int c = it / F4, q4 = it - c * F4;
+        if (it < items && j0 + 4 * q4 < a.d) {
+          const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+          double* o = prod + c * PS + 4 * q4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const double df = __dsub_rn((double)qrow_s[j0 + 4 * q4 + t], (double)xs[t]);
+            o[t] = __dmul_rn(df, df);
+          }
+        }
+      }
+      __syncthreads();
+      if (j0 + F < a.d) fetch(j0 + F);                         // in flight during the ordered adds
+      if (tid < want) {
+        const int nf = a.d - j0 < F ? a.d - j0 : F;
+        const double* pc = prod + tid * PS;
+        for (int j = 0; j < nf; ++j) acc = __dadd_rn(acc, pc[j]);
+      }
+      __syncthreads();
+    }
+    if (tid < want) cand_d[tid] = acc;
+  } else {
+    for (int c = tid; c < want; c += kBlock) {
+      const int idx = cand_idx[c];
+      cand_d[c] = oracle_d2(q_lds ? qrow_s : qrow, a.db + (int64_t)idx * a.d, a.d);
+    }
   }
   __syncthreads();
   // ---- order by (d64, index).  Up to 256 candidates: every candidate counts the candidates ahead of it
