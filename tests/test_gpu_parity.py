@@ -1969,6 +1969,14 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
                                               _lib.ptr(pre), _lib.ptr(base), 0.5, 2.0, _lib.ptr(W), _lib.ptr(part),
                                               _lib.stream()), "mgp_spmm_fused")
                 outs.append((Y.cpu().double().numpy(), part.double().sum(0).cpu().numpy(), nb))
+                if mode == 1 and C > 16:
+                    # the same forced dictionary path WITHOUT input pre-scaling (the kernel's PRE = false instantiation)
+                    Y2 = torch.full_like(X, float("nan"))
+                    part2 = torch.full((max(nb, 1), C), float("nan"), device=dev)
+                    _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y2), 1.25, 1.0, None,
+                                                  _lib.ptr(pre), _lib.ptr(base), 0.5, 2.0, _lib.ptr(W), _lib.ptr(part2),
+                                                  _lib.stream()), "mgp_spmm_fused")
+                    nopre = (Y2.cpu().double().numpy(), part2.double().sum(0).cpu().numpy())
         finally:
             lib.mgp_spmm_set_tile_mode(1)
             lib.mgp_spmm_set_dict_mode(1)
@@ -1984,6 +1992,15 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
         for Y, d, nb in outs:
             assert np.abs(Y - ref).max() < 2e-5 * scale, (shape, C)
             assert np.abs(d - dref).max() < 2e-4 * scale * max(n, 16) ** 0.5, (shape, C)
+        if C > 16:
+            X0 = X.cpu().double().numpy()
+            SX0 = np.zeros((n, C))
+            np.add.at(SX0, rows, vals[:, None] * X0[col])
+            ref0 = 0.5 * base.cpu().double().numpy() + 2.0 * pre.cpu().double().numpy()[:, None] * (
+                1.25 * X0 + data.diag.cpu().double().numpy()[:, None] * X0 - SX0)
+            sc0 = max(np.abs(ref0).max(), 1e-6)
+            assert np.abs(nopre[0] - ref0).max() < 2e-5 * sc0, (shape, C)
+            assert np.abs(nopre[1] - (W.cpu().double().numpy() * ref0).sum(0)).max() < 2e-4 * sc0 * max(n, 16) ** 0.5, (shape, C)
 
 
 @pytest.mark.parametrize("kind", ["gauss", "cube", "huge", "tiny", "mixed", "spike"])

@@ -359,7 +359,7 @@ def test_kernel_block_pp_instruction_stream_respects_its_own_waits():
     spec = importlib.util.spec_from_file_location("check_kblock_isa", os.path.join(root, "tools", "check_kblock_isa.py"))
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
-    body = ["\tglobal_load_dwordx4 v[64:67], v5, s[20:21]", "\tv_mfma_f32_32x32x2_f32 v[0:15], v100, v101, v[0:15]",
+    body = ["\tbuffer_load_dwordx4 v[64:67], v5, s[20:23], s30 offen", "\tv_mfma_f32_32x32x2_f32 v[0:15], v100, v101, v[0:15]",
             "\ts_waitcnt vmcnt(0)", "\tds_write2_b32 v6, v64, v65 offset1:1"] + \
            ["\tbuffer_store_dwordx4 v[%d:%d], v90, s[16:19], s56 offen" % (4 * q, 4 * q + 3) for q in range(16)] + ["\ts_nop 4", "\tv_mov_b32_e32 v0, 0"]
     def kernels(lines):

@@ -15,7 +15,7 @@ for C in (20, 32, 64, 84, 100, 128, 192, 256):
     X = torch.randn(g.n, C, device=dev); Y = torch.empty_like(X)
     out = []
     for mode in (1, 2, 0, 3):
-        lib.mgp_spmm_set_dict_mode(1 if mode == 1 else 0)
+        lib.mgp_spmm_set_dict_mode(2 if mode == 1 else 0)            # 2: the dictionary kernel wherever the shape allows
         lib.mgp_spmm_set_tile_wide_mode(2 if mode == 2 else 0)
         lib.mgp_spmm_set_v4_mode(0 if mode == 3 else 2)
         ms = ctypes.c_float(0.0)
