@@ -58,6 +58,13 @@ struct SpmmArgs {
   float* copy_x;          // nullable: the epilogue stores the row's raw input x[row] here (r = b)
   float* dot2_partials;   // nullable: per-workgroup partials of sum dotw[row]^2 (||b||^2)
   int tick_reset;         // tick != NULL: write {1, 0, 0} (iteration 1, not done, no status) instead of adding 1
+#ifdef MGP_STAMP
+  // lab build only: the stamps go BEHIND the skip / tick words, space that only cg.hip's CgPlan reserves (its state block
+  // + 1024 + 8192 floats).  Other callers of the tile kernel with skip / tick (pcg.hip's 16-float state, the Lanczos and
+  // dist plans) reserve nothing, so stamping is opt-in per process: tools/lab/stamp_solve.py calls mgp_stamp_enable(1)
+  // and runs CgPlan solves only.
+  int stamp_on = 0;
+#endif
 };
 
 typedef int mgp_v4i __attribute__((ext_vector_type(4)));
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
   const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
   const int tid = threadIdx.x, sub = tid & 3;
 #ifdef MGP_STAMP   // lab build (tools/lab/stamp_solve.py): block 0 leaves its start / end time behind the CG state words
-  int* st_base = p.skip ? const_cast<int*>(p.skip) - 1 : p.tick;
+  int* st_base = !p.stamp_on ? nullptr : (p.skip ? const_cast<int*>(p.skip) - 1 : p.tick);
   if (st_base && blockIdx.x == 0 && tid == 0) {
     const int si = atomicAdd(st_base + 8, 1);
     reinterpret_cast<unsigned long long*>(st_base + 16)[si & 255] = wall_clock64() * 8 + 0;
@@ -1384,6 +1391,10 @@ static int spmm_rows_per_pass(int C) {
   return kBlock / spmm_cols_group(C) * 4;
 }
 
+#ifdef MGP_STAMP
+int g_stamp_enable = 0;
+extern "C" int mgp_stamp_enable(int on) { g_stamp_enable = on ? 1 : 0; return 0; }
+#endif
 int g_tile_mode = 1;
 
 extern "C" int mgp_spmm_set_tile_mode(int on) {
@@ -1649,6 +1660,9 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
   SpmmArgs p{L->n, L->rowptr, L->col, L->vals, L->diag, X, Y, C, a, b, pre, post, base, cb, co,
              dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset, MgpCommit{nullptr, nullptr, nullptr, nullptr},
              nullptr, nullptr, 0};
+#ifdef MGP_STAMP
+  p.stamp_on = g_stamp_enable;
+#endif
   if (commit) {
     if (!use_tiles(L, C)) return MGP_ERR_UNSUPPORTED;   // the row records ride in the tile kernel only
     p.commit = *commit;

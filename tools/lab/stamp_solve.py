@@ -22,6 +22,7 @@ for _ in range(50):
 torch.cuda.synchronize()
 print("ms per solve (host clock, stamped build): %.4f" % ((time.perf_counter() - t0) / 50 * 1e3))
 h = ctypes.CDLL(_lib.LIB_PATH)
+h.mgp_stamp_enable(1)       # the tile kernel stamps behind CgPlan's state words only when asked (other plans reserve no room)
 h.mgp_cg_plan_debug_stamps.restype = ctypes.c_int
 h.mgp_cg_plan_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_int)]
 buf = (ctypes.c_ulonglong * 256)(); cnt = ctypes.c_int(0)
