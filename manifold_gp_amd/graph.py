@@ -207,8 +207,12 @@ def graph_for_coo(idx, val, n):
 
 class LaplacianData:
     """degree_unnorm D~, degree D, diag, sqrt(D), 1/sqrt(D), CSR values S for one (eps, self_loops)."""
+    _next_uid = [1]
 
     def __init__(self, graph, eps, self_loops):
+        # never reused, unlike id(): what caches key on (solvers._cached_plan)
+        self.uid = LaplacianData._next_uid[0]
+        LaplacianData._next_uid[0] += 1
         dev = graph.device
         n = graph.n
         self.graph = graph

@@ -117,7 +117,9 @@ def _cached_plan(desc, C, kw):
     operator (the nested CG of a Schur-complement matvec, _average_variance in a training loop)."""
     # a plan is bound to the stream that was current when it was created (its launches, its graph replays and the
     # copy of X are ordered there only): a solve issued under another torch.cuda.stream gets its own plan
-    key = (id(desc.data), desc.nu, desc.kappa, desc.scale, desc.form, desc.noise,
+    # (keyed on the Laplacian data's monotonically assigned uid -- an id() could be reused by a new object once the old one
+    # is gone; the pre / post pointers are safe because a cached plan keeps its descriptor, hence those tensors, alive)
+    key = (getattr(desc.data, "uid", None) or id(desc.data), desc.nu, desc.kappa, desc.scale, desc.form, desc.noise,
            desc.pre.data_ptr() if desc.pre is not None else 0, desc.post.data_ptr() if desc.post is not None else 0,
            int(C), settings.cg_tolerance.value(), settings.max_cg_iterations.value(), settings.cg_stop_mode.value(),
            settings.cg_jacobi_preconditioner.value(), tuple(sorted(kw.items())),
