@@ -287,7 +287,9 @@ typedef struct {
   int32_t check_every; /* iterations per graph launch / host convergence poll (0 = default) */
   int32_t use_graph;   /* 1 = hipGraph replay (default), 0 = eager launches */
   int32_t max_refine;  /* stop_mode 1 only: iterative-refinement rounds on the TRUE residual B - A x
-                          (0 = off); `resid` then reports true relative residuals */
+                          (0 = off); `resid` then reports true relative residuals.  A refined solve stops (status 1)
+                          once every true relative residual is <= 2 tol: the fp32 evaluation of B - A x scatters by about
+                          that factor around the tolerance */
 } mgp_cg_params_t;
 
 size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);

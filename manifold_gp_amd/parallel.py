@@ -259,7 +259,9 @@ class PcgPlan:
                  use_graph=True, refine=0, recurrence="pipelined"):
         """recurrence: "pipelined" (one collective per iteration) or "chronopoulos-gear" (two; robust on ill-conditioned
         systems).  refine > 0: the pipelined solve becomes the inner solver of up to `refine` rounds of iterative refinement on
-        the TRUE residual (csrc/pcg.hip, "Attainable accuracy"); status 4 = the recurrence stagnated (no refinement)."""
+        the TRUE residual (csrc/pcg.hip, "Attainable accuracy"); a refined solve reports status 1 once the true relative
+        residual is <= 2 tol (its fp32 evaluation scatters by about that factor around the tolerance; `resid` holds the
+        value reached); status 4 = the recurrence stagnated (no refinement)."""
         self.pop = PartitionedOperator(desc, part, rank)
         self.part, self.rank = part, rank
         dev = desc.data.graph.device
