@@ -429,8 +429,8 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   // One thread per candidate running oracle_d2 (below, kept for wide retry sets and odd shapes) leaves 3/4 of the
   // workgroup idle and makes every load instruction touch 64 different rows.  (Measured, round 3: 22.3 -> 21.6 ms per
   // 60k x 784 search, no more -- with three rows per CU in flight the kernel is bound by its TRAFFIC, not by a row's
-  // latency: per 7 500-row chunk it reads the 1.8 GB key slab once and 75 candidate rows of 3 136 bytes per query,
-  // another 1.76 GB, in 0.77 ms = 4.7 TB/s of the ~6.3 TB/s the memory system delivers.)  The SUM of a
+  // latency: per 7 500-row chunk it requests the 1.8 GB key slab once and 75 candidate rows of 3 136 bytes per query,
+  // another 1.76 GB, in 0.77 ms = 4.6 TB/s through L2, 2.8 - 3.3 TB/s from HBM by the counters.)  The SUM of a
   // candidate must run in ascending feature order (the oracle's rounding), the PRODUCTS (q_j - x_j)^2 need not: per
   // chunk of F features all 256 threads form the products of all candidates -- 8 consecutive lanes read one
   // candidate's 128 bytes, coalesced -- and leave them in LDS as doubles; thread c then adds candidate c's F products in
