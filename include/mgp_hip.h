@@ -368,9 +368,10 @@ int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* 
  * check of the spectral stage needs (tests/test_gpu_configs.py: float64 Rayleigh-Ritz of the block with the oracle's
  * matrix, the gap behind the kept modes, a Davis-Kahan bound).
  * Return value of both: MGP_OK when all m residuals are <= tol * lambda_max, and ALSO when the iteration has reached the
- * fp32 residual floor (a few ulp of |L|: the filter at its degree cap, no pair converging, the largest residual within
- * 15 % of its value two rounds earlier): info[2] (pairs under tol) < m tells the two apart and `resid` holds what was
- * reached.  MGP_ERR_NOT_CONVERGED: max_restarts rounds without either. */
+ * fp32 residual floor (a few ulp of |L|: a round with the filter at its degree cap that does not even halve the largest
+ * residual and converges no further pair), or when the measured gap between the wanted block and its last guard column says
+ * that a further round at the degree cap would not even halve the residual: info[2] (pairs under tol) < m tells these
+ * from convergence and `resid` holds what was reached.  MGP_ERR_NOT_CONVERGED: max_restarts rounds without either. */
 int mgp_lanczos_block_size(int m, const mgp_lanczos_params_t* p);
 int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs,
                             float* resid, int32_t* info, float* block_evals, float* block_evecs, float* block_resid,
