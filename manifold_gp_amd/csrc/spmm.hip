@@ -1275,12 +1275,12 @@ __global__ __launch_bounds__(kDictThreads) void spmm_dict_kernel(SpmmArgs p, Til
         ++cur;
       }
       __builtin_amdgcn_sched_barrier(0);
-        if (k + 1 < nsl) {
+      if (k + 1 < nsl) {
         __syncthreads();                               // every group is done with slice k: the buffer may be overwritten
-            write_rows(k + 1);
+        write_rows(k + 1);
       }
       __syncthreads();
-      }
+    }
     // ---- epilogue of this lane's 4 NV columns
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
