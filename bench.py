@@ -316,8 +316,10 @@ def _main(quiet):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # torch-side collectives (setup all-gathers, barriers) give up after 10 minutes instead of hanging on a dead peer
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
 
     if world > 1 or os.environ.get("MGP_FORCE_DIST") == "1":
         from manifold_gp_amd import parallel
