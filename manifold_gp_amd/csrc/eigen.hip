@@ -171,83 +171,156 @@ __global__ void copy_cols_kernel(const float* __restrict__ V, int64_t n, int ld,
 }
 
 // ---------------------------------------------------------------- host: symmetric eigensolver (fp64)
-// Householder tridiagonalisation + implicit-shift QL (the EISPACK tred2 / tql2 pair in its public-domain
-// JAMA form), ~ (4/3 + 3) n^3 flops: 2-3 ms for the 125 x 125 Rayleigh-Ritz problems of the block
-// eigensolver, against ~20 ms for the cyclic Jacobi it replaces (which made the host the bottleneck of
-// mgp_lanczos_smallest once the SpMM was fixed).  A [n x n] row-major symmetric (destroyed); evals
-// ascending; eigenvectors = columns of V (row-major [n x n]).
-void tred2(int n, int ld, double* V, double* d, double* e) {
-  for (int j = 0; j < n; ++j) d[j] = V[(size_t)(n - 1) * ld + j];
-  for (int i = n - 1; i > 0; --i) {
-    double scale = 0.0, h = 0.0;
-    for (int k = 0; k < i; ++k) scale += fabs(d[k]);
-    if (scale == 0.0) {
-      e[i] = d[i - 1];
-      for (int j = 0; j < i; ++j) {
-        d[j] = V[(size_t)(i - 1) * ld + j];
-        V[(size_t)i * ld + j] = 0.0;
-        V[(size_t)j * ld + i] = 0.0;
-      }
-    } else {
-      for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
-      double f = d[i - 1];
-      double g = sqrt(h);
-      if (f > 0) g = -g;
-      e[i] = scale * g;
-      h -= f * g;
-      d[i - 1] = f - g;
-      for (int j = 0; j < i; ++j) e[j] = 0.0;
-      for (int j = 0; j < i; ++j) {
-        f = d[j];
-        V[(size_t)j * ld + i] = f;
-        g = e[j] + V[(size_t)j * ld + j] * f;
-        for (int k = j + 1; k <= i - 1; ++k) {
-          g += V[(size_t)k * ld + j] * d[k];
-          e[k] += V[(size_t)k * ld + j] * f;
-        }
-        e[j] = g;
-      }
-      f = 0.0;
-      for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
-      const double hh = f / (h + h);
-      for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
-      for (int j = 0; j < i; ++j) {
-        f = d[j];
-        g = e[j];
-        for (int k = j; k <= i - 1; ++k) V[(size_t)k * ld + j] -= (f * e[k] + g * d[k]);
-        d[j] = V[(size_t)(i - 1) * ld + j];
-        V[(size_t)i * ld + j] = 0.0;
-      }
-    }
-    d[i] = h;
+// Householder tridiagonalisation + implicit-shift QL, restated so that every O(n^3) loop walks a ROW of a row-major
+// array and the eigenvector update runs on host threads:
+//   1. T = Q^T A Q on the lower triangle (symmetric rank-2 updates, 4/3 n^3 flops);
+//   2. Z^T = Q^T accumulated by right multiplications (4/3 n^3);
+//   3. QL on (d, e) alone -- its plane rotations are RECORDED (they do not depend on the vectors);
+//   4. the ~n^2 recorded rotations are applied to Z^T, rows i / i+1, over column slices of 32: a slice is an
+//      L1-resident private copy owned by one host thread (3 n^3 flops, the largest part, now parallel).
+// Round 3: the b = 128 Rayleigh-Ritz problem took 2.0 ms per round in the column-walking EISPACK form this replaces
+// (4 rounds = 8 of the 48 ms of the 60k eigensolve).  Dot products use four interleaved partial sums in a fixed
+// order and -ffp-contract=off holds for the host pass too, so the result does not depend on the thread count or on
+// whether the AVX2 clones run.  A [n x n] row-major symmetric; evals ascending; eigenvectors = columns of V.
+#define MGP_HOST_INLINE static inline __attribute__((always_inline))
+
+MGP_HOST_INLINE double dot4(const double* __restrict__ a, const double* __restrict__ b, int n) {
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  int i = 0;
+  for (; i + 4 <= n; i += 4) {
+    s0 += a[i] * b[i];
+    s1 += a[i + 1] * b[i + 1];
+    s2 += a[i + 2] * b[i + 2];
+    s3 += a[i + 3] * b[i + 3];
   }
-  for (int i = 0; i < n - 1; ++i) {   // accumulate the transformations
-    V[(size_t)(n - 1) * ld + i] = V[(size_t)i * ld + i];
-    V[(size_t)i * ld + i] = 1.0;
-    const double h = d[i + 1];
-    if (h != 0.0) {
-      for (int k = 0; k <= i; ++k) d[k] = V[(size_t)k * ld + (i + 1)] / h;
-      for (int j = 0; j <= i; ++j) {
-        double g = 0.0;
-        for (int k = 0; k <= i; ++k) g += V[(size_t)k * ld + (i + 1)] * V[(size_t)k * ld + j];
-        for (int k = 0; k <= i; ++k) V[(size_t)k * ld + j] -= g * d[k];
-      }
-    }
-    for (int k = 0; k <= i; ++k) V[(size_t)k * ld + (i + 1)] = 0.0;
-  }
-  for (int j = 0; j < n; ++j) {
-    d[j] = V[(size_t)(n - 1) * ld + j];
-    V[(size_t)(n - 1) * ld + j] = 0.0;
-  }
-  V[(size_t)(n - 1) * ld + (n - 1)] = 1.0;
-  e[0] = 0.0;
+  double s = (s0 + s2) + (s1 + s3);
+  for (; i < n; ++i) s += a[i] * b[i];
+  return s;
 }
 
-void tql2(int n, int ld, double* V, double* d, double* e) {
-  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+struct PlaneRot { int i; double c, s; };
+
+// T = Q^T A Q, Q = H_0 H_1 ... H_{n-3}, H_k = I - tau_k v_k v_k^T with v_k in indices k+1 .. n-1 (v_k[k+1] = 1; row k
+// of hv).  Only the LOWER triangle of W is read and written.  d = diagonal of T, e[i] = T[i+1, i].
+MGP_HOST_INLINE void householder_tridiag_impl(int n, int ld, double* W, double* d, double* e, double* hv, double* tau,
+                                              double* p, double* w) {
+  for (int k = 0; k + 2 < n; ++k) {
+    const int s = n - k - 1;
+    double* v = hv + (size_t)k * ld + (k + 1);
+    double scale = 0.0, tail = 0.0;
+    for (int j = 0; j < s; ++j) {
+      v[j] = W[(size_t)(k + 1 + j) * ld + k];
+      scale = std::max(scale, fabs(v[j]));
+      if (j) tail = std::max(tail, fabs(v[j]));
+    }
+    d[k] = W[(size_t)k * ld + k];
+    const double alpha = v[0];
+    if (tail == 0.0) { tau[k] = 0.0; e[k] = alpha; continue; }   // the column is tridiagonal already: H_k = I
+    double ss = 0.0;
+    for (int j = 0; j < s; ++j) { const double t = v[j] / scale; ss += t * t; }
+    const double nrm = scale * sqrt(ss);
+    const double beta = alpha > 0.0 ? -nrm : nrm;
+    const double tk = (beta - alpha) / beta;
+    const double inv = 1.0 / (alpha - beta);
+    v[0] = 1.0;
+    for (int j = 1; j < s; ++j) v[j] *= inv;
+    tau[k] = tk;
+    e[k] = beta;
+    double* B = W + (size_t)(k + 1) * ld + (k + 1);
+    // p = tau B v: row j of the lower triangle gives its own dot product and its share of the entries above it
+    for (int j = 0; j < s; ++j) {
+      const double* __restrict__ row = B + (size_t)j * ld;
+      const double vj = v[j];
+      const double t = dot4(row, v, j);
+      for (int i = 0; i < j; ++i) p[i] += row[i] * vj;
+      p[j] = t + row[j] * vj;
+    }
+    for (int j = 0; j < s; ++j) p[j] *= tk;
+    const double hh = 0.5 * tk * dot4(p, v, s);
+    for (int j = 0; j < s; ++j) w[j] = p[j] - hh * v[j];
+    for (int j = 0; j < s; ++j) {          // B -= v w^T + w v^T
+      double* __restrict__ row = B + (size_t)j * ld;
+      const double vj = v[j], wj = w[j];
+      for (int i = 0; i <= j; ++i) row[i] -= vj * w[i] + wj * v[i];
+    }
+  }
+  if (n >= 2) { d[n - 2] = W[(size_t)(n - 2) * ld + (n - 2)]; e[n - 2] = W[(size_t)(n - 1) * ld + (n - 2)]; }
+  d[n - 1] = W[(size_t)(n - 1) * ld + (n - 1)];
   e[n - 1] = 0.0;
+}
+
+// Zt = Q^T = H_{n-3} ... H_0 as ((I H_{n-3}) H_{n-4}) ... H_0: M <- M - tau (M v) v^T touches rows and columns
+// k+1 .. n-1 only (the rows above are still rows of the identity).
+MGP_HOST_INLINE void householder_accumulate_impl(int n, int ld, const double* hv, const double* tau, double* Zt) {
+  for (int r = 0; r < n; ++r) {
+    for (int c = 0; c < n; ++c) Zt[(size_t)r * ld + c] = 0.0;
+    Zt[(size_t)r * ld + r] = 1.0;
+  }
+  for (int k = n - 3; k >= 0; --k) {
+    if (tau[k] == 0.0) continue;
+    const int s = n - k - 1;
+    const double* __restrict__ v = hv + (size_t)k * ld + (k + 1);
+    for (int r = k + 1; r < n; ++r) {
+      double* __restrict__ row = Zt + (size_t)r * ld + (k + 1);
+      const double g = tau[k] * dot4(row, v, s);
+      for (int i = 0; i < s; ++i) row[i] -= g * v[i];
+    }
+  }
+}
+
+// rows i, i+1 of Zt <- the recorded rotations, columns [k0, k1): worked on in a compact private copy (n x len: 32 KB
+// at n = 128 and 32 columns), so no cache line is shared with the neighbouring slices' threads
+MGP_HOST_INLINE void apply_rots_impl(int n, int ld, double* Zt, const std::vector<PlaneRot>& rots, int k0, int k1) {
+  const int len = k1 - k0;
+  if (len <= 0) return;
+  std::vector<double> loc((size_t)n * len);
+  for (int r = 0; r < n; ++r) memcpy(&loc[(size_t)r * len], Zt + (size_t)r * ld + k0, len * sizeof(double));
+  for (const PlaneRot& q : rots) {
+    double* __restrict__ r0 = &loc[(size_t)q.i * len];
+    double* __restrict__ r1 = r0 + len;
+    const double c = q.c, s = q.s;
+    for (int k = 0; k < len; ++k) {
+      const double h = r1[k], g = r0[k];
+      r1[k] = s * g + c * h;
+      r0[k] = c * g - s * h;
+    }
+  }
+  for (int r = 0; r < n; ++r) memcpy(Zt + (size_t)r * ld + k0, &loc[(size_t)r * len], len * sizeof(double));
+}
+
+// the same three loops compiled twice: baseline x86-64 and AVX2 (picked at run time; identical arithmetic)
+void householder_tridiag_base(int n, int ld, double* W, double* d, double* e, double* hv, double* tau, double* p, double* w) {
+  householder_tridiag_impl(n, ld, W, d, e, hv, tau, p, w);
+}
+__attribute__((target("avx2"))) void householder_tridiag_avx2(int n, int ld, double* W, double* d, double* e, double* hv,
+                                                              double* tau, double* p, double* w) {
+  householder_tridiag_impl(n, ld, W, d, e, hv, tau, p, w);
+}
+void householder_accumulate_base(int n, int ld, const double* hv, const double* tau, double* Zt) {
+  householder_accumulate_impl(n, ld, hv, tau, Zt);
+}
+__attribute__((target("avx2"))) void householder_accumulate_avx2(int n, int ld, const double* hv, const double* tau, double* Zt) {
+  householder_accumulate_impl(n, ld, hv, tau, Zt);
+}
+void apply_rots_base(int n, int ld, double* Zt, const std::vector<PlaneRot>& rots, int k0, int k1) {
+  apply_rots_impl(n, ld, Zt, rots, k0, k1);
+}
+__attribute__((target("avx2"))) void apply_rots_avx2(int n, int ld, double* Zt, const std::vector<PlaneRot>& rots, int k0, int k1) {
+  apply_rots_impl(n, ld, Zt, rots, k0, k1);
+}
+
+inline double pythag(double a, double b) {
+  const double r2 = a * a + b * b;
+  if (r2 > 1e-280 && r2 < 1e280) return sqrt(r2);
+  return hypot(a, b);
+}
+
+// implicit-shift QL on the symmetric tridiagonal (d, e[i] = T[i+1, i]): eigenvalues into d (unsorted), the plane
+// rotations (acting on vector indices i, i+1) appended to `rots` in the order they have to be applied
+void tridiag_ql(int n, double* d, double* e, std::vector<PlaneRot>& rots) {
   double f = 0.0, tst1 = 0.0;
   const double eps = 2.220446049250313e-16;
+  e[n - 1] = 0.0;
   for (int l = 0; l < n; ++l) {
     tst1 = std::max(tst1, fabs(d[l]) + fabs(e[l]));
     int m = l;
@@ -261,7 +334,7 @@ void tql2(int n, int ld, double* V, double* d, double* e) {
         ++iter;
         double g = d[l];
         double p = (d[l + 1] - g) / (2.0 * e[l]);
-        double r = hypot(p, 1.0);
+        double r = pythag(p, 1.0);
         if (p < 0) r = -r;
         d[l] = e[l] / (p + r);
         d[l + 1] = e[l] * (p + r);
@@ -279,17 +352,13 @@ void tql2(int n, int ld, double* V, double* d, double* e) {
           s2 = s;
           g = c * e[i];
           h = c * p;
-          r = hypot(p, e[i]);
+          r = pythag(p, e[i]);
           e[i + 1] = s * r;
           s = e[i] / r;
           c = p / r;
           p = c * d[i] - s * g;
           d[i + 1] = h + s * (c * g + s * d[i]);
-          for (int k = 0; k < n; ++k) {
-            h = V[(size_t)k * ld + i + 1];
-            V[(size_t)k * ld + i + 1] = s * V[(size_t)k * ld + i] + c * h;
-            V[(size_t)k * ld + i] = c * V[(size_t)k * ld + i] - s * h;
-          }
+          rots.push_back(PlaneRot{i, c, s});
         }
         p = -s * s2 * c3 * el1 * e[l] / dl1;
         e[l] = s * p;
@@ -356,25 +425,45 @@ bool cholesky_whiten(int b, const std::vector<double>& Gn, const std::vector<dou
 
 void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& evals, std::vector<double>& V) {
   // (name kept from the Jacobi days: every caller wants "eigh of a small symmetric matrix")
-  // The work matrix has a padded leading dimension: tred2 / tql2 walk columns, and with ld = n a
-  // power-of-two n (block sizes 128, 256) maps a whole column onto a handful of L1 sets of the host
-  // CPU -- measured 4-6x slower than n +- 4.
-  const int ld = (n % 16 == 0) ? n + 3 : n;
-  std::vector<double> W((size_t)n * ld);
-  for (int i = 0; i < n; ++i)      // use the symmetric part
-    for (int j = 0; j < n; ++j) W[(size_t)i * ld + j] = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
-  std::vector<double> d(n), e(n);
-  if (n == 1) { evals.assign(1, W[0]); V.assign(1, 1.0); return; }
-  tred2(n, ld, W.data(), d.data(), e.data());
-  tql2(n, ld, W.data(), d.data(), e.data());
-  std::vector<int> order(n);
-  for (int i = 0; i < n; ++i) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
+  // Padded leading dimension: with ld = n a power-of-two n (block sizes 128, 256) maps the rows of a column slice onto
+  // a handful of L1 sets of the host CPU.
   evals.resize(n);
   V.assign((size_t)n * n, 0.0);
+  if (n == 1) { evals[0] = A[0]; V[0] = 1.0; return; }
+  const int ld = (n + 7) / 8 * 8 + 8;
+  std::vector<double> W((size_t)n * ld), hv((size_t)n * ld, 0.0), Zt((size_t)n * ld), d(n), e(n), tau(n, 0.0), p(n, 0.0), w(n);
+  for (int i = 0; i < n; ++i)      // use the symmetric part
+    for (int j = 0; j <= i; ++j) W[(size_t)i * ld + j] = 0.5 * (A[(size_t)i * n + j] + A[(size_t)j * n + i]);
+  const bool avx2 = __builtin_cpu_supports("avx2");
+  (avx2 ? householder_tridiag_avx2 : householder_tridiag_base)(n, ld, W.data(), d.data(), e.data(), hv.data(), tau.data(),
+                                                               p.data(), w.data());
+  (avx2 ? householder_accumulate_avx2 : householder_accumulate_base)(n, ld, hv.data(), tau.data(), Zt.data());
+  std::vector<PlaneRot> rots;
+  rots.reserve((size_t)n * n);
+  tridiag_ql(n, d.data(), e.data(), rots);
+  auto apply = avx2 ? apply_rots_avx2 : apply_rots_base;
+  const unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<unsigned>(hw ? hw : 1u, 8u);
+  nt = std::min(nt, n / 32);
+  if (nt <= 1) {
+    apply(n, ld, Zt.data(), rots, 0, n);
+  } else {
+    std::vector<std::thread> th;
+    th.reserve(nt);
+    for (int t = 0; t < nt; ++t) {
+      const int k0 = (int)((int64_t)n * t / nt) / 8 * 8;
+      const int k1 = t + 1 == nt ? n : (int)((int64_t)n * (t + 1) / nt) / 8 * 8;
+      th.emplace_back([&, k0, k1]() { apply(n, ld, Zt.data(), rots, k0, k1); });
+    }
+    for (auto& x : th) x.join();
+  }
+  std::vector<int> order(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return d[a] < d[b]; });
   for (int j = 0; j < n; ++j) {
     evals[j] = d[order[j]];
-    for (int k = 0; k < n; ++k) V[(size_t)k * n + j] = W[(size_t)k * ld + order[j]];
+    const double* z = &Zt[(size_t)order[j] * ld];
+    for (int k = 0; k < n; ++k) V[(size_t)k * n + j] = z[k];
   }
 }
 

@@ -187,7 +187,7 @@ def test_synthetic_workloads_are_deterministic():
     assert abs(eps_min - np.sqrt(0.4 / (-4 * np.log(1e-4)))) < 1e-9 and eps == eps_min
 
 
-@pytest.mark.parametrize("n", [1, 2, 7, 64, 125])
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 33, 64, 100, 125, 128, 200])
 def test_host_symeig_matches_lapack(n):
     """The small dense fp64 eigensolver inside the block eigensolver (host-only entry of the C-ABI):
     eigenvalues, orthonormality and reconstruction against numpy, including a rank-deficient Gram
@@ -199,6 +199,9 @@ def test_host_symeig_matches_lapack(n):
     B = rng.standard_normal((n, max(1, n // 3)))
     mats.append(B @ B.T)                                        # rank-deficient PSD
     mats.append(np.diag(np.repeat([1.0, 1.0 + 1e-12, 5.0], -(-n // 3))[:n]))   # (nearly) degenerate diagonal
+    mats.append(np.zeros((n, n)))                               # every Householder step is the identity
+    mats.append(np.diag(np.arange(1.0, n + 1)) + np.diag(np.ones(n - 1), 1) + np.diag(np.ones(n - 1), -1))   # tridiagonal already
+    mats.append(1e150 * rng.standard_normal((n, n)))            # the scaled norms / the guarded sqrt(a^2 + b^2)
     for M in mats:
         A = np.ascontiguousarray(0.5 * (M + M.T))
         ev = np.empty(n)
@@ -211,6 +214,11 @@ def test_host_symeig_matches_lapack(n):
         np.testing.assert_allclose(ev, ref, rtol=0, atol=1e-12 * scale * n)
         np.testing.assert_allclose(V.T @ V, np.eye(n), rtol=0, atol=1e-12 * n)
         np.testing.assert_allclose(V @ np.diag(ev) @ V.T, A, rtol=0, atol=1e-12 * scale * n)
+        # the vector update runs over column slices on host threads: same bits on every call
+        ev2 = np.empty(n)
+        V2 = np.empty((n, n))
+        assert lib.mgp_host_symeig(n, A.ctypes.data, ev2.ctypes.data, V2.ctypes.data) == 0
+        assert np.array_equal(ev, ev2) and np.array_equal(V, V2)
 
 
 def test_struct_fields_mirror_header_and_integration_stub():
