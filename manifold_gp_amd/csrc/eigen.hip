@@ -25,6 +25,9 @@
 #include <algorithm>
 #include <vector>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <chrono>
 #include <cstdio>
 #include "mgp_common.h"
@@ -251,16 +254,17 @@ MGP_HOST_INLINE void householder_tridiag_impl(int n, int ld, double* W, double* 
 
 // Zt = Q^T = H_{n-3} ... H_0 as ((I H_{n-3}) H_{n-4}) ... H_0: M <- M - tau (M v) v^T touches rows and columns
 // k+1 .. n-1 only (the rows above are still rows of the identity).
-MGP_HOST_INLINE void householder_accumulate_impl(int n, int ld, const double* hv, const double* tau, double* Zt) {
-  for (int r = 0; r < n; ++r) {
+MGP_HOST_INLINE void householder_accumulate_impl(int n, int ld, const double* hv, const double* tau, double* Zt, int r0, int r1) {
+  // rows [r0, r1) only: a row of M runs through all the H_k on its own, so row ranges are independent jobs
+  for (int r = r0; r < r1; ++r) {
     for (int c = 0; c < n; ++c) Zt[(size_t)r * ld + c] = 0.0;
     Zt[(size_t)r * ld + r] = 1.0;
   }
-  for (int k = n - 3; k >= 0; --k) {
+  for (int k = std::min(n - 3, r1 - 2); k >= 0; --k) {
     if (tau[k] == 0.0) continue;
     const int s = n - k - 1;
     const double* __restrict__ v = hv + (size_t)k * ld + (k + 1);
-    for (int r = k + 1; r < n; ++r) {
+    for (int r = std::max(r0, k + 1); r < r1; ++r) {
       double* __restrict__ row = Zt + (size_t)r * ld + (k + 1);
       const double g = tau[k] * dot4(row, v, s);
       for (int i = 0; i < s; ++i) row[i] -= g * v[i];
@@ -296,11 +300,12 @@ __attribute__((target("avx2"))) void householder_tridiag_avx2(int n, int ld, dou
                                                               double* tau, double* p, double* w) {
   householder_tridiag_impl(n, ld, W, d, e, hv, tau, p, w);
 }
-void householder_accumulate_base(int n, int ld, const double* hv, const double* tau, double* Zt) {
-  householder_accumulate_impl(n, ld, hv, tau, Zt);
+void householder_accumulate_base(int n, int ld, const double* hv, const double* tau, double* Zt, int r0, int r1) {
+  householder_accumulate_impl(n, ld, hv, tau, Zt, r0, r1);
 }
-__attribute__((target("avx2"))) void householder_accumulate_avx2(int n, int ld, const double* hv, const double* tau, double* Zt) {
-  householder_accumulate_impl(n, ld, hv, tau, Zt);
+__attribute__((target("avx2"))) void householder_accumulate_avx2(int n, int ld, const double* hv, const double* tau, double* Zt, int r0,
+                                                                 int r1) {
+  householder_accumulate_impl(n, ld, hv, tau, Zt, r0, r1);
 }
 void apply_rots_base(int n, int ld, double* Zt, const std::vector<PlaneRot>& rots, int k0, int k1) {
   apply_rots_impl(n, ld, Zt, rots, k0, k1);
@@ -370,60 +375,118 @@ void tridiag_ql(int n, double* d, double* e, std::vector<PlaneRot>& rots) {
   }
 }
 
-// fn(i) for i in [0, n) on up to 8 host threads (contiguous ranges; every output row has one owner)
-template <class F>
-void parallel_rows(int n, F fn) {
-  unsigned hw = std::thread::hardware_concurrency();
-  int nt = (int)std::min<unsigned>(hw ? hw : 1u, 8u);
-  if (nt > n / 16) nt = n / 16;
-  if (nt <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (int t = 0; t < nt; ++t) {
-    const int i0 = (int)((int64_t)n * t / nt), i1 = (int)((int64_t)n * (t + 1) / nt);
-    th.emplace_back([=]() { for (int i = i0; i < i1; ++i) fn(i); });
+// Host worker pool of one eigensolve: the Rayleigh-Ritz step has four short parallel sections per round (two b^3
+// products, the eigenvector rotations, W = T S); starting fresh threads for each cost as much as their arithmetic.
+// run(njobs, fn) calls fn(job) once per job on the workers and the calling thread and returns when all are done.  Which
+// thread takes which job varies, the arithmetic of a job does not: every output element belongs to exactly one job.
+class HostPool {
+ public:
+  explicit HostPool(int workers) {
+    for (int t = 0; t < workers; ++t) th_.emplace_back([this]() { work(); });
   }
-  for (auto& x : th) x.join();
+  ~HostPool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+    cv_.notify_all();
+    for (auto& x : th_) x.join();
+  }
+  HostPool(const HostPool&) = delete;
+  HostPool& operator=(const HostPool&) = delete;
+  int threads() const { return (int)th_.size() + 1; }
+  void run(int njobs, const std::function<void(int)>& fn) {
+    if (njobs <= 0) return;
+    std::unique_lock<std::mutex> lk(mu_);
+    job_ = &fn; njobs_ = njobs; next_ = 0; pending_ = njobs; ++gen_;
+    lk.unlock();
+    cv_.notify_all();
+    lk.lock();
+    take(lk);
+    done_.wait(lk, [&]() { return pending_ == 0; });
+    job_ = nullptr;
+  }
+  // fn(i) for i in [0, n): contiguous chunks of `chunk` rows as jobs
+  void rows(int n, int chunk, const std::function<void(int)>& fn) {
+    const int nj = (n + chunk - 1) / chunk;
+    const std::function<void(int)> job = [&](int j) {
+      const int i1 = std::min(n, (j + 1) * chunk);
+      for (int i = j * chunk; i < i1; ++i) fn(i);
+    };
+    run(nj, job);
+  }
+
+ private:
+  void take(std::unique_lock<std::mutex>& lk) {      // called with the lock held
+    while (next_ < njobs_) {
+      const int j = next_++;
+      const std::function<void(int)>* f = job_;
+      lk.unlock();
+      (*f)(j);
+      lk.lock();
+      if (--pending_ == 0) done_.notify_all();
+    }
+  }
+  void work() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+      cv_.wait(lk, [&]() { return stop_ || gen_ != seen; });
+      if (stop_) return;
+      seen = gen_;
+      take(lk);
+    }
+  }
+  std::vector<std::thread> th_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* job_ = nullptr;
+  int njobs_ = 0, next_ = 0, pending_ = 0;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+};
+
+int host_pool_workers() {
+  const unsigned hw = std::thread::hardware_concurrency();
+  return (int)std::min<unsigned>(hw ? hw : 1u, 8u) - 1;
 }
 
 // Gn (b x b, unit diagonal, symmetric positive definite) = C C^T; T = D C^-T (b x b) so that
 // T^T (D^-1 Gn D^-1) T = I.  False when a pivot falls under 1e-10 (relative to the unit diagonal): the caller
 // then needs the rank-revealing path.
 bool cholesky_whiten(int b, const std::vector<double>& Gn, const std::vector<double>& dg, std::vector<double>& T) {
+  // every inner loop walks rows: the dot products with four interleaved partial sums (a single running sum is a chain of
+  // dependent adds), the inverse row by row as axpys
   std::vector<double> C((size_t)b * b, 0.0);
-  for (int j = 0; j < b; ++j) {
-    double s = Gn[(size_t)j * b + j];
-    for (int k = 0; k < j; ++k) s -= C[(size_t)j * b + k] * C[(size_t)j * b + k];
-    if (!(s > 1e-10)) return false;
-    const double cjj = sqrt(s);
-    C[(size_t)j * b + j] = cjj;
-    for (int i = j + 1; i < b; ++i) {
-      double v = Gn[(size_t)i * b + j];
-      const double* ci = &C[(size_t)i * b];
+  for (int i = 0; i < b; ++i) {
+    double* ci = &C[(size_t)i * b];
+    for (int j = 0; j < i; ++j) {
       const double* cj = &C[(size_t)j * b];
-      for (int k = 0; k < j; ++k) v -= ci[k] * cj[k];
-      C[(size_t)i * b + j] = v / cjj;
+      ci[j] = (Gn[(size_t)i * b + j] - dot4(ci, cj, j)) / cj[j];
     }
+    const double s = Gn[(size_t)i * b + i] - dot4(ci, ci, i);
+    if (!(s > 1e-10)) return false;
+    ci[i] = sqrt(s);
   }
-  // Ci = C^-1 (lower), column by column: C Ci = I
+  // Ci = C^-1 (lower): row i = (e_i - sum_{k < i} C[i][k] Ci[k][:]) / C[i][i]
   std::vector<double> Ci((size_t)b * b, 0.0);
-  for (int j = 0; j < b; ++j) {
-    Ci[(size_t)j * b + j] = 1.0 / C[(size_t)j * b + j];
-    for (int i = j + 1; i < b; ++i) {
-      double v = 0.0;
-      const double* ci = &C[(size_t)i * b];
-      for (int k = j; k < i; ++k) v -= ci[k] * Ci[(size_t)k * b + j];
-      Ci[(size_t)i * b + j] = v / ci[i];
+  for (int i = 0; i < b; ++i) {
+    double* __restrict__ ri = &Ci[(size_t)i * b];
+    const double* ci = &C[(size_t)i * b];
+    for (int k = 0; k < i; ++k) {
+      const double c = ci[k];
+      const double* __restrict__ rk = &Ci[(size_t)k * b];
+      for (int j = 0; j <= k; ++j) ri[j] -= c * rk[j];
     }
+    const double inv = 1.0 / ci[i];
+    for (int j = 0; j < i; ++j) ri[j] *= inv;
+    ri[i] = inv;
   }
-  // T = D C^-T: T[i][j] = dg[i] * Ci[j][i]
+  // T = D C^-T (upper triangular): T[i][j] = dg[i] * Ci[j][i]
   T.assign((size_t)b * b, 0.0);
   for (int i = 0; i < b; ++i)
     for (int j = i; j < b; ++j) T[(size_t)i * b + j] = dg[i] * Ci[(size_t)j * b + i];
   return true;
 }
 
-void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& evals, std::vector<double>& V) {
+void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& evals, std::vector<double>& V, HostPool* pool = nullptr) {
   // (name kept from the Jacobi days: every caller wants "eigh of a small symmetric matrix")
   // Padded leading dimension: with ld = n a power-of-two n (block sizes 128, 256) maps the rows of a column slice onto
   // a handful of L1 sets of the host CPU.
@@ -437,25 +500,30 @@ void jacobi_eigh(int n, std::vector<double>& A, std::vector<double>& evals, std:
   const bool avx2 = __builtin_cpu_supports("avx2");
   (avx2 ? householder_tridiag_avx2 : householder_tridiag_base)(n, ld, W.data(), d.data(), e.data(), hv.data(), tau.data(),
                                                                p.data(), w.data());
-  (avx2 ? householder_accumulate_avx2 : householder_accumulate_base)(n, ld, hv.data(), tau.data(), Zt.data());
+  auto accumulate = avx2 ? householder_accumulate_avx2 : householder_accumulate_base;
+  if (pool && n >= 64) {
+    // later rows pass through more reflectors: jobs of 8 rows, taken in turn by whoever is free
+    const int nj = (n + 7) / 8;
+    pool->run(nj, [&](int j) { accumulate(n, ld, hv.data(), tau.data(), Zt.data(), j * 8, std::min(n, j * 8 + 8)); });
+  } else {
+    accumulate(n, ld, hv.data(), tau.data(), Zt.data(), 0, n);
+  }
   std::vector<PlaneRot> rots;
   rots.reserve((size_t)n * n);
   tridiag_ql(n, d.data(), e.data(), rots);
   auto apply = avx2 ? apply_rots_avx2 : apply_rots_base;
-  const unsigned hw = std::thread::hardware_concurrency();
-  int nt = (int)std::min<unsigned>(hw ? hw : 1u, 8u);
-  nt = std::min(nt, n / 32);
-  if (nt <= 1) {
-    apply(n, ld, Zt.data(), rots, 0, n);
+  // column slices of 32 (the last one takes the remainder); on the caller's pool when there is one
+  const int nsl = std::max(1, n / 32);
+  auto slice = [&](int t) {
+    const int k0 = t * 32, k1 = t + 1 == nsl ? n : (t + 1) * 32;
+    apply(n, ld, Zt.data(), rots, k0, k1);
+  };
+  if (nsl == 1) {
+    slice(0);
+  } else if (pool) {
+    pool->run(nsl, slice);
   } else {
-    std::vector<std::thread> th;
-    th.reserve(nt);
-    for (int t = 0; t < nt; ++t) {
-      const int k0 = (int)((int64_t)n * t / nt) / 8 * 8;
-      const int k1 = t + 1 == nt ? n : (int)((int64_t)n * (t + 1) / nt) / 8 * 8;
-      th.emplace_back([&, k0, k1]() { apply(n, ld, Zt.data(), rots, k0, k1); });
-    }
-    for (auto& x : th) x.join();
+    for (int q = 0; q < nsl; ++q) slice(q);
   }
   std::vector<int> order(n);
   for (int i = 0; i < n; ++i) order[i] = i;
@@ -570,7 +638,8 @@ extern "C" int mgp_gram_f64(const float* A, int64_t n, int b, double* G, void* w
 extern "C" int mgp_host_symeig(int n, const double* A, double* evals, double* V) {
   if (n <= 0 || !A || !evals || !V) return MGP_ERR_ARG;
   std::vector<double> a(A, A + (size_t)n * n), ev, vv;
-  jacobi_eigh(n, a, ev, vv);
+  HostPool pool(n >= 64 ? host_pool_workers() : 0);      // as inside the block eigensolver
+  jacobi_eigh(n, a, ev, vv, &pool);
   memcpy(evals, ev.data(), (size_t)n * sizeof(double));
   memcpy(V, vv.data(), (size_t)n * n * sizeof(double));
   return MGP_OK;
@@ -642,6 +711,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   int nlock = 0;
   double a = ub / 4.0, a0 = 0.0;
   int deg = (p && p->degree > 0) ? p->degree : 10;
+  HostPool pool(host_pool_workers());      // lives for this call: joined on every return path
   std::vector<double> G((size_t)b * b), H((size_t)b * b), th, S, lam, U;
   std::vector<float> wt((size_t)b * b), thf(b);
   std::vector<double> rp((size_t)w.rchunks * b), res(b, 1e300);
@@ -705,10 +775,12 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
     // (nearly) dependent columns -- pivot ratio under 1e-5, i.e. cond(Gn) ~ 1e10 -- takes the rank-revealing
     // eigendecomposition instead (3 ms) and drops the dependent directions
     std::vector<double> T;
+    bool tri = true;
     if (cholesky_whiten(b, Gn, dg, T)) {
       kept = b;
     } else {
-      jacobi_eigh(b, Gn, lam, U);
+      tri = false;
+      jacobi_eigh(b, Gn, lam, U, &pool);
       const double lmax = lam[b - 1];
       int k0 = 0;
       while (k0 < b && lam[k0] <= 1e-10 * lmax) ++k0;
@@ -719,35 +791,37 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
         for (int j = 0; j < kept; ++j) T[(size_t)i * kept + j] = dg[i] * U[(size_t)i * b + k0 + j] / sqrt(lam[k0 + j]);
     }
     auto tp1 = std::chrono::steady_clock::now();
-    // Hp = T^T Hs T   (rows of the outputs are independent: split over host threads, fixed order inside)
+    // Hp = T^T Hs T   (rows of the outputs are independent: jobs of 8 rows on the pool, fixed order inside).  After the
+    // Cholesky whitening T is upper triangular (tri): T[l][j] = 0 for j < l, which leaves 1/2 and 1/3 of the two products.
     std::vector<double> HT((size_t)b * kept, 0.0), Hp((size_t)kept * kept, 0.0);
-    parallel_rows(b, [&](int i) {
-      double* o = &HT[(size_t)i * kept];
+    pool.rows(b, 8, [&](int i) {
+      double* __restrict__ o = &HT[(size_t)i * kept];
       for (int l = 0; l < b; ++l) {
         const double h = 0.5 * (H[(size_t)i * b + l] + H[(size_t)l * b + i]);
         if (h == 0.0) continue;
-        const double* t = &T[(size_t)l * kept];
-        for (int j = 0; j < kept; ++j) o[j] += h * t[j];
+        const double* __restrict__ t = &T[(size_t)l * kept];
+        for (int j = tri ? l : 0; j < kept; ++j) o[j] += h * t[j];
       }
     });
-    parallel_rows(kept, [&](int j) {
-      double* o = &Hp[(size_t)j * kept];
-      for (int i = 0; i < b; ++i) {
+    pool.rows(kept, 8, [&](int j) {
+      double* __restrict__ o = &Hp[(size_t)j * kept];
+      const int i1 = tri ? j + 1 : b;
+      for (int i = 0; i < i1; ++i) {
         const double t = T[(size_t)i * kept + j];
-        const double* h = &HT[(size_t)i * kept];
+        const double* __restrict__ h = &HT[(size_t)i * kept];
         for (int l = 0; l < kept; ++l) o[l] += t * h[l];
       }
     });
     auto tp2 = std::chrono::steady_clock::now();
-    jacobi_eigh(kept, Hp, th, S);
+    jacobi_eigh(kept, Hp, th, S, &pool);
     auto tp3 = std::chrono::steady_clock::now();
     // W = T S (b x kept); upload W^T rows = Ritz directions, zero-padded to b
     std::fill(wt.begin(), wt.end(), 0.f);
-    parallel_rows(b, [&](int i) {
+    pool.rows(b, 8, [&](int i) {
       std::vector<double> acc(kept, 0.0);
-      for (int l = 0; l < kept; ++l) {
+      for (int l = tri ? i : 0; l < kept; ++l) {
         const double t = T[(size_t)i * kept + l];
-        const double* sr = &S[(size_t)l * kept];
+        const double* __restrict__ sr = &S[(size_t)l * kept];
         for (int j = 0; j < kept; ++j) acc[j] += t * sr[j];
       }
       for (int j = 0; j < kept; ++j) wt[(size_t)j * b + i] = (float)acc[j];
