@@ -725,6 +725,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   };
   for (outer = 0; outer < max_outer; ++outer) {
     // ---- scaled Chebyshev filter of degree `deg` damping [a, ub], normalised at a0, on the active columns
+    const auto tr0 = std::chrono::steady_clock::now();
     const int ba = b - nlock;
     deg_used = deg;
     const double e = (ub - a) / 2.0, c = (ub + a) / 2.0;
@@ -758,6 +759,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
     // ---- Rayleigh-Ritz: G = V^T V, H = V^T L V (fp64), generalized eigenproblem on the host
     MGP_TRY(launch_gram(w.buf[iF], w.buf[iF], n, b, w, w.G, st));
     MGP_TRY(launch_gram(w.buf[iF], w.buf[iLV], n, b, w, w.H, st));
+    const auto tr1 = std::chrono::steady_clock::now();   // everything of this round is queued; the copies below wait for it
     MGP_HIP_TRY(hipMemcpyAsync(G.data(), w.G, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, st));
     MGP_HIP_TRY(hipMemcpyAsync(H.data(), w.H, (size_t)b * b * sizeof(double), hipMemcpyDeviceToHost, st));
     MGP_HIP_TRY(hipStreamSynchronize(st));
@@ -843,6 +845,12 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
     MGP_LAUNCH_CHECK();
     MGP_HIP_TRY(hipMemcpyAsync(rp.data(), w.rpart, (size_t)w.rchunks * b * sizeof(double), hipMemcpyDeviceToHost, st));
     MGP_HIP_TRY(hipStreamSynchronize(st));
+    if (getenv("MGP_EIG_TIMING")) {
+      auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      const auto tr2 = std::chrono::steady_clock::now();
+      fprintf(stderr, "[eig] round %d: enqueue %.2f  filter + Gram on the GPU (wait) %.2f  host %.2f  rotate + residual %.2f ms\n", outer, ms(tr0, tr1), ms(tr1, tp0),
+              ms(tp0, tp4), ms(tp4, tr2));
+    }
     for (int j = 0; j < b; ++j) {
       double s = 0.0;
       for (int cch = 0; cch < w.rchunks; ++cch) s += rp[(size_t)cch * b + j];
