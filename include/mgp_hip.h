@@ -376,6 +376,12 @@ int mgp_lanczos_block_size(int m, const mgp_lanczos_params_t* p);
 int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs,
                             float* resid, int32_t* info, float* block_evals, float* block_evecs, float* block_resid,
                             void* work, size_t work_bytes, void* stream);
+/* Upper end of the eigensolver's Chebyshev filter: 1 (default) = lambda_max estimated from a 32-dimensional Krylov space
+ * (+ 3 % or more), checked against the Ritz values of every round, with the Gershgorin bound as the fallback; 0 = the
+ * Gershgorin bound (rigorous; about twice lambda_max on k-NN graph Laplacians, i.e. ~40 % more filter applies).  The residual
+ * test uses the Gershgorin bound as its norm of L in both modes.  2 (tests only): half the estimate, a bound that is
+ * certainly short, so that the fallback is exercised.  Process-wide. */
+int mgp_lanczos_set_bound_mode(int mode);
 
 /* k-step Lanczos tridiagonalisation of a precision-family operator with full re-orthogonalisation
  * (classical Gram-Schmidt against all previous vectors, twice).  Replaces

@@ -89,6 +89,7 @@ SIGNATURES = {
     "mgp_cg_set_poll_spin": (c_int, [c_int]),
     "mgp_cg_set_init_free": (c_int, [c_int]),
     "mgp_host_symeig": (c_int, [c_int, _P, _P, _P]),
+    "mgp_lanczos_set_bound_mode": (c_int, [c_int]),
     "mgp_lanczos_tridiag_block_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int, c_int]),
     "mgp_lanczos_tridiag_block": (c_int, [POINTER(OperatorT), _P, c_int, c_int, POINTER(c_float), POINTER(c_float), _P,
                                          c_size_t, _P]),

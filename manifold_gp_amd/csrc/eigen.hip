@@ -546,6 +546,43 @@ void tridiag_eigh(int k, const std::vector<double>& alpha, const std::vector<dou
   jacobi_eigh(k, T, evals, evecs);
 }
 
+// largest Ritz value of (H, G) on the leading k of kfull basis vectors (G = K^T K, H = K^T L K, fp64): rank-revealing
+// whitening (directions under 1e-6 of the largest Gram eigenvalue are rounding of the fp32 vectors), then one small
+// symmetric eigensolve.  NaN when the Gram block is unusable.
+double top_ritz(int kfull, int k, const std::vector<double>& G, const std::vector<double>& H) {
+  std::vector<double> dg(k), Gn((size_t)k * k), lam, U;
+  for (int i = 0; i < k; ++i) {
+    const double g = G[(size_t)i * kfull + i];
+    if (!(g > 0.0) || !std::isfinite(g)) return NAN;
+    dg[i] = 1.0 / sqrt(g);
+  }
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) Gn[(size_t)i * k + j] = 0.5 * (G[(size_t)i * kfull + j] + G[(size_t)j * kfull + i]) * dg[i] * dg[j];
+  jacobi_eigh(k, Gn, lam, U);
+  int k0 = 0;
+  while (k0 < k && !(lam[k0] > 1e-6 * lam[k - 1])) ++k0;
+  const int kept = k - k0;
+  if (kept < 1) return NAN;
+  std::vector<double> T((size_t)k * kept), HT((size_t)k * kept, 0.0), Hp((size_t)kept * kept, 0.0), th, S;
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < kept; ++j) T[(size_t)i * kept + j] = dg[i] * U[(size_t)i * k + k0 + j] / sqrt(lam[k0 + j]);
+  for (int i = 0; i < k; ++i)
+    for (int l = 0; l < k; ++l) {
+      const double h = 0.5 * (H[(size_t)i * kfull + l] + H[(size_t)l * kfull + i]);
+      for (int j = 0; j < kept; ++j) HT[(size_t)i * kept + j] += h * T[(size_t)l * kept + j];
+    }
+  for (int j = 0; j < kept; ++j)
+    for (int i = 0; i < k; ++i) {
+      const double t = T[(size_t)i * kept + j];
+      for (int l = 0; l < kept; ++l) Hp[(size_t)j * kept + l] += t * HT[(size_t)i * kept + l];
+    }
+  jacobi_eigh(kept, Hp, th, S);
+  return th[kept - 1];
+}
+
+int g_eig_bound_mode = 1;   // 1: the filter's upper end from a Krylov estimate of lambda_max; 0: Gershgorin;
+                            // 2 (tests): HALF the estimate, a bound that is certainly short -- the fallback must catch it
+
 struct EigWork {
   float* buf[5];
   double* gpart;
@@ -650,6 +687,11 @@ extern "C" size_t mgp_lanczos_workspace_bytes(int64_t n, int m, const mgp_lanczo
   return eig_bytes(n, m, p);
 }
 
+extern "C" int mgp_lanczos_set_bound_mode(int mode) {
+  g_eig_bound_mode = mode == 2 ? 2 : (mode ? 1 : 0);
+  return MGP_OK;
+}
+
 extern "C" int mgp_lanczos_block_size(int m, const mgp_lanczos_params_t* p) { return m > 0 ? block_size_for(m, p) : 0; }
 
 extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals,
@@ -699,6 +741,60 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   ub *= 1.0 + 1e-6;
   if (!(ub > 0.0)) return MGP_ERR_ARG;
 
+  // ---- the filter's upper end.  Gershgorin is rigorous and loose: on the k-NN graph Laplacians of this package lambda_max
+  // is about HALF of it (60k RMNIST-like graph: 15.4 of 29.7; 1M swiss roll: 649 of 1239), and the degree a Chebyshev filter
+  // needs grows with sqrt(ub - a) -- a bound twice too large costs 40 % more applies.  So: a 32-dimensional Krylov space of
+  // one random vector in the Chebyshev basis of [0, ub] (the same fused three-term SpMV launches as the filter, C = 1; the
+  // basis stays bounded and well conditioned, unlike the monomials), Rayleigh-Ritz with the Gram kernels, the largest
+  // Ritz value theta_32 <= lambda_max; the filter gets theta_32 + max(3 %, twice what the last 16 dimensions still moved).
+  // The residual test keeps the Gershgorin bound as its norm of L, so `tol` means what it meant.  An estimate that fell
+  // short would let the filter AMPLIFY the top of the spectrum; that shows as a Ritz value above the supposed bound in
+  // the next Rayleigh-Ritz step and is answered there (Gershgorin, fresh block).
+  double ubf = ub;
+  const int kk = 32;
+  if (g_eig_bound_mode && b >= kk && n >= 8 * kk) {
+    float* K = w.buf[0];
+    float* LK = w.buf[1];
+    float* y[3] = {w.buf[2], w.buf[3], w.buf[4]};
+    const int g1 = (int)std::min<int64_t>(4096, mgp_cdiv(n, kBlock));
+    hipLaunchKernelGGL(random_cols_kernel, dim3(g1), dim3(kBlock), 0, st, y[0], n, 1, 0, 1, seed ^ 0x5bd1e995ULL);
+    MGP_LAUNCH_CHECK();
+    const double ce = ub / 2.0;     // centre = half width of [0, ub]
+    auto put = [&](const float* src, int j) {
+      hipLaunchKernelGGL(move_cols_kernel, dim3(g1), dim3(kBlock), 0, st, src, n, 1, 0, 1, K, kk, j);
+    };
+    put(y[0], 0);
+    // T_1 = (L - c) / e
+    MGP_TRY(mgp_spmm_fused_ex(L, y[0], 1, y[1], (float)(-1.0), (float)(1.0 / ce), nullptr, nullptr, nullptr, 0.f, 1.f, nullptr,
+                              nullptr, nullptr, nullptr, stream));
+    put(y[1], 1);
+    int i0 = 0, i1 = 1, i2 = 2;
+    for (int j = 2; j < kk; ++j) {
+      // T_j = 2 (L - c) / e T_{j-1} - T_{j-2}
+      MGP_TRY(mgp_spmm_fused_ex(L, y[i1], 1, y[i2], (float)(-2.0), (float)(2.0 / ce), nullptr, nullptr, y[i0], -1.f, 1.f, nullptr,
+                                nullptr, nullptr, nullptr, stream));
+      put(y[i2], j);
+      const int t = i0; i0 = i1; i1 = i2; i2 = t;
+    }
+    MGP_LAUNCH_CHECK();
+    MGP_TRY(mgp_spmm_fused_ex(L, K, kk, LK, 0.f, 1.f, nullptr, nullptr, nullptr, 0.f, 1.f, nullptr, nullptr, nullptr, nullptr,
+                              stream));
+    MGP_TRY(launch_gram(K, K, n, kk, w, w.G, st));
+    MGP_TRY(launch_gram(K, LK, n, kk, w, w.H, st));
+    std::vector<double> Gk((size_t)kk * kk), Hk((size_t)kk * kk);
+    MGP_HIP_TRY(hipMemcpyAsync(Gk.data(), w.G, (size_t)kk * kk * sizeof(double), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipMemcpyAsync(Hk.data(), w.H, (size_t)kk * kk * sizeof(double), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    const double th_full = top_ritz(kk, kk, Gk, Hk), th_half = top_ritz(kk, kk / 2, Gk, Hk);
+    if (std::isfinite(th_full) && std::isfinite(th_half) && th_full > 0.0) {
+      const double cand = th_full + std::max(0.03 * th_full, 2.0 * fabs(th_full - th_half));
+      if (cand < ub) ubf = cand;
+      if (g_eig_bound_mode == 2) ubf = 0.5 * th_full;
+    }
+    if (getenv("MGP_EIG_TIMING"))
+      fprintf(stderr, "[eig] upper end: Gershgorin %.5g, Krylov(32) theta %.5g (16: %.5g) -> filter bound %.5g\n", ub, th_full, th_half, ubf);
+  }
+
   const int rgrid = (int)std::min<int64_t>(4096, mgp_cdiv(n * b, kBlock));
   hipLaunchKernelGGL(random_cols_kernel, dim3(rgrid), dim3(kBlock), 0, st, w.buf[0], n, b, 0, b, seed);
   MGP_LAUNCH_CHECK();
@@ -709,7 +805,13 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   // block -- but stays in the Rayleigh-Ritz basis, so it keeps being refined and the block stays orthogonal.
   int bV = 0, bLV = 1, c0 = 2, c1 = 3, c2 = 4;
   int nlock = 0;
-  double a = ub / 4.0, a0 = 0.0;
+  // Degree cap: 200 was tuned with the Gershgorin bound as the filter's upper end (80: 8 rounds / 497 applies at m = 100, 200:
+  // 4 / 343, 300: 4 / 443).  What a degree buys goes with 1 / sqrt(ub - a), so under a tighter bound the same filter strength
+  // is degree 200 sqrt(ubf / ub) (146 when lambda_max is half of Gershgorin); more only over-solves the last round (60k graph,
+  // cap 120 / 146 / 200 / 240: 247 / 273 / 327 / 367 applies for residuals 2.7 / 2.6 / 1.9 / 1.9e-4, tolerance 3.0e-4).
+  int kCap = std::max(100, std::min(200, (int)lround(200.0 * sqrt(ubf / ub))));
+  double a = ubf / 4.0, a0 = 0.0;
+  double top_prev = 1e300;      // largest Ritz value of the previous round's block (they only come down)
   int deg = (p && p->degree > 0) ? p->degree : 10;
   HostPool pool(host_pool_workers());      // lives for this call: joined on every return path
   std::vector<double> G((size_t)b * b), H((size_t)b * b), th, S, lam, U;
@@ -728,7 +830,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
     const auto tr0 = std::chrono::steady_clock::now();
     const int ba = b - nlock;
     deg_used = deg;
-    const double e = (ub - a) / 2.0, c = (ub + a) / 2.0;
+    const double e = (ubf - a) / 2.0, c = (ubf + a) / 2.0;
     double sig = e / (a0 - c);
     const double tau = 2.0 / sig;
     int iX = c0, iY = c1, iN = c2;
@@ -817,6 +919,28 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
     auto tp2 = std::chrono::steady_clock::now();
     jacobi_eigh(kept, Hp, th, S, &pool);
     auto tp3 = std::chrono::steady_clock::now();
+    // The estimated upper end fell short if a Ritz value lies above it (proof: Ritz values never exceed lambda_max), or if
+    // the block's largest Ritz value, which only comes down from round to round, jumps up towards the top of the spectrum
+    // (the filter amplified what it should have damped).  Then: Gershgorin from here on and a fresh block.
+    if (ubf < ub && (th[kept - 1] > ubf * (1.0 + 1e-3) || (th[kept - 1] > 2.0 * top_prev && th[kept - 1] > 0.25 * ubf))) {
+      if (getenv("MGP_EIG_TIMING"))
+        fprintf(stderr, "[eig] round %d: largest Ritz value %.5g against the estimated bound %.5g: back to Gershgorin %.5g\n", outer,
+                th[kept - 1], ubf, ub);
+      ubf = ub;
+      kCap = 200;
+      hipLaunchKernelGGL(random_cols_kernel, dim3(rgrid), dim3(kBlock), 0, st, w.buf[bV], n, b, 0, b, seed + 104729ULL * (outer + 1));
+      MGP_LAUNCH_CHECK();
+      nlock = 0;
+      a = ub / 4.0;
+      a0 = 0.0;
+      deg = (p && p->degree > 0) ? p->degree : 10;
+      top_prev = 1e300;
+      rmax_prev1 = 1e300;
+      nconv_prev1 = 0;
+      nconv = 0;
+      continue;
+    }
+    top_prev = th[kept - 1];
     // W = T S (b x kept); upload W^T rows = Ritz directions, zero-padded to b
     std::fill(wt.begin(), wt.end(), 0.f);
     pool.rows(b, 8, [&](int i) {
@@ -886,7 +1010,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
       {
         double rmx = 0.0;
         for (int j = 0; j < m; ++j) rmx = std::max(rmx, res[j]);
-        if (deg_used >= 200 && rmx > 0.5 * rmax_prev1 && nconv <= nconv_prev1 && rmx <= 1e-3 * ub) { floor_hit = true; ++outer; break; }
+        if (deg_used >= kCap && rmx > 0.5 * rmax_prev1 && nconv <= nconv_prev1 && rmx <= 1e-3 * ub) { floor_hit = true; ++outer; break; }
         rmax_prev1 = rmx;
         nconv_prev1 = nconv;
       }
@@ -899,10 +1023,11 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
       a = th[kept - 1];
       a0 = std::min(th[0], 0.0);
       const double gap = std::max(a - th[m - 1], 1e-12 * ub);
-      int dnew = (int)ceil(3.0 / (2.0 * sqrt(gap / (ub - a))));
+      int dnew = (int)ceil(3.0 / (2.0 * sqrt(gap / (ubf - a))));
       // degree cap 200 (80 until late in round 1: 8 rounds / 497 applies at m = 100 where 200 needs 4 / 343; the
       // scaled three-term recurrence is normalised at a0, so the block does not overflow at these degrees)
-      deg = std::min(std::max(dnew, 8), 200);
+      deg = std::min(std::max(dnew, 8), kCap);
+      if (getenv("MGP_EIG_TIMING")) fprintf(stderr, "[eig] round %d: a %.4e  theta_m %.4e  gap %.3e  degree asked %d\n", outer, a, th[m - 1], gap, dnew);
       if (p && p->degree > 0) deg = p->degree;
       // The same exit, predicted instead of observed.  A round of degree d multiplies the slowest wanted pair's error by
       // about exp(-3 d / dnew) (dnew = the degree that gives e^-3 at the measured gap between the wanted block and its
@@ -910,7 +1035,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
       // > 0.5: the wanted modes sit in a cluster with their guards -- on the 60k RMNIST-like graph 128 Ritz values lie
       // within 1e-6 lambda_max), every further 200-apply round would buy less than a factor 2: stop before running it
       // (C3 at tol 1e-6: 4 rounds / 50 ms instead of 5 / 67 ms, same residual 2.5e-4 as tol 1e-5 reaches).
-      if (!(p && p->degree > 0) && deg_used >= 200 && dnew > 200 && exp(-3.0 * 200.0 / (double)dnew) > 0.5) {
+      if (!(p && p->degree > 0) && deg_used >= kCap && dnew > kCap && exp(-3.0 * kCap / (double)dnew) > 0.5) {
         double rmx = 0.0;
         for (int j = 0; j < m; ++j) rmx = std::max(rmx, res[j]);
         if (rmx <= 1e-3 * ub) { floor_hit = true; ++outer; break; }

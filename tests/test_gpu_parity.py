@@ -464,6 +464,45 @@ def test_eigensolver_disconnected_components(mgp, dev):
     np.testing.assert_allclose(evals.cpu().numpy(), w, rtol=0, atol=2e-6 * np.abs(np.diag(A)).max())
 
 
+def test_eigensolver_filter_bound_modes(mgp, dev):
+    """The upper end of the eigensolver's Chebyshev filter (mgp_lanczos_set_bound_mode): the Gershgorin bound (0), the
+    Krylov estimate of lambda_max (1, the default: about half of Gershgorin on k-NN graph Laplacians, fewer applies) and a
+    bound that is deliberately HALF of lambda_max (2): the filter then amplifies the top of the spectrum, the Ritz-value
+    check of the next round has to notice, and the solve has to come back right on the Gershgorin bound.  All three
+    against dense float64 eigh, residuals and orthonormality included."""
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.solvers import lanczos_smallest
+    rng = np.random.default_rng(11)
+    n = 4000
+    t = rng.random(n)
+    x = (np.stack([np.cos(6.28318 * t), np.sin(6.28318 * t), 0.3 * np.cos(3 * 6.28318 * t)], 1)
+         + 0.01 * rng.normal(size=(n, 3))).astype(np.float32)
+    knn = mgp.utils.NearestNeighbors(T(x, dev))
+    idx, val = knn.graph(10)
+    op = mgp.operators.GraphLaplacianOperator(val, idx, n, torch.tensor([[0.05]], device=dev), "symmetric",
+                                              graph=knn.knn_graph)
+    A = op.to_dense().double().cpu().numpy()
+    w = np.linalg.eigvalsh(0.5 * (A + A.T))
+    scale = np.abs(np.diag(A)).max()
+    gersh = np.abs(A).sum(1).max()
+    assert w[-1] < 0.75 * gersh, (w[-1], gersh)          # what the estimate is for: Gershgorin is loose here
+    applies = {}
+    try:
+        for mode in (0, 1, 2):
+            _lib.lib().mgp_lanczos_set_bound_mode(mode)
+            evals, evecs, resid = lanczos_smallest(op.data, 24, tol=1e-6)
+            applies[mode] = int(lanczos_smallest.last_info[1])
+            np.testing.assert_allclose(evals.cpu().numpy(), w[:24], rtol=0, atol=5e-6 * scale, err_msg="mode %d" % mode)
+            R = op.matmul(evecs) - evecs * evals.view(1, -1)
+            assert float(R.norm(dim=0).max()) <= 2e-5 * scale, (mode, float(R.norm(dim=0).max()))
+            assert float((evecs.t() @ evecs - torch.eye(24, device=dev)).abs().max()) < 5e-5, mode
+    finally:
+        _lib.lib().mgp_lanczos_set_bound_mode(1)
+    print("filter applies: Gershgorin %d, estimate %d, short bound + fallback %d" % (applies[0], applies[1], applies[2]))
+    assert applies[1] <= applies[0], applies
+    assert applies[2] > applies[1], applies              # the short bound cost a wasted round before the fallback
+
+
 def test_eigensolver_on_unordered_nodes_uses_the_locality_order(mgp, dev):
     """Nodes handed over in random order: the graph carries tiles over a locality order and the eigensolver
     runs on the matrix relabelled by it (solvers.lanczos_smallest).  Eigenvalues against dense eigh and the
