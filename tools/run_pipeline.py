@@ -85,8 +85,12 @@ def main():
         sw = S.matmul(w)
     res["schur_matvec_ms(6k labelled, nested CG on 54k)"] = round(t, 2)
     res["schur_symmetry_rel"] = float((torch.dot(w, sv) - torch.dot(v, sw)).abs() / (sv.norm() * w.norm()))
-    print(json.dumps(res, indent=1))
+    return res
 
 
 if __name__ == "__main__":
-    main()
+    # twice in one process: the first pass pays code-object loading, workspace allocation and hipBLAS / rocPRIM start-up
+    # in whatever stage touches them first; the second pass (fresh tensors, fresh kernel object) is what a training loop sees
+    first = main()
+    second = main()
+    print(json.dumps({"first_pass": first, "second_pass": second}, indent=1))
