@@ -66,6 +66,11 @@ int mgp_knn_search(const float* db, int64_t N, int d, const float* q, int64_t n,
  * (default 1).  mgp_knn_last_direct_chunks: chunks of the last slab search that were redone. */
 int mgp_knn_set_mfma(int on);
 int64_t mgp_knn_last_direct_chunks(void);
+/* Self-search (q == db, n == N: the graph build, nearest_neighbors.py:35-37 called on the training inputs) with the whole
+ * N x N key matrix inside the workspace (N <= 92k: 32 GiB): key(x, y) = key(y, x), so the matrix-core kernel computes the
+ * tile pairs on and above the diagonal only and stores each off-diagonal tile twice (as it is and transposed): half the
+ * MFMA work, the same selection, the same results bit for bit.  Default 1; 0 computes every tile (tests, A/B runs). */
+int mgp_knn_set_symmetric(int on);
 
 /* ---------------------------------------------------------------------------------------------
  * Graph: k-NN lists -> symmetrised graph.  Replaces NearestNeighbors.graph

@@ -3,7 +3,8 @@
 // Replaces faiss IndexFlatL2 / IndexIVFFlat(nlist=1) (+ Gpu variants) `search` as called from
 // manifold_gp/utils/nearest_neighbors.py:35-37.
 //
-// Pipeline per chunk of query rows (fp32 distance slab of 1-8 GiB of HBM, see chunk_rows):
+// Pipeline per chunk of query rows (fp32 distance slab of 1-8 GiB of HBM, see chunk_rows; as many queries as points and
+// N <= 92k: ONE chunk holding the whole N x N key matrix, of which a self-search computes the upper triangle only):
 //   1. keys: d >= 32: dist_mfma_kernel (knn_mfma.hip, centred bf16-split GEMM form on the matrix cores);
 //      else, or for a chunk where many rows fail the absolute check:
 //      dist_tile_kernel   fp32 direct-difference distances, 128x128 tile per workgroup,
@@ -613,12 +614,17 @@ int64_t chunk_rows(int64_t N, int64_t n) {
   if (qc >= 2048) qc = qc / 2048 * 2048;
   if (qc < kTile) qc = kTile;
   const int64_t ncap = mgp_cdiv(n, kTile) * kTile;
+  // As many queries as points and the WHOLE key matrix within 32 GiB (N <= 92k; the card has 288 GB): one chunk.  The
+  // key kernel walks the query tiles in groups by itself (knn_mfma.hip), and when the queries ARE the points -- the graph
+  // build -- it computes only the tile pairs on and above the diagonal, which needs every row of the matrix in place.
+  if (n == N && (int64_t)ld * ncap <= ((int64_t)1 << 33)) return ncap;
   return qc < ncap ? qc : ncap;
 }
 
 // candidate distances on the matrix cores (knn_mfma.hip) from 32 features up; mgp_knn_set_mfma(0) forces
 // the direct-difference tiles
 int g_knn_mfma = 1;
+int g_knn_sym = 1;        // self-search: upper-triangle key tiles only (mgp_knn_set_symmetric(0): every tile)
 int64_t g_last_direct_chunks = 0;
 // (the centring + split of the points is a fixed ~1 ms at 60k x 784: it pays from ~1000 queries on)
 bool use_mfma(int d, int64_t n) { return g_knn_mfma && d >= 32 && n >= 1024; }
@@ -660,6 +666,8 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   double* scratch = ar.take<double>((size_t)kExactBatch * N);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
   const bool mfma = use_mfma(d, n);
+  // self-search with the whole key matrix in one chunk: key(x, y) = key(y, x), half the tiles are computed
+  const bool sym = mfma && g_knn_sym && q == db && n == N && qc >= n;
   MgpKnnMfma mm{};
   double alpha = 0.0, beta = 0.0;
   if (mfma) {
@@ -693,9 +701,9 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
     // (two chunks in a row redone: this data does not suit the absolute bound, stop paying for MFMA passes)
     for (int pass = (mfma && streak_direct < 2) ? 0 : 1; pass < 2; ++pass) {
       if (pass == 0) {
-        MGP_TRY(mgp_knn_mfma_prepare_queries(q + q0 * d, rows, d, mm, st));
-        MGP_TRY(mgp_knn_mfma_tiles(mm, rows, N, slab, ld, st));
-        a.qn2 = mm.qn2; a.r2max = mm.r2max; a.alpha = alpha; a.beta = beta;
+        if (!sym) MGP_TRY(mgp_knn_mfma_prepare_queries(q + q0 * d, rows, d, mm, st));
+        MGP_TRY(mgp_knn_mfma_tiles(mm, rows, N, slab, ld, st, sym));
+        a.qn2 = sym ? mm.pn2 : mm.qn2; a.r2max = mm.r2max; a.alpha = alpha; a.beta = beta;
       } else {
         if (d % 4 == 0) hipLaunchKernelGGL(dist_tile_kernel<true>, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
         else hipLaunchKernelGGL(dist_tile_kernel<false>, grid, dim3(kBlock), 0, st, db, N, d, q + q0 * d, rows, slab, ld);
@@ -739,6 +747,11 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   MGP_HIP_TRY(hipStreamSynchronize(st));
   if (stats) { stats[0] = n_wide; stats[1] = n_exact; stats[2] = n_chunks; stats[3] = cand0; }
   g_last_direct_chunks = n_direct;
+  return MGP_OK;
+}
+
+extern "C" int mgp_knn_set_symmetric(int on) {
+  g_knn_sym = on ? 1 : 0;
   return MGP_OK;
 }
 

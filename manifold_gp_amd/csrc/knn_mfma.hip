@@ -147,7 +147,8 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
                                                            const float* __restrict__ qn2, int64_t nq,
                                                            const uint16_t* __restrict__ Ph, const uint16_t* __restrict__ Pl,
                                                            const float* __restrict__ pn2, int64_t N, int dpad,
-                                                           float* __restrict__ out, int64_t ld, int ny_per_xcd) {
+                                                           float* __restrict__ out, int64_t ld, int ny_per_xcd, int nx,
+                                                           int sym) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int kTileE = kMT * kBK;                 // bf16 elements of one operand tile (8 KB)
   __shared__ __attribute__((aligned(16))) uint16_t sm[2][4][kTileE];
@@ -156,12 +157,21 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
   // blocks are dealt round-robin over the 8 XCDs: XCD c takes the query tiles c, c + 8, ... and walks the
   // point tiles with its query tiles innermost, so that a point tile fetched into that XCD's L2 is used
   // by all its query tiles at about the same time and the few query tiles stay L2-resident.
-  const int xcd = blockIdx.x % MGP_NXCD;
-  const int t = blockIdx.x / MGP_NXCD;
+  // A launch over more than 8 * ny_per_xcd query tiles walks them in GROUPS of that many, one group after the other
+  // (blocks are dispatched in index order): what a chunk per launch did, so that a group's query tiles stay L2-resident.
+  // sym (the queries ARE the points: graph build): key(x, y) = key(y, x) -- the same products, and the bound of the
+  // header holds for any summation order -- so only the tile pairs on and above the diagonal are computed and every
+  // off-diagonal tile is stored twice, as it is and transposed: half the MFMA work for the same slab.
+  const int per_group = MGP_NXCD * ny_per_xcd * nx;
+  const int grp = blockIdx.x / per_group;
+  const int bl = blockIdx.x - grp * per_group;
+  const int xcd = bl % MGP_NXCD;
+  const int t = bl / MGP_NXCD;
   const int ty = t % ny_per_xcd, tx = t / ny_per_xcd;
-  const int64_t qt = xcd + MGP_NXCD * ty;
+  const int64_t qt = (int64_t)grp * MGP_NXCD * ny_per_xcd + xcd + MGP_NXCD * ty;
   const int64_t q0 = qt * kMT, p0 = (int64_t)tx * kMT;
   if (q0 >= nq) return;
+  if (sym && tx < qt) return;
   knn_f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -246,6 +256,35 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
         if (q0 + rl < nq && p0 + wn * 64 + j * 16 + r < N) orow[j * 16] = v > 0.f ? v : 0.f;
       }
     }
+  if (sym && tx != qt) {
+    // the transposed tile: rows = this tile's points, columns = its queries; a lane's four consecutive rows (e) of
+    // one column become four consecutive floats of one row: a 16-byte store (q0, the 16-row blocks and ld are multiples
+    // of 4; the tile edge falls back to single floats)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t prow = p0 + wn * 64 + j * 16 + r;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t qc0 = q0 + wm * 64 + i * 16 + g * 4;
+        knn_f32x4 v4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (qn[i][e] + pn[j]) - 2.f * acc[i][j][e];
+          v4[e] = v > 0.f ? v : 0.f;
+        }
+        float* trow = out + prow * ld + qc0;
+        if (prow < N) {
+          if (qc0 + 3 < nq) {
+            *reinterpret_cast<knn_f32x4*>(trow) = v4;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (qc0 + e < nq) trow[e] = v4[e];
+          }
+        }
+      }
+    }
+  }
 #endif
 }
 
@@ -317,13 +356,18 @@ int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpK
   return MGP_OK;
 }
 
-int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab, int64_t ld, hipStream_t st) {
+int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab, int64_t ld, hipStream_t st, bool sym) {
   const int64_t nx = mgp_cdiv(N, kMT), ny = mgp_cdiv(rows, kMT);
-  const int ny_per_xcd = (int)mgp_cdiv(ny, MGP_NXCD);
-  const int64_t blocks = (int64_t)MGP_NXCD * ny_per_xcd * nx;
-  if (blocks > 0x7fffffff) return MGP_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(dist_mfma_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, m.Qh, m.Ql, m.qn2, rows, m.Ph, m.Pl, m.pn2,
-                     N, m.dpad, slab, ld, ny_per_xcd);
+  // at most 8 query tiles per XCD at a time (their operand tiles stay in that XCD's L2 while the point tiles stream by:
+  // the shape the 8 192-row chunks were tuned for); more query tiles than that are walked group by group in one launch
+  const int ny_per_xcd = ny > 8 * MGP_NXCD ? 8 : (int)mgp_cdiv(ny, MGP_NXCD);
+  const int64_t groups = mgp_cdiv(ny, (int64_t)MGP_NXCD * ny_per_xcd);
+  const int64_t blocks = groups * MGP_NXCD * ny_per_xcd * nx;
+  if (blocks > 0x7fffffff || nx > 0x7fffffff) return MGP_ERR_UNSUPPORTED;
+  if (sym && rows != N) return MGP_ERR_ARG;
+  // sym: the queries are the points -- their split and norms serve both sides
+  hipLaunchKernelGGL(dist_mfma_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, sym ? m.Ph : m.Qh, sym ? m.Pl : m.Ql,
+                     sym ? m.pn2 : m.qn2, rows, m.Ph, m.Pl, m.pn2, N, m.dpad, slab, ld, ny_per_xcd, (int)nx, sym ? 1 : 0);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }

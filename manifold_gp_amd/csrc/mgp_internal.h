@@ -113,7 +113,7 @@ size_t mgp_knn_mfma_bytes(int64_t N, int64_t qc, int d);
 int mgp_knn_mfma_take(MgpArena& ar, int64_t N, int64_t qc, int d, MgpKnnMfma* m);
 int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnMfma& m, hipStream_t st);
 int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpKnnMfma& m, hipStream_t st);
-int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab, int64_t ld, hipStream_t st);
+int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab, int64_t ld, hipStream_t st, bool sym = false);
 void mgp_knn_mfma_bound(int dpad, double* alpha, double* beta);
 
 // fp64 operator apply from the fp32 matrix (true residual of the CG refinement); work64 = 4 n C doubles

@@ -2080,6 +2080,40 @@ def test_knn_matrix_core_keys_equal_direct_keys(mgp, dev, kind):
     assert np.array_equal(I1[:64].cpu().numpy(), Ir) and np.array_equal(D1[:64].cpu().numpy(), Dr), kind
 
 
+@pytest.mark.parametrize("n,d,k", [(3001, 40, 17), (8323, 96, 30), (12000, 33, 5), (1026, 784, 50)])
+def test_knn_self_search_upper_triangle_tiles(mgp, dev, n, d, k):
+    """Self-search (the graph build: queries == points, same buffer): the matrix-core key kernel computes the tile
+    pairs on and above the diagonal only and stores every off-diagonal tile twice, as it is and transposed
+    (mgp_knn_set_symmetric, default 1).  Ragged sizes -- n not a multiple of 128 nor of 4, so the transposed 16-byte
+    stores meet the matrix edge -- clustered rows (near ties across tiles) and duplicates: same lists as with every
+    tile computed, as the direct-difference keys, and as the oracle."""
+    from manifold_gp_amd import _lib
+    from oracle import knn as oknn
+    rng = np.random.default_rng(n + d)
+    cent = rng.normal(size=(40, d)) * 3
+    x = (cent[rng.integers(0, 40, n)] + rng.normal(size=(n, d))).astype(np.float32)
+    x[n - 7:] = x[:7]                                      # duplicates straddling the first and the last tile
+    xt = T(x, dev)
+    nn = mgp.utils.NearestNeighbors(xt)
+    D1, I1 = nn.search(xt, k)                              # same tensor: q == db
+    assert nn.last_stats["chunks"] == 1 and nn.last_stats["chunks_redone_direct"] == 0, nn.last_stats
+    lib = _lib.lib()
+    try:
+        lib.mgp_knn_set_symmetric(0)
+        D0, I0 = nn.search(xt, k)
+        lib.mgp_knn_set_symmetric(1)
+        lib.mgp_knn_set_mfma(0)
+        Dd, Id = nn.search(xt, k)
+    finally:
+        lib.mgp_knn_set_symmetric(1)
+        lib.mgp_knn_set_mfma(1)
+    assert torch.equal(I1, I0) and torch.equal(D1, D0)
+    assert torch.equal(I1, Id) and torch.equal(D1, Dd)
+    rows = np.r_[0:40, n // 2:n // 2 + 40, n - 40:n]
+    Dr, Ir = oknn.knn_search(x, x[rows], k)
+    assert np.array_equal(I1[rows].cpu().numpy(), Ir) and np.array_equal(D1[rows].cpu().numpy(), Dr)
+
+
 def test_knn_fp32_overflowing_distances_take_the_exact_path(mgp, dev):
     """Coordinates around 1e19..1e20: squared fp32 distances overflow to inf and order nothing; the exact fp64
     scan must take over (the oracle works in fp64)."""

@@ -20,6 +20,11 @@ print("search ms", [round(t, 1) for t in ts], "stats", getattr(knn, "last_stats"
 _, ts = timed(lambda: knn.graph(50))
 print("graph(50) (search + symmetrise + CSR + tiles) ms", [round(t, 1) for t in ts])
 from manifold_gp_amd import _lib
+_lib.lib().mgp_knn_set_symmetric(0)
+(Ds, Is), ts = timed(lambda: knn.search(x, 50))
+print("every tile (symmetric mode off): search ms", [round(t, 1) for t in ts], "stats", knn.last_stats)
+print("identical to the upper-triangle search", bool(torch.equal(I, Is)), bool(torch.equal(D, Ds)))
+_lib.lib().mgp_knn_set_symmetric(1)
 _lib.lib().mgp_knn_set_mfma(0)
 (D0, I0), ts = timed(lambda: knn.search(x, 50))
 print("direct tiles: search ms", [round(t, 1) for t in ts], "stats", knn.last_stats)
