@@ -10,13 +10,15 @@
 //   The low end of a graph-Laplacian spectrum is clustered and, for a k-NN graph with several
 //   connected components, degenerate; single-vector Lanczos needs thousands of steps there and
 //   misses multiplicities (the reference itself abandoned its Lanczos call for dense eigh,
-//   riemann_kernel.py:120).  So: (1) Gershgorin gives a safe upper bound ub of the spectrum,
+//   riemann_kernel.py:120).  So: (1) Gershgorin gives a safe upper bound ub of the spectrum (the norm the
+//   residual test is relative to) and a 32-dimensional Krylov space a tight one, ubf ~ 1.03 lambda_max -- about half
+//   of Gershgorin on k-NN graph Laplacians, checked against the Ritz values of every round, Gershgorin as fallback,
 //   (2) a block of b = m + pad vectors is filtered by a scaled Chebyshev polynomial of L that
-//   damps [a, ub] (a = largest Ritz value of the previous round) -- d fused SpMM launches, the
+//   damps [a, ubf] (a = largest Ritz value of the previous round) -- d fused SpMM launches, the
 //   matrix is streamed once per launch for all b columns, (3) Rayleigh-Ritz in the filtered
 //   block: Gram matrices V^T V, V^T L V accumulated in fp64 on device, b x b generalized
-//   eigenproblem in fp64 on the host (Jacobi), rotation V <- V W on the fp32 MFMA kernel,
-//   (4) residuals ||L v - theta v|| decide convergence.
+//   eigenproblem in fp64 on the host (Householder + QL on a worker pool), rotation V <- V W on the fp32
+//   MFMA kernel, (4) residuals ||L v - theta v|| <= tol ub decide convergence.
 //
 // mgp_lanczos_tridiag: q_{j+1} beta_j = A q_j - alpha_j q_j - beta_{j-1} q_{j-1} with classical
 //   Gram-Schmidt against ALL previous vectors, twice; alpha/beta stay on device until the end.
