@@ -71,6 +71,17 @@ int64_t mgp_knn_last_direct_chunks(void);
  * tile pairs on and above the diagonal only and stores each off-diagonal tile twice (as it is and transposed): half the
  * MFMA work, the same selection, the same results bit for bit.  Default 1; 0 computes every tile (tests, A/B runs). */
 int mgp_knn_set_symmetric(int on);
+/* Prepared index (d >= 32): the part of a search that depends on the points alone -- column means, the centred bf16 split
+ * in the key kernel's tile layout, norms -- built once (faiss: index.train / index.add, nearest_neighbors.py:20-33) and
+ * handed to every search.  Without it a search prepares the points itself (~1 ms at 60k x 784) and therefore keeps small
+ * query batches (< 1024 rows) on the fp32 direct-difference tiles; with it the matrix cores rank the candidates of any batch
+ * (600 queries against 60k x 784: 1.3 -> 0.5 ms).  The index is a SNAPSHOT of db at build time (faiss copies its vectors):
+ * rebuild it when db changes.  Results are the oracle's bit for bit either way.  mgp_knn_index_bytes: 0 when d < 32. */
+size_t mgp_knn_index_bytes(int64_t N, int d);
+int mgp_knn_index_build(const float* db, int64_t N, int d, void* index, size_t index_bytes, void* stream);
+int mgp_knn_search_indexed(const float* db, int64_t N, int d, const void* index, size_t index_bytes, const float* q,
+                           int64_t n, int k, float* D, int32_t* I, void* work, size_t work_bytes, int64_t* stats,
+                           void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Graph: k-NN lists -> symmetrised graph.  Replaces NearestNeighbors.graph

@@ -68,6 +68,9 @@ SIGNATURES = {
                                POINTER(c_int64), _P]),
     "mgp_knn_set_mfma": (c_int, [c_int]),
     "mgp_knn_set_symmetric": (c_int, [c_int]),
+    "mgp_knn_index_bytes": (c_size_t, [c_int64, c_int]),
+    "mgp_knn_index_build": (c_int, [_P, c_int64, c_int, _P, c_size_t, _P]),
+    "mgp_knn_search_indexed": (c_int, [_P, c_int64, c_int, _P, c_size_t, _P, c_int64, c_int, _P, _P, _P, c_size_t, _P, _P]),
     "mgp_knn_last_direct_chunks": (c_int64, []),
     "mgp_graph_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mgp_graph_tiles_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -645,13 +645,17 @@ static size_t bruteforce_bytes(int64_t N, int64_t n, int d, int k) {
   b += 2 * mgp_align((size_t)qc * sizeof(int));
   b += mgp_align(64);
   b += mgp_align((size_t)kExactBatch * N * sizeof(double));
-  if (use_mfma(d, n)) b += mgp_knn_mfma_bytes(N, qc, d);
+  // matrix-core keys: the query side of a chunk whenever d allows them (a search through a prepared index takes them at
+  // any number of queries), the point side only when this search has to prepare the points itself
+  if (d >= 32) b += mgp_knn_mfma_query_bytes(qc, d);
+  if (use_mfma(d, n)) b += mgp_knn_mfma_index_bytes(N, d);
   return b + 1024;
 }
 
 // the slab pipeline (any d): distance tiles -> radix select -> fp64 re-rank -> sufficiency check
 int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
-                       int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream) {
+                       int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream, const void* index,
+                       size_t index_bytes) {
   if (!db || !q || !D || !I || !work) return MGP_ERR_ARG;
   if (N <= 0 || n <= 0 || d <= 0 || k <= 0 || k > N || k > 1024 || N > INT_MAX) return MGP_ERR_ARG;
   if (work_bytes < bruteforce_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
@@ -665,13 +669,22 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   int* counter = ar.take<int>(16);
   double* scratch = ar.take<double>((size_t)kExactBatch * N);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
-  const bool mfma = use_mfma(d, n);
+  // a prepared index (mgp_knn_index_build: the points' column means, bf16 split and norms) makes the matrix-core keys pay
+  // at any number of queries; without one the ~1 ms of preparing 60k x 784 points pays from ~1000 queries on
+  const bool indexed = index != nullptr && g_knn_mfma && d >= 32;
+  if (indexed && index_bytes < mgp_knn_mfma_index_bytes(N, d)) return MGP_ERR_WORKSPACE;
+  const bool mfma = indexed || use_mfma(d, n);
   // self-search with the whole key matrix in one chunk: key(x, y) = key(y, x), half the tiles are computed
   const bool sym = mfma && g_knn_sym && q == db && n == N && qc >= n;
   MgpKnnMfma mm{};
   double alpha = 0.0, beta = 0.0;
-  if (mfma) {
-    MGP_TRY(mgp_knn_mfma_take(ar, N, qc, d, &mm));
+  if (d >= 32) MGP_TRY(mgp_knn_mfma_query_take(ar, qc, d, &mm));
+  if (indexed) {
+    MgpArena ia(const_cast<void*>(index), index_bytes);
+    MGP_TRY(mgp_knn_mfma_index_take(ia, N, d, &mm));
+    mgp_knn_mfma_bound(mm.dpad, &alpha, &beta);
+  } else if (mfma) {
+    MGP_TRY(mgp_knn_mfma_index_take(ar, N, d, &mm));
     MGP_TRY(mgp_knn_mfma_prepare_points(db, N, d, mm, st));
     mgp_knn_mfma_bound(mm.dpad, &alpha, &beta);
   }
@@ -775,6 +788,33 @@ int64_t fallback_rows(int64_t n) {          // rows the low-d path may hand back
 }
 
 }  // namespace
+
+// Prepared index: what every search against the same points would otherwise recompute (column means, centred bf16
+// split in the key kernel's tile layout, norms, R^2).  A snapshot of db at build time, as faiss's add() copies.
+extern "C" size_t mgp_knn_index_bytes(int64_t N, int d) {
+  if (N <= 0 || d < 32) return 0;
+  return mgp_knn_mfma_index_bytes(N, d) + 256;
+}
+
+extern "C" int mgp_knn_index_build(const float* db, int64_t N, int d, void* index, size_t index_bytes, void* stream) {
+  if (!db || !index || N <= 0 || d < 32 || N > INT_MAX) return MGP_ERR_ARG;
+  if (index_bytes < mgp_knn_index_bytes(N, d)) return MGP_ERR_WORKSPACE;
+  MgpArena ia(index, index_bytes);
+  MgpKnnMfma mm{};
+  MGP_TRY(mgp_knn_mfma_index_take(ia, N, d, &mm));
+  return mgp_knn_mfma_prepare_points(db, N, d, mm, mgp_stream(stream));
+}
+
+extern "C" int mgp_knn_search_indexed(const float* db, int64_t N, int d, const void* index, size_t index_bytes, const float* q,
+                                      int64_t n, int k, float* D, int32_t* I, void* work, size_t work_bytes, int64_t* stats,
+                                      void* stream) {
+  if (!index) return mgp_knn_search(db, N, d, q, n, k, D, I, work, work_bytes, stats, stream);
+  if (!db || !q || !D || !I || !work) return MGP_ERR_ARG;
+  if (N <= 0 || n <= 0 || d < 32 || k <= 0 || k > N || k > 1024 || N > INT_MAX) return MGP_ERR_ARG;
+  if (index_bytes < mgp_knn_index_bytes(N, d)) return MGP_ERR_WORKSPACE;
+  if (work_bytes < mgp_knn_workspace_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
+  return mgp_knn_bruteforce(db, N, d, q, n, k, D, I, work, work_bytes, stats, stream, index, index_bytes);
+}
 
 extern "C" size_t mgp_knn_workspace_bytes(int64_t N, int64_t n, int d, int k) {
   if (N <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;

@@ -307,29 +307,47 @@ constexpr int kMaxPartialBlocks = 1024;
 
 int mgp_knn_mfma_dpad(int d) { return (int)(mgp_cdiv(d, kBK) * kBK); }
 
-size_t mgp_knn_mfma_bytes(int64_t N, int64_t qc, int d) {
+// The POINT side of the operands (split tiles, norms, column means, R^2): what an index keeps between searches.
+size_t mgp_knn_mfma_index_bytes(int64_t N, int d) {
   const int dpad = mgp_knn_mfma_dpad(d);
   size_t b = 0;
   b += 2 * mgp_align((size_t)(mgp_cdiv(N, kMT) * kMT) * dpad * sizeof(uint16_t));
-  b += 2 * mgp_align((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad * sizeof(uint16_t));
-  b += mgp_align((size_t)N * sizeof(float)) + mgp_align((size_t)qc * sizeof(float));
+  b += mgp_align((size_t)N * sizeof(float));
   b += mgp_align((size_t)d * sizeof(float)) + mgp_align((size_t)kMaxPartialBlocks * d * sizeof(float)) + mgp_align(64);
   return b;
 }
 
-int mgp_knn_mfma_take(MgpArena& ar, int64_t N, int64_t qc, int d, MgpKnnMfma* m) {
+int mgp_knn_mfma_index_take(MgpArena& ar, int64_t N, int d, MgpKnnMfma* m) {
   const int dpad = mgp_knn_mfma_dpad(d);
   m->dpad = dpad;
   m->Ph = ar.take<uint16_t>((size_t)(mgp_cdiv(N, kMT) * kMT) * dpad);
   m->Pl = ar.take<uint16_t>((size_t)(mgp_cdiv(N, kMT) * kMT) * dpad);
-  m->Qh = ar.take<uint16_t>((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad);
-  m->Ql = ar.take<uint16_t>((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad);
   m->pn2 = ar.take<float>(N);
-  m->qn2 = ar.take<float>(qc);
   m->mu = ar.take<float>(d);
   m->partial = ar.take<float>((size_t)kMaxPartialBlocks * d);
   m->r2max = ar.take<unsigned>(16);
   return ar.ok() ? MGP_OK : MGP_ERR_WORKSPACE;
+}
+
+// ... and the QUERY side of one chunk
+size_t mgp_knn_mfma_query_bytes(int64_t qc, int d) {
+  const int dpad = mgp_knn_mfma_dpad(d);
+  return 2 * mgp_align((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad * sizeof(uint16_t)) + mgp_align((size_t)qc * sizeof(float));
+}
+
+int mgp_knn_mfma_query_take(MgpArena& ar, int64_t qc, int d, MgpKnnMfma* m) {
+  const int dpad = mgp_knn_mfma_dpad(d);
+  m->Qh = ar.take<uint16_t>((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad);
+  m->Ql = ar.take<uint16_t>((size_t)(mgp_cdiv(qc, kMT) * kMT) * dpad);
+  m->qn2 = ar.take<float>(qc);
+  return ar.ok() ? MGP_OK : MGP_ERR_WORKSPACE;
+}
+
+size_t mgp_knn_mfma_bytes(int64_t N, int64_t qc, int d) { return mgp_knn_mfma_index_bytes(N, d) + mgp_knn_mfma_query_bytes(qc, d); }
+
+int mgp_knn_mfma_take(MgpArena& ar, int64_t N, int64_t qc, int d, MgpKnnMfma* m) {
+  MGP_TRY(mgp_knn_mfma_index_take(ar, N, d, m));
+  return mgp_knn_mfma_query_take(ar, qc, d, m);
 }
 
 // mean of the points, their split and norms, R^2 = max |c_y|^2

@@ -90,7 +90,8 @@ int mgp_operator_apply_tail(const mgp_operator_t* op, const float* X, int C, flo
 
 // k-NN internals (knn.hip / knn_lowd.hip)
 int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
-                       int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream);
+                       int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream,
+                       const void* index = nullptr, size_t index_bytes = 0);
 int mgp_knn_lowd_eligible(int64_t N, int64_t n, int d, int k);
 size_t mgp_knn_lowd_workspace_bytes(int64_t N, int64_t n, int d, int k);
 int mgp_knn_lowd(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D, int32_t* I, void* work,
@@ -111,6 +112,10 @@ struct MgpKnnMfma {
 int mgp_knn_mfma_dpad(int d);
 size_t mgp_knn_mfma_bytes(int64_t N, int64_t qc, int d);
 int mgp_knn_mfma_take(MgpArena& ar, int64_t N, int64_t qc, int d, MgpKnnMfma* m);
+size_t mgp_knn_mfma_index_bytes(int64_t N, int d);
+int mgp_knn_mfma_index_take(MgpArena& ar, int64_t N, int d, MgpKnnMfma* m);
+size_t mgp_knn_mfma_query_bytes(int64_t qc, int d);
+int mgp_knn_mfma_query_take(MgpArena& ar, int64_t qc, int d, MgpKnnMfma* m);
 int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnMfma& m, hipStream_t st);
 int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpKnnMfma& m, hipStream_t st);
 int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab, int64_t ld, hipStream_t st, bool sym = false);

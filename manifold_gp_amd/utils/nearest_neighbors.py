@@ -1,8 +1,9 @@
 """NearestNeighbors on MI355X: the interface of manifold_gp/utils/nearest_neighbors.py:10-63
 (train / search / graph, `min_ivf`, `nlist`, `nprobe`) over the exact HIP k-NN kernels.
 
-faiss' Flat and IVFFlat(nlist=1) indices are both exhaustive searches, so `train` only records the
-points; `search` returns (D f32 squared-L2 ascending, I int64); `graph` returns the reference's
+faiss' Flat and IVFFlat(nlist=1) indices are both exhaustive searches, so `train` records the points and, from
+32 features up, prepares what every search against them needs (the matrix-core operands of the candidate keys:
+`mgp_knn_index_build`); `search` returns (D f32 squared-L2 ascending, I int64); `graph` returns the reference's
 (idx[2,M] int64 with row<col sorted, val[M] mean squared distance) and keeps the padded CSR of the
 same graph in `self.knn_graph` for the operators."""
 import ctypes
@@ -19,6 +20,8 @@ class NearestNeighbors():
         self.min_ivf = 5000
         self.knn_graph = None
         self.last_stats = None
+        self._index = None
+        self._index_version = None
         if x is not None:
             self.train(x, nlist)
 
@@ -30,7 +33,20 @@ class NearestNeighbors():
         self._xc = _lib.f32c(x)
         self.nlist = nlist
         self.is_trained = True
+        self._build_index()
         return self
+
+    def _build_index(self):
+        """The part of a search that depends on the points alone (faiss: index.train / index.add,
+        nearest_neighbors.py:20-33): built once per train() -- and again when x was modified in place since (torch's
+        version counter), because the index is a snapshot.  None when d < 32 (nothing to prepare)."""
+        N, d = self._xc.shape
+        nb = int(lib().mgp_knn_index_bytes(N, d))
+        self._index = None
+        self._index_version = self.x._version
+        if nb > 0:
+            self._index = torch.empty(nb, dtype=torch.uint8, device=self._xc.device)
+            check(lib().mgp_knn_index_build(ptr(self._xc), N, d, ptr(self._index), nb, stream()), "mgp_knn_index_build")
 
     def search(self, x, k, nprobe=1):
         _lib.require_device(x)
@@ -47,8 +63,16 @@ class NearestNeighbors():
         wb = lib().mgp_knn_workspace_bytes(N, n, d, k)
         work = _lib.workspace(wb, "knn", q.device)
         stats = (ctypes.c_int64 * 4)()
-        check(lib().mgp_knn_search(ptr(self._xc), N, d, ptr(q), n, k, ptr(D), ptr(I), ptr(work), work.numel(),
-                                   stats, stream()), "mgp_knn_search")
+        if self._index is not None and self.x._version != self._index_version:
+            self._xc = _lib.f32c(self.x)
+            self._build_index()                            # x changed in place since train(): the snapshot is stale
+        if self._index is not None:
+            check(lib().mgp_knn_search_indexed(ptr(self._xc), N, d, ptr(self._index), self._index.numel(), ptr(q), n, k,
+                                               ptr(D), ptr(I), ptr(work), work.numel(), stats, stream()),
+                  "mgp_knn_search_indexed")
+        else:
+            check(lib().mgp_knn_search(ptr(self._xc), N, d, ptr(q), n, k, ptr(D), ptr(I), ptr(work), work.numel(),
+                                       stats, stream()), "mgp_knn_search")
         self.last_stats = dict(rows_redone_wide=stats[0], rows_redone_exact=stats[1], chunks=stats[2],
                                candidates=stats[3], chunks_redone_direct=int(lib().mgp_knn_last_direct_chunks()))
         return D, I.long()

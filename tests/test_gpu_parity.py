@@ -2114,6 +2114,55 @@ def test_knn_self_search_upper_triangle_tiles(mgp, dev, n, d, k):
     assert np.array_equal(I1[rows].cpu().numpy(), Ir) and np.array_equal(D1[rows].cpu().numpy(), Dr)
 
 
+def test_knn_prepared_index_small_batches_and_stale_snapshot(mgp, dev):
+    """The prepared index (mgp_knn_index_build / mgp_knn_search_indexed; NearestNeighbors.train builds it): small
+    query batches -- 1, 77, 600 rows, which a search without index keeps on the direct-difference tiles -- rank their
+    candidates on the matrix cores and return the oracle's lists; the plain entry point agrees; and the index is a
+    snapshot: after an in-place change of the points the wrapper rebuilds it (version counter), while the C entry
+    point used with the STALE index on changed points is the caller's error the docs name -- not exercised."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    from oracle import knn as oknn
+    rng = np.random.default_rng(5)
+    n, d, k = 9000, 64, 12
+    cent = rng.normal(size=(30, d)) * 2
+    x = (cent[rng.integers(0, 30, n)] + rng.normal(size=(n, d))).astype(np.float32)
+    xt = T(x, dev)
+    nn = mgp.utils.NearestNeighbors(xt)
+    assert nn._index is not None and nn._index.numel() == _lib.lib().mgp_knn_index_bytes(n, d)
+    for nq in (1, 77, 600):
+        qs = (x[rng.integers(0, n, nq)] + 0.1 * rng.normal(size=(nq, d))).astype(np.float32)
+        D1, I1 = nn.search(T(qs, dev), k)
+        Dr, Ir = oknn.knn_search(x, qs, k)
+        assert np.array_equal(I1.cpu().numpy(), Ir) and np.array_equal(D1.cpu().numpy(), Dr), nq
+        # the plain entry point (no index: direct-difference tiles at these sizes)
+        lib = _lib.lib()
+        q = T(qs, dev)
+        D0 = torch.empty(nq, k, dtype=torch.float32, device=dev)
+        I0 = torch.empty(nq, k, dtype=torch.int32, device=dev)
+        wb = lib.mgp_knn_workspace_bytes(n, nq, d, k)
+        work = torch.empty(wb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.mgp_knn_search(_lib.ptr(xt), n, d, _lib.ptr(q), nq, k, _lib.ptr(D0), _lib.ptr(I0), _lib.ptr(work), wb,
+                                      None, _lib.stream()), "mgp_knn_search")
+        assert torch.equal(I0.long(), I1) and torch.equal(D0, D1), nq
+    # in-place change of the points: the wrapper notices (tensor version) and rebuilds its snapshot
+    x2 = x.copy()
+    x2[: n // 2] += 5.0
+    xt.copy_(T(x2, dev))
+    qs = x2[rng.integers(0, n, 50)]
+    D2, I2 = nn.search(T(qs, dev), k)
+    Dr, Ir = oknn.knn_search(x2, qs, k)
+    assert np.array_equal(I2.cpu().numpy(), Ir) and np.array_equal(D2.cpu().numpy(), Dr)
+    # an index that is too small is refused
+    D0 = torch.empty(50, k, dtype=torch.float32, device=dev)
+    I0 = torch.empty(50, k, dtype=torch.int32, device=dev)
+    wb = _lib.lib().mgp_knn_workspace_bytes(n, 50, d, k)
+    work = torch.empty(wb, dtype=torch.uint8, device=dev)
+    rc = _lib.lib().mgp_knn_search_indexed(_lib.ptr(xt), n, d, _lib.ptr(nn._index), 1024, _lib.ptr(T(qs, dev)), 50, k,
+                                           _lib.ptr(D0), _lib.ptr(I0), _lib.ptr(work), wb, None, _lib.stream())
+    assert rc == -2, rc                                    # MGP_ERR_WORKSPACE
+
+
 def test_knn_fp32_overflowing_distances_take_the_exact_path(mgp, dev):
     """Coordinates around 1e19..1e20: squared fp32 distances overflow to inf and order nothing; the exact fp64
     scan must take over (the oracle works in fp64)."""
