@@ -346,6 +346,12 @@ double* mgp_cg_plan_x64(void* plan);
  * solve that takes k iterations runs k applies, not k + 1.  Same iterates, residuals and flags. */
 int mgp_cg_plan_last_applies(void* plan);
 int mgp_cg_plan_destroy(void* plan);
+/* 1 after a solve of this plan returned MGP_ERR_TIMEOUT (a dead peer / hung collective of a multi-rank job): kernels and
+ * collectives that reference the plan's buffers are still queued, so the plan is POISONED -- further solves return
+ * MGP_ERR_TIMEOUT at once and mgp_cg_plan_destroy frees and synchronises nothing (the memory is leaked on purpose; the
+ * caller must keep the workspace alive and exit non-zero). */
+int mgp_cg_plan_poisoned(void* plan);
+int mgp_cg_plan_poison(void* plan);     /* mark it so by hand: the caller has learnt by other means that a peer rank is gone */
 int mgp_cg_solve(const mgp_operator_t* op, const float* B, int C, float* X, const float* minv,
                  const mgp_cg_params_t* params, int32_t* iters, float* resid, void* work,
                  size_t work_bytes, void* stream);
@@ -387,7 +393,9 @@ int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* 
  * fp32 residual floor (a few ulp of |L|: a round with the filter at its degree cap that does not even halve the largest
  * residual and converges no further pair), or when the measured gap between the wanted block and its last guard column says
  * that a further round at the degree cap would not even halve the residual: info[2] (pairs under tol) < m tells these
- * from convergence and `resid` holds what was reached.  MGP_ERR_NOT_CONVERGED: max_restarts rounds without either. */
+ * from convergence and `resid` holds what was reached.  Both early exits require the largest residual to be within
+ * max(50 tol, 2e-5) * lambda_max (2e-5 = 10 x the measured fp32 floor); the Python wrapper warns (EigenFloorWarning) whenever
+ * info[2] < m.  MGP_ERR_NOT_CONVERGED: max_restarts rounds without either. */
 int mgp_lanczos_block_size(int m, const mgp_lanczos_params_t* p);
 int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs,
                             float* resid, int32_t* info, float* block_evals, float* block_evecs, float* block_resid,
@@ -518,6 +526,7 @@ int mgp_pcg_plan_enqueue(void* plan, int phase, int par, const float* B); /* 0: 
 int mgp_pcg_plan_poll(void* plan, int32_t* iters, float* resid, int32_t* status); /* 1 = undecided */
 float* mgp_pcg_plan_x(void* plan);
 int mgp_pcg_plan_destroy(void* plan);
+int mgp_pcg_plan_poisoned(void* plan);   /* as mgp_cg_plan_poisoned */
 
 #ifdef __cplusplus
 }

@@ -128,6 +128,8 @@ SIGNATURES = {
     "mgp_cg_plan_x64": (c_void_p, [_P]),
     "mgp_cg_plan_last_applies": (c_int, [_P]),
     "mgp_cg_plan_destroy": (c_int, [_P]),
+    "mgp_cg_plan_poisoned": (c_int, [_P]),
+    "mgp_cg_plan_poison": (c_int, [_P]),
     "mgp_dist_unique_id_bytes": (c_int, []),
     "mgp_dist_unique_id": (c_int, [_P]),
     "mgp_dist_init": (c_int, [c_int, c_int, _P, POINTER(c_void_p)]),
@@ -146,6 +148,7 @@ SIGNATURES = {
     "mgp_pcg_plan_poll": (c_int, [_P, POINTER(c_int32), POINTER(c_float), POINTER(c_int32)]),
     "mgp_pcg_plan_x": (c_void_p, [_P]),
     "mgp_pcg_plan_destroy": (c_int, [_P]),
+    "mgp_pcg_plan_poisoned": (c_int, [_P]),
     "mgp_lanczos_workspace_bytes": (c_size_t, [c_int64, c_int, POINTER(LanczosParamsT)]),
     "mgp_lanczos_smallest": (c_int, [POINTER(CsrT), c_int, POINTER(LanczosParamsT), POINTER(c_float), _P,
                                      POINTER(c_float), POINTER(c_int32), _P, c_size_t, _P]),
@@ -233,6 +236,22 @@ def workspace(nbytes, tag, device):
         buf = torch.empty(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8, device=device)
         _WORK[key] = buf
     return buf
+
+
+def release_workspace(tag, device=None):
+    """Drop the cached scratch of `tag` (all devices when device is None): the 60k x 60k key slab of a graph build is
+    ~18 GB that nothing needs once the lists exist (the allocator hands it to the next large request)."""
+    for key in [k for k in _WORK if k[0] == tag and (device is None or k[1] == str(device))]:
+        del _WORK[key]
+
+
+_LEAKED = []
+
+
+def leak(*objects):
+    """Keep `objects` (workspace tensors of a poisoned plan: queued kernels still reference them) alive for the rest of the
+    process."""
+    _LEAKED.extend(objects)
 
 
 def csr_struct(n, rowptr, col, vals, diag, ncols=0, tiles=None, tile_vals=None):

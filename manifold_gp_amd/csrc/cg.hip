@@ -1082,6 +1082,7 @@ void host_block_release(HostBlock b, hipStream_t stream) {
 }
 
 struct CgPlan {
+  bool poisoned = false;     // a solve ended in MGP_ERR_TIMEOUT: destroy leaks instead of waiting (mgp_cg_plan_solve)
   HostBlock host_block;
   mgp_operator_t op;
   MgpDist dist;             // row partition (is_dist): op.L holds the local rows only
@@ -1564,7 +1565,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   return MGP_OK;
 }
 
-extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid,
+static int cg_plan_solve_body(void* plan, const float* B, float* X, int32_t* iters, float* resid,
                                  int32_t* status) {
   CgPlan* pl = static_cast<CgPlan*>(plan);
   if (!pl || !B) return MGP_ERR_ARG;   // X == NULL: leave the solution in the plan (mgp_cg_plan_x)
@@ -1670,9 +1671,34 @@ extern "C" double* mgp_cg_plan_x64(void* plan) {
   return (pl && !pl->is_dist) ? pl->xacc64 : nullptr;
 }
 
+// A solve that ends in MGP_ERR_TIMEOUT leaves kernels / collectives queued on the stream that still reference the plan's
+// buffers, and the peer they wait for is gone: the plan is POISONED.  Destroying a poisoned plan frees nothing and
+// synchronises nothing (hipFree / hipGraphExecDestroy / hipStreamDestroy would wait on the dead collective, which is the
+// hang the timeout exists to avoid): the memory is leaked on purpose and the process is expected to exit non-zero.
+extern "C" int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid, int32_t* status) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  if (pl && pl->poisoned) return MGP_ERR_TIMEOUT;
+  const int rc = cg_plan_solve_body(plan, B, X, iters, resid, status);
+  if (rc == MGP_ERR_TIMEOUT && pl) pl->poisoned = true;
+  return rc;
+}
+
+extern "C" int mgp_cg_plan_poisoned(void* plan) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  return pl && pl->poisoned ? 1 : 0;
+}
+
+extern "C" int mgp_cg_plan_poison(void* plan) {      // a caller that learns by other means that a peer rank is gone
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  if (!pl) return MGP_ERR_ARG;
+  pl->poisoned = true;
+  return MGP_OK;
+}
+
 extern "C" int mgp_cg_plan_destroy(void* plan) {
   CgPlan* pl = static_cast<CgPlan*>(plan);
   if (!pl) return MGP_ERR_ARG;
+  if (pl->poisoned) return MGP_OK;      // leaked on purpose, see above
   if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
   if (pl->exec_first) (void)hipGraphExecDestroy(pl->exec_first);
   if (pl->graph_first) (void)hipGraphDestroy(pl->graph_first);

@@ -823,6 +823,10 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   double rmax_prev1 = 1e300;
   int nconv_prev1 = 0, deg_used = 0;
   bool floor_hit = false;
+  // the two early exits below hand the block back with MGP_OK and info[2] < m; they apply only once the largest residual
+  // is within 50 x the tolerance asked for, or within 10 x the measured fp32 floor (1.8e-6 ub, see there) for tolerances
+  // below it -- a block further out than that is NOT "at the floor" and keeps iterating / ends as MGP_ERR_NOT_CONVERGED
+  const double floor_guard = std::max(50.0 * tol, 2e-5);
   auto move_cols = [&](const float* src, int sld, int sc0, int mcols, float* dst, int dld, int dc0) {
     const int grid = (int)std::min<int64_t>(4096, mgp_cdiv(n * mcols, kBlock));
     hipLaunchKernelGGL(move_cols_kernel, dim3(grid), dim3(kBlock), 0, st, src, n, sld, sc0, mcols, dst, dld, dc0);
@@ -1012,7 +1016,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
       {
         double rmx = 0.0;
         for (int j = 0; j < m; ++j) rmx = std::max(rmx, res[j]);
-        if (deg_used >= kCap && rmx > 0.5 * rmax_prev1 && nconv <= nconv_prev1 && rmx <= 1e-3 * ub) { floor_hit = true; ++outer; break; }
+        if (deg_used >= kCap && rmx > 0.5 * rmax_prev1 && nconv <= nconv_prev1 && rmx <= floor_guard * ub) { floor_hit = true; ++outer; break; }
         rmax_prev1 = rmx;
         nconv_prev1 = nconv;
       }
@@ -1040,7 +1044,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
       if (!(p && p->degree > 0) && deg_used >= kCap && dnew > kCap && exp(-3.0 * kCap / (double)dnew) > 0.5) {
         double rmx = 0.0;
         for (int j = 0; j < m; ++j) rmx = std::max(rmx, res[j]);
-        if (rmx <= 1e-3 * ub) { floor_hit = true; ++outer; break; }
+        if (rmx <= floor_guard * ub) { floor_hit = true; ++outer; break; }
       }
     }
   }

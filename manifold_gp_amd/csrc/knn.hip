@@ -606,7 +606,15 @@ __global__ __launch_bounds__(kBlock) void exact_row_kernel(const float* __restri
 
 constexpr int kExactBatch = 16;
 
-int64_t chunk_rows(int64_t N, int64_t n) {
+// candidate distances on the matrix cores (knn_mfma.hip) from 32 features up; mgp_knn_set_mfma(0) forces
+// the direct-difference tiles
+int g_knn_mfma = 1;
+int g_knn_sym = 1;        // self-search: upper-triangle key tiles only (mgp_knn_set_symmetric(0): every tile)
+int64_t g_last_direct_chunks = 0;
+// (the centring + split of the points is a fixed ~1 ms at 60k x 784: it pays from ~1000 queries on)
+bool use_mfma(int d, int64_t n) { return g_knn_mfma && d >= 32 && n >= 1024; }
+
+int64_t chunk_rows(int64_t N, int64_t n, int d) {
   const int64_t ld = mgp_cdiv(N, 4) * 4;
   // fp32 distance slab: 2 GiB (8 192 query rows at N = 60k: 8 query tiles per XCD share a point tile in L2, and half
   // the chunks / host polls of the 1 GiB slab -- measured 3 % faster), up to 8 GiB for large N so that a chunk still
@@ -624,17 +632,11 @@ int64_t chunk_rows(int64_t N, int64_t n) {
   // As many queries as points and the WHOLE key matrix within 32 GiB (N <= 92k; the card has 288 GB): one chunk.  The
   // key kernel walks the query tiles in groups by itself (knn_mfma.hip), and when the queries ARE the points -- the graph
   // build -- it computes only the tile pairs on and above the diagonal, which needs every row of the matrix in place.
-  if (n == N && (int64_t)ld * ncap <= ((int64_t)1 << 33)) return ncap;
+  // Only when that symmetric path can run at all (matrix-core keys on, d >= 32): a search with as many OTHER queries as
+  // points also sizes for it (the workspace query does not see the pointers), any other search keeps the 2-8 GiB slab.
+  if (n == N && g_knn_mfma && g_knn_sym && d >= 32 && (int64_t)ld * ncap <= ((int64_t)1 << 33)) return ncap;
   return qc < ncap ? qc : ncap;
 }
-
-// candidate distances on the matrix cores (knn_mfma.hip) from 32 features up; mgp_knn_set_mfma(0) forces
-// the direct-difference tiles
-int g_knn_mfma = 1;
-int g_knn_sym = 1;        // self-search: upper-triangle key tiles only (mgp_knn_set_symmetric(0): every tile)
-int64_t g_last_direct_chunks = 0;
-// (the centring + split of the points is a fixed ~1 ms at 60k x 784: it pays from ~1000 queries on)
-bool use_mfma(int d, int64_t n) { return g_knn_mfma && d >= 32 && n >= 1024; }
 
 int next_pow2(int v) {
   int p = 1;
@@ -647,7 +649,7 @@ int next_pow2(int v) {
 static size_t bruteforce_bytes(int64_t N, int64_t n, int d, int k) {
   if (N <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
   const int64_t ld = mgp_cdiv(N, 4) * 4;
-  const int64_t qc = chunk_rows(N, n);
+  const int64_t qc = chunk_rows(N, n, d);
   size_t b = mgp_align((size_t)qc * ld * sizeof(float));
   b += 2 * mgp_align((size_t)qc * sizeof(int));
   b += mgp_align(64);
@@ -668,7 +670,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   if (work_bytes < bruteforce_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
   hipStream_t st = mgp_stream(stream);
   const int64_t ld = mgp_cdiv(N, 4) * 4;
-  const int64_t qc = chunk_rows(N, n);
+  const int64_t qc = chunk_rows(N, n, d);
   MgpArena ar(work, work_bytes);
   float* slab = ar.take<float>((size_t)qc * ld);
   int* list_a = ar.take<int>(qc);

@@ -484,6 +484,7 @@ __global__ __launch_bounds__(kBlock) void cgp_update_kernel(PcgArgs a) {
 }
 
 struct PcgPlan {
+  bool poisoned = false;     // a solve ended in MGP_ERR_TIMEOUT: destroy leaks instead of waiting
   int recurrence;            // 0 pipelined (one collective per iteration), 1 Chronopoulos-Gear (two)
   mgp_operator_t op;
   int64_t launch_rows[kMaxNu];
@@ -836,7 +837,7 @@ extern "C" int mgp_pcg_plan_poll(void* plan, int32_t* iters, float* resid, int32
 
 // full solve (single rank, or one rank of an RCCL job): the solution is left in the plan's x buffer at the global
 // length, own rows valid (mgp_pcg_plan_x); X (nullable): own rows copied to X[0 .. n_loc)
-extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int32_t* iters, float* resid, int32_t* status) {
+static int pcg_plan_solve_body(void* plan, const float* B, float* X_loc, int32_t* iters, float* resid, int32_t* status) {
   PcgPlan* pl = static_cast<PcgPlan*>(plan);
   if (!pl || !B) return MGP_ERR_ARG;
   if (pl->virt) return MGP_ERR_UNSUPPORTED;               // virtual ranks are driven by mgp_pcg_plan_enqueue
@@ -925,9 +926,24 @@ extern "C" float* mgp_pcg_plan_x(void* plan) {
   return pl ? pl->args.x : nullptr;
 }
 
+// MGP_ERR_TIMEOUT poisons the plan (cg.hip, mgp_cg_plan_solve): destroy then leaks instead of waiting on a dead peer
+extern "C" int mgp_pcg_plan_solve(void* plan, const float* B, float* X_loc, int32_t* iters, float* resid, int32_t* status) {
+  PcgPlan* pl = static_cast<PcgPlan*>(plan);
+  if (pl && pl->poisoned) return MGP_ERR_TIMEOUT;
+  const int rc = pcg_plan_solve_body(plan, B, X_loc, iters, resid, status);
+  if (rc == MGP_ERR_TIMEOUT && pl) pl->poisoned = true;
+  return rc;
+}
+
+extern "C" int mgp_pcg_plan_poisoned(void* plan) {
+  PcgPlan* pl = static_cast<PcgPlan*>(plan);
+  return pl && pl->poisoned ? 1 : 0;
+}
+
 extern "C" int mgp_pcg_plan_destroy(void* plan) {
   PcgPlan* pl = static_cast<PcgPlan*>(plan);
   if (!pl) return MGP_ERR_ARG;
+  if (pl->poisoned) return MGP_OK;
   if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
   if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
   if (pl->host_state) (void)hipHostFree(pl->host_state);

@@ -1723,20 +1723,15 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     const int S = dict_slots(L, C), cap = dict_stream_cap(L);
 #define MGP_DICT_LAUNCH(NV)                                                                                         \
   do {                                                                                                              \
-    static bool attr_set[2] = {false, false};                                                                       \
+    /* the attribute is per DEVICE and the call is cheap next to a launch: set every time (a process that drives a  \
+       second GPU, or two host threads, must not depend on a process-wide flag) */                                  \
     if (pre) {                                                                                                      \
-      if (!attr_set[1]) {                                                                                           \
-        MGP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_dict_kernel<NV, true>),                 \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kDictLdsBudget));               \
-        attr_set[1] = true;                                                                                         \
-      }                                                                                                             \
+      MGP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_dict_kernel<NV, true>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kDictLdsBudget));                 \
       hipLaunchKernelGGL((spmm_dict_kernel<NV, true>), dim3(grid), dim3(kDictThreads), lds, st, p, ta, S, cap);     \
     } else {                                                                                                        \
-      if (!attr_set[0]) {                                                                                           \
-        MGP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_dict_kernel<NV, false>),                \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kDictLdsBudget));               \
-        attr_set[0] = true;                                                                                         \
-      }                                                                                                             \
+      MGP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_dict_kernel<NV, false>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kDictLdsBudget));                 \
       hipLaunchKernelGGL((spmm_dict_kernel<NV, false>), dim3(grid), dim3(kDictThreads), lds, st, p, ta, S, cap);    \
     }                                                                                                               \
   } while (0)

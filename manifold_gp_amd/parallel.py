@@ -163,6 +163,8 @@ class DistCgPlan:
 
     def close(self):
         if self.handle:
+            if lib().mgp_cg_plan_poisoned(self.handle):
+                _lib.leak(self.__dict__.copy())            # timed-out solve: keep every buffer alive (solvers.CgPlan.close)
             lib().mgp_cg_plan_destroy(self.handle)
             self.handle = ctypes.c_void_p(0)
 
@@ -315,6 +317,8 @@ class PcgPlan:
 
     def close(self):
         if self.handle:
+            if lib().mgp_pcg_plan_poisoned(self.handle):
+                _lib.leak(self.__dict__.copy())            # timed-out solve: keep every buffer alive (solvers.CgPlan.close)
             lib().mgp_pcg_plan_destroy(self.handle)
             self.handle = ctypes.c_void_p(0)
 

@@ -98,6 +98,10 @@ class CgPlan:
 
     def close(self):
         if self.handle:
+            if lib().mgp_cg_plan_poisoned(self.handle):
+                # a solve timed out (dead peer): queued work still references the plan's buffers -- keep them alive, free
+                # nothing, synchronise nothing; the process is expected to exit non-zero (include/mgp_hip.h)
+                _lib.leak(self.__dict__.copy())
             lib().mgp_cg_plan_destroy(self.handle)
             self.handle = ctypes.c_void_p(0)
 
@@ -388,6 +392,10 @@ def dense_symeig(operator):
 
 
 # ------------------------------------------------------------------------------ Lanczos
+class EigenFloorWarning(UserWarning):
+    """mgp_lanczos_smallest returned MGP_OK with info[2] < m (residual floor / unseparable guards)."""
+
+
 def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=60, seed=1337, return_block=False):
     """m smallest eigenpairs of L_sym (CSR in `lap_data`) by the HIP filtered block iteration.
     Returns (evals[m] device, evecs[n,m] device, resid[m] host list); with return_block=True a fourth item
@@ -434,6 +442,13 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
                       % (info[0], info[2], m, max(resid)))
     else:
         check(rc, "mgp_lanczos_smallest")
+        if info[2] < m:
+            # MGP_OK with fewer than m pairs under tol: the solver stopped at the residual floor of fp32 arithmetic (or
+            # could not separate the wanted block from its guards at the degree cap).  Not silent: the reference runs a
+            # dense eigh here (riemann_kernel.py:124), the caller must see how far from `tol` the block is
+            warnings.warn("eigensolver stopped at the fp32 residual floor after %d rounds with %d/%d pairs below tol "
+                          "(max residual %.3g, tol %.3g of lambda_max; residuals are in the third return value)"
+                          % (info[0], info[2], m, max(resid), tol), EigenFloorWarning)
     ev = torch.tensor(list(evals), dtype=torch.float32, device=dev)
     lanczos_smallest.last_info = list(info)
     if order is not None:

@@ -80,6 +80,8 @@ class NearestNeighbors():
     def graph(self, k, symmetric=True, self_loop=False, nprobe=1):
         val, idx = self.search(self.x, k, nprobe)
         n = self.x.shape[0]
+        if n * n * 4 > (1 << 31):
+            _lib.release_workspace("knn", self.x.device)    # the self-search's whole-matrix key slab (up to 32 GiB)
         if symmetric and not self_loop:
             self.knn_graph = KnnGraph.from_knn(val, idx.to(torch.int32), points=self.x if self.x.shape[1] <= 3 else None)
             return self.knn_graph.edge_index, self.knn_graph.edge_value

@@ -37,3 +37,23 @@ def ref_round_equal(a, b, decimals=5, count=10):
     a = [round(float(v), decimals) for v in np.asarray(a).reshape(-1)[:count]]
     b = [round(float(v), decimals) for v in np.asarray(b).reshape(-1)[:count]]
     return a == b
+
+
+def ref_round_equal_or_boundary(a, b32, b64, decimals=5, count=10, ulp=1.5e-6):
+    """The same criterion at the reference's 5 decimals, against the reference's float32 output `b32`, with the one escape
+    rounding-then-comparing needs: an entry may round differently ONLY where the float64 run of the same reference function
+    (`b64`) lies within `ulp` of a rounding boundary -- there the reference's own float32 operator and its float32 dense twin
+    differ by more than their distance to the boundary (5e-7 on these vectors) and flip against each other too -- and then
+    the entry must still be within `ulp` of the float64 value.  Returns (ok, number of boundary entries)."""
+    a, b32, b64 = (np.asarray(v, np.float64).reshape(-1)[:count] for v in (a, b32, b64))
+    boundary = 0
+    for x, y32, y64 in zip(a, b32, b64):
+        if round(float(x), decimals) == round(float(y32), decimals):
+            continue
+        scaled = y64 * 10 ** decimals
+        dist = abs(scaled - np.floor(scaled) - 0.5) / 10 ** decimals
+        if dist < ulp and abs(x - y64) < ulp:
+            boundary += 1
+            continue
+        return False, boundary
+    return True, boundary

