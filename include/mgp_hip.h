@@ -313,6 +313,12 @@ size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);
  * operator apply (one kernel less per step).  Experiment, default 0 (no gain measured at N = 60k);
  * affects plans created afterwards. */
 int mgp_cg_set_fuse(int on);
+/* C == 1 plans: the LAST update launch of a plan's first graph also takes the stopping decision of the step behind it and
+ * leaves the end-of-graph mark (the workgroup whose dot-product partials arrive last does both: agent-scope release /
+ * atomic arrive / acquire inside the launch), instead of a single-workgroup decision launch + a marker launch behind it.
+ * Same sums in the same order, same rule, same flags.  Default 1; 0 = the separate launches (A/B measurements, tests);
+ * returns the previous setting; affects graphs captured afterwards. */
+int mgp_cg_set_decide_in_update(int on);
 /* Plans with more than 16 columns sum the dot-product partials of a step ONCE (cg_reduce_kernel, one small launch
  * ahead of the update) instead of in every workgroup of the update kernel.  Default 1; 0 = the every-workgroup
  * scheme at any C (A/B measurements, tests); affects plans created afterwards. */

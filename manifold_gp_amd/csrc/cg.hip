@@ -65,6 +65,7 @@ struct CgArgs {
   // many columns (C > 16): cg_reduce_kernel has summed the partials of this step -> [3][C] gamma, ||r||^2, delta;
   // the update kernel reads 3 C floats instead of re-reducing (2 nbv + nbs) C of them in every workgroup.  NULL: off.
   float* tot;
+  int* arrive;   // [9][32] arrival counters of the deciding update launch (8 groups + top, a 128-byte line each), zero between launches
 };
 
 // sh[k][sl * TC + cc] holds the partial of slice sl for column cc; result in sh[k][cc] for cc < TC.
@@ -430,10 +431,31 @@ struct alignas(32) CgScalars {
 constexpr int kC1GammaSlots = 2;    // nbv <= kMaxGridVec = 2 * 256
 constexpr int kC1DeltaSlots = 16;   // nbs <= 4096
 
+// DECIDE (the LAST update of a plan's first graph): the workgroup whose partials arrive last also takes the stopping decision
+// of the NEXT step -- ||r_k||^2 summed over the partials this very launch wrote, in cg_decide_c1_kernel's order, the same rule,
+// the same flags -- and leaves the end-of-graph mark.  The single-workgroup decision launch + the marker launch (4.5 + 4.0 us
+// and two kernel boundaries of a ~57 us solve at N = 60k) go away.  Hand-off inside the launch: lane 0 of every workgroup
+// stores its ||r||^2 partial write-through (sc1), drains its stores (s_waitcnt vmcnt(0)), makes one returning agent-scope
+// atomic add on its group's arrival counter (CgArgs::arrive); the lane that completes the count joins the workgroup barrier, then all lanes of that workgroup
+// read the partials with sc1 loads (MI355X_MICROARCH.md, inter-workgroup visibility, table of sc1 hand-offs: "one lane of
+// each storing workgroup ... the workgroup whose add came last, told by the value its add returned").  The counter needs no reset between solves:
+// in a launch either every workgroup arrives or none does (the early exits below are taken by all of them or by none), and
+// the last arriver puts it back to zero.
+__device__ __forceinline__ void cg_mark_end_of_graph(const CgArgs& a) {
+  const int c = a.state[5] + 1;
+  a.state[5] = c;
+  __threadfence_system();
+  a.host_state[4] = c;
+}
+
+// DS: slots of 256 SpMV-workgroup partials a lane sums (4 covers nbs <= 1024, i.e. graphs up to 65 536 nodes: each slot is two
+// loads with their address arithmetic -- 24 fewer loads in front of the kernel's one wait than the general 16)
+template <bool DECIDE, int DS>
 __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   __shared__ float sh_w[kBlock / 64][6];
   __shared__ float sh_o[kBlock / 64][2];
   __shared__ int sh_state[2];
+  __shared__ int sh_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const CgScalars sc = *reinterpret_cast<const CgScalars*>(a.gamma_old);
   const int st_it = sc.it, st_done = sc.done;
@@ -454,7 +476,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   const float f_u = a.u[rs], f_p = a.p[rs], f_s = a.s[rs], f_w = a.w[rs], f_x = a.x[rs], f_r = a.r[rs];
   const float l_m = (a.minv ? a.minv : a.x)[rs], l_pre = (a.us ? a.pre : a.x)[rs];
   const float f_m = a.minv ? l_m : 1.f, f_pre = a.us ? l_pre : 1.f;
-  float gv[2][kC1GammaSlots], rv[2][kC1GammaSlots], dv[kC1DeltaSlots];
+  float gv[2][kC1GammaSlots], rv[2][kC1GammaSlots], dv[DS];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -465,10 +487,10 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
       rv[h][q] = a.pd_rr[(int64_t)h * a.nbv + bc];
     }
   }
-  float bv[kC1DeltaSlots];
+  float bv[DS];
   const float* __restrict__ pbb = a.pd_bb ? a.pd_bb : a.pd_delta;     // stand-in: unconditional loads
 #pragma unroll
-  for (int q = 0; q < kC1DeltaSlots; ++q) {
+  for (int q = 0; q < DS; ++q) {
     const int b = tid + q * kBlock;
     const int bc = b < a.nbs ? b : a.nbs - 1;
     dv[q] = a.pd_delta[bc];
@@ -484,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
     t[2] += on ? rv[0][q] : 0.f; t[3] += on ? rv[1][q] : 0.f;
   }
 #pragma unroll
-  for (int q = 0; q < kC1DeltaSlots; ++q) {
+  for (int q = 0; q < DS; ++q) {
     const bool on = tid + q * kBlock < a.nbs;
     t[4] += on ? dv[q] : 0.f;
     t[5] += on ? bv[q] : 0.f;
@@ -505,6 +527,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
     // (b = 0 or not finite) before this workgroup started -- the solve ends here and x, which nobody has
     // initialised, must still come out zero (every workgroup that gets to the decision itself does the same below)
     if (a.pd_bb != nullptr && it == 1) for (int64_t r = rf; r < r1; r += kBlock) a.x[r] = 0.f;
+    if (DECIDE && blockIdx.x == 0 && tid == 0) cg_mark_end_of_graph(a);     // decided earlier: nobody arrives below
     return;
   }
   const int par = it & 1, prev = par ^ 1;
@@ -549,6 +572,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   if (done) {
     // an init-free solve that ends before its first update (b = 0): nobody has zeroed x
     if (fresh) for (int64_t r = rf; r < r1; r += kBlock) a.x[r] = 0.f;
+    if (DECIDE && blockIdx.x == 0 && tid == 0) cg_mark_end_of_graph(a);     // every workgroup takes this exit: nobody arrives
     return;
   }
 
@@ -594,8 +618,32 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
   if (lane == 0) { sh_o[wave][0] = ng; sh_o[wave][1] = nrr; }
   __syncthreads();
   if (tid == 0) {
-    a.pd_gamma[(int64_t)par * a.nbv + lb] = (sh_o[0][0] + sh_o[1][0]) + (sh_o[2][0] + sh_o[3][0]);
-    a.pd_rr[(int64_t)par * a.nbv + lb] = (sh_o[0][1] + sh_o[1][1]) + (sh_o[2][1] + sh_o[3][1]);
+    const float o_g = (sh_o[0][0] + sh_o[1][0]) + (sh_o[2][0] + sh_o[3][0]);
+    const float o_r = (sh_o[0][1] + sh_o[1][1]) + (sh_o[2][1] + sh_o[3][1]);
+    if (!DECIDE) {
+      a.pd_gamma[(int64_t)par * a.nbv + lb] = o_g;
+      a.pd_rr[(int64_t)par * a.nbv + lb] = o_r;
+    } else {
+      // write-through (sc1) stores, drained, then the arrive; the last arriver reads the partials with sc1 loads below.
+      // (An agent-scope release fence here writes back every dirty L2 line of the vectors this launch has just stored:
+      // measured +3.4 us per solve against the separate decision launch it was meant to save.)
+      a.pd_gamma[(int64_t)par * a.nbv + lb] = o_g;                     // read by the next launch only
+      __hip_atomic_store(&a.pd_rr[(int64_t)par * a.nbv + lb], o_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // two levels (one word takes ~88 arrivals per us: 235 workgroups on it were 3 us of the launch): the workgroups
+      // with equal blockIdx % 8 -- one XCD under round-robin placement, which only speed depends on -- count on a line of
+      // their own, the last of each group counts on the top word
+      const int grp = blockIdx.x & 7, members = ((int)gridDim.x - grp + 7) >> 3, groups = (int)gridDim.x < 8 ? (int)gridDim.x : 8;
+      int last = 0;
+      if (__hip_atomic_fetch_add(a.arrive + 32 * grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1) {
+        __hip_atomic_store(a.arrive + 32 * grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(a.arrive + 32 * 8, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1) {
+          __hip_atomic_store(a.arrive + 32 * 8, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = 1;
+        }
+      }
+      sh_last = last;
+    }
   }
 #ifdef MGP_STAMP
   if (blockIdx.x == 0 && tid == 0) {
@@ -603,6 +651,50 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
     reinterpret_cast<unsigned long long*>(a.state + 16)[si & 255] = wall_clock64() * 8 + 3;
   }
 #endif
+  if (!DECIDE) return;
+  __syncthreads();
+  if (!sh_last) return;
+  // ---- the last arriver: stopping decision of step it + 1 (cg_decide_c1_kernel, same sums in the same order)
+  {
+    const int itn = it + 1;
+    float t2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < kC1GammaSlots; ++q) {
+      const int b = tid + q * kBlock;
+      const float v = __hip_atomic_load(&a.pd_rr[(int64_t)par * a.nbv + (b < a.nbv ? b : a.nbv - 1)], __ATOMIC_RELAXED,
+                                        __HIP_MEMORY_SCOPE_AGENT);
+      t2 += (b < a.nbv) ? v : 0.f;
+    }
+    t2 = mgp_wave_sum(t2);
+    __syncthreads();                          // sh_o is reused below: everyone has read sh_last / the first use is over
+    if (lane == 0) sh_o[wave][0] = t2;
+    __syncthreads();
+    if (tid != 0) return;
+    const float rr2n = (sh_o[0][0] + sh_o[1][0]) + (sh_o[2][0] + sh_o[3][0]);
+    const float reln = (bb > 0.f) ? sqrtf(rr2n / bb) : 0.f;
+    int dn = 0, stn = 0;
+    if (a.stop_mode == 0) {
+      if (itn > a.min_iter && reln < a.tol) { dn = 1; stn = 1; }
+    } else if (reln <= a.tol) { dn = 1; stn = 1; }
+    if (!isfinite(reln)) { dn = 1; stn = 3; }
+    if (!dn && itn > a.max_iter) { dn = 1; stn = 2; }
+    // The host reads nothing but host-mapped words (the solution stays in stream order).  The decision travels as ONE
+    // naturally aligned 8-byte record {residual bits, step << 8 | status << 4 | 3} at host_state[8..9], written by one store
+    // instruction (one PCIe write, observed whole by the host's 8-byte read): no drain between "the details" and "the
+    // flag" -- that wait for a host-memory write to be acknowledged was ~1 us of every solve -- and no
+    // __threadfence_system(), which would also write back every dirty L2 line of the vectors this launch has just stored.
+    // run_cg clears the record before every solve and unpacks it into the words the other deciding kernels write.
+    const int c = a.state[5] + 1;
+    a.state[5] = c;
+    if (dn) {
+      a.resid[0] = reln;
+      a.state[2] = stn; a.state[1] = 1;
+      const unsigned long long rec = (unsigned long long)__builtin_bit_cast(unsigned, reln) |
+                                     ((unsigned long long)(unsigned)((itn << 8) | (stn << 4) | 3) << 32);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.host_state + 8), rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(a.host_state + 4, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // end-of-graph mark
+  }
 }
 
 // ---- Stopping decision alone (C == 1).  The update kernel of step k+1 is where ||r_k|| <= tol is noticed, after
@@ -1141,6 +1233,7 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   b += 2 * mgp_align((size_t)nbs * C * sizeof(float));          // pd_delta, pd_bb
   b += mgp_align((6 * (size_t)C + 16 + 1024 + 8192) * sizeof(float));   // gamma_old[2] alpha_old[2] bb resid state (+ lab stamps)
   b += mgp_align(3 * (size_t)C * sizeof(float));                 // tot (cg_reduce_kernel)
+  b += mgp_align(9 * 32 * sizeof(int));                         // arrival counters (cg_update_c1_kernel<true>)
   b += mgp_align((size_t)256 * C * 2 * sizeof(float));          // refinement partials
   b += 6 * 2 * nc + mgp_align((size_t)256 * C * 2 * sizeof(double));   // fp64 refinement: xacc, A x, 4 chain buffers
   return b + 1024;
@@ -1150,6 +1243,7 @@ constexpr int kReduceOnceAbove = 16;
 int g_cg_reduce_once = 1;   // mgp_cg_set_reduce_once(0): every update workgroup re-reduces the partials at any C (A/B, tests)
 int g_cg_poll_spin = 64;    // flag reads between two looks at the clock in the flag-only poll window; 0: no such window (mgp_cg_set_poll_spin)
 int g_cg_init_free = 1;   // C == 1 plans start without a cg_init launch (mgp_cg_set_init_free(0): classic start)
+int g_cg_decide_in_update = 1;   // the first graph's last update decides + marks (mgp_cg_set_decide_in_update(0): separate launches)
 int g_cg_fuse = 0;   // measured at N = 60k: step 16.3 us fused vs 16.3 us unfused -- off until it wins
 
 // one CG step = operator apply (w = A u, partials of u . w, ticks the iteration counter; skipped once
@@ -1157,7 +1251,18 @@ int g_cg_fuse = 0;   // measured at N = 60k: step 16.3 us fused vs 16.3 us unfus
 // graph therefore ends right behind a decision and a solve that needs k steps runs exactly k bodies.
 // Fused form: the update kernel also runs launch 0 of the NEXT apply, so a body is (launches 1..nu-1 of
 // the chain, fused step) and the solve opens with a plain launch 0 (enqueue_head).
-int enqueue_body(CgPlan* pl, hipStream_t st) {
+void launch_update_c1(CgPlan* pl, hipStream_t st, bool decide_last) {
+  const dim3 grid(pl->args.nbv), block(kBlock);
+  if (pl->args.nbs <= 4 * kBlock) {
+    if (decide_last) hipLaunchKernelGGL((cg_update_c1_kernel<true, 4>), grid, block, 0, st, pl->args);
+    else hipLaunchKernelGGL((cg_update_c1_kernel<false, 4>), grid, block, 0, st, pl->args);
+  } else {
+    if (decide_last) hipLaunchKernelGGL((cg_update_c1_kernel<true, kC1DeltaSlots>), grid, block, 0, st, pl->args);
+    else hipLaunchKernelGGL((cg_update_c1_kernel<false, kC1DeltaSlots>), grid, block, 0, st, pl->args);
+  }
+}
+
+int enqueue_body(CgPlan* pl, hipStream_t st, bool decide_last = false) {
   if (pl->fused) {
     const MgpCommit cm{pl->args.rn, pl->args.sn, pl->op.pre, pl->rws};
     MGP_TRY(mgp_operator_apply_tail(&pl->op, pl->args.rn, 1, pl->args.w, pl->args.rn, pl->pd_delta, pl->args.state + 1,
@@ -1170,7 +1275,7 @@ int enqueue_body(CgPlan* pl, hipStream_t st) {
                                   pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, pl->args.state + 1,
                                   pl->args.state, pl->op_work, pl->op_work_bytes, st));
   if (pl->C == 1 && pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock) {
-    hipLaunchKernelGGL(cg_update_c1_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+    launch_update_c1(pl, st, decide_last);
   } else {
     if (pl->args.tot) {
       hipLaunchKernelGGL(cg_reduce_kernel, dim3((unsigned)mgp_cdiv(pl->C, 4), 3), dim3(kBlock), 0, st, pl->args);
@@ -1185,10 +1290,10 @@ int enqueue_body(CgPlan* pl, hipStream_t st) {
 // Init-free solve: the first (apply, update) pair.  The apply reads `rhs` directly (launch 0 scales it by op->pre,
 // copies it to r), leaves the partials of r . A r and ||r||^2 and resets the iteration state; the update then runs
 // as iteration 1 with p = s = x = 0.  One launch (cg_init, ~3.8 us at N = 60k) less per solve.
-int enqueue_first_body(CgPlan* pl, hipStream_t st, const float* rhs, bool record) {
+int enqueue_first_body(CgPlan* pl, hipStream_t st, const float* rhs, bool record, bool decide_last = false) {
   MGP_TRY(mgp_operator_apply_first(&pl->op, rhs, pl->args.r, pl->args.w, pl->pd_delta, pl->pd_bb, pl->args.state,
                                    record ? pl->first_record : nullptr, pl->op_work, pl->op_work_bytes, st));
-  hipLaunchKernelGGL(cg_update_c1_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+  launch_update_c1(pl, st, decide_last);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
@@ -1219,9 +1324,12 @@ void capture_first(CgPlan* pl, int len) {
                         pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock;
     const int bodies = decide ? len - 1 : len;
     int done_bodies = 0;
+    // decide: the graph's LAST update also takes the next step's decision and leaves the end-of-graph mark (g_cg_decide_in_update;
+    // 0: the separate cg_decide_c1_kernel + cg_marker_kernel launches of rounds 1-3)
+    const bool in_update = decide && g_cg_decide_in_update;
     if (pl->init_free) {
       // root node = launch 0 of the first apply, reading a placeholder rhs that is patched before every launch
-      rc = enqueue_first_body(pl, pl->cap_stream, (const float*)pl->args.x, true);
+      rc = enqueue_first_body(pl, pl->cap_stream, (const float*)pl->args.x, true, in_update && bodies == 1);
       done_bodies = 1;
     } else {
       hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, pl->cap_stream, pl->args,
@@ -1229,12 +1337,12 @@ void capture_first(CgPlan* pl, int len) {
       rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
       if (rc == MGP_OK) rc = enqueue_head(pl, pl->cap_stream);
     }
-    for (int i = done_bodies; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
-    if (decide && rc == MGP_OK) {
+    for (int i = done_bodies; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream, in_update && i == bodies - 1);
+    if (decide && !in_update && rc == MGP_OK) {
       hipLaunchKernelGGL(cg_decide_c1_kernel, dim3(1), dim3(kBlock), 0, pl->cap_stream, pl->args);
       rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
     }
-    if (rc == MGP_OK) {
+    if (!in_update && rc == MGP_OK) {
       hipLaunchKernelGGL(cg_marker_kernel, dim3(1), dim3(1), 0, pl->cap_stream, pl->args.state, pl->args.host_state);
       rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
     }
@@ -1411,6 +1519,8 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   }
   pl->pd_bb = ar.take<float>((size_t)a.nbs * C);
   a.pd_bb = nullptr;
+  a.arrive = ar.take<int>(9 * 32);
+  if (a.arrive) MGP_HIP_TRY(hipMemsetAsync(a.arrive, 0, 9 * 32 * sizeof(int), pl->stream));
   pl->init_free = false;
   if (g_cg_init_free && C == 1 && !dist && !minv && !pl->fused && (op->form == 0 || op->form == 2) &&
       mgp_tile_plan(&op->L, 1, nullptr, nullptr, nullptr) && a.nbv <= kC1GammaSlots * kBlock &&
@@ -1451,6 +1561,12 @@ extern "C" int mgp_cg_set_reduce_once(int on) {
   return MGP_OK;
 }
 
+extern "C" int mgp_cg_set_decide_in_update(int on) {
+  const int prev = g_cg_decide_in_update;
+  g_cg_decide_in_update = on ? 1 : 0;
+  return prev;
+}
+
 extern "C" int mgp_cg_set_fuse(int on) {
   g_cg_fuse = on ? 1 : 0;
   return MGP_OK;
@@ -1481,6 +1597,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   const size_t nc = (size_t)pl->args.n * pl->C;
   pl->host_state[1] = 0;
   pl->host_state[3] = 0;
+  *reinterpret_cast<volatile uint64_t*>(pl->host_state + 8) = 0;     // the deciding update's 8-byte record
   bool first = true;
   const auto t_begin = std::chrono::steady_clock::now();
   if (pl->solves++ >= 1 && !pl->graphs_tried) capture_graphs(pl);
@@ -1501,6 +1618,9 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
     const bool launched_first = first && pl->has_first;
     if (launched_first) {
       ++pl->marker_seq;
+      // (round 4, measured and removed: the first (apply, update) pair launched eagerly in front of a graph holding steps
+      // 2 .. k, to hide the replay's launch latency behind it -- 59.9 us per 60k solve against 55.2 with the whole solve in
+      // the graph, tools/lab/ab_decide.py: three eager launches and a graph launch behind them cost more than one replay)
       MGP_HIP_TRY(hipGraphLaunch(pl->exec_first, st));
     } else if (pl->has_graph) {
       MGP_HIP_TRY(hipGraphLaunch(pl->exec, st));
@@ -1522,6 +1642,21 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
     // flag (measured: 60.5 -> 58.4 us per 60k solve with no query during the solve -- the queries themselves, a
     // runtime lock each, delay the launch's progress); continuation chunks poll as before.
     volatile int32_t* flag = pl->host_state + 1;
+    // the deciding update launch (cg_update_c1_kernel<true>) reports through one 8-byte record instead of the flag words:
+    // unpack it into them, so that everything below reads one format
+    volatile uint64_t* record = reinterpret_cast<volatile uint64_t*>(pl->host_state + 8);
+    auto decided = [&]() -> bool {
+      if (*flag) return true;
+      const uint64_t rec = *record;
+      if (!(rec >> 32 & 1)) return false;
+      const uint32_t lo = (uint32_t)rec, hi = (uint32_t)(rec >> 32);
+      memcpy(pl->host_resid, &lo, sizeof(float));
+      pl->host_state[0] = (int32_t)(hi >> 8);
+      pl->host_state[2] = (int32_t)((hi >> 4) & 15);
+      pl->host_state[3] = (int32_t)((hi >> 1) & 1);
+      pl->host_state[1] = 1;
+      return true;
+    };
     if (launched_first && g_cg_poll_spin > 0) {
       // (not even one query every 20 us: two or three of them during a 55 us solve took the whole gain back.)  The
       // graph's last node (cg_marker_kernel) reports a first graph that ran to its end undecided; the time budget --
@@ -1529,20 +1664,20 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
       const int64_t budget = 10 * pl->last_solve_ns + 2000000;
       const auto t_spin = std::chrono::steady_clock::now();
       volatile int32_t* marker = pl->host_state + 4;
-      while (!*flag && *marker != pl->marker_seq) {
-        for (int spin = 0; spin < g_cg_poll_spin && !*flag && *marker != pl->marker_seq; ++spin) __builtin_ia32_pause();
+      while (!decided() && *marker != pl->marker_seq) {
+        for (int spin = 0; spin < g_cg_poll_spin && !decided() && *marker != pl->marker_seq; ++spin) __builtin_ia32_pause();
         if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_spin).count() > budget) break;
       }
     }
-    if (!*flag && pl->is_dist && pl->dist.world > 1) {
+    if (!decided() && pl->is_dist && pl->dist.world > 1) {
       MGP_TRY(mgp_stream_wait_bounded(st));      // collectives on the stream: a dead peer must not hang this rank
     }
-    while (!*flag) {
+    while (!decided()) {
       const hipError_t q = hipStreamQuery(st);
       if (q == hipSuccess) break;
       if (q != hipErrorNotReady) return (int)q;
     }
-    if (*flag) break;
+    if (decided()) break;
     if (++guard > pl->prm.max_iter / (pl->chunk < 4 ? pl->chunk : 4) + 4) break;
   }
   // the first graph follows the workload: when two solves in a row needed the same number of steps and

@@ -239,8 +239,17 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
   // the CG graph's skip flag / iteration tick: loaded here, consumed only after the first tile's
   // metadata loads have been issued, so that the flag costs no round trip of its own
-  const int skipv = p.skip ? *p.skip : 0;
-  const int tickv = (p.tick && blockIdx.x == 0) ? *p.tick : 0;
+  // The CG graph's skip flag / iteration tick are fetched through the VECTOR memory path, at the top of the tile loop, and
+  // tested when the tile's own loads have all been issued.  As scalar loads at the head of the kernel (rounds 1-3) they cost
+  // every launch a round trip beyond L2 (~0.5 us) in front of everything else: scalar loads return out of order, so the
+  // first use of ANY later scalar -- the kernel arguments -- waits for lgkmcnt(0), flag included (s_load_dword +
+  // s_waitcnt lgkmcnt(0) at the top of the .s).  `lane0` is a zero the compiler cannot see through (mbcnt is a divergent
+  // source): a uniform address would be selected back to the scalar cache, and a provably uniform VALUE is moved to an SGPR
+  // (v_readfirstlane behind s_waitcnt) in the loop preheader.
+  const int lane0 = __builtin_amdgcn_mbcnt_lo(0u, 0u);
+  const int* __restrict__ skip_ptr = (p.skip ? p.skip : reinterpret_cast<const int*>(p.rowptr)) + lane0;
+  const int* __restrict__ tick_ptr = (p.tick ? p.tick : reinterpret_cast<const int*>(p.rowptr)) + lane0;
+  int skipl = 0, tickl = 0;
   constexpr int TR = BS / 4;
   constexpr int NQ = 4;
   const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
@@ -267,13 +276,14 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
   const int64_t t0 = (int64_t)lb * t.tiles_per_block;
   const int64_t t1 = t0 + t.tiles_per_block < t.ntiles ? t0 + t.tiles_per_block : t.ntiles;
   for (int64_t tile = t0; tile < t1; ++tile) {
+    skipl = *skip_ptr;
+    tickl = *tick_ptr;
     const int64_t r0 = tile * TR;
     const int64_t r1 = r0 + TR < p.n ? r0 + TR : p.n;
     const int e0 = rowptr[r0], e1 = rowptr[r1];
     const int dp = tile_ptr[tile];
     const int D = tile_ptr[tile + 1] - dp;
     const int qb = e0 >> 2, Q = (e1 - e0) >> 2;
-    if (skipv) return;
     // phase 0 (loads are retired in issue order, so the order below is the order they are needed in):
     // dictionary ids first, then the matrix stream, then the row-phase operands -- all unconditional on
     // clamped addresses, all in flight before the first wait
@@ -282,6 +292,8 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     for (int k = 0; k < NQ; ++k) {
       const int j = tid + k * BS;
       c[k] = (unsigned)tile_cols[j < D ? dp + j : 0];   // empty tile: dp may be one past the end
+      // (round 4, measured and removed: a fixed-stride copy of the dictionaries, whose ids can be requested in the same round
+      // trip as the tile's offsets instead of behind it -- 5.46 against 5.43 us back to back, 56.0 against 54.0 us per solve)
     }
     __builtin_amdgcn_sched_barrier(0);
     mgp_v4f v[NQ];
@@ -330,6 +342,7 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     const float l_cp0 = (p.commit.pack4 ? p.commit.src0 : x)[grr], l_cp1 = (p.commit.pack4 ? p.commit.src1 : x)[grr];
     const float l_cp2 = ((p.commit.pack4 && p.commit.pre) ? p.commit.pre : x)[grr];
     __builtin_amdgcn_sched_barrier(0);
+    if (p.skip && skipl) return;          // CG converged: every load above went to a valid address, nothing is written
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       const int j = tid + k * BS;
@@ -392,9 +405,9 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     }
     if (tile + 1 < t1) __syncthreads();                // the next tile overwrites xl / part
   }
-  if (p.tick && blockIdx.x == 0 && tid == 0 && !skipv) {
+  if (p.tick && blockIdx.x == 0 && tid == 0 && !(p.skip && skipl)) {
     if (p.tick_reset) { p.tick[0] = 1; p.tick[1] = 0; p.tick[2] = 0; }
-    else *p.tick = tickv + 1;
+    else *p.tick = tickl + 1;
   }
   if (p.dot_partials) {
     __shared__ float red[2][BS / MGP_WAVE];
@@ -1678,23 +1691,27 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
                 L->tile_rowptr, L->tile_vals, L->tile_rowid, L->tile_max_entries, 0};
     const int grid = tile_grid(L, &ta.tiles_per_block);
     const size_t lds = tile_lds_bytes(L);
-    if (first && first->record) {
-      TileLaunchRecord rec{p, ta};
-      memcpy(first->record, &rec, sizeof(rec));
-    }
-#define MGP_TILE_LAUNCH(BS)                                                                              \
+#define MGP_TILE_LAUNCH_K(KERNEL, BS)                                                                   \
   do {                                                                                                   \
     if (g_spmv_timer.on && 2 * g_spmv_timer.used + 1 < (int)g_spmv_timer.ev.size()) {                    \
       hipEvent_t e0 = g_spmv_timer.ev[2 * g_spmv_timer.used], e1 = g_spmv_timer.ev[2 * g_spmv_timer.used + 1]; \
       ++g_spmv_timer.used;                                                                               \
-      if (pre) hipExtLaunchKernelGGL((spmv_tile_kernel<true, BS>), dim3(grid), dim3(BS), lds, st, e0, e1, 0, p, ta);  \
-      else hipExtLaunchKernelGGL((spmv_tile_kernel<false, BS>), dim3(grid), dim3(BS), lds, st, e0, e1, 0, p, ta);     \
-    } else if (pre) hipLaunchKernelGGL((spmv_tile_kernel<true, BS>), dim3(grid), dim3(BS), lds, st, p, ta);      \
-    else hipLaunchKernelGGL((spmv_tile_kernel<false, BS>), dim3(grid), dim3(BS), lds, st, p, ta);         \
+      hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(BS), lds, st, e0, e1, 0, p, ta);                    \
+    } else hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(BS), lds, st, p, ta);                             \
   } while (0)
+#define MGP_TILE_LAUNCH(BS)                                                                              \
+  do {                                                                                                   \
+    if (pre) MGP_TILE_LAUNCH_K((spmv_tile_kernel<true, BS>), BS);                                        \
+    else MGP_TILE_LAUNCH_K((spmv_tile_kernel<false, BS>), BS);                                           \
+  } while (0)
+    if (first && first->record) {
+      TileLaunchRecord rec{p, ta};
+      memcpy(first->record, &rec, sizeof(rec));
+    }
     if (L->tile_rows == 32) MGP_TILE_LAUNCH(128);
     else if (L->tile_rows == 64) MGP_TILE_LAUNCH(256);
     else MGP_TILE_LAUNCH(512);
+#undef MGP_TILE_LAUNCH_K
 #undef MGP_TILE_LAUNCH
   } else if (use_tiles_small(L, C)) {
     if (((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(base) |
