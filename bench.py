@@ -113,9 +113,11 @@ def build_workload(args, dev, rank, world, shard_knn=False, scale_nodes=True):
                 t_graph=t_graph)
 
 
-def time_spmv_kernel(wl, reps=200):
+def time_spmv_kernel(wl, reps=200, as_given=False):
     """Average duration of the dominant kernel (fused C=1 SpMV, L_sym) launched back to back from C
-    (mgp_spmm_repeat), HIP events on the launch stream (= torch's current stream)."""
+    (mgp_spmm_repeat), HIP events on the launch stream (= torch's current stream).  The matrix is the one the iterative
+    solvers run on: for a graph handed over without locality that is P L P^T in the library's locality order
+    (solvers.CgPlan); as_given=True times the product in the caller's order instead (what one `lap.matmul(v)` launches)."""
     import ctypes
     from manifold_gp_amd import _lib
     lap = wl["lap"]
@@ -124,7 +126,8 @@ def time_spmv_kernel(wl, reps=200):
     out = torch.empty_like(v)
     lib = _lib.lib()
     lib.mgp_spmm_set_group_hint(g.spmv_lanes)
-    csr = lap.data.csr()
+    rel = None if as_given else lap.data.relabelled()
+    csr = (rel or lap.data).csr()
     st = _lib.stream()
     ms = ctypes.c_float(0.0)
     _lib.check(lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(v), 1, _lib.ptr(out), 20, None, st), "mgp_spmm_repeat")
@@ -172,11 +175,29 @@ def hbm_streaming_roofline(dev, order, reps=100):
     g = wl["graph"]
     t_k = time_spmv_kernel(wl, reps=reps)
     B = spmm_bytes(g.n, g.M)
+    ordered = g.tiles is not None and g.tiles.get("rowid") is not None
     out = dict(workload=wl["name"], nodes=g.n, edges=g.M, bytes_per_launch=B, avg_launch_us=round(t_k * 1e6, 2),
                achieved=round(B / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(B / t_k / 1e9 / HBM_PEAK_GBS, 4),
-               tile_order=("input order" if g.tiles is None or g.tiles.get("rowid") is None else "locality order (Z-curve)"),
+               tile_order=("locality order (Z-curve); the solvers iterate on the relabelled matrix, vectors permuted in / out once "
+                           "per solve" if ordered else "input order"),
                entries_per_dictionary_column=round(g.tiles["reuse"], 2) if g.tiles is not None else None,
                knn_graph_build_s=round(wl["t_graph"], 3))
+    if ordered:
+        t_g = time_spmv_kernel(wl, reps=reps, as_given=True)
+        out["single_product_in_caller_order_us"] = round(t_g * 1e6, 2)
+    # the C5 posterior-mean solve (I + noise s Q) x = y, tol 1e-6, fp64-residual refinement: caller-order y in, caller-order
+    # x out -- what a user of the path times; the two input orders must cost the same
+    from manifold_gp_amd.solvers import CgPlan
+    plan = CgPlan(wl["desc"], 1, tol=1e-6, max_iter=5000, stop_mode=1, check_every=8, refine=3)
+    y = wl["y"].view(-1, 1).contiguous()
+    plan.solve(y, copy=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    plan.solve(y, copy=False)
+    torch.cuda.synchronize()
+    out["cg_solve"] = dict(ms=round((time.perf_counter() - t0) * 1e3, 2), iterations=plan.iters, status=plan.status,
+                           true_rel_residual=float(max(plan.resid)))
+    plan.close()
     del wl
     torch.cuda.empty_cache()
     return out
@@ -459,7 +480,8 @@ def _main(quiet):
         line["cg_multi_rhs"] = multi_rhs_solve(wl)
         hb = hbm_streaming_roofline(dev, "morton")
         hb["random_order_input"] = {k: v for k, v in hbm_streaming_roofline(dev, "random").items()
-                                    if k in ("avg_launch_us", "achieved", "frac", "tile_order", "entries_per_dictionary_column")}
+                                    if k in ("avg_launch_us", "achieved", "frac", "tile_order", "entries_per_dictionary_column",
+                                             "single_product_in_caller_order_us", "cg_solve")}
         hb["traffic"], hb["traffic_source"] = None, None
         for cand in ("r03_s5_pmc_traffic.json", "r02_s5_pmc_traffic.json"):
             pmc = os.path.join(ROOT, "profiles", cand)

@@ -122,6 +122,16 @@ class KnnGraph:
             return None
         return vals.index_select(0, self.tiles["emap"])
 
+    def has_locality_order(self):
+        t = self.tiles
+        return t is not None and t.get("rowid") is not None and t.get("emap") is not None
+
+    def relabelled(self):
+        """RelabelledGraph of this graph (cached); only for graphs whose tiles follow a locality order."""
+        if getattr(self, "_relabelled", None) is None:
+            self._relabelled = RelabelledGraph(self)
+        return self._relabelled
+
     @property
     def edge_index(self):
         """idx[2, M] int64, row<col, sorted -- what NearestNeighbors.graph returns."""
@@ -189,6 +199,77 @@ class KnnGraph:
         return g
 
 
+class RelabelledGraph:
+    """The structure of P A P^T for a KnnGraph whose tiles follow a locality order (tiles["rowid"]): row p of this graph is
+    node order[p] of the caller's.  The CSR in that order already exists as the tile view (tile_rowptr, values gathered
+    through emap); what is new is only the column ids and the dictionaries' ids mapped to the new labels -- so that the
+    VECTORS of an iteration can live in this order too and every kernel (tile SpMV, vector updates, dictionaries) streams
+    instead of gathering / scattering through `rowid` at 4-byte granularity.  Built once per graph, on demand."""
+
+    def __init__(self, g):
+        t = g.tiles
+        dev = g.device
+        self.n, self.nnz, self.M, self.spmv_lanes = g.n, g.nnz, g.M, g.spmv_lanes
+        self.device = dev
+        self.order = t["rowid"].long()                                  # new position -> caller's node id
+        self.inv = torch.empty_like(self.order)
+        self.inv[self.order] = torch.arange(g.n, device=dev)            # caller's node id -> new position
+        self.order32, self.inv32 = self.order.to(torch.int32), self.inv.to(torch.int32)
+        self.rowptr = t["tile_rowptr"]
+        self.col = self.inv.index_select(0, g.col.long().index_select(0, t["emap"])).to(torch.int32)
+        self.tiles = dict(tile_ptr=t["tile_ptr"], tile_cols=self.inv.index_select(0, t["tile_cols"].long()).to(torch.int32),
+                          lid=t["lid"], rows=t["rows"], max_cols=t["max_cols"], max_entries=t["max_entries"],
+                          reuse=t.get("reuse"))
+
+    def permute(self, v):
+        """caller's order -> this order, along dim 0"""
+        return v.index_select(0, self.order)
+
+    def unpermute(self, v, out=None):
+        """this order -> caller's order, along dim 0"""
+        return torch.index_select(v, 0, self.inv, out=out)
+
+
+class RelabelledData:
+    """LaplacianData of the relabelled graph (same eps): values = the tile-order copy the data already holds, node vectors
+    permuted once.  Quacks like LaplacianData for Descriptor / the solvers."""
+
+    def __init__(self, data):
+        rg = data.graph.relabelled()
+        self.graph = rg
+        self.uid = LaplacianData._next_uid[0]
+        LaplacianData._next_uid[0] += 1
+        self.eps, self.self_loops = data.eps, data.self_loops
+        self.vals = data.vals_t
+        for name in ("degree_unnorm", "degree", "diag", "dsqrt", "dinvsqrt"):
+            setattr(self, name, rg.permute(getattr(data, name)).contiguous())
+        self.vals_t = None
+        self._perm_cache = {}
+        self._source = data                     # (keeps vals_t alive)
+
+    def csr(self):
+        g = self.graph
+        return _lib.csr_struct(g.n, g.rowptr, g.col, self.vals, self.diag, tiles=g.tiles)
+
+    def permuted(self, v):
+        """A node vector of the source data (pre / post of a descriptor) in this order; the data's own vectors map to the
+        copies made above, anything else (a mask folded into pre / post) is gathered once and kept."""
+        if v is None:
+            return None
+        src = self._source
+        for name in ("dsqrt", "dinvsqrt", "degree", "degree_unnorm", "diag"):
+            if v.data_ptr() == getattr(src, name).data_ptr():
+                return getattr(self, name)
+        key = (v.data_ptr(), v._version)
+        hit = self._perm_cache.get(key)
+        if hit is None:
+            if len(self._perm_cache) > 8:
+                self._perm_cache.clear()
+            hit = (v, self.graph.permute(v).contiguous())      # (the source tensor is kept alive with its pointer key)
+            self._perm_cache[key] = hit
+        return hit[1]
+
+
 _COO_CACHE = {}
 
 
@@ -254,6 +335,14 @@ class LaplacianData:
 
     def csr(self):
         return self.graph.csr_with(self.vals, self.diag, self.vals_t)
+
+    def relabelled(self):
+        """RelabelledData (cached) when the graph's tiles follow a locality order, else None."""
+        if not self.graph.has_locality_order() or self.vals_t is None:
+            return None
+        if getattr(self, "_relabelled", None) is None:
+            self._relabelled = RelabelledData(self)
+        return self._relabelled
 
     def edge_values(self, which):
         """0: W (adjacency_unnorm_mat), 1: A (adjacency_mat), 2: S (laplacian_triu) in COO order."""

@@ -38,6 +38,14 @@ class Descriptor:
             post = row_mask if post is None else post * row_mask
         return replace(self, pre=pre, post=post)
 
+    def relabelled(self):
+        """(descriptor of P A P^T, RelabelledGraph) when the graph's tiles follow a locality order -- the form the iterative
+        solvers run on: same operator on permuted vectors -- else (None, None)."""
+        rel = getattr(self.data, "relabelled", lambda: None)()
+        if rel is None:
+            return None, None
+        return replace(self, data=rel, pre=rel.permuted(self.pre), post=rel.permuted(self.post)), rel.graph
+
     def struct(self):
         d = self.data
         g = d.graph

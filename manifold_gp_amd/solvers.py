@@ -14,12 +14,28 @@ from ._lib import CgParamsT, LanczosParamsT, check, lib, ptr, stream
 
 
 # ------------------------------------------------------------------------------ CG
+RELABEL_SOLVES = [True]        # iterative solves on a graph with locality-ordered tiles run on P A P^T (CgPlan.__init__)
+
+
 class CgPlan:
     """A reusable HIP CG solver for one operator descriptor and column count: owns the workspace
     and the captured iteration graph (mgp_cg_plan_* in include/mgp_hip.h)."""
 
     def __init__(self, desc, C, tol=None, max_iter=None, min_iter=None, stop_mode=None, jacobi=None,
                  check_every=0, use_graph=True, refine=0):
+        # A graph handed over without locality carries tiles over a locality order (graph.build_tiles_auto).  On the CSR as
+        # given, every SpMV of the solve gathers x and scatters y through that order at 4-byte granularity and every vector
+        # update works in the caller's order (1M swiss roll in random order: 134 us per SpMV against 81 for the same points
+        # handed over Z-ordered).  The plan therefore iterates on P A P^T -- the relabelled CSR + dictionaries the tile view
+        # already is, node vectors permuted once per operator -- and permutes the right-hand side in and the solution out:
+        # two gathers of n C floats per solve against hundreds of SpMVs.  Caller-order `rhs` in, caller-order result out
+        # (graph_laplacian_operator.py:108-124).  RELABEL_SOLVES[0] = False: iterate in the caller's order (A/B, tests).
+        self._rg = None
+        if RELABEL_SOLVES[0]:
+            rdesc, rg = desc.relabelled()
+            if rdesc is not None:
+                desc, self._rg = rdesc, rg
+        self._xout = None
         self.desc = desc
         self.C = int(C)
         dev = desc.data.graph.device
@@ -74,7 +90,8 @@ class CgPlan:
             raise RuntimeError("no float64 solution: the plan was created without refinement")
         off = int(p) - self.work.data_ptr()
         nb = self.desc.n * self.C * 8
-        return self.work[off:off + nb].view(torch.float64).view(self.desc.n, self.C)
+        v = self.work[off:off + nb].view(torch.float64).view(self.desc.n, self.C)
+        return v if self._rg is None else self._rg.unpermute(v)      # (a copy, in the caller's order)
 
     def solve(self, B, out=None, copy=True):
         if B.device.type != "cuda":
@@ -82,6 +99,8 @@ class CgPlan:
         if B.dtype != torch.float32 or not B.is_contiguous():
             B = _lib.f32c(B)
         assert B.shape == (self.desc.n, self.C)
+        if self._rg is not None:
+            return self._solve_relabelled(B, out, copy)
         if copy:
             X = torch.empty_like(B) if out is None else out
         else:
@@ -95,6 +114,22 @@ class CgPlan:
             X = self.solution_view()
         self.iters, self.status = self._iters.value, self._status.value
         return X
+
+    def _solve_relabelled(self, B, out, copy):
+        """The solve on P A P^T: right-hand side gathered into the locality order, solution gathered back."""
+        rg = self._rg
+        Br = rg.permute(B)
+        rc = self._solve_fn(self.handle, Br.data_ptr(), None, self._iters_ref, self._resid, self._status_ref)
+        if rc != 0:
+            check(rc, "mgp_cg_plan_solve")
+        self.iters, self.status = self._iters.value, self._status.value
+        if copy:
+            X = torch.empty_like(B) if out is None else out
+        else:                                   # copy=False: a plan-owned buffer, overwritten by the next solve
+            if self._xout is None:
+                self._xout = torch.empty_like(B)
+            X = self._xout
+        return rg.unpermute(self.solution_view(), out=X)
 
     def close(self):
         if self.handle:
@@ -408,19 +443,11 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
     # The block iteration gathers an X row per entry: on the CSR as given those rows are scattered over a
     # block of n x b floats (HBM-bound, 4.3 ms per 84-column SpMM at N = 1M); on the SAME matrix relabelled
     # by that order (P L P^T: same spectrum, eigenvectors permuted back below) they sit in cache.
-    t = g.tiles
     order = None
-    if t is not None and t.get("rowid") is not None and t.get("emap") is not None and lap_data.vals_t is not None:
-        order = t["rowid"].long()
-        inv = torch.empty_like(order)
-        inv[order] = torch.arange(order.numel(), device=dev)
-        col_p = inv.index_select(0, g.col.long().index_select(0, t["emap"])).to(torch.int32)
-        diag_p = lap_data.diag.index_select(0, order).contiguous()
-        # the tile dictionaries describe this very row order; only their column ids are in the old labelling
-        tiles_p = dict(tile_ptr=t["tile_ptr"], tile_cols=inv.index_select(0, t["tile_cols"].long()).to(torch.int32),
-                       lid=t["lid"], rows=t["rows"], max_cols=t["max_cols"], max_entries=t["max_entries"])
-        keep = (t["tile_rowptr"], col_p, lap_data.vals_t, diag_p, tiles_p)      # referenced until the call returns
-        csr = _lib.csr_struct(g.n, keep[0], keep[1], keep[2], keep[3], tiles=tiles_p)
+    rel = getattr(lap_data, "relabelled", lambda: None)()      # graph.RelabelledData: built once per graph / bandwidth
+    if rel is not None:
+        order = rel.graph.order
+        csr = rel.csr()
     else:
         csr = lap_data.csr()
     prm = LanczosParamsT(int(max_basis), int(degree), int(max_restarts), float(tol), int(seed))

@@ -1617,6 +1617,41 @@ def test_locality_order_for_unordered_inputs(mgp, dev):
     finally:
         lib.mgp_cg_set_fuse(0)
     assert float((sols[0] - sols[1]).abs().max()) < 2e-4 * float(sols[0].abs().max())
+    # the plans above iterate on P A P^T (solvers.RELABEL_SOLVES: vectors in the locality order, right-hand side permuted in,
+    # solution permuted out); the same solves in the caller's order (graph_laplacian_operator.py:108-124: caller-order rhs
+    # in, caller-order result out) give the same answer -- one column, several columns, a masked (Schur-block) descriptor,
+    # the float64 solution of a refined solve
+    from manifold_gp_amd import solvers
+    rel = lap.data.relabelled()
+    assert rel is not None and torch.equal(rel.graph.order, t["rowid"].long())
+    assert torch.equal(rel.graph.unpermute(rel.graph.permute(y)), y)
+    B5 = torch.randn(n, 5, device=dev)
+    mask = (torch.rand(n, device=dev) < 0.8).float()
+    dmask = Q._descriptor().masked(mask, mask).with_(scale=0.7)
+    out = {}
+    try:
+        for relabel in (True, False):
+            solvers.RELABEL_SOLVES[0] = relabel
+            plan = CgPlan(desc, 1, tol=1e-6, max_iter=20000, stop_mode=1, refine=2)
+            assert (plan._rg is not None) == relabel
+            x1 = plan.solve(y).clone()
+            x64 = plan.solution64_view().clone()
+            assert torch.equal(x64.float(), x1)
+            x1b = plan.solve(y, copy=False).clone()                       # plan-owned output buffer
+            assert torch.equal(x1b, x1)
+            plan.close()
+            plan = CgPlan(desc, 5, tol=1e-6, max_iter=20000, stop_mode=1)
+            x5 = plan.solve(B5).clone()
+            plan.close()
+            plan = CgPlan(dmask.with_(form=2, noise=1e-2), 1, tol=1e-6, max_iter=20000, stop_mode=1)
+            xm = plan.solve(y).clone()
+            plan.close()
+            out[relabel] = (x1, x5, xm)
+    finally:
+        solvers.RELABEL_SOLVES[0] = True
+    for a, b in zip(out[True], out[False]):
+        assert float((a - b).abs().max()) < 2e-4 * float(b.abs().max())
+    assert float((desc.apply(out[True][1]) - B5).norm() / B5.norm()) < 2e-5
     # gradient wrt the bandwidth through the ordered tiles (tangent values take the same entry map)
     eps = torch.tensor([[0.35]], device=dev, requires_grad=True)
     op = mgp.operators.GraphLaplacianOperator(g.edge_value, g.edge_index, n, eps, "symmetric", graph=g)
