@@ -23,6 +23,7 @@ with round 1's replicated-vector plan.  `--workload s5` is the 1M-node graph tha
 import argparse
 import json
 import os
+import re
 import statistics
 import sys
 import time
@@ -40,6 +41,21 @@ def spmm_bytes(n, M, C=1):
     """full symmetric CSR, fp32 values, int32 col, int32 rowptr, fp32 diag,
     x read once, y written once."""
     return 8 * (2 * M) + 4 * (n + 1) + 4 * n + 8 * n * C
+
+
+def source_hash():
+    """sha256 over the kernel sources and headers of this tree (first 16 hex digits): what a committed profile summary must
+    carry for the bench line to quote it (tools/summarize_profile.py writes it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "manifold_gp_amd", "csrc", "*.hip")) +
+                   glob.glob(os.path.join(ROOT, "manifold_gp_amd", "csrc", "*.h")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def log(*a):
@@ -418,28 +434,36 @@ def _main(quiet):
     # line then reproduces from profiles/ -- and (2) otherwise.
     t_b2b = time_spmv_kernel(wl)
     t_in, n_in = time_spmv_in_solve(wl, args, refine, y)
-    t_prof, prof_src = None, None
-    pmc_name = "r03_pmc_traffic.json" if args.workload == "c3" else "r03_s5_pmc_traffic.json"
-    for cand in (pmc_name, pmc_name.replace("r03", "r02")):
-        pf = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(pf) and not args.nodes:
-            try:
-                pj = json.load(open(pf))
-                ns = pj.get("spmv_kernel_trace_mean_ns") or pj.get("spmv_kernel (no pre-scaling)", {}).get("kernel_trace_median_ns")
-                if ns:
-                    t_prof, prof_src = ns * 1e-9, "profiles/%s (%s of %s launches, rocprofv3 --kernel-trace of this command)" % (
-                        cand, "mean" if pj.get("spmv_kernel_trace_mean_ns") else "median",
-                        pj.get("spmv_kernel_trace_launches") or pj.get("spmv_kernel (no pre-scaling)", {}).get("kernel_trace_launches"))
-                    break
-            except Exception:
-                pass
-    t_k = t_prof or t_in or t_b2b
-
+    # (3) is quoted only from a profile taken on THIS source tree: tools/summarize_profile.py stores a hash of csrc/ + include/
+    # in the summary; a summary whose hash differs from the tree's, or whose mean differs from this run's back-to-back
+    # figure by more than 10 %, is stale -- `frac` then quotes the live in-solve figure and the line says so
+    t_prof, prof_src, prof_hash, prof_file = None, None, None, None
+    suffix = "_pmc_traffic.json" if args.workload == "c3" else "_s5_pmc_traffic.json"
+    cands = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+" + suffix, f)), reverse=True) \
+        if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+    for cand in cands:
+        if args.nodes:
+            break
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            ns = pj.get("spmv_kernel_trace_mean_ns") or pj.get("spmv_kernel (no pre-scaling)", {}).get("kernel_trace_median_ns")
+            if ns:
+                t_prof, prof_file, prof_hash = ns * 1e-9, cand, pj.get("source_hash")
+                prof_src = "profiles/%s (%s of %s launches, rocprofv3 --kernel-trace of this command)" % (
+                    cand, "mean" if pj.get("spmv_kernel_trace_mean_ns") else "median",
+                    pj.get("spmv_kernel_trace_launches") or pj.get("spmv_kernel (no pre-scaling)", {}).get("kernel_trace_launches"))
+                break
+        except Exception:
+            pass
+    tree_hash = source_hash()
+    profile_age_ok = bool(t_prof) and prof_hash == tree_hash and abs(t_prof - t_b2b) <= 0.10 * t_b2b
+    t_k = (t_prof if profile_age_ok else None) or t_in or t_b2b
     def fig(t, note):
         return dict(avg_launch_us=round(t * 1e6, 2), achieved=round(B / t / 1e9, 1), frac=round(B / t / 1e9 / HBM_PEAK_GBS, 4), note=note)
     roof = dict(bound="hbm", achieved=round(B / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=round(B / t_k / 1e9 / HBM_PEAK_GBS, 4), traffic=None,
-                measured=("in_graph_profile: " + prof_src) if t_prof else ("live_eager_in_solve" if t_in else "live_back_to_back"),
+                measured=("in_graph_profile: " + prof_src) if profile_age_ok else ("live_eager_in_solve" if t_in else "live_back_to_back"),
+                profile_age_ok=profile_age_ok, source_hash=tree_hash, profile_source_hash=prof_hash,
                 live_back_to_back=fig(t_b2b, "this run: 200 graph-replayed launches of the kernel with nothing in between, HIP events"),
                 live_eager_in_solve=fig(t_in, "this run: begin / end timestamps of %d launches inside 40 eager CG solves "
                                               "(hipExtLaunchKernelGGL event pairs)" % n_in) if t_in else None,
@@ -452,20 +476,17 @@ def _main(quiet):
                       "traffic is served by the cache; the kernel is latency-bound, DESIGN.md section 6) -- the HBM figure is "
                       "roofline_hbm.frac (1M-node graph, streams from HBM)"
                       if B < 2.5e8 else "working set %.0f MB streams from HBM") % (B / 1e6))
-    # HBM bytes per launch from the PMC passes of the same command (tools/profile.sh ->
-    # tools/summarize_profile.py): FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE
-    # NOT a run-time counter: the figure is read from the committed PMC summary of the same command
-    pmc_name = "r03_pmc_traffic.json" if args.workload == "c3" else "r03_s5_pmc_traffic.json"
-    for cand in (pmc_name, pmc_name.replace("r03", "r02"), pmc_name.replace("r03", "r01")):
-        pmc = os.path.join(ROOT, "profiles", cand)
-        if os.path.exists(pmc) and not args.nodes:
-            try:
-                roof["traffic"] = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
-                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
-                                         "2 x FETCH_SIZE + WRITE_SIZE; not measured in this run)" % cand
-                break
-            except Exception:
-                pass
+    # HBM bytes per launch from the PMC passes of the same command (tools/profile.sh -> tools/summarize_profile.py):
+    # FETCH_SIZE x 2 (gfx950 correction) + WRITE_SIZE.  NOT a run-time counter: read from the committed PMC summary, with
+    # the same staleness flag as above
+    if prof_file:
+        try:
+            roof["traffic"] = json.load(open(os.path.join(ROOT, "profiles", prof_file))).get("spmv_hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                                     "2 x FETCH_SIZE + WRITE_SIZE; not measured in this run; profile of this source tree: %s)" \
+                                     % (prof_file, prof_hash == tree_hash)
+        except Exception:
+            pass
     line = dict(metric="CG-solve wall-time + SpMV HBM GB/s, N=60k RMNIST graph", value=round(value, 2),
                 unit="GB/s (algorithmic SpMV bytes inside the CG solve)", n_gpus=1, steps=args.steps,
                 warmup=args.warmup, preheat_solves=preheat, ms_per_step=round(dt / args.steps * 1e3, 4),
@@ -483,12 +504,13 @@ def _main(quiet):
                                     if k in ("avg_launch_us", "achieved", "frac", "tile_order", "entries_per_dictionary_column",
                                              "single_product_in_caller_order_us", "cg_solve")}
         hb["traffic"], hb["traffic_source"] = None, None
-        for cand in ("r03_s5_pmc_traffic.json", "r02_s5_pmc_traffic.json"):
-            pmc = os.path.join(ROOT, "profiles", cand)
-            if os.path.exists(pmc):
-                hb["traffic"] = json.load(open(pmc)).get("spmv_hbm_bytes_per_launch")
-                hb["traffic_source"] = "profiles/%s (bench.py --workload s5 under rocprofv3 --pmc)" % cand
-                break
+        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+_s5_pmc_traffic.json", f)),
+                           reverse=True):
+            pj = json.load(open(os.path.join(ROOT, "profiles", cand)))
+            hb["traffic"] = pj.get("spmv_hbm_bytes_per_launch")
+            hb["traffic_source"] = "profiles/%s (bench.py --workload s5 under rocprofv3 --pmc; profile of this source tree: %s)" \
+                                   % (cand, pj.get("source_hash") == tree_hash)
+            break
         line["roofline_hbm"] = hb
     if not args.no_cpu_baseline:
         cb, xs = cpu_baseline(wl, its)

@@ -609,6 +609,10 @@ def test_bench_line_contract(dev):
     # what actually ran is in the line: the untimed pre-heat, the step with an alternating right-hand side (graph node
     # re-pointed every solve), and the two live timings of the dominant kernel that bracket its in-solve duration
     assert "preheat_solves" in line and line["ms_per_step_alternating_rhs"] > 0
+    # `frac` quotes the committed in-graph profile only when that profile was taken on this source tree and agrees with this
+    # run's back-to-back figure; otherwise the live in-solve figure (a reduced node count never matches a profile)
+    assert roof["profile_age_ok"] is False and roof["measured"] == "live_eager_in_solve"
+    assert len(roof["source_hash"]) == 16 and abs(roof["avg_launch_us"] - roof["live_eager_in_solve"]["avg_launch_us"]) < 1e-6
     b2b, eag = roof["live_back_to_back"], roof["live_eager_in_solve"]
     assert b2b["avg_launch_us"] > 0 and eag["avg_launch_us"] > 0 and "measured" in roof
     assert 0.5 * b2b["avg_launch_us"] < eag["avg_launch_us"] < 4 * b2b["avg_launch_us"]

@@ -62,6 +62,10 @@ def main(tag):
     d = durs(pats["spmv_kernel (no pre-scaling)"])
     res["spmv_kernel_trace_mean_ns"] = (sum(d) / len(d)) if d else None
     res["spmv_kernel_trace_launches"] = len(d)
+    # which source tree was profiled: bench.py quotes this summary only while the tree's hash is the same
+    sys.path.insert(0, ROOT)
+    import bench
+    res["source_hash"] = bench.source_hash()
     json.dump(res, open(os.path.join(out, tag + "_pmc_traffic.json"), "w"), indent=1)
     for name in ("bench_trace.json", "bench_fetch.json"):
         src = os.path.join(base, name)
