@@ -211,6 +211,13 @@ int mgp_spmm_set_tile_wide_mode(int on);
  * Replaces torch_sparse.spmm at manifold_gp/operators/graph_laplacian_operator.py:118-119 for the [N, 100] right-hand
  * sides of precision_matern_operator.py:50-53 and the eigensolver's blocks. */
 int mgp_spmm_set_dict_mode(int on);
+/* 16 < C <= 128 with C % 4 == 0 on 64-row tiles in row order (round 4): the dictionary kernel as ONE persistent 512-thread
+ * workgroup per CU, 8 lanes per row, the dictionary slices in a two-buffer LDS ring filled by LDS-DMA across tile boundaries, the
+ * matrix stream decoded once per tile into (value, slice, LDS offset), the walk of a slice a counted loop
+ * (csrc/spmm.hip spmm_dict8_kernel).  Built, bit-identical to the dictionary kernel above, NOT faster: 151 us against 91 us
+ * per launch at C = 128 on the 60k graph (a barrier per slice makes every stage as long as its longest row run; docs/kernels/
+ * spmm.md).  Default 0 = never; 1 = wherever the shape allows (tests, lab runs); returns the previous setting. */
+int mgp_spmm_set_dict8_mode(int on);
 /* Measurement hook (bench.py `roofline`): between begin and end every EAGER launch of the C == 1 tile kernel carries
  * its own start / stop event pair (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps); end returns the sum of
  * the kernel durations and the number of launches timed (at most max_launches).  No effect on results. */

@@ -85,6 +85,7 @@ SIGNATURES = {
     "mgp_spmm_set_tile_small_mode": (c_int, [c_int]),
     "mgp_spmm_set_tile_wide_mode": (c_int, [c_int]),
     "mgp_spmm_set_dict_mode": (c_int, [c_int]),
+    "mgp_spmm_set_dict8_mode": (c_int, [c_int]),
     "mgp_spmm_timing_begin": (c_int, [c_int]),
     "mgp_spmm_timing_end": (c_int, [POINTER(c_float), POINTER(c_int)]),
     "mgp_spmm_set_v4_mode": (c_int, [c_int]),

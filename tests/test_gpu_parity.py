@@ -2058,14 +2058,18 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
         pre = torch.rand(n, device=dev) + 0.5
         base = torch.randn(n, C, device=dev)
         W = torch.randn(n, C, device=dev)
-        outs = []
+        outs, nopre = [], []
         try:
             # 0: no tile kernels (C > 16: the float4-lane gather kernel); 1: kernels picked as in production; 2: the wide
             # dictionary kernel forced; 3: no tile kernels, per-column gather kernel
             # (round 3: mode 1 forces the lanes-over-columns dictionary kernel for C > 16 -- production takes it only for
             # X blocks that do not sit in the caches; mode 2 turns it off so that the older chunked dictionary kernel runs;
             # mode 4 is production's own choice)
+            # (round 4: mode 4 = production's own choice of the kernels above, PLUS the persistent 8-lanes-per-row LDS-DMA
+            # dictionary kernel switched on -- off by default, not faster -- which then runs for 16 < C <= 128 on row-order
+            # tiles; its PRE = false instantiation too)
             for mode in (0, 1, 2, 3, 4):
+                lib.mgp_spmm_set_dict8_mode(1 if mode == 4 else 0)
                 lib.mgp_spmm_set_tile_mode(1 if mode in (1, 2, 4) else 0)
                 lib.mgp_spmm_set_dict_mode(0 if mode == 2 else (2 if mode == 1 else 1))
                 lib.mgp_spmm_set_tile_wide_mode(2 if mode == 2 else 1)
@@ -2078,15 +2082,16 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
                                               _lib.ptr(pre), _lib.ptr(base), 0.5, 2.0, _lib.ptr(W), _lib.ptr(part),
                                               _lib.stream()), "mgp_spmm_fused")
                 outs.append((Y.cpu().double().numpy(), part.double().sum(0).cpu().numpy(), nb))
-                if mode == 1 and C > 16:
+                if mode in (1, 4) and C > 16:
                     # the same forced dictionary path WITHOUT input pre-scaling (the kernel's PRE = false instantiation)
                     Y2 = torch.full_like(X, float("nan"))
                     part2 = torch.full((max(nb, 1), C), float("nan"), device=dev)
                     _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y2), 1.25, 1.0, None,
                                                   _lib.ptr(pre), _lib.ptr(base), 0.5, 2.0, _lib.ptr(W), _lib.ptr(part2),
                                                   _lib.stream()), "mgp_spmm_fused")
-                    nopre = (Y2.cpu().double().numpy(), part2.double().sum(0).cpu().numpy())
+                    nopre = nopre + [(Y2.cpu().double().numpy(), part2.double().sum(0).cpu().numpy())]
         finally:
+            lib.mgp_spmm_set_dict8_mode(0)
             lib.mgp_spmm_set_tile_mode(1)
             lib.mgp_spmm_set_dict_mode(1)
             lib.mgp_spmm_set_tile_wide_mode(1)
@@ -2108,8 +2113,10 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
             ref0 = 0.5 * base.cpu().double().numpy() + 2.0 * pre.cpu().double().numpy()[:, None] * (
                 1.25 * X0 + data.diag.cpu().double().numpy()[:, None] * X0 - SX0)
             sc0 = max(np.abs(ref0).max(), 1e-6)
-            assert np.abs(nopre[0] - ref0).max() < 2e-5 * sc0, (shape, C)
-            assert np.abs(nopre[1] - (W.cpu().double().numpy() * ref0).sum(0)).max() < 2e-4 * sc0 * max(n, 16) ** 0.5, (shape, C)
+            assert len(nopre) == 2
+            for y0, d0 in nopre:
+                assert np.abs(y0 - ref0).max() < 2e-5 * sc0, (shape, C)
+                assert np.abs(d0 - (W.cpu().double().numpy() * ref0).sum(0)).max() < 2e-4 * sc0 * max(n, 16) ** 0.5, (shape, C)
 
 
 @pytest.mark.parametrize("kind", ["gauss", "cube", "huge", "tiny", "mixed", "spike"])
