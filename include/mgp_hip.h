@@ -495,6 +495,9 @@ int mgp_dist_unique_id_bytes(void);
 int mgp_dist_unique_id(void* id_out);                          /* rank 0 */
 int mgp_dist_init(int rank, int world, const void* id_bytes, void** comm_out);
 int mgp_dist_destroy(void* comm);
+/* size of the communicator, this process's rank in it and its HIP device, as RCCL reports them (ncclCommCount /
+ * ncclCommUserRank / ncclCommCuDevice): what bench.py's N > 1 line carries as `rccl_ranks` */
+int mgp_dist_comm_info(void* comm, int32_t* count, int32_t* user_rank, int32_t* device);
 int mgp_dist_allgather(void* comm, int rank, int world, float* buf, int64_t count_per_rank,
                        void* stream);                          /* in place, slice p at p*count */
 int mgp_operator_apply_part(const mgp_operator_t* op_local, void* comm, int rank, int world,

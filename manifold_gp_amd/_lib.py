@@ -136,6 +136,7 @@ SIGNATURES = {
     "mgp_dist_unique_id": (c_int, [_P]),
     "mgp_dist_init": (c_int, [c_int, c_int, _P, POINTER(c_void_p)]),
     "mgp_dist_destroy": (c_int, [_P]),
+    "mgp_dist_comm_info": (c_int, [_P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     "mgp_dist_allgather": (c_int, [_P, c_int, c_int, _P, c_int64, _P]),
     "mgp_operator_apply_part": (c_int, [POINTER(OperatorT), _P, c_int, c_int, _P, c_int, _P, _P, c_size_t, _P]),
     "mgp_cg_dist_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int, c_int]),

@@ -29,6 +29,20 @@ extern "C" int mgp_dist_init(int rank, int world, const void* id_bytes, void** c
   return MGP_OK;
 }
 
+// What RCCL itself says about a communicator: its size, this process's rank in it and the HIP device it is bound to
+// (ncclCommCount / ncclCommUserRank / ncclCommCuDevice).  bench.py gathers these from every rank into the N > 1 line
+// (`rccl_ranks`), so that a scale record shows that the collectives ran over the communicator it claims.
+extern "C" int mgp_dist_comm_info(void* comm, int32_t* count, int32_t* user_rank, int32_t* device) {
+  if (!comm || !count || !user_rank || !device) return MGP_ERR_ARG;
+  int c = 0, r = 0, d = 0;
+  ncclResult_t e = ncclCommCount(static_cast<ncclComm_t>(comm), &c);
+  if (e == ncclSuccess) e = ncclCommUserRank(static_cast<ncclComm_t>(comm), &r);
+  if (e == ncclSuccess) e = ncclCommCuDevice(static_cast<ncclComm_t>(comm), &d);
+  if (e != ncclSuccess) return 1000 + (int)e;
+  *count = c; *user_rank = r; *device = d;
+  return MGP_OK;
+}
+
 extern "C" int mgp_dist_destroy(void* comm) {
   if (!comm) return MGP_ERR_ARG;
   ncclResult_t r = ncclCommDestroy(static_cast<ncclComm_t>(comm));

@@ -132,6 +132,23 @@ def init_comm(rank, world):
     return comm
 
 
+def comm_info(comm, world, group=None):
+    """What RCCL reports about libmgp_hip's communicator on EVERY rank, gathered to all (torch.distributed): dict with
+    comm_count / user_rank / device lists indexed by torch rank.  The bench's N > 1 line carries it as `rccl_ranks`: a scale
+    record then shows by itself that the data path ran over an RCCL communicator of the size it claims."""
+    import torch.distributed as dist
+    c, r, d = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(0)
+    check(lib().mgp_dist_comm_info(comm, ctypes.byref(c), ctypes.byref(r), ctypes.byref(d)), "mgp_dist_comm_info")
+    mine = [int(c.value), int(r.value), int(d.value)]
+    if world > 1:
+        allr = [None] * world
+        dist.all_gather_object(allr, mine, group=group)
+    else:
+        allr = [mine]
+    return dict(comm_count=[a[0] for a in allr], user_rank=[a[1] for a in allr], device=[a[2] for a in allr],
+                consistent=all(a[0] == world for a in allr) and sorted(a[1] for a in allr) == list(range(world)))
+
+
 class DistCgPlan:
     """HIP CG over a row-partitioned operator (mgp_cg_plan_create_dist)."""
 
@@ -370,19 +387,23 @@ def virtual_pcg_solve(desc, part, B_pad, tol=1e-6, max_iter=1000, stop_mode=1, c
     return x, res[0], res[1], ghosts
 
 
-def solve_columns_sharded(desc, B, rank, world, group=None, **kw):
+def solve_columns_sharded(desc, B, rank, world, group=None, solver=None, **kw):
     """Independent right-hand sides dealt to the ranks: columns [rank::world] are solved here with the single-GPU
     plan (solvers.cg_solve), the results are all-gathered once.  No collective inside the solves: this is how the
-    multi-column workloads of the path (`_average_variance`, SLQ probes) use several GPUs.  B [n, C] replicated."""
-    from .solvers import cg_solve
+    multi-column workloads of the path (`_average_variance`, SLQ probes) use several GPUs.  B [n, C] replicated; C need
+    not be a multiple of `world` (ranks with one column less send a zero column that nobody reads).
+    solver: callable (desc, B_cols, **kw) -> (X, iterations, residuals), default solvers.cg_solve (the HIP path; the
+    gloo CPU tests pass the oracle's solver to exercise the dealing / gathering on its own)."""
     import torch.distributed as dist
+    if solver is None:
+        from .solvers import cg_solve as solver
     C = B.shape[1]
     mine = list(range(rank, C, world))
     per = -(-C // world)
-    Xl = torch.zeros(B.shape[0], per, device=B.device)
+    Xl = torch.zeros(B.shape[0], per, device=B.device, dtype=B.dtype)
     its = 0
     if mine:
-        X, its, _ = cg_solve(desc, B[:, mine].contiguous(), **kw)
+        X, its, _ = solver(desc, B[:, mine].contiguous(), **kw)
         Xl[:, :len(mine)] = X
     if world == 1:
         return Xl[:, :C], its
@@ -609,6 +630,7 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
                        average_variance=float((Xs * Bm).sum() / columns),
                        how="columns [rank::world] solved with the single-GPU plan on the replicated graph, one all-gather of "
                            "the solutions; time = max over ranks, barriers on both sides")
+    rccl = comm_info(comm, world)          # (collective: every rank takes part)
     if rank == 0:
         how = ("rows AND vectors partitioned over %d ranks, %s, %d ghost rows on rank 0"
                % (world, "Chronopoulos-Gear recurrence: two RCCL collectives per iteration (gathered vector + gamma partials; "
@@ -633,6 +655,7 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
                                   frac=round(value / world / hbm_peak, 4), traffic=None,
                                   note="per-GPU share of the whole-job rate (includes collectives and vector "
                                        "kernels); the kernel-only figure is the N=1 line"))
+        line["rccl_ranks"] = rccl
         if sharded is not None:
             line["cg_multi_rhs_sharded"] = sharded
         line["unmeasured_note"] = ("the partitioned solver has run with more than one RCCL rank only in the driver's scale "

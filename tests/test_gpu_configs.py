@@ -507,6 +507,40 @@ def test_c4_semisupervised_60k_schur(mgp, dev, rmnist60k):
     assert losses[-1] < losses[0]
 
 
+@pytest.mark.parametrize("recurrence", ["pipelined", "chronopoulos-gear"])
+def test_c4_partition_60k_eight_virtual_ranks(mgp, dev, rmnist60k, recurrence):
+    """Config C4's partition at its size (rows AND vectors of the 60k graph over the 8 GPUs of a node)
+    on ONE GPU with 8 VIRTUAL ranks: every rank builds its own row block, ghost layers, tile view and plan exactly as its
+    process of the RCCL job would; the all-gather is the identity on a shared buffer.  Against the single-GPU solve:
+    same solution to round-off, same iteration count, every rank's ghost-row count inside the envelope the partition of
+    this graph gives (measured 13-21 thousand rows for nu = 2: one neighbour layer of a 7 500-row block), padding rows
+    stay zero, true residual of the assembled solution."""
+    from manifold_gp_amd.graph import LaplacianData
+    from manifold_gp_amd.parallel import RowPartition, pad_graph, virtual_pcg_solve
+    from manifold_gp_amd.solvers import cg_solve
+    w = rmnist60k
+    kern, hp, eps, y = w["kern"], w["hp"], w["eps"], w["y"]
+    g = kern.knn.knn_graph
+    world = 8
+    with torch.no_grad():
+        base = kern.precision()._descriptor().with_(scale=hp["outputscale"], form=2, noise=hp["noise"])
+        xs, its1, _ = cg_solve(base, y, tol=1e-6, stop_mode=1)
+        part = RowPartition(g.n, world)
+        assert part.n_loc == 7552 and part.n_pad == 8 * 7552       # whole 64-row tiles per rank: 416 padding rows on the last one
+        gp = pad_graph(g, part.n_pad)
+        data = LaplacianData(gp, eps, True)
+        desc = base.with_(data=data, pre=data.dsqrt, post=data.dsqrt)
+        x, its, status, ghosts = virtual_pcg_solve(desc, part, part.pad(y), tol=1e-6, max_iter=4000, stop_mode=1,
+                                                   recurrence=recurrence)
+        r = base.apply(x[:g.n]) - y
+    print("C4 partition, 8 virtual ranks, %s: %d iterations (one GPU: %d), ghost rows per rank %s" % (recurrence, its, its1, ghosts))
+    assert status == 1 and abs(its - its1) <= 1
+    assert len(ghosts) == world and all(5000 <= gh <= 30000 for gh in ghosts), ghosts
+    assert float(x[g.n:].abs().max()) == 0.0                                 # padding rows: b = 0 -> x = 0
+    assert float((x[:g.n] - xs.view(-1)).abs().max()) < 2e-4 * float(xs.abs().max())
+    assert float(r.norm() / y.norm()) < 2e-5
+
+
 # ============================================================================= C5
 def test_c5_swiss_roll_1m_pipeline(mgp, dev):
     """C5: 1 000 000 points on a swiss roll in R^3 handed over in random order, k = 64, symmetric, nu = 2.

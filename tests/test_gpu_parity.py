@@ -2444,12 +2444,15 @@ def test_pcg_rccl_world1_and_sharded_columns(mgp, golden, dev):
     """The RCCL path with a communicator of size 1: the grouped in-place all-gathers are issued (and captured in the
     iteration graph) all the same; iterates equal the communicator-free plan bit for bit.  Plus the column-sharded
     multi-right-hand-side helper at world 1."""
-    from manifold_gp_amd.parallel import PcgPlan, init_comm, solve_columns_sharded
+    from manifold_gp_amd.parallel import PcgPlan, comm_info, init_comm, solve_columns_sharded
     from manifold_gp_amd.solvers import cg_solve
     g = golden("dumbbell_k50_noloop")
     desc, dd, part = _padded_descriptor(mgp, g, dev, "randomwalk", 2, 2, 1)
     y = part.pad(T(g["train_y"], dev))
     comm = init_comm(0, 1)
+    # what RCCL itself reports about the communicator (the bench's N > 1 line carries this per rank as `rccl_ranks`)
+    info = comm_info(comm, 1)
+    assert info["comm_count"] == [1] and info["user_rank"] == [0] and info["device"] == [dev.index or 0] and info["consistent"]
     for rec in ("pipelined", "chronopoulos-gear"):
         a = PcgPlan(dd, part, 0, comm=comm, tol=1e-6, max_iter=20000, stop_mode=1, recurrence=rec)
         b = PcgPlan(dd, part, 0, comm=None, tol=1e-6, max_iter=20000, stop_mode=1, recurrence=rec)

@@ -219,6 +219,67 @@ def test_partitioned_pipelined_cg_world2_gloo(golden):
     assert np.abs(out["x"] - ref).max() < 1e-8 * np.abs(ref).max(), np.abs(out["x"] - ref).max() / np.abs(ref).max()
 
 
+def _worker_sharded(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from manifold_gp_amd.parallel import solve_columns_sharded
+        from oracle.laplacian import LaplacianOracle
+        from oracle.sparse import SparsePrecision
+        g = dict(np.load(os.path.join(ROOT, "tests", "golden", "dumbbell_k10_loop.npz")))
+        n = g["train_x"].shape[0]
+        lap = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "randomwalk", True, dtype=np.float64)
+        sq = SparsePrecision(lap, 2, float(g["kappa"]), 0.7)
+        calls = []
+
+        def oracle_solver(desc, Bc, **kw):             # stands for solvers.cg_solve: the float64 oracle CG, column by column
+            calls.append(Bc.shape[1])
+            X = sq.solve(Bc.numpy(), matvec=lambda z: sq.posterior_system(z, 1e-2), tol=1e-12)
+            return torch.from_numpy(X), 7 + rank, [0.0] * Bc.shape[1]
+
+        rng = np.random.default_rng(3)
+        B = torch.from_numpy(rng.normal(size=(n, 5)))                  # 5 columns over 2 ranks: 3 + 2
+        X, its = solve_columns_sharded(None, B, rank, world, solver=oracle_solver)
+        xs = [torch.empty_like(X) for _ in range(world)]
+        dist.all_gather(xs, X)
+        if rank == 0:
+            q.put(dict(ok=True, same=all(torch.equal(xs[0], t) for t in xs), X=X.numpy(), B=B.numpy(), calls=calls, its=its))
+    except Exception as e:  # pragma: no cover
+        if rank == 0:
+            q.put(dict(ok=False, err=repr(e)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_columns_world2_gloo_with_a_column_count_not_divisible_by_the_world(golden):
+    """parallel.solve_columns_sharded (the multi-right-hand-side workloads' way of using several GPUs: columns dealt
+    round-robin, one all-gather of the solutions) under gloo with two processes and FIVE columns: rank 0 solves columns
+    0, 2, 4, rank 1 columns 1, 3 and sends a zero pad column; every rank ends with all five solutions in place."""
+    from oracle.laplacian import LaplacianOracle
+    from oracle.sparse import SparsePrecision
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+    assert out["ok"], out.get("err")
+    assert out["same"] and out["calls"] == [3] and out["its"] == 7
+    g = golden("dumbbell_k10_loop")
+    n = g["train_x"].shape[0]
+    lap = LaplacianOracle(g["edge_value"], g["edge_index"], n, float(g["eps"]), "randomwalk", True, dtype=np.float64)
+    sq = SparsePrecision(lap, 2, float(g["kappa"]), 0.7)
+    R = sq.posterior_system(out["X"], 1e-2) - out["B"]
+    assert np.abs(R).max() < 1e-9 * np.abs(out["B"]).max()
+
+
 def test_ghost_layers_and_rank_order_on_cpu_tensors():
     """parallel.ghost_layers is index bookkeeping: on a path graph with two extra chords the layers of a row block
     are its successive neighbour shells."""
