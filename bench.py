@@ -473,7 +473,7 @@ def _main(quiet):
                        ("spmv_kernel<%d,1,false,false,256> (fused CSR SpMV, C=1, %d lanes per row)" % (g.spmv_lanes, g.spmv_lanes)),
                 bytes_per_launch=B, avg_launch_us=round(t_k * 1e6, 2),
                 note=("working set %.0f MB is Infinity-Cache resident: the 8 TB/s HBM peak is NOMINAL for this launch (counter "
-                      "traffic is served by the cache; the kernel is latency-bound, DESIGN.md section 6) -- the HBM figure is "
+                      "traffic is served by the cache; the kernel is latency-bound, docs/measurement.md) -- the HBM figure is "
                       "roofline_hbm.frac (1M-node graph, streams from HBM)"
                       if B < 2.5e8 else "working set %.0f MB streams from HBM") % (B / 1e6))
     # HBM bytes per launch from the PMC passes of the same command (tools/profile.sh -> tools/summarize_profile.py):

@@ -1244,7 +1244,7 @@ int g_cg_reduce_once = 1;   // mgp_cg_set_reduce_once(0): every update workgroup
 int g_cg_poll_spin = 64;    // flag reads between two looks at the clock in the flag-only poll window; 0: no such window (mgp_cg_set_poll_spin)
 int g_cg_init_free = 1;   // C == 1 plans start without a cg_init launch (mgp_cg_set_init_free(0): classic start)
 int g_cg_decide_in_update = 1;   // the first graph's last update decides + marks (mgp_cg_set_decide_in_update(0): separate launches)
-int g_cg_fuse = 0;   // measured at N = 60k: step 16.3 us fused vs 16.3 us unfused -- off until it wins
+int g_cg_fuse = 0;   // measured at N = 60k: step 16.3 us fused vs 16.3 us unfused -- off until it wins (docs/kernels/cg.md)
 
 // one CG step = operator apply (w = A u, partials of u . w, ticks the iteration counter; skipped once
 // converged) followed by the fused update kernel, which also takes the stopping decision: every

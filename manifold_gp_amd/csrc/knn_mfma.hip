@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
 #endif
 }
 
-// Tried in round 2 and removed (tools/lab notes in DESIGN.md section 4): a 256 x 128 tile shared by eight waves with a
+// Tried in round 2 and removed (docs/kernels/knn.md): a 256 x 128 tile shared by eight waves with a
 // three-stage LDS ring (144 KB, one workgroup per CU; copies requested two stages ahead, the next stage's fragments read
 // into a second register set during the MFMAs, three separate __shared__ arrays so that the compiler's LDS-DMA alias
 // check lets copies stay in flight across a stage), also as a persistent kernel.  Bit-identical keys, 131 instead of 98

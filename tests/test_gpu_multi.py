@@ -1,6 +1,6 @@
 """More than one GPU: the partitioned solvers over real RCCL, one process per GPU, against the
 single-GPU solve.  Skipped on a one-GPU box -- which is all the build box ever offered, so this test has NOT run on
-hardware yet (DESIGN.md section 5 marks every N > 1 statement accordingly)."""
+hardware yet (docs/multi_gpu.md marks every N > 1 statement accordingly)."""
 import os
 import socket
 import subprocess

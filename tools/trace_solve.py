@@ -1,11 +1,13 @@
 #!/usr/bin/env python
 """Print the kernel timeline of the last CG solve in a rocprofv3 --kernel-trace CSV: start offset, duration, gap to the
-previous kernel, name.  The solve is located by its closing cg_decide launch (or, for the classic start, cg_init)."""
+previous kernel, name.  The solve is located by its closing decision launch (the deciding update, or cg_decide in older traces)."""
 import csv, glob, os, re, sys
 base = sys.argv[1]
 f = max(glob.glob(base + "/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-end = max(i for i, r in enumerate(rows) if "cg_decide" in r["Kernel_Name"] or "cg_update" in r["Kernel_Name"])
+# (round 4: a solve's first graph ends in the deciding update launch, cg_update_c1_kernel<true, ..>; older traces: cg_decide)
+dec = [i for i, r in enumerate(rows) if "cg_update_c1_kernel<true" in r["Kernel_Name"] or "cg_decide" in r["Kernel_Name"]]
+end = dec[-1] if dec else max(i for i, r in enumerate(rows) if "cg_update" in r["Kernel_Name"])
 # walk back to the start of that solve: the gap before its first kernel is a host round trip (>= 8 us)
 start = end
 while start > 0 and int(rows[start]["Start_Timestamp"]) - int(rows[start - 1]["End_Timestamp"]) < 8000:
