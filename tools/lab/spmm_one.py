@@ -1,4 +1,4 @@
-"""Lab: one SpMM configuration on the C3 graph, 40 launches (for PMC passes): spmm_one.py <C> <v4 mode 0/2> [wide 0/2] [dict 0/2]"""
+"""Lab: one SpMM configuration on the C3 graph, 40 launches (for PMC passes): spmm_one.py <C> <v4 mode 0/2> [wide 0/2] [dict 0/2] [dict8 0/1]"""
 import ctypes, os, sys, argparse
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
@@ -11,6 +11,7 @@ lib = _lib.lib(); lib.mgp_spmm_set_group_hint(g.spmv_lanes)
 csr = lap.data.csr()
 C = int(sys.argv[1]); lib.mgp_spmm_set_v4_mode(int(sys.argv[2])); lib.mgp_spmm_set_tile_wide_mode(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 lib.mgp_spmm_set_dict_mode(int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+lib.mgp_spmm_set_dict8_mode(int(sys.argv[5]) if len(sys.argv) > 5 else 0)
 X = torch.randn(g.n, C, device=dev); Y = torch.empty_like(X)
 ms = ctypes.c_float(0.0)
 _lib.check(lib.mgp_spmm_repeat(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y), 40, ctypes.byref(ms), _lib.stream()), "repeat")
