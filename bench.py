@@ -89,6 +89,15 @@ def build_workload(args, dev, rank, world, shard_knn=False, scale_nodes=True):
         raise SystemExit("unknown workload " + args.workload)
     t_data = time.time() - t0
     x, y = x_t, y_t
+    if shard_knn and args.workload == "s5" and args.s5_order == "random":
+        # the row partition of the multi-GPU solvers cuts the node order into contiguous blocks: on an order without locality
+        # every block's ghost layer would be the whole graph.  The single-GPU solvers relabel internally (solvers.CgPlan); the
+        # partitioned job relabels the PROBLEM: points and targets permuted into the library's locality order (the Z-curve,
+        # mgp_morton_order) before the graph is built -- the solution is then reported in that order
+        from manifold_gp_amd.graph import morton_order
+        order = morton_order(x).long()
+        x, y = x.index_select(0, order).contiguous(), y.index_select(0, order).contiguous()
+        name += " -> relabelled by the library's Z-curve for the row partition"
     torch.cuda.synchronize()
     t0 = time.time()
     knn = mgp.utils.NearestNeighbors(x)
