@@ -281,6 +281,13 @@ class PcgPlan:
         the TRUE residual (csrc/pcg.hip, "Attainable accuracy"); a refined solve reports status 1 once the true relative
         residual is <= 2 tol (its fp32 evaluation scatters by about that factor around the tolerance; `resid` holds the
         value reached); status 4 = the recurrence stagnated (no refinement)."""
+        g0 = desc.data.graph
+        if part.world > 1 and getattr(g0, "has_locality_order", lambda: False)():
+            # the row partition cuts the node order into contiguous blocks: on an order without locality (the library had to
+            # pick a locality order for this graph's tiles) every block's ghost layer is most of the graph.  Correct, slow.
+            import warnings
+            warnings.warn("partitioned CG over a node order without locality: permute the points into a locality order "
+                          "(graph.morton_order / bfs_order) before building the graph, as bench.py does for --s5-order random")
         self.pop = PartitionedOperator(desc, part, rank)
         self.part, self.rank = part, rank
         dev = desc.data.graph.device
