@@ -458,10 +458,14 @@ int mgp_features_oos(const float* evals_dev, const float* evecs, int64_t n, int 
                      int k, float bump_scale, float bump_decay, float* Z, void* stream);
 int mgp_kernel_block(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale,
                      float* K, void* stream);
-/* A/B and test knob: 0 / 1 (default) = one 128x128 tile per workgroup, by the lean kernel (single-instruction staging loads,
- * 16-byte stores) where the operands allow it (n1, n2 >= 128, m and n2 multiples of 4, 16-byte aligned) and by the general
- * one elsewhere; 2 = where they allow it, one 512-thread workgroup per CU whose two halves walk tiles and take turns on the
- * matrix pipe; 3 = as 2 with every store dropped (timing only); 4 = the general kernel always. */
+/* K = scale * Z1 Z2^T on the fp32 MFMA.  Which kernel runs (A/B and test knob; results agree to fp32 rounding, the three
+ * LDS kernels bit for bit with each other): 0 (default) = by shape: the resident-operand kernel where the operands allow it
+ * (16 <= m <= 128, m and n2 multiples of 4, n1 >= 64, n2 >= 32, 16-byte aligned: a wave keeps 64 rows of Z1 in registers and
+ * streams Z2, no LDS), else the lean one-tile kernel, else the general one; 1 = one 128x128 tile per workgroup, by the lean
+ * kernel (single-instruction staging loads, 16-byte stores) where the operands allow it (n1, n2 >= 128, m and n2 multiples of
+ * 4, 16-byte aligned) and by the general one elsewhere; 2 = where they allow it, one 512-thread workgroup per CU whose two
+ * halves walk tiles and take turns on the matrix pipe; 3 = as 2 with every store dropped (timing only); 4 = the general kernel
+ * always; 5 = as 0; 6 = as 5 with every store dropped (timing only). */
 int mgp_kernel_block_set_pipe(int mode);
 int mgp_kernel_diag(const float* Z1, const float* Z2, int64_t n, int m, float scale, float* out,
                     void* stream);

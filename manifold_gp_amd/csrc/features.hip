@@ -626,6 +626,178 @@ __global__ __launch_bounds__(kBlock, 4) void kernel_block_one(const float* __res
   kb_store_done();
 }
 
+constexpr int kKbResStores = 16;   // store instructions per 32-row block: one dword per accumulator register
+
+// kernel_block_res: loads of quads J0 .. J1 - 1 of the streamed operand (inline asm: see the kernel), the wait in front of their use,
+// and the groups of a block in their order (ragged last group first).  NRB = 32-row blocks of Z1 the wave holds (2, or 1 for
+// the wave of a short last row group: ONE chain of MFMAs in the same order as a full group's, because the rows it shares with
+// the group before it -- it is moved back to end at n1 -- are written by both waves and must get the same bits from both;
+// split over two accumulators, even / odd steps, the shared rows came out different by a rounding from run to run).
+template <int J, int J0, int J1>
+__device__ __forceinline__ void kb_res_loads(f32x4 (&sb)[J], int off, __amdgpu_buffer_rsrc_t rs) {
+  if constexpr (J0 < J1) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen offset:%3" : "=v"(sb[J0]) : "v"(off), "s"(rs), "n"(32 * J0));
+    kb_res_loads<J, J0 + 1, J1>(sb, off, rs);
+  }
+}
+template <int J0, int J1, int N, int J>
+__device__ __forceinline__ void kb_res_wait(f32x4 (&sb)[J]) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sb[J0]) : "n"(N));
+#pragma unroll
+  for (int j = J0 + 1; j < J1; ++j) asm volatile("" : "+v"(sb[j]));
+}
+template <int J, bool ODD, int NRB, int GI>
+__device__ __forceinline__ void kb_res_groups(f32x4 (&sb)[J], const f32x4 (&ra)[NRB][J], f32x16& acc0, f32x16& acc1, int offn,
+                                              __amdgpu_buffer_rsrc_t rs, int h, f32x4 zero4) {
+  constexpr int NG = (J + 3) / 4;
+  if constexpr (GI < NG) {
+    constexpr int grp = (GI + NG - 1) % NG, j0 = 4 * grp, j1 = j0 + 4 < J ? j0 + 4 : J;
+    kb_res_wait<j0, j1, J - (j1 - j0) + kKbResStores * NRB>(sb);
+    if constexpr (ODD && j1 == J) sb[J - 1] = h ? zero4 : sb[J - 1];
+#pragma unroll
+    for (int j = j0; j < j1; ++j) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[0][j][e], sb[j][e], acc0, 0, 0, 0);
+        if constexpr (NRB == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[1][j][e], sb[j][e], acc1, 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    kb_res_loads<J, j0, j1>(sb, offn, rs);
+    __builtin_amdgcn_sched_barrier(0);
+    kb_res_groups<J, ODD, NRB, GI + 1>(sb, ra, acc0, acc1, offn, rs, h, zero4);
+  }
+}
+
+// one wave's walk over the column blocks [b0, b1) for the NRB row blocks that start at row0
+template <int Q, int NRB>
+__device__ __forceinline__ void kb_res_walk(const float* __restrict__ Z1, int64_t n1, const float* __restrict__ Z2, int64_t n2,
+                                            float scale, float* __restrict__ K, int64_t ldk, int64_t row0, int b0, int b1,
+                                            int records) {
+  constexpr int J = (Q + 1) / 2, m = 4 * Q;
+  constexpr bool ODD = (Q & 1) != 0;
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z1), (short)0, (int)(n1 * m * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Z2), (short)0, (int)(n2 * m * 4), 0x00020000);
+#ifdef MGP_KB_STORE_WINDOW
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(records == 0 ? K : K + row0 * ldk, (short)0,
+                                                                       records == 0 ? 2048 * 8192 : (int)(((32 * NRB - 1) * ldk + n2) * 4), 0x00020000);
+#else
+  const int kext = records == 0 ? 0 : (int)(((32 * NRB - 1) * ldk + n2) * 4);
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(K + row0 * ldk, (short)0, kext, 0x00020000);
+#endif
+
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 ra[NRB][J];
+  f32x4 sb[J];
+  const int last_col0 = (int)n2 - 32;
+  auto col_of = [&](int b) { return b * 32 > last_col0 ? last_col0 : b * 32; };
+  auto z2_off = [&](int col0) { return ((col0 + c) * m + 4 * h) * 4; };         // host side: n2 m < 2^29
+  // prologue: the resident operand and the first block's streamed operand in ONE round trip (all inline asm: compiler-visible
+  // loads of Z1 were sunk below the streamed operand's wait -- two round trips in a row)
+#pragma unroll
+  for (int i = 0; i < NRB; ++i) kb_res_loads<J, 0, J>(ra[i], (int)(((row0 + 32 * i + c) * m + 4 * h) * 4), rs1);
+  kb_res_loads<J, 0, J>(sb, z2_off(col_of(b0)), rs2);
+  kb_res_wait<0, J, 0>(sb);
+#pragma unroll
+  for (int i = 0; i < NRB; ++i) {
+    kb_res_wait<0, J, 0>(ra[i]);
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      if (ODD && j == J - 1) ra[i][j] = h ? zero4 : ra[i][j];
+      ra[i][j] *= scale;
+    }
+  }
+  // The streamed operand's loads are inline asm with the kernel's own vmcnt waits (as in kernel_block_pp): as compiler-visible
+  // loads every block began with `s_waitcnt vmcnt(1)` / `vmcnt(0)` -- the wait-count pass merges the loop's back edge with the
+  // prologue's pending loads and takes the stricter count -- i.e. with a wait for the previous block's last load AND its
+  // stores.  Quads go in groups of four (the loads of a group share cache lines and are issued together), the ragged last
+  // group first: a block's memory operations are then  L(g_0) ... L(g_last) S x 4 NRB,  each L(g) right behind the MFMAs that
+  // read g's registers for the last time, and in front of group g's MFMAs of the next block exactly J - |g| loads and 4 NRB
+  // stores are younger than L(g): `vmcnt(J - |g| + 4 NRB)` waits for L(g) and for nothing issued after it (the vector memory
+  // operations of one wave complete in order on gfx9, loads and stores alike: the compiler's own wait counts rely on it).
+#ifdef MGP_KB_STORE_WINDOW
+  const int row_k = records == 0 ? 128 : (int)ldk * 4;
+#else
+  const int row_k = (int)ldk * 4;                       // bytes per row of K
+#endif
+  const int lane_k = 4 * h * row_k + c * 4;
+  for (int b = b0; b < b1; ++b) {
+    const int col0 = col_of(b);
+    const int offn = z2_off(col_of(b + 1 < b1 ? b + 1 : b));
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc0[e] = 0.f, acc1[e] = 0.f;
+    kb_res_groups<J, ODD, NRB, 0>(sb, ra, acc0, acc1, offn, rs2, h, zero4);
+    // register r of acc_i (Z1 is the MFMA's first operand): row row0 + 32 i + 8 (r / 4) + 4 h + r % 4, column col0 + c -- a dword
+    // store per register writes two full 128-byte lines (h = 0, 1), non-temporal like the general kernel's.  The row part
+    // goes into the vector offset (one VALU add per store, in the other wave's shadow), not into the scalar offset, which
+    // the descriptor's range check does not see.
+#ifdef MGP_KB_STORE_WINDOW
+    // lab build (tools/lab/build_kb_variant.sh window -DMGP_KB_STORE_WINDOW): with knob 6 the stores are not dropped but land in a
+    // private 8 KB window per wave at the start of K, which stays in L2 -- the store instructions without their HBM traffic
+    const int okd = records == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8192 + (4 * h * 32 + c) * 4 : lane_k + col0 * 4;
+#else
+    const int okd = lane_k + col0 * 4;
+#endif
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ro = (8 * (r / 4) + r % 4) * row_k;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc0[r]), rsk, okd + ro, 0, 2);
+      if constexpr (NRB == 2) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc1[r]), rsk, okd + ro + 32 * row_k, 0, 2);
+    }
+    __builtin_amdgcn_sched_barrier(0);     // the waits above count these stores: none may move into the next block
+  }
+}
+
+// The kernel block at m <= 128 modes (C3's posterior block: 600 x 60000, m = 100) without LDS and without barriers.  The modes of
+// a 64-row group of Z1 are m registers per lane: a wave keeps them RESIDENT (scaled once), streams 32-row blocks of Z2 straight
+// from global memory into the MFMA operand layout and owns a 64 x 32 piece of K per block -- 2 x 4J MFMAs = 6656 cycles of the
+// pipe at m = 100, in which it issues 13 loads and 32 stores and waits for nothing: the streamed operand of block b + 1 is
+// loaded into the registers block b's MFMAs have just read for the last time (four quads at a time, so that the four loads
+// that share cache lines are issued together), one and a half thousand cycles and more before its first use.  Waves are
+// independent; two per SIMD cover each other's store phases.  Measured at 600 x 60000 x 100 (tools/lab/kblock_shapes.py,
+// tools/lab/pmc_kbres.sh): 79 us against the lean LDS kernel's 100 on the same box, 68 with every store dropped, matrix pipe
+// busy 48 us (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs at 2.4 GHz).
+//  * Z1 is the MFMA's first operand, so accumulator register r of lane (c, h) is row 8 (r / 4) + 4 h + r % 4, column c of the
+//    32 x 32 block: a dword store per register writes two full 128-byte lines.  (With Z2 first a lane holds four consecutive
+//    columns of one row and a block leaves in 8 stores of 16 bytes per lane = 32 pieces of 32 bytes each: 4 % slower here.)
+//  * operand layout: lane (c = lane & 31, h = lane >> 5) holds quads 2 j + h of "its" row, so MFMA step 4 j + e multiplies modes
+//    (8 j + e, 8 j + 4 + e): a 16-byte load per lane per quad, no transposition.  Not the (2 s, 2 s + 1) pairing of the LDS kernels:
+//    the sum over modes is taken in another order and `scale` multiplies Z1 instead of the sum -- same value to fp32 rounding,
+//    not the same bits (the parity test holds it to the fp64 product like the others and to the lean kernel at the same bound).
+//  * an odd quad count (m = 100: 25) leaves quad 2 J - 1 of the h = 1 lanes past the row: both operands are zeroed there (the
+//    address itself is inside the operand or dropped by the descriptor).
+//  * work: G = ceil(n1 / 64) row groups; when the last group has 32 rows or fewer it is ONE row block (600 rows: 9 groups + 24
+//    rows -> 19 row blocks of MFMA work instead of 20), and its wave walks twice as many column blocks.  The column blocks are
+//    cut into S super-ranges; in each, every full group has two waves (a half each) and a short last group one wave: wave
+//    w -> (s = w / WT, k = w % WT), WT = waves per super-range.  The waves of a super-range run side by side (same workgroups,
+//    same XCD: logical workgroup ids are dealt to XCDs in runs) and read Z2 once from HBM between them.  Edge groups / blocks
+//    are moved back to end at n1 / n2 like the lean kernels' tiles.
+//  * every address goes through a descriptor of the operand's exact extent (Z1, Z2) or of the row group's rows of K.
+template <int Q>
+__global__ __launch_bounds__(kBlock, 2) void kernel_block_res(const float* __restrict__ Z1, int64_t n1,
+                                                              const float* __restrict__ Z2, int64_t n2, float scale,
+                                                              float* __restrict__ K, int64_t ldk, int G, int S, int nblk,
+                                                              int short_last, int records) {
+  const int nwg = (int)gridDim.x;                       // host side: a multiple of 8
+  const int lb = ((int)blockIdx.x & 7) * (nwg >> 3) + ((int)blockIdx.x >> 3);
+  const int w = __builtin_amdgcn_readfirstlane(lb * (kBlock / 64) + (int)(threadIdx.x >> 6));
+  const int WT = 2 * G - short_last;
+  if (w >= WT * S) return;
+  const int s = w / WT, k = w % WT;
+  const int s0 = (int)((unsigned)s * (unsigned)nblk / (unsigned)S);            // host side: S nblk < 2^31
+  const int s1 = (int)((unsigned)(s + 1) * (unsigned)nblk / (unsigned)S);
+  const int mid = (s0 + s1 + 1) >> 1;
+  if (short_last && k == WT - 1) {
+    kb_res_walk<Q, 1>(Z1, n1, Z2, n2, scale, K, ldk, n1 - 32, s0, s1, records);
+  } else {
+    int64_t row0 = (int64_t)(k >> 1) * 64;
+    if (row0 + 64 > n1) row0 = n1 - 64;
+    kb_res_walk<Q, 2>(Z1, n1, Z2, n2, scale, K, ldk, row0, (k & 1) ? mid : s0, (k & 1) ? s1 : mid, records);
+  }
+}
+
 __global__ void kernel_diag_kernel(const float* __restrict__ Z1, const float* __restrict__ Z2, int64_t n, int m,
                                    float scale, float* __restrict__ out) {
   // one 16-lane group per row
@@ -756,11 +928,20 @@ constexpr int kPpBlocks = 256;     // one 512-thread workgroup per CU, two tile 
 //   4096 x 60000 x 100 (15008)       628 | 493 | 544      8192 x 8192 x 256 (4096)     300 | 280 | 283
 //   600 x 60000 x 128                120 | 123 | 119      32768 x 60000 x 128 (120064) 4829 | 4761 | 4609
 // (clock 2.31 GHz on random operands, 2.39 on zeros: the chip does not hold its clock down here; with the stores dropped the
-// walk reaches 127-129 TFLOP/s.)  The lean one-tile kernel is the default wherever its conditions hold; the walk is a knob:
-// it wins a few per cent on the largest blocks only, its static split loses to the hardware's own dispatch of 2000-4000 tiles.
-// 0 / 1 = lean one tile per workgroup where the operands allow it (default), 2 = the two-half walk where they allow it,
+// walk reaches 127-129 TFLOP/s.)  Among the LDS kernels the lean one-tile kernel is taken wherever its conditions hold; the walk is
+// a knob: it wins a few per cent on the largest blocks only, its static split loses to the hardware's dispatch of 2000-4000 tiles.
+// Round 4, the resident-operand kernel (tools/lab/kblock_shapes.py res, us: lean | resident, same box, back to back):
+//   600 x 60000 x 100     99.8 |  79.4      600 x 60000 x 52     72.5 |  49.6      1000 x 50000 x 64    84.9 |  63.7
+//   600 x 60000 x 124    103.4 |  81.3      600 x 60000 x 128   104.9 |  83.7      4096 x 60000 x 128  612.2 | 507.8 (124 TFLOP/s)
+//   8192 x 60000 x 100  1012.6 | 881.0      20000 x 20000 x 88  798.4 | 637.6      64 x 60000 x 100     21.1 |  13.1
+// It is faster at every shape it admits (16 <= m <= 128, multiples of 4), so the default takes it wherever it applies.
+// 0 = by shape (default): the resident-operand kernel where the operands allow it, else the lean one-tile kernel, else the
+// general one; 1 = lean one tile per workgroup where the operands allow it, 2 = the two-half walk where they allow it,
 // 3 = as 2 with every store dropped (timing), 4 = the general kernel always (kernel_block_mfma: any shape, any alignment)
-int g_kblock_pipe = 1;
+// 5 = as 0 (the resident-operand kernel, kernel_block_res, where the operands allow it), 6 = as 5 with every store dropped (timing)
+int g_kblock_pipe = 0;
+constexpr int kResMinModes = 16, kResMaxModes = 128;
+constexpr int kResWaves = 2048;    // 256 CUs x 4 SIMDs x 2 waves: every wave of kernel_block_res is resident from the start
 
 // K row stride ldk >= n2 (internal: the eigensolver rotates blocks in place of wider buffers)
 int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale, float* K,
@@ -774,6 +955,38 @@ int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2
   const bool lean = x4 && g_kblock_pipe != 4 && n1 >= kKB && n2 >= kKB && ldk * 512 < (int64_t(1) << 31) &&
                     ntiles < (int64_t(1) << 30) && n1 * m < (int64_t(1) << 29) && n2 * m < (int64_t(1) << 29);
   const bool walk = g_kblock_pipe == 2 || g_kblock_pipe == 3;
+  // the resident-operand kernel: 16 <= m <= 128 (4..32 quads: Z1's 64-row group in 4 ceil(Q / 2) x 2 registers, 245 VGPRs at m = 128),
+  // n1 >= 64, n2 >= 32
+  const int64_t G = mgp_cdiv(n1, 64), nblk = mgp_cdiv(n2, 32);
+  const bool res_ok = x4 && m >= kResMinModes && m <= kResMaxModes && n1 >= 64 && n2 >= 32 && 2 * G <= kResWaves && ldk * 512 < (int64_t(1) << 31) &&
+                      n1 * m < (int64_t(1) << 29) && n2 * m < (int64_t(1) << 29);
+  const bool res = res_ok && (g_kblock_pipe == 0 || g_kblock_pipe == 5 || g_kblock_pipe == 6);
+  if (res) {
+    // a last group of 32 rows or fewer is one row block (n1 >= 64: it is moved back to end at n1)
+    const int short_last = (n1 - (G - 1) * 64 <= 32 && G > 1) ? 1 : 0;
+    const int64_t WT = 2 * G - short_last;
+    // two waves per SIMD whatever the register count (m <= 48 would admit four: measured, no gain -- those blocks are bound
+    // by their stores)
+    const int64_t S = std::max<int64_t>(1, std::min<int64_t>((nblk + 1) / 2, kResWaves / WT));
+    const int64_t nwg = (mgp_cdiv(WT * S, kBlock / 64) + 7) / 8 * 8;
+    const int records = g_kblock_pipe == 6 ? 0 : 1;
+#define MGP_KB_LAUNCH(Q)                                                                                                    \
+  case Q:                                                                                                                   \
+    hipLaunchKernelGGL(kernel_block_res<Q>, dim3((unsigned)nwg), dim3(kBlock), 0, mgp_stream(stream), Z1, n1, Z2, n2, scale, K, ldk, \
+                       (int)G, (int)S, (int)nblk, short_last, records);                                                     \
+    break
+    switch (m / 4) {
+      MGP_KB_LAUNCH(4); MGP_KB_LAUNCH(5); MGP_KB_LAUNCH(6); MGP_KB_LAUNCH(7); MGP_KB_LAUNCH(8); MGP_KB_LAUNCH(9);
+      MGP_KB_LAUNCH(10); MGP_KB_LAUNCH(11); MGP_KB_LAUNCH(12); MGP_KB_LAUNCH(13); MGP_KB_LAUNCH(14); MGP_KB_LAUNCH(15);
+      MGP_KB_LAUNCH(16); MGP_KB_LAUNCH(17); MGP_KB_LAUNCH(18); MGP_KB_LAUNCH(19); MGP_KB_LAUNCH(20); MGP_KB_LAUNCH(21);
+      MGP_KB_LAUNCH(22); MGP_KB_LAUNCH(23); MGP_KB_LAUNCH(24); MGP_KB_LAUNCH(25); MGP_KB_LAUNCH(26); MGP_KB_LAUNCH(27);
+      MGP_KB_LAUNCH(28); MGP_KB_LAUNCH(29); MGP_KB_LAUNCH(30); MGP_KB_LAUNCH(31); MGP_KB_LAUNCH(32);
+      default: return MGP_ERR_ARG;
+    }
+#undef MGP_KB_LAUNCH
+    MGP_LAUNCH_CHECK();
+    return MGP_OK;
+  }
   if (lean && walk) {
     // tile id = column tile * row tiles + row tile, so the tiles in flight together share their Z2 rows
     const int64_t nb = (ntiles + 1) / 2 < kPpBlocks ? (ntiles + 1) / 2 : kPpBlocks;
@@ -817,7 +1030,7 @@ extern "C" int mgp_kernel_block(const float* Z1, int64_t n1, const float* Z2, in
 }
 
 extern "C" int mgp_kernel_block_set_pipe(int mode) {
-  if (mode < 0 || mode > 4) return MGP_ERR_ARG;    // 3 (lab): the walk with every store dropped; 4: as 0 with the general kernel
+  if (mode < 0 || mode > 6) return MGP_ERR_ARG;    // 0: by shape (default); 1: lean one-tile; 2, 3: walk; 4: general; 5, 6: resident
   g_kblock_pipe = mode;
   return MGP_OK;
 }

@@ -614,10 +614,11 @@ def test_kernel_block_mfma_layout(mgp, dev):
 @pytest.mark.parametrize("n1,n2,m", [(128, 256, 16), (131, 260, 8), (300, 1028, 36), (517, 388, 100), (256, 640, 48),
                                      (200, 132, 60), (384, 384, 128), (129, 129 * 4, 12)])
 def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, m):
-    """mgp_kernel_block's three kernels on the same operands: the general one (knob 4), the lean one-tile-per-workgroup one (0)
+    """mgp_kernel_block's three LDS kernels on the same operands: the general one (knob 4), the lean one-tile-per-workgroup one (1)
     and the two-half tile walk (2): every ragged last stage m % 16 in {0, 4, 8, 12}, single-stage m, last row / column tiles
     moved back over their neighbours, odd tile counts so that one half has a tile less.  Both against fp64, and bit-identical to each other (same
-    operands, same summation order); a NaN canary catches an entry nobody wrote."""
+    operands, same summation order); a NaN canary catches an entry nobody wrote.  The default (knob 0) picks among these and the
+    resident-operand kernel by shape: same bound against fp64."""
     from manifold_gp_amd import _lib
     lib = _lib.lib()
     g = torch.Generator(device="cpu").manual_seed(n1 * 7 + n2 * 3 + m)
@@ -626,7 +627,7 @@ def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, 
     ref = 1.7 * (Z1.double() @ Z2.double().t())
     outs = []
     try:
-        for knob in (4, 0, 2):
+        for knob in (4, 1, 2, 0):
             assert lib.mgp_kernel_block_set_pipe(knob) == 0
             K = torch.full((n1, n2), float("nan"), device=dev)
             for _ in range(3):          # back to back: a launch must not depend on what the one before left in LDS / registers
@@ -636,7 +637,7 @@ def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, 
             assert float((K.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max()) * max(1.0, m / 16) ** 0.5 + 1e-6, knob
             outs.append(K)
     finally:
-        lib.mgp_kernel_block_set_pipe(1)
+        lib.mgp_kernel_block_set_pipe(0)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     assert lib.mgp_kernel_block_set_pipe(7) != 0
     if n2 % 4 == 0:                     # knob 3 (timing arm): the walk with a zero-byte descriptor writes nothing
@@ -647,7 +648,59 @@ def test_kernel_block_two_half_walk_vs_one_tile_per_workgroup(mgp, dev, n1, n2, 
             torch.cuda.synchronize()
             assert bool(torch.isnan(K).all())
         finally:
-            lib.mgp_kernel_block_set_pipe(1)
+            lib.mgp_kernel_block_set_pipe(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n1,n2,m", [(600, 20004, 100), (64, 70000, 104), (130, 40000, 76), (2072, 8200, 52), (517, 388, 100),
+                                     (200, 132, 60), (600, 60000, 100), (64, 32, 56), (1000, 6400 + 36, 96), (300, 9000, 16), (200, 70000, 36),
+                                     (600, 12000, 128), (256, 5000, 112), (90, 40000, 124)])
+def test_kernel_block_resident_operand_kernel(mgp, dev, n1, n2, m):
+    """kernel_block_res (knob 5: Z1's 64-row groups resident in registers, Z2 streamed in 32-row blocks, no LDS) against fp64 and
+    against the lean kernel: several blocks per wave (the rolling reload of the streamed operand: stale registers would show),
+    one block per wave, the C3 posterior shape, odd and even quad counts (m = 100, 76, 60, 52, 36, 124 / 104, 56, 96, 16, 128, 112: the
+    admitted range is 16 <= m <= 128), the last row group
+    and the last column block moved back, a single row group, the smallest admissible block.  Different summation order than
+    the LDS kernels (mode pairs (8 j + e, 8 j + 4 + e), scale applied to Z1): equal to fp32 rounding, not bit for bit.  A NaN
+    canary catches an entry nobody wrote; NaN rows of Z2 / Z1 must stay in their own columns / rows (the zeroed quad past an odd
+    m reads the NEXT row's first modes)."""
+    from manifold_gp_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(n1 * 5 + n2 * 11 + m)
+    Z1 = torch.randn(n1, m, generator=g).to(dev)
+    Z2 = torch.randn(n2, m, generator=g).to(dev)
+    ref = 0.6 * (Z1.double() @ Z2.double().t())
+    bound = 2e-6 * float(ref.abs().max()) * max(1.0, m / 16) ** 0.5 + 1e-6
+    try:
+        assert lib.mgp_kernel_block_set_pipe(5) == 0
+        K = torch.full((n1, n2), float("nan"), device=dev)
+        for _ in range(3):
+            assert lib.mgp_kernel_block(_lib.ptr(Z1), n1, _lib.ptr(Z2), n2, m, 0.6, _lib.ptr(K), _lib.stream()) == 0
+        torch.cuda.synchronize()
+        assert not torch.isnan(K).any()
+        assert float((K.double() - ref).abs().max()) < bound
+        assert lib.mgp_kernel_block_set_pipe(1) == 0
+        K1 = torch.empty_like(K)
+        assert lib.mgp_kernel_block(_lib.ptr(Z1), n1, _lib.ptr(Z2), n2, m, 0.6, _lib.ptr(K1), _lib.stream()) == 0
+        assert float((K - K1).abs().max()) < bound
+        # timing arm: nothing is written
+        assert lib.mgp_kernel_block_set_pipe(6) == 0
+        Kn = torch.full((n1, n2), float("nan"), device=dev)
+        assert lib.mgp_kernel_block(_lib.ptr(Z1), n1, _lib.ptr(Z2), n2, m, 0.6, _lib.ptr(Kn), _lib.stream()) == 0
+        torch.cuda.synchronize()
+        assert bool(torch.isnan(Kn).all())
+        # a NaN row stays a NaN column / row of K and touches nothing else
+        assert lib.mgp_kernel_block_set_pipe(5) == 0
+        Z2n = Z2.clone(); Z2n[n2 // 2 + 1] = float("nan")
+        Z1n = Z1.clone(); Z1n[n1 // 3 + 1] = float("nan")
+        assert lib.mgp_kernel_block(_lib.ptr(Z1n), n1, _lib.ptr(Z2n), n2, m, 0.6, _lib.ptr(Kn), _lib.stream()) == 0
+        torch.cuda.synchronize()
+        bad = torch.isnan(Kn)
+        expect = torch.zeros_like(bad); expect[n1 // 3 + 1, :] = True; expect[:, n2 // 2 + 1] = True
+        assert torch.equal(bad, expect)
+        assert torch.equal(Kn[~expect], K[~expect])
+    finally:
+        lib.mgp_kernel_block_set_pipe(0)
 
 
 def test_spectral_posterior_vs_woodbury_fp64(mgp, golden, dev):

@@ -357,8 +357,9 @@ def test_factorised_solve_is_chosen_only_for_unmasked_chains():
 def test_kernel_block_pp_instruction_stream_respects_its_own_waits():
     """kernel_block_pp's staging loads are inline asm the compiler does not track (features.hip): tools/check_kblock_isa.py
     compiles the file for gfx950 and verifies that nothing touches a destination register of such a load before the kernel's own
-    vmcnt wait, and that the tile's 16 stores keep their data registers until the s_nop.  The checker itself is exercised on a
-    doctored stream first."""
+    vmcnt wait, and that the tile's 16 stores keep their data registers until the s_nop; for kernel_block_res, whose waits are
+    `vmcnt(N)` with N > 0, it replays each loop against an in-order queue of its loads and stores.  The checker itself is
+    exercised on doctored streams first."""
     import importlib.util
     import shutil
     import subprocess
@@ -384,6 +385,21 @@ def test_kernel_block_pp_instruction_stream_respects_its_own_waits():
     clobber = body[:-2] + ["\tv_pk_mul_f32 v[60:61], s[6:7], v[2:3]"] + body[-2:]
     assert any("before the s_nop" in p for p in chk.check(kernels(clobber)))
     assert any("expected the tile's 16" in p for p in chk.check(kernels(body[:10] + body[-2:])))
+    # kernel_block_res: waits with vmcnt(N > 0) against an in-order queue of the loop's loads and stores (check_res)
+    def res_kernel(wait2=32, wait1=16, extra=(), stores2=32):
+        loads = ["\tbuffer_load_dwordx4 v[%d:%d], v1, s[20:23], 0 offen offset:%d" % (40 + 4 * j, 43 + 4 * j, 32 * j) for j in range(3)]
+        mf = ["\tv_mfma_f32_32x32x2_f32 v[0:15], v100, v%d, v[0:15]" % (40 + e) for e in range(12)]
+        def walk(label, wait, nst, br):
+            return loads + ["\ts_waitcnt vmcnt(0)", "%s:" % label, "\ts_waitcnt vmcnt(%d)" % wait] + mf + list(extra) + loads + \
+                   ["\tbuffer_store_dword v%d, v90, s[16:19], 0 offen nt" % (r % 16) for r in range(nst)] + ["\t%s %s" % (br, label)]
+        return "\n".join(["_ZN12_GLOBAL__N_116kernel_block_resILi5EEEvPKflS2_lfPfliiiii:"] + walk(".LBB9_2", wait2, stores2, "s_cbranch_vccnz") +
+                         walk(".LBB9_4", wait1, 16, "s_cbranch_scc0") + ["\t.end_amdhsa_kernel"])
+    assert chk.check_res(res_kernel(), expect=1) == []
+    assert any("still in flight" in p for p in chk.check_res(res_kernel(wait2=33), expect=1))       # one operation too many allowed
+    assert any("still in flight" in p for p in chk.check_res(res_kernel(wait1=19), expect=1))
+    assert any("loads /" in p for p in chk.check_res(res_kernel(stores2=31, wait2=31), expect=1))
+    assert any("not straight-line" in p for p in chk.check_res(res_kernel(extra=("\ts_cbranch_scc1 .LBB9_9",)), expect=1))
+    assert any("expected 29" in p for p in chk.check_res(res_kernel()))
     if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")) is None:
         pytest.skip("hipcc not found: only the checker's own logic was tested")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_kblock_isa.py")], capture_output=True, text=True, timeout=600)

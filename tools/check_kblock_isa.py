@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Static check of the instruction streams of kernel_block_pp and kernel_block_one (manifold_gp_amd/csrc/features.hip).
+"""Static check of the instruction streams of kernel_block_pp, kernel_block_one and kernel_block_res (manifold_gp_amd/csrc/features.hip;
+kernel_block_res: see check_res).
 
 Its staging loads are inline asm (`buffer_load_dwordx4 ... offen` through descriptors of the operands' exact extents) whose completion the compiler does not track: the kernel waits for
 them with its own `s_waitcnt vmcnt(0)`.  That is only sound if NO instruction touches a destination register of such a load
@@ -70,6 +71,76 @@ def check(asm):
     return problems
 
 
+def check_res(asm, expect=29):
+    """kernel_block_res<Q>: the streamed operand's loads are inline asm and the kernel waits for them with `s_waitcnt vmcnt(N)`,
+    N > 0, counting on the wave's vector memory operations completing in order.  For each of its two loops (the walk with two
+    row blocks and the one with one) this replays the loop body three times against an in-order queue of its loads and stores:
+    entered with nothing in flight (a `vmcnt(0)` and no memory operation between it and the loop head), a `vmcnt(N)` retires all
+    but the N youngest operations, and no instruction may read or write a destination register of a load still in the queue.
+    Also: the body is straight-line, holds ceil(Q / 2) loads and 16 stores per row block, every store a dword store."""
+    lines = asm.split("\n")
+    starts = [(i, int(m.group(1))) for i, l in enumerate(lines)
+              for m in [re.match(r"^_ZN\d+_GLOBAL__N_1\d+kernel_block_resILi(\d+)EE.*:\s*(;.*)?$", l)] if m]
+    problems = []
+    for a, q in starts:
+        b = next(i for i in range(a, len(lines)) if ".end_amdhsa_kernel" in lines[i])
+        name = "kernel_block_res<%d>" % q
+        body = [(i, lines[i].strip()) for i in range(a + 1, b)]
+        body = [(i, t) for i, t in body if t and not t.startswith(";") and not t.startswith(".") or re.match(r"^\.LBB\d+_\d+:", t)]
+        labels = {t.split(":")[0]: k for k, (i, t) in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", t)}
+        loops = []
+        for k, (i, t) in enumerate(body):
+            m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", t)
+            if m and m.group(1) in labels and labels[m.group(1)] < k:
+                loops.append((labels[m.group(1)], k))
+        if len(loops) != 2:
+            problems.append("%s: %d loops, expected the two walks" % (name, len(loops)))
+            continue
+        for head, tail in loops:
+            # entry: back from the loop head to the nearest vmcnt(0); nothing in between may be a memory operation or a label
+            k = head - 1
+            while k >= 0 and not (body[k][1].startswith("s_waitcnt") and "vmcnt(0)" in body[k][1]):
+                t = body[k][1]
+                if t.startswith((".LBB", "buffer_", "global_", "flat_", "scratch_")):
+                    problems.append("%s: between the prologue's vmcnt(0) and the loop head: %s" % (name, t))
+                k -= 1
+            if k < 0:
+                problems.append("%s: no vmcnt(0) in front of a loop" % name)
+            inner = [t for i, t in body[head + 1:tail]]
+            if any(t.startswith(".LBB") or t.startswith("s_cbranch") or t.startswith("s_branch") for t in inner):
+                problems.append("%s: the loop body is not straight-line" % name)
+            nload = sum(t.startswith("buffer_load_dwordx4") for t in inner)
+            nstore = sum(t.startswith("buffer_store") for t in inner)
+            if nload != (q + 1) // 2 or nstore not in (16, 32) or any(t.startswith("buffer_store") and not t.startswith("buffer_store_dword v") for t in inner):
+                problems.append("%s: %d loads / %d stores in a loop body (expected %d / 16 or 32 dword stores)" % (name, nload, nstore, (q + 1) // 2))
+            queue = []          # in issue order: a set of destination registers per load, None per store
+            for it in range(3):
+                for t in inner:
+                    op = t.split()[0]
+                    m = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t)
+                    if m:
+                        n = int(m.group(1))
+                        if len(queue) > n:
+                            queue = queue[len(queue) - n:]
+                        continue
+                    inflight = set().union(*[r for r in queue if r]) if queue else set()
+                    if regs_of(t) & inflight:
+                        problems.append("%s: touches a register of a load still in flight (iteration %d): %s" % (name, it, t))
+                    if op.startswith("buffer_load"):
+                        m = re.match(r"buffer_load_dwordx4 v\[(\d+):(\d+)\]", t)
+                        if not m:
+                            problems.append("%s: a load the check does not know: %s" % (name, t))
+                            continue
+                        queue.append(set(range(int(m.group(1)), int(m.group(2)) + 1)))
+                    elif op.startswith("buffer_store"):
+                        queue.append(None)
+                    elif op.startswith(("global_", "flat_", "scratch_")):
+                        problems.append("%s: unexpected memory instruction: %s" % (name, t))
+    if len(starts) != expect:
+        problems.append("expected %d instantiations of kernel_block_res, found %d" % (expect, len(starts)))
+    return problems
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     src = os.path.join(ROOT, "manifold_gp_amd", "csrc", "features.hip")
@@ -81,10 +152,11 @@ def main():
         if r.returncode != 0:
             print(r.stderr[-2000:])
             return 2
-        problems = check(open(out).read())
+        asm = open(out).read()
+        problems = check(asm) + check_res(asm)
     for p in problems:
         print(p)
-    print("kernel_block_pp / kernel_block_one instruction streams:", "clean" if not problems else "%d problem(s)" % len(problems))
+    print("kernel_block_pp / kernel_block_one / kernel_block_res instruction streams:", "clean" if not problems else "%d problem(s)" % len(problems))
     return 1 if problems else 0
 
 

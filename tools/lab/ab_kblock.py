@@ -57,4 +57,4 @@ for (n1, n2, m) in shapes:
     row["modes_max_diff"] = max(float((outs[0] - outs[2]).abs().max()), float((outs[0] - outs[4]).abs().max()))
     res.append(row)
     print(json.dumps(row), flush=True)
-lib.mgp_kernel_block_set_pipe(1)
+lib.mgp_kernel_block_set_pipe(0)

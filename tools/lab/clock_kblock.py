@@ -26,4 +26,4 @@ for mode in (0, 2, 3):
     us = e0.elapsed_time(e1) / 10 * 1e3
     print("mode %d: %.0f us per launch = %.1f TFLOP/s (%s operands)" % (mode, us, 2.0 * n1 * n2 * m / us / 1e6,
                                                                        "zero" if os.environ.get("KB_ZERO") == "1" else "random"))
-lib.mgp_kernel_block_set_pipe(1)
+lib.mgp_kernel_block_set_pipe(0)

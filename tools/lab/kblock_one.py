@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 from manifold_gp_amd import _lib
 lib = _lib.lib()
 n1, n2, m = (int(v) for v in sys.argv[1:4])
-lib.mgp_kernel_block_set_pipe(int(sys.argv[4]) if len(sys.argv) > 4 else 1)
+lib.mgp_kernel_block_set_pipe(int(sys.argv[4]) if len(sys.argv) > 4 else 0)
 torch.manual_seed(0)
 Z1 = torch.randn(n1, m, device="cuda:0"); Z2 = torch.randn(n2, m, device="cuda:0"); K = torch.empty(n1, n2, device="cuda:0")
 st = _lib.stream()

@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] != "-":
     _lib.LIB_PATH = os.path.abspath(sys.argv[1])      # A/B: another build of the library
 lib = _lib.lib()
 res = []
-pipe = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+pipe = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 lib.mgp_kernel_block_set_pipe(pipe)
 for (n1, n2, m) in ((600, 60000, 100), (1010, 60000, 100), (4096, 60000, 100), (60000, 128, 128), (8192, 8192, 256), (600, 60000, 124), (256, 60000, 100)):
     Z1 = torch.randn(n1, m, device="cuda:0"); Z2 = torch.randn(n2, m, device="cuda:0")
