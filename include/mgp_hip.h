@@ -192,6 +192,12 @@ typedef struct {
   const int32_t* tile_rowptr;  /* [n+1] entry offsets in tile order */
   const float* tile_vals;      /* [nnz] vals gathered through emap */
   const int32_t* tile_rowid;   /* [n] original row of every tile-order position (= row_order) */
+  /* dense 16-row tiles for the matrix-core SpMM at 48 <= C <= 256 (mgp_spmm_mt_fill); all NULL / 0 = not built */
+  const int32_t* mt_sptr;      /* [mt_tiles + 1] steps (of four distinct columns) before tile t; multiples of 4 */
+  const int32_t* mt_dcol;      /* [4 mt_steps + 192] the tiles' distinct columns, padded per tile to whole blocks of 16 */
+  const float* mt_img;         /* [64 (mt_steps + 32)] tile values in MFMA operand order */
+  int32_t mt_tiles;            /* ceil(n / 16) */
+  int32_t mt_steps;            /* mt_sptr[mt_tiles] */
 } mgp_csr_t;
 
 /* workgroups that write dot partials for this CSR (format aware; use this one to size dot_partials) */
@@ -211,6 +217,22 @@ int mgp_spmm_set_tile_wide_mode(int on);
  * Replaces torch_sparse.spmm at manifold_gp/operators/graph_laplacian_operator.py:118-119 for the [N, 100] right-hand
  * sides of precision_matern_operator.py:50-53 and the eigensolver's blocks. */
 int mgp_spmm_set_dict_mode(int on);
+/* 48 <= C <= 256 with C % 4 == 0 (round 4): the SpMM on the fp32 MATRIX CORES over 16-row tiles stored dense in their own distinct
+ * columns (csrc/spmm.hip spmm_mt_kernel): a tile's distinct X rows cross the vector memory path once per tile and 64-column
+ * block, straight into the MFMA operand layout; no LDS, no barrier.  Taken (before every other wide kernel) when the CSR
+ * carries mt_* and the call has no dot-product partials and no row offset; a row's sum is taken in ascending column order.
+ * N = 60k, C = 128: 60 us against 94 for the gather kernel.  mgp_spmm_set_mt_mode(0) = never; returns the previous setting.
+ * mgp_spmm_mt_fill builds mt_dcol / mt_img from a CSR in natural row order and its 16-row tile dictionaries
+ * (mgp_graph_tiles with tile_rows = 16: tile_ptr16, tile_cols16, lid16) and the step offsets sptr (per tile
+ * 4 ceil(D / 16) steps, exclusive prefix sum, `steps` = the total).
+ * Replaces torch_sparse.spmm at manifold_gp/operators/graph_laplacian_operator.py:118-119 for the eigensolver's blocks and
+ * the [N, 100] right-hand sides of precision_matern_operator.py:50-53. */
+int mgp_spmm_set_mt_mode(int on);
+/* which kernel mgp_spmm_fused would launch for this CSR / width (tests, docs): 0 = gather, 1 = C == 1 tile kernel, 2 = small-C
+ * tile kernel, 3 = matrix-core tiles, 4 = 8-lanes-per-row dictionary, 5 = lanes-over-columns dictionary, 6 = chunked dictionary */
+int mgp_spmm_kernel_choice(const mgp_csr_t* L, int C, int with_dot, int64_t row_offset);
+int mgp_spmm_mt_fill(int64_t n, const int32_t* rowptr, const float* vals, const uint16_t* lid16, const int32_t* tile_ptr16,
+                     const int32_t* tile_cols16, const int32_t* sptr, int64_t steps, int32_t* dcol, float* img, void* stream);
 /* 16 < C <= 128 with C % 4 == 0 on 64-row tiles in row order (round 4): the dictionary kernel as ONE persistent 512-thread
  * workgroup per CU, 8 lanes per row, the dictionary slices in a two-buffer LDS ring filled by LDS-DMA across tile boundaries, the
  * matrix stream decoded once per tile into (value, slice, LDS offset), the walk of a slice a counted loop

@@ -39,7 +39,8 @@ class CsrT(Structure):
                 ("ncols", c_int64), ("tile_ptr", c_void_p), ("tile_cols", c_void_p), ("lid", c_void_p),
                 ("tile_rows", c_int32), ("tile_max_cols", c_int32), ("tile_max_entries", c_int32),
                 ("tile_reserved", c_int32), ("tile_rowptr", c_void_p), ("tile_vals", c_void_p),
-                ("tile_rowid", c_void_p)]
+                ("tile_rowid", c_void_p),
+                ("mt_sptr", c_void_p), ("mt_dcol", c_void_p), ("mt_img", c_void_p), ("mt_tiles", c_int32), ("mt_steps", c_int32)]
 
 
 class OperatorT(Structure):
@@ -86,6 +87,9 @@ SIGNATURES = {
     "mgp_spmm_set_tile_wide_mode": (c_int, [c_int]),
     "mgp_spmm_set_dict_mode": (c_int, [c_int]),
     "mgp_spmm_set_dict8_mode": (c_int, [c_int]),
+    "mgp_spmm_set_mt_mode": (c_int, [c_int]),
+    "mgp_spmm_kernel_choice": (c_int, [POINTER(CsrT), c_int, c_int, c_int64]),
+    "mgp_spmm_mt_fill": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     "mgp_spmm_timing_begin": (c_int, [c_int]),
     "mgp_spmm_timing_end": (c_int, [POINTER(c_float), POINTER(c_int)]),
     "mgp_spmm_set_v4_mode": (c_int, [c_int]),
@@ -257,10 +261,11 @@ def leak(*objects):
     _LEAKED.extend(objects)
 
 
-def csr_struct(n, rowptr, col, vals, diag, ncols=0, tiles=None, tile_vals=None):
+def csr_struct(n, rowptr, col, vals, diag, ncols=0, tiles=None, tile_vals=None, mt=None):
     """tiles: None or the dict KnnGraph.tiles holds (tile_ptr, tile_cols, lid tensors + rows / max_cols /
     max_entries; for tiles over a row order also tile_rowptr / rowid / emap).  tile_vals: `vals` gathered
-    through tiles["emap"] -- required with ordered tiles, which are otherwise left out of the struct."""
+    through tiles["emap"] -- required with ordered tiles, which are otherwise left out of the struct.
+    mt: None or a graph.MtPlan built over the same rowptr / col / vals."""
     s = CsrT(int(n), rowptr.data_ptr(), col.data_ptr(), vals.data_ptr(), diag.data_ptr(), int(ncols))
     if tiles is not None and (tiles.get("rowid") is None or tile_vals is not None):
         s.tile_ptr, s.tile_cols, s.lid = tiles["tile_ptr"].data_ptr(), tiles["tile_cols"].data_ptr(), tiles["lid"].data_ptr()
@@ -268,4 +273,7 @@ def csr_struct(n, rowptr, col, vals, diag, ncols=0, tiles=None, tile_vals=None):
         if tiles.get("rowid") is not None:
             s.tile_rowptr, s.tile_rowid = tiles["tile_rowptr"].data_ptr(), tiles["rowid"].data_ptr()
             s.tile_vals = tile_vals.data_ptr()
+    if mt is not None:        # graph.MtPlan: dense 16-row tiles for the matrix-core SpMM (48 <= C <= 256)
+        s.mt_sptr, s.mt_dcol, s.mt_img = mt.sptr.data_ptr(), mt.dcol.data_ptr(), mt.img.data_ptr()
+        s.mt_tiles, s.mt_steps = mt.tiles, mt.steps
     return s

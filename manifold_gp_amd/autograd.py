@@ -34,7 +34,7 @@ def _spmm(data, X, a, b, pre, post, base, cb, co, tangent=False):
         t = data.tangent()
         csr = g.csr_with(t.d_vals, t.d_diag, t.d_vals_t)
     else:
-        csr = data.csr()
+        csr = data.csr(wide=X.shape[1] >= 48)
     X = _lib.f32c(X)
     out = torch.empty_like(X)
     C = X.shape[1]

@@ -12,7 +12,11 @@ pids=()
 for src in "$here"/*.hip; do
   o="$obj/$(basename "${src%.hip}").o"
   if [ ! -f "$o" ] || [ "$src" -nt "$o" ] || [ "$inc/mgp_hip.h" -nt "$o" ] || [ "$here/mgp_common.h" -nt "$o" ] || [ "$here/mgp_internal.h" -nt "$o" ]; then
-    $HIPCC $FLAGS -c "$src" -o "$o" &
+    extra=""
+    # spmm.hip: keep the MFMA accumulators of spmm_mt_kernel in VGPRs (the default AGPR form copied 48 registers per loop
+    # iteration between the two files of the unified register file); no other kernel of that file uses the matrix cores
+    [ "$(basename "$src")" = spmm.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+    $HIPCC $FLAGS $extra -c "$src" -o "$o" &
     pids+=($!)
   fi
 done

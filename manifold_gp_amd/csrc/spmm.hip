@@ -1724,6 +1724,200 @@ __global__ __launch_bounds__(kD8Threads) void spmm_dict8_kernel(SpmmArgs p, Tile
   if (p.tick && blockIdx.x == 0 && tid == 0) *p.tick = tickv + 1;
 }
 
+// ---------------------------------------------------------------- 16 < C <= 256 on the MATRIX CORES: dense 16-row tiles
+// The gather kernels above move one X row through the vector memory path per ENTRY (3.6 M x 512 bytes at N = 60k, C = 128:
+// 91 us, bound by the L1 miss path); the LDS dictionary kernels move it once per 64-row tile but pay for it in barriers and
+// LDS reads per entry (151 us).  Here a tile is 16 rows and is stored DENSE in its own D distinct columns, in the operand layout
+// of v_mfma_f32_16x16x4_f32 (mgp_spmm_mt_fill: step s of a tile is 64 floats, lane (i, kq) = A[row i][distinct column
+// 4 s + kq]; 21 % of the cells are non-zero on the C3 graph).  A wave owns (tile, 64-column block): per step it loads its
+// image dword and, for the step's four distinct columns, 16 bytes of X per lane -- lane (j, kq) takes X[d(4 s + kq)][64 cb +
+// 4 j .. + 3], whose four components are the B operands of four MFMAs that produce output columns 64 cb + 4 j + e.  Every
+// distinct X row crosses the memory path once per tile (5.3 entries share it), nothing goes through LDS, no barrier, no
+// atomics, and the sum of a row is taken in ascending column order whatever the entry order of the CSR.
+//  * steps go in BLOCKS of four; a wave keeps three blocks of operands in flight ahead of the one it multiplies (ring of four
+//    register sets, loop unrolled by four blocks = one 64-entry batch of the tile's column list): with one block in flight
+//    the launch was bound by its longest tile x the memory latency.  All loads are inline asm into fixed registers and the
+//    waits are `s_waitcnt vmcnt(N)`, N = the loads younger than the block waited for (a wave's vector memory operations
+//    complete in order).  Order of a body's memory operations (body = blocks k .. k + 3, R(i) = the LR loads of block i,
+//    D(b) = the column-list batch of blocks 4 b .. 4 b + 3):
+//        ... R(k) R(k+1) R(k+2) | D(k/4 + 2) . wait(k) R(k+3) . wait(k+1) R(k+4) . wait(k+2) R(k+5) . wait(k+3) R(k+6) | ...
+//    so wait(k), wait(k+1), wait(k+2) leave 2 LR + 1 operations in flight and wait(k+3) 2 LR.  tools/check_kblock_isa.py
+//    replays the loop against an in-order queue (CPU test).
+//  * the requests run up to 6 blocks and 2 batches past a tile's end into the next tile's (valid) data or the padding behind
+//    the last tile; steps past the end are multiplied by zero.  Before the epilogue EVERYTHING in flight is waited for: the
+//    compiler believes an asm load's destination is written at the asm statement and reuses the register afterwards -- the
+//    first pipelined lab version computed its store addresses in registers a late load then overwrote (a memory fault).
+//  * consecutive tiles (locality order: they share X rows) run on ONE XCD, so that its L2 holds its slice of X (76.7 -> 67.4 us).
+//  * measured at N = 60k, C = 128 (tools/lab/spmm_mt_lab.py, raw product): 60.5 us against 94.4 for the gather kernel.
+struct MtArgs {
+  const int32_t* sptr;   // [T + 1] steps before tile t; every tile has a multiple of 4
+  const int32_t* dcol;   // [4 * steps + 192] distinct columns per step, padded with a valid column whose image cells are 0
+  const float* img;      // [64 * (steps + 32)]
+  int T, NCB;
+  int img_bytes, dic_bytes;
+};
+
+template <bool PRE>
+struct MtBuf {
+  float a[4];
+  mgp_v4f b[4];
+  float pr[PRE ? 4 : 1];
+};
+
+template <bool PRE>
+__device__ __forceinline__ void mt_request(MtBuf<PRE>& nb, int dq, int p0, int kq, int joff, int rowbytes, int so,
+                                           __amdgpu_buffer_rsrc_t rimg, __amdgpu_buffer_rsrc_t rx, __amdgpu_buffer_rsrc_t rpre,
+                                           int lane4) {
+  int off[4], offp[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int d = __builtin_amdgcn_ds_bpermute((4 * (p0 + p) + kq) * 4, dq);
+    off[p] = d * rowbytes + joff;
+    offp[p] = d * 4;
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(nb.a[p]) : "v"(lane4), "s"(rimg), "s"(so), "n"(256 * p));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(nb.b[p]) : "v"(off[p]), "s"(rx));
+    if constexpr (PRE) asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(nb.pr[p]) : "v"(offp[p]), "s"(rpre));
+  }
+  // the addresses stay live (= in registers of their own) until the last load of the group has been issued: the compiler
+  // believes a load's destination is written AT the asm statement and is free to compute a later address in an earlier
+  // load's destination, which the hardware may overwrite first when the issue of the later load stalls
+  asm volatile("" :: "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]));
+  if constexpr (PRE) asm volatile("" :: "v"(offp[0]), "v"(offp[1]), "v"(offp[2]), "v"(offp[3]));
+}
+
+template <int N, bool PRE>
+__device__ __forceinline__ void mt_wait(MtBuf<PRE>& cb) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cb.a[0]) : "n"(N));
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    asm volatile("" : "+v"(cb.a[p]), "+v"(cb.b[p]));
+    if constexpr (PRE) asm volatile("" : "+v"(cb.pr[p]));
+  }
+}
+
+template <bool PRE>
+__device__ __forceinline__ void mt_mfma(const MtBuf<PRE>& cb, int s0, int S, mgp_v4f (&acc)[4]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    float av = s0 + p < S ? cb.a[p] : 0.f;       // a step past the tile's end holds the next tile's operands
+    if constexpr (PRE) av *= cb.pr[p];           // x[col] * pre[col]: the scale rides on the matrix value
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cb.b[p][e], acc[e], 0, 0, 0);
+  }
+}
+
+template <bool PRE>
+__global__ __launch_bounds__(kBlock) void spmm_mt_kernel(SpmmArgs p, MtArgs m) {
+  constexpr int LR = PRE ? 12 : 8;      // loads per block request
+  if (p.skip && *p.skip) return;
+  if (p.tick && blockIdx.x == 0 && threadIdx.x == 0) *p.tick += 1;
+  const int lane = threadIdx.x & 63, j = lane & 15, kq = lane >> 4;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int w = __builtin_amdgcn_readfirstlane(lb * (kBlock / 64) + (int)(threadIdx.x >> 6));
+  const int t = w / m.NCB, cb = w % m.NCB;           // the column blocks of a tile side by side: they share its image
+  if (t >= m.T) return;
+  const int C = p.C;
+  const int base = __builtin_amdgcn_readfirstlane(m.sptr[t]), S = __builtin_amdgcn_readfirstlane(m.sptr[t + 1]) - base;
+  const int blk0 = base >> 2, NB = S >> 2;
+  const int64_t nx = p.n + p.goff;                   // rows of X the columns can name (host side: goff == 0)
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), (short)0, (int)(nx * C * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.img), (short)0, m.img_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdic = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(m.dcol), (short)0, m.dic_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? p.pre : p.X), (short)0, (int)(nx * 4), 0x00020000);
+  const int lane4 = lane * 4, rowbytes = C * 4, joff = cb * 256 + j * 16;
+  mgp_v4f acc[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+  MtBuf<PRE> buf0, buf1, buf2, buf3;
+  int dq0, dq1, dq2;          // column-list batches of the body in hand, of the next one, and the one in flight
+  const int dic0 = blk0 * 64, img0 = blk0 * 1024;      // byte offsets of the tile's first block
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dq0) : "v"(lane4), "s"(rdic), "s"(dic0));
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:256" : "=v"(dq1) : "v"(lane4), "s"(rdic), "s"(dic0));
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(dq0), "+v"(dq1));
+  mt_request<PRE>(buf0, dq0, 0, kq, joff, rowbytes, img0, rimg, rx, rpre, lane4);
+  mt_request<PRE>(buf1, dq0, 4, kq, joff, rowbytes, img0 + 1024, rimg, rx, rpre, lane4);
+  mt_request<PRE>(buf2, dq0, 8, kq, joff, rowbytes, img0 + 2048, rimg, rx, rpre, lane4);
+  for (int k = 0; k < NB; k += 4) {
+    const int so = img0 + k * 1024, sd = dic0 + k * 64;
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:512" : "=v"(dq2) : "v"(lane4), "s"(rdic), "s"(sd));
+    mt_wait<2 * LR + 1, PRE>(buf0);
+    mt_request<PRE>(buf3, dq0, 12, kq, joff, rowbytes, so + 3 * 1024, rimg, rx, rpre, lane4);
+    __builtin_amdgcn_sched_barrier(0);      // requests stay in front of the block's MFMAs (left alone, the scheduler sinks them)
+    mt_mfma<PRE>(buf0, 4 * k, S, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_wait<2 * LR + 1, PRE>(buf1);
+    mt_request<PRE>(buf0, dq1, 0, kq, joff, rowbytes, so + 4 * 1024, rimg, rx, rpre, lane4);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_mfma<PRE>(buf1, 4 * k + 4, S, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_wait<2 * LR + 1, PRE>(buf2);
+    mt_request<PRE>(buf1, dq1, 4, kq, joff, rowbytes, so + 5 * 1024, rimg, rx, rpre, lane4);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_mfma<PRE>(buf2, 4 * k + 8, S, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_wait<2 * LR, PRE>(buf3);
+    mt_request<PRE>(buf2, dq1, 8, kq, joff, rowbytes, so + 6 * 1024, rimg, rx, rpre, lane4);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_mfma<PRE>(buf3, 4 * k + 12, S, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    dq0 = dq1;
+    // the batch requested at the top of this body is older than R(k+3), which wait(k+3) has seen land: 3 LR = R(k+4..k+6)
+    // waits for nothing new, it only tells the compiler where dq2 becomes readable
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dq2) : "n"(3 * LR));
+    dq1 = dq2;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(dq0), "+v"(dq1));
+  mt_wait<0, PRE>(buf0); mt_wait<0, PRE>(buf1); mt_wait<0, PRE>(buf2); mt_wait<0, PRE>(buf3);
+  // acc[e][r]: row 16 t + 4 kq + r, column c0 + e with c0 = 64 cb + 4 j
+  const int c0 = 64 * cb + 4 * j;
+  if (c0 < C) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = (int64_t)16 * t + 4 * kq + r;
+      if (row < p.n) {
+        const int64_t gr = row + p.goff;
+        mgp_v4f xs = *reinterpret_cast<const mgp_v4f*>(p.X + gr * C + c0);
+        if (PRE) xs *= p.pre[gr];
+        const mgp_v4f av = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+        const mgp_v4f lx = p.diag[row] * xs - av;
+        mgp_v4f tt = p.a * xs + p.b * lx;
+        if (p.post) tt *= p.post[gr];
+        mgp_v4f y = p.co * tt;
+        if (p.base) y += p.cb * *reinterpret_cast<const mgp_v4f*>(p.base + gr * C + c0);
+        *reinterpret_cast<mgp_v4f*>(p.Y + gr * C + c0) = y;
+      }
+    }
+  }
+}
+
+// the image and the padded column list of the tiles: one thread per row scatters its entries
+__global__ __launch_bounds__(kBlock) void spmm_mt_fill_kernel(int64_t n, const int32_t* __restrict__ rowptr,
+                                                               const float* __restrict__ vals, const uint16_t* __restrict__ lid,
+                                                               const int32_t* __restrict__ tile_ptr, const int32_t* __restrict__ tile_cols,
+                                                               const int32_t* __restrict__ sptr, int32_t* __restrict__ dcol,
+                                                               float* __restrict__ img) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // over 16 ceil(n / 16) positions: the last tile may be short
+  if (r >= ((n + 15) >> 4 << 4)) return;
+  const int64_t t = r >> 4;
+  const int i = (int)(r & 15);
+  const int64_t s0 = sptr[t];
+  if (r < n) {
+    for (int e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+      const float v = vals[e];
+      if (v == 0.f) continue;                       // padding entries
+      const int slot = lid[e];
+      img[(s0 + (slot >> 2)) * 64 + (slot & 3) * 16 + i] += v;
+    }
+  }
+  // this row's share of the tile's padded column list: entries i, i + 16, ...
+  const int d0 = tile_ptr[t], D = tile_ptr[t + 1] - d0;
+  const int total = 4 * (sptr[t + 1] - (int)s0);
+  for (int q = i; q < total; q += 16) dcol[4 * s0 + q] = D > 0 ? tile_cols[d0 + (q < D ? q : D - 1)] : 0;
+}
+
 // In-solve duration of the C = 1 tile kernel, measured live (bench.py `roofline`): between mgp_spmm_timing_begin and
 // mgp_spmm_timing_end every launch of spmv_tile_kernel is made with hipExtLaunchKernelGGL and its own start / stop event
 // pair -- the events take the dispatch's begin / end timestamps (what rocprofv3 --kernel-trace reports), not the gaps
@@ -2007,6 +2201,39 @@ static bool aligned16(const void* a, const void* b, const void* c, const void* d
            reinterpret_cast<uintptr_t>(d)) & 15) == 0;
 }
 
+// 48 <= C <= 256 on the matrix cores (spmm_mt_kernel): taken when the CSR carries the dense 16-row tile image (mgp_spmm_mt_fill;
+// the host wrapper builds it for graphs in natural row order whose tiles are at least 1/8 full), the call has no dot-product
+// partials and no row offset.  mgp_spmm_set_mt_mode(0) = never (A/B runs, tests).
+int g_mt_mode = 1;
+constexpr int kMtMinCols = 48;
+static bool mt_shape_ok(const mgp_csr_t* L, int C, const float* dotw, int64_t row_offset) {
+  if (!g_mt_mode || !L->mt_img || !L->mt_sptr || !L->mt_dcol || L->mt_tiles <= 0 || L->mt_steps <= 0) return false;
+  // below 48 columns most lanes of a wave's 64-column block idle: the gather kernel is faster there (C = 32: 34 us against 41)
+  if (C < kMtMinCols || C > 256 || (C & 3) != 0 || dotw || row_offset != 0 || L->tile_rowid) return false;
+  if ((int64_t)L->n * C * 4 >= (int64_t(1) << 31) || ((int64_t)L->mt_steps + 32) * 256 >= (int64_t(1) << 31)) return false;
+  return L->mt_tiles == (int32_t)mgp_cdiv(L->n, 16);
+}
+
+extern "C" int mgp_spmm_set_mt_mode(int on) {
+  const int prev = g_mt_mode;
+  g_mt_mode = on ? 1 : 0;
+  return prev;
+}
+
+extern "C" int mgp_spmm_mt_fill(int64_t n, const int32_t* rowptr, const float* vals, const uint16_t* lid16,
+                                const int32_t* tile_ptr16, const int32_t* tile_cols16, const int32_t* sptr, int64_t steps,
+                                int32_t* dcol, float* img, void* stream) {
+  if (n <= 0 || !rowptr || !vals || !lid16 || !tile_ptr16 || !tile_cols16 || !sptr || !dcol || !img || steps <= 0 || (steps & 3))
+    return MGP_ERR_ARG;
+  hipStream_t st = mgp_stream(stream);
+  MGP_HIP_TRY(hipMemsetAsync(img, 0, (size_t)(steps + 32) * 256, st));
+  MGP_HIP_TRY(hipMemsetAsync(dcol + 4 * steps, 0, 192 * sizeof(int32_t), st));
+  hipLaunchKernelGGL(spmm_mt_fill_kernel, dim3((unsigned)mgp_cdiv(n + 15, kBlock)), dim3(kBlock), 0, st, n, rowptr, vals, lid16,
+                     tile_ptr16, tile_cols16, sptr, dcol, img);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
 extern "C" int mgp_spmm_set_dict_mode(int on) {
   g_dict_mode = on == 2 ? 2 : (on ? 1 : 0);
   return MGP_OK;
@@ -2019,6 +2246,21 @@ int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (dict_shape_ok(L, C)) return dict_grid(L);
   if (use_tiles_wide(L, C)) return tile_grid(L, nullptr);
   return mgp_spmm_dot_blocks(L->n, C);
+}
+
+// which kernel a call of mgp_spmm_fused with this CSR / width would launch (tests, docs): 0 = gather (C == 1: row groups),
+// 1 = C == 1 tile kernel, 2 = small-C tile kernel, 3 = matrix-core tiles, 4 = 8-lanes-per-row dictionary, 5 = lanes-over-columns
+// dictionary, 6 = chunked dictionary
+extern "C" int mgp_spmm_kernel_choice(const mgp_csr_t* L, int C, int with_dot, int64_t row_offset) {
+  if (!L || L->n <= 0 || C <= 0 || C > 256) return MGP_ERR_ARG;
+  static const float one = 1.f;
+  if (use_tiles(L, C)) return 1;
+  if (use_tiles_small(L, C)) return 2;
+  if (mt_shape_ok(L, C, with_dot ? &one : nullptr, row_offset)) return 3;
+  if (d8_shape_ok(L, C)) return 4;
+  if (dict_shape_ok(L, C)) return 5;
+  if (use_tiles_wide(L, C)) return 6;
+  return 0;
 }
 
 extern "C" int mgp_spmm_dot_blocks_csr(const mgp_csr_t* L, int C) {
@@ -2178,6 +2420,12 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     else if (C == 12) MGP_TILE_SMALL_LAUNCH(3);
     else MGP_TILE_SMALL_LAUNCH(4);
 #undef MGP_TILE_SMALL_LAUNCH
+  } else if (mt_shape_ok(L, C, dotw, row_offset) && aligned16(X, Y, base, nullptr)) {
+    MtArgs ma{L->mt_sptr, L->mt_dcol, L->mt_img, L->mt_tiles, (C + 63) / 64, (int)(((int64_t)L->mt_steps + 32) * 256),
+              (int)(((int64_t)L->mt_steps * 4 + 192) * 4)};
+    const int grid = (int)mgp_cdiv((int64_t)ma.T * ma.NCB, kBlock / 64);
+    if (pre) hipLaunchKernelGGL((spmm_mt_kernel<true>), dim3(grid), dim3(kBlock), 0, st, p, ma);
+    else hipLaunchKernelGGL((spmm_mt_kernel<false>), dim3(grid), dim3(kBlock), 0, st, p, ma);
   } else if (d8_shape_ok(L, C)) {
     if (!aligned16(X, Y, base, dotw)) return MGP_ERR_ARG;   // (the plan counted this kernel's dot-partial blocks)
     TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,

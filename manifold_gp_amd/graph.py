@@ -62,6 +62,53 @@ def build_tiles(n, rowptr, col, nnz, tile_rows=None, order=None):
     return None
 
 
+MT_MIN_NODES = 4096         # below this a wide SpMM is a few microseconds whatever the kernel
+MT_MIN_FILL = 0.125         # non-zero share of the dense tiles below which the gather kernels are taken instead
+MT_ENABLED = [True]
+
+
+class MtPlan:
+    """Dense 16-row tiles of one CSR (natural row order) for the matrix-core SpMM at 48 <= C <= 256 (csrc/spmm.hip
+    spmm_mt_kernel): sptr [T + 1] steps before tile t, dcol the tiles' distinct columns padded to whole blocks of 16, img the
+    values in MFMA operand order (mgp_spmm_mt_fill).  `build` returns None when the graph is small, the tiles would be less
+    than MT_MIN_FILL full (no locality in the row order: 16 rows then name ~850 distinct columns) or the image would not fit a
+    32-bit byte offset."""
+
+    def __init__(self, sptr, dcol, img, tiles, steps, fill):
+        self.sptr, self.dcol, self.img, self.tiles, self.steps, self.fill = sptr, dcol, img, tiles, steps, fill
+
+    @staticmethod
+    def structure(graph):
+        """The part that depends on the sparsity pattern only, cached on the graph object (a new bandwidth refills the image,
+        nothing else): 16-row tile dictionaries, step offsets, fill.  None when the image does not pay."""
+        if not hasattr(graph, "_mt_structure"):
+            graph._mt_structure = None
+            n, nnz = graph.n, graph.nnz
+            t = build_tiles(n, graph.rowptr, graph.col, nnz, tile_rows=16) if (MT_ENABLED[0] and n >= MT_MIN_NODES and nnz > 0) else None
+            if t is not None:
+                D = (t["tile_ptr"][1:] - t["tile_ptr"][:-1]).long()
+                S = (D + 15) // 16 * 4                                     # steps per tile: whole blocks of four
+                sptr = torch.zeros(D.numel() + 1, dtype=torch.int64, device=graph.col.device)
+                torch.cumsum(S, 0, out=sptr[1:])
+                steps = int(sptr[-1])
+                fill = 2 * graph.M / max(1, 64 * steps)                    # off-diagonal entries / cells of the dense tiles
+                if steps > 0 and fill >= MT_MIN_FILL and (steps + 32) * 256 < 2 ** 31:
+                    graph._mt_structure = dict(tiles=t, sptr=sptr.to(torch.int32), steps=steps, fill=fill, ntiles=int(D.numel()))
+        return graph._mt_structure
+
+    @classmethod
+    def build(cls, graph, vals):
+        st = cls.structure(graph)
+        if st is None:
+            return None
+        t, steps = st["tiles"], st["steps"]
+        dcol = torch.empty(4 * steps + 192, dtype=torch.int32, device=vals.device)
+        img = torch.empty(64 * (steps + 32), dtype=torch.float32, device=vals.device)
+        check(lib().mgp_spmm_mt_fill(graph.n, ptr(graph.rowptr), ptr(vals), ptr(t["lid"]), ptr(t["tile_ptr"]), ptr(t["tile_cols"]),
+                                     ptr(st["sptr"]), steps, ptr(dcol), ptr(img), stream()), "mgp_spmm_mt_fill")
+        return cls(st["sptr"], dcol, img, st["ntiles"], steps, st["fill"])
+
+
 def morton_order(x):
     """Z-curve order of points with d <= 3 (mgp_morton_order): int32 [n] permutation."""
     n, d = x.shape
@@ -111,10 +158,10 @@ class KnnGraph:
     def device(self):
         return self.tri_val.device
 
-    def csr_with(self, vals, diag, tile_vals=None):
+    def csr_with(self, vals, diag, tile_vals=None, mt=None):
         """mgp_csr_t over this graph's structure with the given entry values / diagonal (tile_vals: the
         values in tile order when the tiles follow a row order, see tile_values)."""
-        return _lib.csr_struct(self.n, self.rowptr, self.col, vals, diag, tiles=self.tiles, tile_vals=tile_vals)
+        return _lib.csr_struct(self.n, self.rowptr, self.col, vals, diag, tiles=self.tiles, tile_vals=tile_vals, mt=mt)
 
     def tile_values(self, vals):
         """`vals` gathered into tile order (None when the tiles are in row order)."""
@@ -247,9 +294,20 @@ class RelabelledData:
         self._perm_cache = {}
         self._source = data                     # (keeps vals_t alive)
 
-    def csr(self):
+    def csr(self, wide=False):
+        """wide: the caller is about to multiply 48 columns or more -- build the matrix-core tile image if there is none
+        yet (once built it rides in every struct)."""
         g = self.graph
-        return _lib.csr_struct(g.n, g.rowptr, g.col, self.vals, self.diag, tiles=g.tiles)
+        return _lib.csr_struct(g.n, g.rowptr, g.col, self.vals, self.diag, tiles=g.tiles, mt=self.mt_plan(wide))
+
+    def mt_plan(self, build=True):
+        """MtPlan of this CSR (built at the first call with build=True; None when it does not pay)."""
+        if not hasattr(self, "_mt"):
+            if not build:
+                return None
+            g = self.graph
+            self._mt = MtPlan.build(g, self.vals)
+        return self._mt
 
     def permuted(self, v):
         """A node vector of the source data (pre / post of a descriptor) in this order; the data's own vectors map to the
@@ -333,8 +391,21 @@ class LaplacianData:
             self._tangent = t
         return self._tangent
 
-    def csr(self):
-        return self.graph.csr_with(self.vals, self.diag, self.vals_t)
+    def csr(self, wide=False):
+        """wide: the caller is about to multiply 48 columns or more -- build the matrix-core tile image if there is none
+        yet (once built it rides in every struct)."""
+        return self.graph.csr_with(self.vals, self.diag, self.vals_t, mt=self.mt_plan(wide))
+
+    def mt_plan(self, build=True):
+        """MtPlan of this CSR (built at the first call with build=True): only for graphs in natural row order -- a graph whose
+        tiles follow a locality ORDER is multiplied through its relabelled copy (RelabelledData), which has its own."""
+        if not hasattr(self, "_mt"):
+            if not build:
+                return None
+            g = self.graph
+            ordered = g.tiles is not None and g.tiles.get("rowid") is not None
+            self._mt = None if ordered else MtPlan.build(g, self.vals)
+        return self._mt
 
     def relabelled(self):
         """RelabelledData (cached) when the graph's tiles follow a locality order, else None."""

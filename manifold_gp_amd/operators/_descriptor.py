@@ -46,12 +46,12 @@ class Descriptor:
             return None, None
         return replace(self, data=rel, pre=rel.permuted(self.pre), post=rel.permuted(self.post)), rel.graph
 
-    def struct(self):
+    def struct(self, wide=False):
         d = self.data
         g = d.graph
         check(lib().mgp_spmm_set_group_hint(g.spmv_lanes), "mgp_spmm_set_group_hint")
         op = OperatorT()
-        op.L = d.csr()
+        op.L = d.csr(wide) if wide else d.csr()
         op.pre = self.pre.data_ptr() if self.pre is not None else None
         op.post = self.post.data_ptr() if self.post is not None else None
         op.nu = int(self.nu)
@@ -66,7 +66,7 @@ class Descriptor:
         _lib.require_device(X)
         squeeze = X.dim() == 1
         X = _lib.f32c(X.unsqueeze(-1) if squeeze else X)
-        op = self.struct()
+        op = self.struct(wide=X.shape[1] >= 48)
         out = torch.empty_like(X)
         C = X.shape[1]
         for c0 in range(0, C, 256):

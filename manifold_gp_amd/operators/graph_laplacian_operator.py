@@ -112,7 +112,7 @@ class GraphLaplacianOperator(LinearOperator):
         if X.shape[0] != n:
             raise RuntimeError("shape mismatch: operator is %d x %d, rhs has %d rows" % (n, n, X.shape[0]))
         check(lib().mgp_spmm_set_group_hint(self.graph.spmv_lanes), "mgp_spmm_set_group_hint")
-        csr = d.csr()
+        csr = d.csr(wide=X.shape[1] >= 48)
         out = torch.empty_like(X)
         for c0 in range(0, X.shape[1], 256):
             Xc = X if X.shape[1] <= 256 else X[:, c0:c0 + 256].contiguous()

@@ -447,9 +447,9 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
     rel = getattr(lap_data, "relabelled", lambda: None)()      # graph.RelabelledData: built once per graph / bandwidth
     if rel is not None:
         order = rel.graph.order
-        csr = rel.csr()
+        csr = rel.csr(wide=True)
     else:
-        csr = lap_data.csr()
+        csr = lap_data.csr(wide=True)
     prm = LanczosParamsT(int(max_basis), int(degree), int(max_restarts), float(tol), int(seed))
     wb = lib().mgp_lanczos_workspace_bytes(g.n, int(m), ctypes.byref(prm))
     work = torch.empty(wb, dtype=torch.uint8, device=dev)

@@ -2172,6 +2172,104 @@ def test_spmm_many_columns_all_epilogue_operands(mgp, golden, dev, shape):
                 assert np.abs(d0 - (W.cpu().double().numpy() * ref0).sum(0)).max() < 2e-4 * sc0 * max(n, 16) ** 0.5, (shape, C)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["curve", "ragged", "unordered", "roll", "thin"])
+def test_spmm_matrix_core_tiles(mgp, dev, shape):
+    """48 <= C <= 256 on the matrix cores (spmm_mt_kernel over the dense 16-row tile image, graph.MtPlan) against a float64
+    reference with every epilogue operand it supports in play (pre / post scalings, base term) and without input pre-scaling
+    (its PRE = false instantiation), and against the gather kernel (mgp_spmm_set_mt_mode(0)): n a multiple of 16 and not,
+    C a multiple of 64 and not (the last 64-column block partly masked), tiles of one or two blocks (k = 4), two or three (k = 12) and 5
+    to 20 (the swiss roll at k = 50: every residue of the loop body of four blocks), a graph whose nodes arrive WITHOUT locality (its own CSR gets no image -- 16 rows name hundreds of
+    columns -- the relabelled copy the solvers run on does), and the swiss roll at k = 50.  mgp_spmm_kernel_choice tells which
+    kernel a call launches: the image must actually be used, and a call with dot-product partials must not take it."""
+    import ctypes
+    import scipy.sparse as sp
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.graph import LaplacianData, MtPlan
+    from tools import synth
+    rng = np.random.default_rng(5)
+    if shape == "roll":
+        x, _ = synth.swiss_roll(20000, seed=3, order="morton")
+        k = 50
+    else:
+        n0 = {"curve": 8192, "ragged": 8192 + 7, "unordered": 6000, "thin": 8192}[shape]
+        t = np.sort(rng.random(n0))
+        x = np.stack([np.cos(6.28 * t) * (1 + t), np.sin(6.28 * t) * (1 + t), 0.3 * np.sin(40 * t)], 1).astype(np.float32)
+        if shape == "unordered":
+            x = x[rng.permutation(n0)]
+        k = 4 if shape == "thin" else 12
+    nn = mgp.utils.NearestNeighbors(T(np.ascontiguousarray(x, dtype=np.float32), dev))
+    nn.graph(k)
+    graph, n = nn.knn_graph, x.shape[0]
+    data = LaplacianData(graph, 0.1, True)
+    lib = _lib.lib()
+    if shape == "unordered":
+        assert graph.has_locality_order()
+    if graph.has_locality_order():                                    # (k = 4: the tile builder prefers its own order as well)
+        assert data.mt_plan() is None
+        data = data.relabelled()                                      # what CgPlan / lanczos_smallest multiply with
+    if shape == "thin":
+        # 16 rows of a k = 4 graph name ~20 columns = two blocks of 16, 11 % full: below the library's threshold (it keeps the
+        # gather kernel there); lowered here to run the kernel on its shortest tiles
+        import manifold_gp_amd.graph as graph_mod
+        assert data.mt_plan() is None
+        del data._mt, data.graph._mt_structure
+        keep, graph_mod.MT_MIN_FILL = graph_mod.MT_MIN_FILL, 0.05
+        try:
+            plan = data.mt_plan()
+        finally:
+            graph_mod.MT_MIN_FILL = keep
+    else:
+        plan = data.mt_plan()
+    assert isinstance(plan, MtPlan) and plan.fill >= (0.05 if shape == "thin" else 0.125) and plan.tiles == -(-n // 16)
+    S = (plan.sptr[1:] - plan.sptr[:-1]).cpu().numpy() // 4
+    assert S.min() >= 1
+    if shape == "roll":
+        assert len(set((S % 4).tolist())) == 4 and S.max() >= 12       # every tail of the four-block loop body
+    if shape == "thin":
+        assert S.max() <= 3
+    g = data.graph
+    rowptr, col = g.rowptr.cpu().numpy().astype(np.int64), g.col.cpu().numpy().astype(np.int64)
+    A = sp.csr_matrix((data.vals.cpu().double().numpy(), col, rowptr), shape=(n, n))
+    diag = data.diag.cpu().double().numpy()[:, None]
+    csr = data.csr(wide=True)
+    for C in (20, 48, 64, 100, 128, 200, 256):
+        # (below 48 columns the gather kernel is faster and keeps the call; the comparison below then is gather against gather)
+        assert (lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 0, 0) == 3) == (C >= 48)
+        assert lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 1, 0) != 3 and lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 0, 16) != 3
+        X = torch.randn(n, C, device=dev)
+        pre = torch.rand(n, device=dev) + 0.5
+        post = torch.rand(n, device=dev) + 0.5
+        base = torch.randn(n, C, device=dev)
+        for use_pre in (True, False):
+            outs = []
+            try:
+                for mt in (1, 0):
+                    lib.mgp_spmm_set_mt_mode(mt)
+                    Y = torch.full_like(X, float("nan"))
+                    for _ in range(2):
+                        _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y), 1.25, 1.0,
+                                                      _lib.ptr(pre) if use_pre else None, _lib.ptr(post), _lib.ptr(base), 0.5, 2.0,
+                                                      None, None, _lib.stream()), "mgp_spmm_fused")
+                    outs.append(Y.cpu().double().numpy())
+            finally:
+                lib.mgp_spmm_set_mt_mode(1)
+            Xs = X.cpu().double().numpy() * (pre.cpu().double().numpy()[:, None] if use_pre else 1.0)
+            ref = 0.5 * base.cpu().double().numpy() + 2.0 * post.cpu().double().numpy()[:, None] * (1.25 * Xs + diag * Xs - A @ Xs)
+            scale = np.abs(ref).max()
+            assert not np.isnan(outs[0]).any()
+            assert np.abs(outs[0] - ref).max() < 2e-5 * scale, (shape, C, use_pre)
+            assert np.abs(outs[1] - ref).max() < 2e-5 * scale, (shape, C, use_pre)
+        # plain product, as the eigensolver's block iteration asks for it
+        Y = torch.full_like(X, float("nan"))
+        _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y), 0.0, 1.0, None, None, None, 0.0, 1.0,
+                                      None, None, _lib.stream()), "mgp_spmm_fused")
+        ref = diag * X.cpu().double().numpy() - A @ X.cpu().double().numpy()
+        assert np.abs(Y.cpu().double().numpy() - ref).max() < 2e-5 * np.abs(ref).max(), (shape, C)
+    # a narrow product does not take it, and a struct without the image never does
+    assert lib.mgp_spmm_kernel_choice(ctypes.byref(csr), 16, 0, 0) != 3 and lib.mgp_spmm_kernel_choice(ctypes.byref(csr), 1, 0, 0) != 3
+
+
 @pytest.mark.parametrize("kind", ["gauss", "cube", "huge", "tiny", "mixed", "spike"])
 def test_knn_matrix_core_keys_equal_direct_keys(mgp, dev, kind):
     """The two key paths of the slab pipeline (bf16-split MFMA + absolute bound; fp32 direct differences +

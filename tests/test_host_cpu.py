@@ -34,11 +34,11 @@ def test_library_exports_every_header_symbol():
 def test_struct_layouts_match_c_abi():
     """mgp_csr_t / mgp_operator_t / params structs: sizes as the C compiler lays them out."""
     from manifold_gp_amd import _lib
-    assert ctypes.sizeof(_lib.CsrT) == 112
-    assert ctypes.sizeof(_lib.OperatorT) == 112 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
+    assert ctypes.sizeof(_lib.CsrT) == 144
+    assert ctypes.sizeof(_lib.OperatorT) == 144 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
     assert ctypes.sizeof(_lib.CgParamsT) == 28
     assert ctypes.sizeof(_lib.LanczosParamsT) == 24
-    assert _lib.OperatorT.pre.offset == 112 and _lib.OperatorT.nu.offset == 128
+    assert _lib.OperatorT.pre.offset == 144 and _lib.OperatorT.nu.offset == 160
 
 
 def test_argument_errors_without_gpu():

@@ -4,6 +4,9 @@ import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
 from manifold_gp_amd.solvers import lanczos_smallest
+from manifold_gp_amd import _lib
+if os.environ.get("MGP_MT") == "0":          # A/B: without the matrix-core tile SpMM
+    _lib.lib().mgp_spmm_set_mt_mode(0)
 class A: workload, nodes, gpus, s5_order = "c3", 0, 1, "morton"
 wl = bench.build_workload(A(), torch.device("cuda:0"), 0, 1)
 data = wl["lap"].data
