@@ -404,3 +404,17 @@ def test_kernel_block_pp_instruction_stream_respects_its_own_waits():
         pytest.skip("hipcc not found: only the checker's own logic was tested")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_kblock_isa.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+    # spmm_mt_kernel (entered with three blocks of loads in flight): the replay is clean on the compiled stream and catches a wait
+    # that lets one operation too many stay in flight, and a missing wait in front of the epilogue
+    asm = chk.compile_to_asm(os.path.join(root, "manifold_gp_amd", "csrc", "spmm.hip"), ["-mllvm", "-amdgpu-mfma-vgpr-form=1"])
+    assert asm is not None and chk.check_replay(asm, chk.MT_PATTERN, 2, "spmm_mt_kernel") == []
+    import re
+    k0 = [m.start() for m in re.finditer(r"^_ZN\d+_GLOBAL__N_1\d+spmm_mt_kernelILb0EE.*:", asm, re.M)][0]
+    k1 = asm.index(".end_amdhsa_kernel", k0)
+    body = asm[k0:k1]
+    assert "s_waitcnt vmcnt(17)" in body and "s_waitcnt vmcnt(16)" in body
+    loose = asm[:k0] + body.replace("s_waitcnt vmcnt(17)", "s_waitcnt vmcnt(18)", 1) + asm[k1:]
+    assert any("still in flight" in p for p in chk.check_replay(loose, chk.MT_PATTERN, 2, "spmm_mt_kernel"))
+    last0 = body.rindex("s_waitcnt vmcnt(0)")
+    nowait = asm[:k0] + body[:last0] + "s_nop 0" + body[last0 + len("s_waitcnt vmcnt(0)"):] + asm[k1:]
+    assert chk.check_replay(nowait, chk.MT_PATTERN, 2, "spmm_mt_kernel") != []

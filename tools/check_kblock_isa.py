@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Static check of the instruction streams of kernel_block_pp, kernel_block_one and kernel_block_res (manifold_gp_amd/csrc/features.hip;
-kernel_block_res: see check_res).
+kernel_block_res: see check_res) and of spmm_mt_kernel (csrc/spmm.hip: see check_replay).
 
 Its staging loads are inline asm (`buffer_load_dwordx4 ... offen` through descriptors of the operands' exact extents) whose completion the compiler does not track: the kernel waits for
 them with its own `s_waitcnt vmcnt(0)`.  That is only sound if NO instruction touches a destination register of such a load
@@ -141,22 +141,96 @@ def check_res(asm, expect=29):
     return problems
 
 
-def main():
+def check_replay(asm, pattern, expect, what):
+    """Kernels whose loads are inline asm waited for with `vmcnt(N)`, N > 0, and whose loop is ENTERED with loads in flight
+    (spmm_mt_kernel: three blocks of operands ahead): the whole function is replayed in text order against an in-order queue of
+    its vector memory operations, every loop body three times (forward branches fall through: the paths that skip code issue
+    fewer operations and wait for the same counts, i.e. for more).  No instruction may read or write a destination register of
+    a load still in the queue; at s_endpgm the queue must be empty of loads."""
+    lines = asm.split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(pattern, l)]
+    problems = []
+    for a in starts:
+        b = next(i for i in range(a, len(lines)) if ".end_amdhsa_kernel" in lines[i])
+        name = what + " " + re.sub(r"^_ZN\d+_GLOBAL__N_1\d+", "", lines[a].split(":")[0])[:40]
+        body = [lines[i].strip() for i in range(a + 1, b)]
+        body = [t for t in body if t and not t.startswith(";") and (not t.startswith(".") or re.match(r"^\.LBB\d+_\d+:", t))]
+        labels = {t.split(":")[0]: k for k, t in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", t)}
+        loops = {}
+        for k, t in enumerate(body):
+            m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", t)
+            if m and m.group(1) in labels and labels[m.group(1)] < k:
+                loops[k] = labels[m.group(1)]
+        if len(loops) != 1:
+            problems.append("%s: %d loops, expected one" % (name, len(loops)))
+            continue
+        (tail, head), = loops.items()
+        trace = body[:tail + 1] + body[head:tail + 1] * 2 + body[tail + 1:]
+        queue, mfma = [], 0
+        for t in trace:
+            op = t.split()[0]
+            if op.startswith(".LBB"):
+                continue
+            m = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                if len(queue) > n:
+                    queue = queue[len(queue) - n:]
+                continue
+            if op == "s_endpgm":
+                if any(r for r in queue):
+                    problems.append("%s: loads in flight at s_endpgm" % name)
+                queue = []
+                continue
+            inflight = set().union(*[r for r in queue if r]) if queue else set()
+            if regs_of(t) & inflight:
+                problems.append("%s: touches a register of a load still in flight: %s" % (name, t))
+            mfma += op.startswith("v_mfma")
+            m = re.match(r"(buffer|global)_load_dword(x(\d))? v(\[(\d+):(\d+)\]|(\d+))", t)
+            if m:
+                lo = int(m.group(5) or m.group(7)); hi = int(m.group(6) or m.group(7))
+                queue.append(set(range(lo, hi + 1)))
+            elif op.startswith(("buffer_load", "global_load", "flat_load", "scratch_")):
+                problems.append("%s: a load the check does not know: %s" % (name, t))
+            elif op.startswith(("buffer_store", "global_store", "flat_store", "global_atomic", "buffer_atomic")):
+                queue.append(None)
+        if mfma == 0:
+            problems.append("%s: no MFMA found" % name)
+    if len(starts) != expect:
+        problems.append("expected %d instantiations of %s, found %d" % (expect, what, len(starts)))
+    return problems
+
+
+def compile_to_asm(src, extra=()):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    src = os.path.join(ROOT, "manifold_gp_amd", "csrc", "features.hip")
     with tempfile.TemporaryDirectory() as d:
-        out = os.path.join(d, "features.s")
+        out = os.path.join(d, "out.s")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"),
-               "-I" + os.path.dirname(src), "--cuda-device-only", "-S", src, "-o", out]
+               "-I" + os.path.dirname(src), "--cuda-device-only", "-S", src, "-o", out] + list(extra)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             print(r.stderr[-2000:])
-            return 2
-        asm = open(out).read()
-        problems = check(asm) + check_res(asm)
+            return None
+        return open(out).read()
+
+
+MT_PATTERN = r"^_ZN\d+_GLOBAL__N_1\d+spmm_mt_kernelILb[01]EE.*:\s*(;.*)?$"
+
+
+def main():
+    csrc = os.path.join(ROOT, "manifold_gp_amd", "csrc")
+    asm = compile_to_asm(os.path.join(csrc, "features.hip"))
+    if asm is None:
+        return 2
+    problems = check(asm) + check_res(asm)
+    # spmm.hip is built with the MFMA accumulators in VGPRs (csrc/build.sh)
+    asm = compile_to_asm(os.path.join(csrc, "spmm.hip"), ["-mllvm", "-amdgpu-mfma-vgpr-form=1"])
+    if asm is None:
+        return 2
+    problems += check_replay(asm, MT_PATTERN, 2, "spmm_mt_kernel")
     for p in problems:
         print(p)
-    print("kernel_block_pp / kernel_block_one / kernel_block_res instruction streams:", "clean" if not problems else "%d problem(s)" % len(problems))
+    print("kernel_block_pp / kernel_block_one / kernel_block_res / spmm_mt_kernel instruction streams:", "clean" if not problems else "%d problem(s)" % len(problems))
     return 1 if problems else 0
 
 
