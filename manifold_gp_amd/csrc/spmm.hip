@@ -1818,8 +1818,10 @@ __global__ __launch_bounds__(kBlock) void spmm_mt_kernel(SpmmArgs p, MtArgs m) {
   const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
   const int w = __builtin_amdgcn_readfirstlane(lb * (kBlock / 64) + (int)(threadIdx.x >> 6));
   const int t = w / m.NCB, cb = w % m.NCB;           // the column blocks of a tile side by side: they share its image
-  if (t >= m.T) return;
   const int C = p.C;
+  if (t >= m.T && !p.dot_partials) return;           // (with dot partials every wave of the workgroup meets at the barrier below)
+  mgp_v4f ds = {0.f, 0.f, 0.f, 0.f};                 // this lane's share of sum_rows dotw * y for columns c0 .. c0 + 3
+  if (t < m.T) {
   const int base = __builtin_amdgcn_readfirstlane(m.sptr[t]), S = __builtin_amdgcn_readfirstlane(m.sptr[t + 1]) - base;
   const int blk0 = base >> 2, NB = S >> 2;
   const int64_t nx = p.n + p.goff;                   // rows of X the columns can name (host side: goff == 0)
@@ -1888,7 +1890,31 @@ __global__ __launch_bounds__(kBlock) void spmm_mt_kernel(SpmmArgs p, MtArgs m) {
         mgp_v4f y = p.co * tt;
         if (p.base) y += p.cb * *reinterpret_cast<const mgp_v4f*>(p.base + gr * C + c0);
         *reinterpret_cast<mgp_v4f*>(p.Y + gr * C + c0) = y;
+        if (p.dot_partials) ds += *reinterpret_cast<const mgp_v4f*>(p.dotw + gr * C + c0) * y;
       }
+    }
+  }
+  }   // t < m.T
+  if (p.dot_partials) {
+    // per workgroup and column: lanes kq = 1..3 onto kq = 0 (fixed order), then the workgroup's waves of the column's block in
+    // wave order.  Any four consecutive waves hold every column block (NCB <= 4), except past the last tile: zeros there.
+    __shared__ float red[kBlock / 64][64];
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = ds[e];
+      v += __shfl_down(v, 16, 64);
+      v += __shfl_down(v, 32, 64);
+      if (kq == 0) red[wave][4 * j + e] = v;
+    }
+    __syncthreads();
+    const int w0 = lb * (kBlock / 64);
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+      float tsum = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < kBlock / 64; ++wv)
+        if ((w0 + wv) % m.NCB == c / 64 && (w0 + wv) / m.NCB < m.T) tsum += red[wv][c & 63];
+      p.dot_partials[(int64_t)lb * C + c] = tsum;
     }
   }
 }
@@ -2206,10 +2232,11 @@ static bool aligned16(const void* a, const void* b, const void* c, const void* d
 // partials and no row offset.  mgp_spmm_set_mt_mode(0) = never (A/B runs, tests).
 int g_mt_mode = 1;
 constexpr int kMtMinCols = 48;
-static bool mt_shape_ok(const mgp_csr_t* L, int C, const float* dotw, int64_t row_offset) {
+static bool mt_shape_ok(const mgp_csr_t* L, int C) {
   if (!g_mt_mode || !L->mt_img || !L->mt_sptr || !L->mt_dcol || L->mt_tiles <= 0 || L->mt_steps <= 0) return false;
   // below 48 columns most lanes of a wave's 64-column block idle: the gather kernel is faster there (C = 32: 34 us against 41)
-  if (C < kMtMinCols || C > 256 || (C & 3) != 0 || dotw || row_offset != 0 || L->tile_rowid) return false;
+  if (C < kMtMinCols || C > 256 || (C & 3) != 0 || L->tile_rowid) return false;
+  if (L->ncols != 0 && L->ncols != L->n) return false;        // a row slice of a partitioned operator never carries an image
   if ((int64_t)L->n * C * 4 >= (int64_t(1) << 31) || ((int64_t)L->mt_steps + 32) * 256 >= (int64_t(1) << 31)) return false;
   return L->mt_tiles == (int32_t)mgp_cdiv(L->n, 16);
 }
@@ -2242,6 +2269,7 @@ extern "C" int mgp_spmm_set_dict_mode(int on) {
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (!L) return MGP_ERR_ARG;
   if (use_tiles(L, C) || use_tiles_small(L, C)) return tile_grid(L, nullptr);
+  if (mt_shape_ok(L, C)) return (int)mgp_cdiv((int64_t)L->mt_tiles * ((C + 63) / 64), kBlock / 64);
   if (d8_shape_ok(L, C)) return d8_grid(L);
   if (dict_shape_ok(L, C)) return dict_grid(L);
   if (use_tiles_wide(L, C)) return tile_grid(L, nullptr);
@@ -2256,7 +2284,8 @@ extern "C" int mgp_spmm_kernel_choice(const mgp_csr_t* L, int C, int with_dot, i
   static const float one = 1.f;
   if (use_tiles(L, C)) return 1;
   if (use_tiles_small(L, C)) return 2;
-  if (mt_shape_ok(L, C, with_dot ? &one : nullptr, row_offset)) return 3;
+  (void)with_dot; (void)one;
+  if (mt_shape_ok(L, C) && row_offset == 0) return 3;
   if (d8_shape_ok(L, C)) return 4;
   if (dict_shape_ok(L, C)) return 5;
   if (use_tiles_wide(L, C)) return 6;
@@ -2420,7 +2449,9 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     else if (C == 12) MGP_TILE_SMALL_LAUNCH(3);
     else MGP_TILE_SMALL_LAUNCH(4);
 #undef MGP_TILE_SMALL_LAUNCH
-  } else if (mt_shape_ok(L, C, dotw, row_offset) && aligned16(X, Y, base, nullptr)) {
+  } else if (mt_shape_ok(L, C)) {
+    if (row_offset != 0) return MGP_ERR_UNSUPPORTED;      // (the dot-partial block count was planned for this kernel)
+    if (!aligned16(X, Y, base, dotw)) return MGP_ERR_ARG;
     MtArgs ma{L->mt_sptr, L->mt_dcol, L->mt_img, L->mt_tiles, (C + 63) / 64, (int)(((int64_t)L->mt_steps + 32) * 256),
               (int)(((int64_t)L->mt_steps * 4 + 192) * 4)};
     const int grid = (int)mgp_cdiv((int64_t)ma.T * ma.NCB, kBlock / 64);

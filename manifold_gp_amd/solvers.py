@@ -39,7 +39,7 @@ class CgPlan:
         self.desc = desc
         self.C = int(C)
         dev = desc.data.graph.device
-        self.op = desc.struct()
+        self.op = desc.struct(wide=self.C >= 48)       # 48 columns and more: the matrix-core tile SpMM (graph.MtPlan)
         stop_mode = settings.cg_stop_mode.value() if stop_mode is None else stop_mode
         self.params = CgParamsT(
             float(settings.cg_tolerance.value() if tol is None else tol),

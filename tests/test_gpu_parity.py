@@ -2181,7 +2181,8 @@ def test_spmm_matrix_core_tiles(mgp, dev, shape):
     C a multiple of 64 and not (the last 64-column block partly masked), tiles of one or two blocks (k = 4), two or three (k = 12) and 5
     to 20 (the swiss roll at k = 50: every residue of the loop body of four blocks), a graph whose nodes arrive WITHOUT locality (its own CSR gets no image -- 16 rows name hundreds of
     columns -- the relabelled copy the solvers run on does), and the swiss roll at k = 50.  mgp_spmm_kernel_choice tells which
-    kernel a call launches: the image must actually be used, and a call with dot-product partials must not take it."""
+    kernel a call launches: the image must actually be used.  The call with weighted dot-product partials (the multi-right-hand-
+    side CG step) goes through the same kernel: per-workgroup partials against the float64 sum."""
     import ctypes
     import scipy.sparse as sp
     from manifold_gp_amd import _lib
@@ -2236,7 +2237,7 @@ def test_spmm_matrix_core_tiles(mgp, dev, shape):
     for C in (20, 48, 64, 100, 128, 200, 256):
         # (below 48 columns the gather kernel is faster and keeps the call; the comparison below then is gather against gather)
         assert (lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 0, 0) == 3) == (C >= 48)
-        assert lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 1, 0) != 3 and lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 0, 16) != 3
+        assert lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 0, 16) != 3
         X = torch.randn(n, C, device=dev)
         pre = torch.rand(n, device=dev) + 0.5
         post = torch.rand(n, device=dev) + 0.5
@@ -2260,6 +2261,19 @@ def test_spmm_matrix_core_tiles(mgp, dev, shape):
             assert not np.isnan(outs[0]).any()
             assert np.abs(outs[0] - ref).max() < 2e-5 * scale, (shape, C, use_pre)
             assert np.abs(outs[1] - ref).max() < 2e-5 * scale, (shape, C, use_pre)
+            # the same call with weighted dot-product partials (the multi-right-hand-side CG step): per-workgroup partials,
+            # as many as mgp_spmm_dot_blocks_csr says, every one written (NaN canary), summing to sum_rows W * Y
+            W = torch.randn(n, C, device=dev)
+            nb = lib.mgp_spmm_dot_blocks_csr(ctypes.byref(csr), C)
+            part = torch.full((nb, C), float("nan"), device=dev)
+            Yd = torch.full_like(X, float("nan"))
+            _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Yd), 1.25, 1.0,
+                                          _lib.ptr(pre) if use_pre else None, _lib.ptr(post), _lib.ptr(base), 0.5, 2.0,
+                                          _lib.ptr(W), _lib.ptr(part), _lib.stream()), "mgp_spmm_fused")
+            assert not torch.isnan(part).any()
+            assert np.abs(Yd.cpu().double().numpy() - ref).max() < 2e-5 * scale
+            dref = (W.cpu().double().numpy() * ref).sum(0)
+            assert np.abs(part.double().sum(0).cpu().numpy() - dref).max() < 2e-4 * scale * max(n, 16) ** 0.5, (shape, C, use_pre)
         # plain product, as the eigensolver's block iteration asks for it
         Y = torch.full_like(X, float("nan"))
         _lib.check(lib.mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(X), C, _lib.ptr(Y), 0.0, 1.0, None, None, None, 0.0, 1.0,
