@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 import torch
 import bench
 from manifold_gp_amd import _lib
+if os.environ.get("MGP_LAB_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["MGP_LAB_LIB"])
 dev = torch.device("cuda:0")
 wl = bench.build_workload(argparse.Namespace(workload=sys.argv[1] if len(sys.argv) > 1 else "c3", nodes=0, s5_order="morton"), dev, 0, 1)
 g, lap = wl["graph"], wl["lap"]
