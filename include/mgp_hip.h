@@ -97,6 +97,14 @@ int mgp_knn_search_indexed(const float* db, int64_t N, int d, const void* index,
  *                   exactly as the reference scatters it twice.
  * Synchronises `stream` (needs M on the host). */
 size_t mgp_graph_workspace_bytes(int64_t n, int k);
+/* The edge list of NearestNeighbors.graph for ANY flag combination (nearest_neighbors.py:39-55), without the CSR that
+ * mgp_graph_build adds for the default one (symmetric, no self loops): self_loop keeps column 0 of the lists (an (i, i) entry
+ * at distance 0), symmetric orients every pair as (min, max), sorts and merges duplicates with the fp32 mean
+ * (torch_sparse.coalesce(op='mean')); not symmetric: the n (k - first) directed pairs in row-major order.  out_* hold
+ * n (k - first) entries (first = 0 with self_loop, else 1); *M = the number written.  Workspace (symmetric only):
+ * mgp_graph_workspace_bytes(n, k + 1). */
+int mgp_graph_edges(const float* D, const int32_t* I, int64_t n, int k, int symmetric, int self_loop, int32_t* out_row,
+                    int32_t* out_col, float* out_val, int64_t* M, void* work, size_t work_bytes, void* stream);
 int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int k, int32_t* tri_row, int32_t* tri_col,
                     float* tri_val, int64_t* M, int32_t* rowptr, int32_t* col, float* d2, int32_t* eid,
                     int64_t* nnz, void* work, size_t work_bytes, void* stream);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "mgp_knn_search_indexed": (c_int, [_P, c_int64, c_int, _P, c_size_t, _P, c_int64, c_int, _P, _P, _P, c_size_t, _P, _P]),
     "mgp_knn_last_direct_chunks": (c_int64, []),
     "mgp_graph_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "mgp_graph_edges": (c_int, [_P, _P, c_int64, c_int, c_int, c_int, _P, _P, _P, POINTER(c_int64), _P, c_size_t, _P]),
     "mgp_graph_tiles_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "mgp_graph_tiles": (c_int, [c_int64, _P, _P, c_int64, c_int, _P, _P, _P, _P, _P, _P, POINTER(c_int64),
                                 POINTER(c_int32), POINTER(c_int32), _P, c_size_t, _P]),

@@ -24,14 +24,14 @@ inline int grid_for(int64_t n) {
 }
 
 __global__ void make_directed_keys(const float* __restrict__ D, const int32_t* __restrict__ I,
-                                   int64_t n, int k, uint64_t* __restrict__ keys,
+                                   int64_t n, int k, int first_col, uint64_t* __restrict__ keys,
                                    float* __restrict__ vals) {
-  const int km1 = k - 1;
+  const int km1 = k - first_col;
   const int64_t total = n * km1;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = t / km1;
-    const int c = (int)(t % km1) + 1;  // nearest_neighbors.py:42-43 drops column 0
+    const int c = (int)(t % km1) + first_col;  // nearest_neighbors.py:42-43 drops column 0 unless self_loop
     const uint32_t j = (uint32_t)I[i * k + c];
     const uint32_t r = (uint32_t)i;
     const uint32_t lo = r < j ? r : j, hi = r < j ? j : r;   // :48-50 orient row<col
@@ -232,7 +232,7 @@ extern "C" int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int 
   GraphWork w;
   if (!carve(w, work, work_bytes, 2 * total, n)) return MGP_ERR_WORKSPACE;
 
-  hipLaunchKernelGGL(make_directed_keys, dim3(grid_for(total)), dim3(kBlock), 0, st, D, I, n, k, w.keys_a, w.vals_a);
+  hipLaunchKernelGGL(make_directed_keys, dim3(grid_for(total)), dim3(kBlock), 0, st, D, I, n, k, 1, w.keys_a, w.vals_a);
   MGP_LAUNCH_CHECK();
   hipcub::DoubleBuffer<uint64_t> kb(w.keys_a, w.keys_b);
   hipcub::DoubleBuffer<float> vb(w.vals_a, w.vals_b);
@@ -253,6 +253,65 @@ extern "C" int mgp_graph_build(const float* D, const int32_t* I, int64_t n, int 
   MGP_HIP_TRY(hipStreamSynchronize(st));
   *M = (int64_t)last_idx + last_head;
   return csr_from_tri(w, tri_row, tri_col, tri_val, *M, n, rowptr, col, d2, eid, nnz, st);
+}
+
+namespace {
+// symmetric = False (nearest_neighbors.py:45-46, 53): every (query, neighbour) pair as it stands, row-major
+__global__ void directed_edges(const float* __restrict__ D, const int32_t* __restrict__ I, int64_t n, int k, int first_col,
+                               int32_t* __restrict__ row, int32_t* __restrict__ col, float* __restrict__ val) {
+  const int km1 = k - first_col;
+  const int64_t total = n * km1;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = t / km1;
+    const int c = (int)(t % km1) + first_col;
+    row[t] = (int32_t)i;
+    col[t] = I[i * k + c];
+    val[t] = D[i * k + c];
+  }
+}
+}  // namespace
+
+// The edge list of NearestNeighbors.graph for ANY flag combination (nearest_neighbors.py:39-55), without the CSR that
+// mgp_graph_build adds for the default one: self_loop keeps column 0 of the lists (the point itself at distance 0: an (i, i)
+// entry), symmetric orients every pair as (min, max), sorts and merges duplicates with the fp32 mean in sorted order
+// (torch_sparse.coalesce(op='mean')); not symmetric: the n (k - first) directed pairs in row-major order.
+// out_* hold n (k - first) entries at most; *M = the number written.  Workspace: mgp_graph_workspace_bytes(n, k + 1).
+extern "C" int mgp_graph_edges(const float* D, const int32_t* I, int64_t n, int k, int symmetric, int self_loop,
+                               int32_t* out_row, int32_t* out_col, float* out_val, int64_t* M, void* work, size_t work_bytes,
+                               void* stream) {
+  if (!D || !I || !out_row || !out_col || !out_val || !M) return MGP_ERR_ARG;
+  const int first = self_loop ? 0 : 1;
+  if (n <= 0 || k <= first || n * (int64_t)(k - first) * 2 > 0x7fffffff) return MGP_ERR_ARG;
+  hipStream_t st = mgp_stream(stream);
+  const int64_t total = n * (int64_t)(k - first);
+  if (!symmetric) {
+    hipLaunchKernelGGL(directed_edges, dim3(grid_for(total)), dim3(kBlock), 0, st, D, I, n, k, first, out_row, out_col, out_val);
+    MGP_LAUNCH_CHECK();
+    *M = total;
+    return MGP_OK;
+  }
+  if (!work) return MGP_ERR_ARG;
+  GraphWork w;
+  if (!carve(w, work, work_bytes, 2 * total, n)) return MGP_ERR_WORKSPACE;
+  hipLaunchKernelGGL(make_directed_keys, dim3(grid_for(total)), dim3(kBlock), 0, st, D, I, n, k, first, w.keys_a, w.vals_a);
+  MGP_LAUNCH_CHECK();
+  hipcub::DoubleBuffer<uint64_t> kb(w.keys_a, w.keys_b);
+  hipcub::DoubleBuffer<float> vb(w.vals_a, w.vals_b);
+  size_t tb = w.cub_bytes;
+  MGP_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w.cub, tb, kb, vb, (int)total, 0, 32 + bits_for(n), st));
+  hipLaunchKernelGGL(mark_heads, dim3(grid_for(total)), dim3(kBlock), 0, st, kb.Current(), total, w.head);
+  MGP_LAUNCH_CHECK();
+  tb = w.cub_bytes;
+  MGP_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(w.cub, tb, w.head, w.uidx, (int)total, st));
+  hipLaunchKernelGGL(segment_mean, dim3(grid_for(total)), dim3(kBlock), 0, st, kb.Current(), vb.Current(), w.head, w.uidx, total,
+                     out_row, out_col, out_val);
+  MGP_LAUNCH_CHECK();
+  int32_t last_idx = 0, last_head = 0;
+  MGP_HIP_TRY(hipMemcpyAsync(&last_idx, w.uidx + (total - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipMemcpyAsync(&last_head, w.head + (total - 1), sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  *M = (int64_t)last_idx + last_head;
+  return MGP_OK;
 }
 
 extern "C" int mgp_graph_from_coo(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val,

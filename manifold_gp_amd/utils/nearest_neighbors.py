@@ -85,20 +85,23 @@ class NearestNeighbors():
         if symmetric and not self_loop:
             self.knn_graph = KnnGraph.from_knn(val, idx.to(torch.int32), points=self.x if self.x.shape[1] <= 3 else None)
             return self.knn_graph.edge_index, self.knn_graph.edge_value
-        # non-default variants: plain torch index bookkeeping (no arithmetic), as
-        # nearest_neighbors.py:42-53
-        if not self_loop:
-            val, idx = val[:, 1:], idx[:, 1:]
-        rows = torch.arange(n, device=self.x.device).repeat_interleave(idx.shape[1])
-        cols = idx.reshape(-1)
-        val = val.reshape(-1)
+        # non-default variants (nearest_neighbors.py:42-53): the edge list alone, no CSR (mgp_graph_edges)
+        first = 0 if self_loop else 1
+        total = n * (k - first)
+        dev = self.x.device
+        row = torch.empty(total, dtype=torch.int32, device=dev)
+        col = torch.empty(total, dtype=torch.int32, device=dev)
+        out = torch.empty(total, dtype=torch.float32, device=dev)
+        M = ctypes.c_int64(0)
+        work = None
         if symmetric:
-            lo, hi = torch.minimum(rows, cols), torch.maximum(rows, cols)
-            key = lo * n + hi
-            uniq, inv, cnt = torch.unique(key, return_inverse=True, return_counts=True)
-            s = torch.zeros(uniq.shape[0], device=val.device).index_add_(0, inv, val)
-            return torch.stack([uniq // n, uniq % n]), s / cnt
-        return torch.stack([rows, cols]), val
+            wb = lib().mgp_graph_workspace_bytes(n, k + 1)
+            work = _lib.workspace(wb, "graph", dev)
+        check(lib().mgp_graph_edges(ptr(_lib.f32c(val)), ptr(idx.to(torch.int32).contiguous()), n, int(k), int(bool(symmetric)),
+                                    int(bool(self_loop)), ptr(row), ptr(col), ptr(out), ctypes.byref(M), ptr(work),
+                                    work.numel() if work is not None else 0, stream()), "mgp_graph_edges")
+        m = M.value
+        return torch.stack([row[:m], col[:m]]).long(), out[:m].clone()
 
     @property
     def min_ivf(self):

@@ -1209,6 +1209,27 @@ def test_graph_variants_and_errors(mgp, golden, dev):
     assert torch.equal(idx_d[1].view(-1, 9).cpu(), torch.from_numpy(g["knn_I"][:, 1:].astype(np.int64)))
     idx_s, val_s = knn.graph(10, self_loop=True)                           # keeps the self column
     assert (idx_s[0] == idx_s[1]).sum() == x.shape[0]
+    # every flag combination (mgp_graph_edges for the non-default ones) against nearest_neighbors.py:39-55 restated in numpy
+    D, I = g["knn_D"], g["knn_I"].astype(np.int64)
+    n = x.shape[0]
+    for symmetric in (False, True):
+        for self_loop in (False, True):
+            first = 0 if self_loop else 1
+            rows = np.repeat(np.arange(n), 10 - first)
+            cols, vals = I[:, first:].reshape(-1), D[:, first:].reshape(-1).astype(np.float32)
+            if symmetric:
+                lo, hi = np.minimum(rows, cols), np.maximum(rows, cols)
+                key = lo * n + hi
+                uniq, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+                ssum = np.zeros(len(uniq), np.float64)
+                np.add.at(ssum, inv, vals.astype(np.float64))
+                want_idx, want_val = np.stack([uniq // n, uniq % n]), (ssum / cnt).astype(np.float32)
+            else:
+                want_idx, want_val = np.stack([rows, cols]), vals
+            got_idx, got_val = knn.graph(10, symmetric=symmetric, self_loop=self_loop)
+            assert got_idx.dtype == torch.int64 and got_val.dtype == torch.float32
+            assert np.array_equal(got_idx.cpu().numpy(), want_idx), (symmetric, self_loop)
+            assert np.allclose(got_val.cpu().numpy(), want_val, rtol=1e-6, atol=0), (symmetric, self_loop)
     with pytest.raises(ValueError):
         knn.search(x[:, :1], 5)
     with pytest.raises(ValueError):
