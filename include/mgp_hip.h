@@ -228,7 +228,8 @@ int mgp_spmm_set_dict_mode(int on);
 /* 48 <= C <= 256 with C % 4 == 0 (round 4): the SpMM on the fp32 MATRIX CORES over 16-row tiles stored dense in their own distinct
  * columns (csrc/spmm.hip spmm_mt_kernel): a tile's distinct X rows cross the vector memory path once per tile and 64-column
  * block, straight into the MFMA operand layout; no LDS, no barrier.  Taken (before every other wide kernel) when the CSR
- * carries mt_* and the call has no dot-product partials and no row offset; a row's sum is taken in ascending column order.
+ * carries mt_* and the call has no row offset (weighted dot-product partials included: one row of partials per workgroup of four
+ * (tile, block) waves, mgp_spmm_dot_blocks_csr counts them); a row's sum is taken in ascending column order.
  * N = 60k, C = 128: 60 us against 94 for the gather kernel.  mgp_spmm_set_mt_mode(0) = never; returns the previous setting.
  * mgp_spmm_mt_fill builds mt_dcol / mt_img from a CSR in natural row order and its 16-row tile dictionaries
  * (mgp_graph_tiles with tile_rows = 16: tile_ptr16, tile_cols16, lid16) and the step offsets sptr (per tile
