@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Run on the GPU box (through gpurun): every committed profile of a round taken again on the current source tree, summaries
-# under gpurun_out/profiles_out/<tag>_* (copy them to profiles/ and commit).  Usage: tools/retake_profiles.sh r04
+# under gpurun_out/profiles_out/<tag>_* (then, here: python tools/assemble_profiles.py <tag>, and commit profiles/).  Usage: tools/retake_profiles.sh r04
 # Needed after ANY change to manifold_gp_amd/csrc/*.hip|*.h or include/*.h: bench.py quotes a profile only while its
 # source_hash equals the tree's (roofline.profile_age_ok).
 set -o pipefail
@@ -32,6 +32,10 @@ fi
 [ $fail = 0 ] && { bash tools/pmc_mfma.sh > "$out/${tag}_pmc_mfma_raw.txt" 2>&1 || fail=1; }
 [ $fail = 0 ] && { bash tools/pmc_kernel.sh mt spmm_mt tools/lab/spmm_one.py 128 2 0 0 0 1 > "$out/${tag}_pmc_spmm_mt_raw.txt" 2>&1 || fail=1; }
 [ $fail = 0 ] && { bash tools/pmc_kernel.sh gather128 'spmm_kernel<64' tools/lab/spmm_one.py 128 0 0 0 0 0 > "$out/${tag}_pmc_spmm_gather_raw.txt" 2>&1 || fail=1; }
+# the kernel block at the C3 posterior shape: matrix-pipe counters and kernel-trace durations, default kernel against the lean one
+[ $fail = 0 ] && { KNOBS="0 1" bash tools/lab/pmc_kbres.sh > "$out/${tag}_pmc_kbres_raw.txt" 2>&1 || fail=1; }
+[ $fail = 0 ] && { KNOBS="0 1 6" bash tools/lab/trace_kbres.sh > "$out/${tag}_trace_kbres_raw.txt" 2>&1 || fail=1; }
+rm -rf gpurun_out/pmc_kbres gpurun_out/trace_kbres
 # gpurun copies at most 64 MiB of gpurun_out/ back: keep the summaries, drop the raw traces
 rm -rf gpurun_out/prof_"${tag}" gpurun_out/prof_"${tag}"_s5 gpurun_out/prof_eig gpurun_out/pmc_mfma gpurun_out/pmc_mt gpurun_out/pmc_gather128
 ls -la "$out"
