@@ -734,7 +734,7 @@ __device__ __forceinline__ void kb_res_walk(const float* __restrict__ Z1, int64_
     // goes into the vector offset (one VALU add per store, in the other wave's shadow), not into the scalar offset, which
     // the descriptor's range check does not see.
 #ifdef MGP_KB_STORE_WINDOW
-    // lab build (tools/lab/build_kb_variant.sh window -DMGP_KB_STORE_WINDOW): with knob 6 the stores are not dropped but land in a
+    // lab build (tools/lab/build_variant.sh window features.hip -DMGP_KB_STORE_WINDOW): with knob 6 the stores are not dropped but land in a
     // private 8 KB window per wave at the start of K, which stays in L2 -- the store instructions without their HBM traffic
     const int okd = records == 0 ? (int)(blockIdx.x * 4 + (threadIdx.x >> 6)) * 8192 + (4 * h * 32 + c) * 4 : lane_k + col0 * 4;
 #else
