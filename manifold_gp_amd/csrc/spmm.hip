@@ -1748,7 +1748,9 @@ __global__ __launch_bounds__(kD8Threads) void spmm_dict8_kernel(SpmmArgs p, Tile
 //    compiler believes an asm load's destination is written at the asm statement and reuses the register afterwards -- the
 //    first pipelined lab version computed its store addresses in registers a late load then overwrote (a memory fault).
 //  * consecutive tiles (locality order: they share X rows) run on ONE XCD, so that its L2 holds its slice of X (76.7 -> 67.4 us).
-//  * measured at N = 60k, C = 128 (tools/lab/spmm_mt_lab.py, raw product): 60.5 us against 94.4 for the gather kernel.
+//  * measured at N = 60k, C = 128 (tools/lab/time_mt.py, Y = L X with the epilogue): 61.7 us against 91.1 for the gather kernel;
+//    tried on it and dropped (docs/scope.md, open levers): one-wave workgroups, the long tiles first / at raised priority,
+//    non-temporal image loads, both 64-column blocks of a tile in one wave.
 struct MtArgs {
   const int32_t* sptr;   // [T + 1] steps before tile t; every tile has a multiple of 4
   const int32_t* dcol;   // [4 * steps + 192] distinct columns per step, padded with a valid column whose image cells are 0
@@ -2228,8 +2230,8 @@ static bool aligned16(const void* a, const void* b, const void* c, const void* d
 }
 
 // 48 <= C <= 256 on the matrix cores (spmm_mt_kernel): taken when the CSR carries the dense 16-row tile image (mgp_spmm_mt_fill;
-// the host wrapper builds it for graphs in natural row order whose tiles are at least 1/8 full), the call has no dot-product
-// partials and no row offset.  mgp_spmm_set_mt_mode(0) = never (A/B runs, tests).
+// the host wrapper builds it for graphs in natural row order whose tiles are at least 1/8 full) and the call has no row offset
+// (weighted dot-product partials included: one row of partials per workgroup).  mgp_spmm_set_mt_mode(0) = never (A/B runs, tests).
 int g_mt_mode = 1;
 constexpr int kMtMinCols = 48;
 static bool mt_shape_ok(const mgp_csr_t* L, int C) {
