@@ -545,7 +545,8 @@ def test_c4_partition_60k_eight_virtual_ranks(mgp, dev, rmnist60k, recurrence):
 def test_c5_swiss_roll_1m_pipeline(mgp, dev):
     """C5: 1 000 000 points on a swiss roll in R^3 handed over in random order, k = 64, symmetric, nu = 2.
     400 sampled k-NN rows bit-exact; the graph picks a locality order for its tiles; L v against the float64
-    oracle at full size; adjoint and linearity properties of the precision; CG with fp64-residual refinement:
+    oracle at full size; a 64-column product through the matrix-core tile kernel against the same oracle; adjoint and
+    linearity properties of the precision; CG with fp64-residual refinement:
     TRUE relative residual (re-evaluated by the float64 oracle) <= a few 1e-6."""
     from manifold_gp_amd.solvers import CgPlan
     from oracle.sparse import SparsePrecision
@@ -580,6 +581,24 @@ def test_c5_swiss_roll_1m_pipeline(mgp, dev):
     assert abs(float(torch.dot(b.double(), Qa.double()) - torch.dot(a.double(), Qb.double()))) < 1e-5 * float(Qa.norm() * b.norm())
     lin = Q.matmul(2.0 * a - 3.0 * b) - (2.0 * Qa - 3.0 * Qb)
     assert float(lin.norm()) < 1e-5 * float(Qa.norm() + Qb.norm())
+    # ---- a 64-column product at this size through the matrix-core tile kernel (what the eigensolver's block iteration and the
+    # many-column solves run on: P L P^T in the library's locality order, graph.MtPlan) against the float64 oracle
+    import ctypes
+    from manifold_gp_amd import _lib
+    rel = lap.data.relabelled()
+    mt = rel.mt_plan()
+    assert mt is not None and mt.tiles == n // 16 and mt.fill > 0.25
+    csr = rel.csr(wide=True)
+    assert _lib.lib().mgp_spmm_kernel_choice(ctypes.byref(csr), 64, 0, 0) == 3
+    Xw = torch.randn(n, 64, generator=torch.Generator().manual_seed(3))
+    Xp = rel.graph.permute(Xw.to(dev)).contiguous()
+    Yp = torch.full_like(Xp, float("nan"))
+    _lib.check(_lib.lib().mgp_spmm_fused(ctypes.byref(csr), _lib.ptr(Xp), 64, _lib.ptr(Yp), 0.0, 1.0, None, None, None, 0.0, 1.0,
+                                         None, None, _lib.stream()), "mgp_spmm_fused")
+    Yw = rel.graph.unpermute(Yp).cpu().numpy()
+    refw = sq.L @ Xw.double().numpy()
+    assert not np.isnan(Yw).any() and np.abs(Yw - refw).max() < 4e-6 * lmax * float(Xw.abs().max())
+    del Xp, Yp, Yw, refw
     # ---- posterior mean in precision form: (I + noise s Q) x = y, fp32 CG + fp64-residual refinement
     desc = Q._descriptor().with_(scale=s, form=2, noise=noise)
     plan = CgPlan(desc, 1, tol=1e-6, max_iter=5000, stop_mode=1, check_every=8, refine=3)
