@@ -511,6 +511,9 @@ int mgp_lowrank_apply(const float* Z, int64_t n, int m, const float* X, int C, f
  *   mgp_lowrank_residual  out = scale * (V - Z T), T device double [m,C] (m C <= 6144), row sums in fp64 */
 size_t mgp_gram_workspace_bytes(int64_t n, int b);
 int mgp_gram_f64(const float* A, int64_t n, int b, double* G, void* work, size_t work_bytes, void* stream);
+/* the partial Gram blocks of mgp_gram_f64 and of the eigensolver on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; default 1) or by
+ * fp64 vector FMAs (0: A/B runs, tests); returns the previous setting */
+int mgp_gram_set_mfma(int on);
 int mgp_lowrank_residual(const float* Z, int64_t n, int m, const double* T, const float* V, int C, double scale,
                          float* out, void* stream);
 

@@ -179,6 +179,7 @@ SIGNATURES = {
     "mgp_lowrank_apply": (c_int, [_P, c_int64, c_int, _P, c_int, c_float, c_float, _P, _P, c_size_t, _P]),
     "mgp_gram_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "mgp_gram_f64": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _P]),
+    "mgp_gram_set_mfma": (c_int, [c_int]),
     "mgp_lowrank_residual": (c_int, [_P, c_int64, c_int, _P, _P, c_int, c_double, _P, _P]),
 }
 

@@ -124,6 +124,66 @@ __global__ __launch_bounds__(kBlock) void gram_kernel(const float* __restrict__ 
     }
 }
 
+// The same partial Gram blocks on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: exact products of the converted fp32 entries,
+// fp64 accumulation): same 64 x 64 tile per block and 16-row LDS stages as gram_kernel; a wave owns 32 x 32 of the tile as
+// 2 x 2 MFMA tiles and per four rows reads two A^T and two B operands from LDS (lane (i, k) = As[row k][col i]: conflict
+// free), converts them and issues four MFMAs -- 16 MFMAs per stage where the vector form issues 256 DFMAs and 128 converts.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+__global__ __launch_bounds__(kBlock) void gram_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                           int64_t n, int b, int64_t rows_per_chunk,
+                                                           double* __restrict__ partial) {
+  __shared__ float As[16][64 + 1];
+  __shared__ float Bs[16][64 + 1];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  const int64_t r0 = (int64_t)blockIdx.z * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > n) r1 = n;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+  f64x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int64_t rr = r0; rr < r1; rr += 16) {
+    for (int e = threadIdx.x; e < 16 * 64; e += kBlock) {
+      const int lr = e >> 6, lc = e & 63;
+      const int64_t r = rr + lr;
+      const int ci = ti * 64 + lc, cj = tj * 64 + lc;
+      As[lr][lc] = (r < r1 && ci < b) ? A[r * b + ci] : 0.f;
+      Bs[lr][lc] = (r < r1 && cj < b) ? B[r * b + cj] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) {
+      double av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = (double)As[k0 + kq][wi + 16 * a + l16];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bv[c] = (double)Bs[k0 + kq][wj + 16 * c + l16];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[c], acc[a][c], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // acc[a][c][r]: row i = wi + 16 a + 4 r + kq, column j = wj + 16 c + l16 of the tile (the f64 16x16x4 result interleaves the
+  // four k-groups of lanes over the rows: register r of lane group kq is row 4 r + kq -- not the f32 layout's 4 kq + r;
+  // found with tools/lab/dbg_gram.py)
+  double* out = partial + (int64_t)blockIdx.z * b * b;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = ti * 64 + wi + 16 * a + 4 * r + kq, j = tj * 64 + wj + 16 * c + l16;
+        if (i < b && j < b) out[(int64_t)i * b + j] = acc[a][c][r];
+      }
+}
+
 __global__ void gram_reduce_kernel(const double* __restrict__ partial, int chunks, int bb, double* __restrict__ G) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < bb; i += gridDim.x * blockDim.x) {
     double s = 0.0;
@@ -636,9 +696,13 @@ size_t eig_bytes(int64_t n, int m, const mgp_lanczos_params_t* p) {
   return s + 4096;
 }
 
+// 1 (default): the partial Gram blocks on the fp64 matrix cores; 0: fp64 vector FMAs (mgp_gram_set_mfma: A/B, tests)
+int g_gram_mfma = 1;
+
 int launch_gram(const float* A, const float* B, int64_t n, int b, EigWork& w, double* out, hipStream_t st) {
   dim3 grid((unsigned)mgp_cdiv(b, 64), (unsigned)mgp_cdiv(b, 64), (unsigned)w.chunks);
-  hipLaunchKernelGGL(gram_kernel, grid, dim3(kBlock), 0, st, A, B, n, b, w.rows_per_chunk, w.gpart);
+  if (g_gram_mfma) hipLaunchKernelGGL(gram_mfma_kernel, grid, dim3(kBlock), 0, st, A, B, n, b, w.rows_per_chunk, w.gpart);
+  else hipLaunchKernelGGL(gram_kernel, grid, dim3(kBlock), 0, st, A, B, n, b, w.rows_per_chunk, w.gpart);
   MGP_LAUNCH_CHECK();
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)mgp_cdiv((int64_t)b * b, kBlock)), dim3(kBlock), 0, st, w.gpart,
                      w.chunks, b * b, out);
@@ -670,6 +734,12 @@ extern "C" int mgp_gram_f64(const float* A, int64_t n, int b, double* G, void* w
   w.gpart = ar.take<double>((size_t)w.chunks * b * b);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
   return launch_gram(A, A, n, b, w, G, mgp_stream(stream));
+}
+
+extern "C" int mgp_gram_set_mfma(int on) {
+  const int prev = g_gram_mfma;
+  g_gram_mfma = on ? 1 : 0;
+  return prev;
 }
 
 // host-only: the small dense symmetric eigensolver used inside the block eigensolver (exported so that

@@ -742,6 +742,27 @@ def test_spectral_posterior_vs_woodbury_fp64(mgp, golden, dev):
     assert np.abs(wd["ZTy"][:, 0].cpu().numpy() - Zn.T @ g["train_y"].astype(np.float64)).max() < 1e-10 * np.abs(G).max()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,b", [(5000, 128), (1546, 50), (20011, 37), (300, 130), (64, 16), (100003, 64)])
+def test_gram_f64_matrix_cores_and_vector_form(mgp, dev, n, b):
+    """A^T A of a tall fp32 block with fp64 accumulation (mgp_gram_f64: the eigensolver's orthogonalisation, the Woodbury solve):
+    the fp64 matrix-core kernel (v_mfma_f64_16x16x4_f64, default) and the vector-FMA kernel against numpy in float64 -- widths
+    that are not multiples of 16 / 64, a row count that is not a multiple of the 16-row stage, more than one 64-column tile."""
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.solvers import gram_f64
+    lib = _lib.lib()
+    A = torch.randn(n, b, generator=torch.Generator().manual_seed(n + b)).to(dev)
+    ref = A.double().cpu().numpy().T @ A.double().cpu().numpy()
+    try:
+        for on in (1, 0):
+            lib.mgp_gram_set_mfma(on)
+            G = gram_f64(A).cpu().numpy()
+            assert np.abs(G - ref).max() < 1e-12 * np.abs(ref).max(), on
+            assert np.abs(G - G.T).max() < 1e-12 * np.abs(ref).max()
+    finally:
+        lib.mgp_gram_set_mfma(1)
+
+
 # ----------------------------------------------------------------------------- full-size properties
 def test_full_size_properties_60k(mgp, dev):
     """BASELINE size (N = 60k, ~50 neighbours): size-independent properties of the HIP path --

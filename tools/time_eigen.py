@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import bench
 from manifold_gp_amd.solvers import lanczos_smallest
 from manifold_gp_amd import _lib
+if os.environ.get("MGP_GRAM") == "0":        # A/B: Gram blocks by fp64 vector FMAs instead of the fp64 matrix cores
+    _lib.lib().mgp_gram_set_mfma(0)
 if os.environ.get("MGP_MT") == "0":          # A/B: without the matrix-core tile SpMM
     _lib.lib().mgp_spmm_set_mt_mode(0)
 class A: workload, nodes, gpus, s5_order = "c3", 0, 1, "morton"
