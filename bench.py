@@ -135,7 +135,7 @@ def build_workload(args, dev, rank, world, shard_knn=False, scale_nodes=True):
     Q = mgp.operators.PrecisionMaternOperator(lap, nu, torch.tensor([[hp["lengthscale"]]], device=dev))
     desc = Q._descriptor().with_(scale=hp["outputscale"], form=2, noise=hp["noise"])
     return dict(mgp=mgp, graph=graph, lap=lap, desc=desc, y=y, nu=nu, name=name, hp=hp, eps=eps, norm=norm,
-                t_graph=t_graph)
+                t_graph=t_graph, knn=knn, x=x, k=k)
 
 
 def time_spmv_kernel(wl, reps=200, as_given=False):
@@ -191,11 +191,11 @@ def time_spmv_in_solve(wl, args, refine, y, solves=40):
     return ms.value / cnt.value * 1e-3, cnt.value      # seconds per launch, launches timed
 
 
-def hbm_streaming_roofline(dev, order, reps=100):
+def hbm_streaming_roofline(dev, order, reps=100, knn_stage=False, nodes=0):
     """Secondary roofline on a working set that does NOT fit the 256 MiB Infinity Cache: config C5's graph
     (1M-point swiss roll, k = 64, ~0.55 GB of CSR per SpMV).  One graph build + `reps` back-to-back launches of the
     same fused C = 1 SpMV kernel, HIP events on the launch stream."""
-    a = argparse.Namespace(workload="s5", nodes=0, s5_order=order)
+    a = argparse.Namespace(workload="s5", nodes=nodes, s5_order=order)
     wl = build_workload(a, dev, 0, 1)
     g = wl["graph"]
     t_k = time_spmv_kernel(wl, reps=reps)
@@ -203,6 +203,7 @@ def hbm_streaming_roofline(dev, order, reps=100):
     ordered = g.tiles is not None and g.tiles.get("rowid") is not None
     out = dict(workload=wl["name"], nodes=g.n, edges=g.M, bytes_per_launch=B, avg_launch_us=round(t_k * 1e6, 2),
                achieved=round(B / t_k / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(B / t_k / 1e9 / HBM_PEAK_GBS, 4),
+               measured="live_back_to_back (this run: %d graph-replayed launches, HIP events)" % reps,
                tile_order=("locality order (Z-curve); the solvers iterate on the relabelled matrix, vectors permuted in / out once "
                            "per solve" if ordered else "input order"),
                entries_per_dictionary_column=round(g.tiles["reuse"], 2) if g.tiles is not None else None,
@@ -210,6 +211,9 @@ def hbm_streaming_roofline(dev, order, reps=100):
     if ordered:
         t_g = time_spmv_kernel(wl, reps=reps, as_given=True)
         out["single_product_in_caller_order_us"] = round(t_g * 1e6, 2)
+    if knn_stage:
+        from tools import bench_stages
+        out["knn"] = bench_stages.knn_stage(wl["x"], wl["k"], knn=wl["knn"])
     # the C5 posterior-mean solve (I + noise s Q) x = y, tol 1e-6, fp64-residual refinement: caller-order y in, caller-order
     # x out -- what a user of the path times; the two input orders must cost the same
     from manifold_gp_amd.solvers import CgPlan
@@ -223,6 +227,9 @@ def hbm_streaming_roofline(dev, order, reps=100):
     out["cg_solve"] = dict(ms=round((time.perf_counter() - t0) * 1e3, 2), iterations=plan.iters, status=plan.status,
                            true_rel_residual=float(max(plan.resid)))
     plan.close()
+    if knn_stage:        # (the Morton-order call only) none / jacobi / Chebyshev-polynomial preconditioners on the same system
+        from tools import bench_stages
+        out["cg_solve"]["preconditioner"] = bench_stages.preconditioner_block(wl["desc"], wl["y"], 1e-6, 3)
     del wl
     torch.cuda.empty_cache()
     return out
@@ -344,7 +351,9 @@ def _main(quiet):
     ap.add_argument("--workload", default="c3", choices=["c3", "s5"])
     ap.add_argument("--nodes", type=int, default=0, help="override nodes per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the cg_multi_rhs / roofline_hbm blocks")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cg_multi_rhs / roofline_hbm / stages blocks")
+    ap.add_argument("--force-extras", action="store_true",
+                    help="with --nodes: run the extra blocks all the same, at reduced sizes (tests of the line's contract)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N > 1: strong = the SAME graph on every world size (the metric's N = 60k), weak = N x nodes")
     ap.add_argument("--tol", type=float, default=1e-6)
@@ -370,7 +379,8 @@ def _main(quiet):
     if world > 1 or os.environ.get("MGP_FORCE_DIST") == "1":
         from manifold_gp_amd import parallel
         try:
-            return parallel.bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, HBM_PEAK_GBS, quiet.emit)
+            return parallel.bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, HBM_PEAK_GBS, quiet.emit,
+                                              cpu_baseline=None if args.no_cpu_baseline else cpu_baseline)
         except BaseException as e:      # a failed or timed-out collective (MGP_ERR_TIMEOUT) must end THIS process with a
             # non-zero code at once -- no communicator teardown (it can hang on a dead peer), never a re-exec
             import traceback
@@ -506,10 +516,15 @@ def _main(quiet):
                             cg_tol=args.tol, cg_iters=its, cg_rel_residual=resid, cg_true_residual_fp32_apply=true_res,
                             spmv_per_solve=spmvs_per_solve, eps=wl["eps"], knn_graph_build_s=round(wl["t_graph"], 3)),
                 cg_solve_ms=round(dt / args.steps * 1e3, 4), roofline=roof)
-    if args.workload == "c3" and not args.nodes and not args.no_extras:
+    if args.workload == "c3" and not args.no_extras and (not args.nodes or args.force_extras):
+        small = 100000 if args.nodes else 0          # (--force-extras: the blocks at sizes a test can afford)
         line["cg_multi_rhs"] = multi_rhs_solve(wl)
-        hb = hbm_streaming_roofline(dev, "morton")
-        hb["random_order_input"] = {k: v for k, v in hbm_streaming_roofline(dev, "random").items()
+        # the C3 `Q` solve (precision_matern_operator.py:53 on Q itself, one column, tol 1e-6, CG on the whole chain)
+        from tools import bench_stages as _bs
+        line["cg_multi_rhs"]["q_solve_preconditioner"] = _bs.preconditioner_block(
+            wl["desc"].with_(scale=1.0, form=0, noise=0.0), wl["y"], 1e-6, 0, max_iter=2000)
+        hb = hbm_streaming_roofline(dev, "morton", knn_stage=True, nodes=small)
+        hb["random_order_input"] = {k: v for k, v in hbm_streaming_roofline(dev, "random", nodes=small).items()
                                     if k in ("avg_launch_us", "achieved", "frac", "tile_order", "entries_per_dictionary_column",
                                              "single_product_in_caller_order_us", "cg_solve")}
         hb["traffic"], hb["traffic_source"] = None, None
@@ -519,10 +534,50 @@ def _main(quiet):
             hb["traffic"] = pj.get("spmv_hbm_bytes_per_launch")
             hb["traffic_source"] = "profiles/%s (bench.py --workload s5 under rocprofv3 --pmc; profile of this source tree: %s)" \
                                    % (cand, pj.get("source_hash") == tree_hash)
+            # the same kernel in the committed kernel trace of `bench.py --workload s5` (another box of the pool, launches inside
+            # the solves' graphs): both figures in the line, as `roofline` does for the C3 graph
+            ns = pj.get("spmv_kernel_trace_mean_ns")
+            if ns:
+                Bh = hb["bytes_per_launch"]
+                hb["live_back_to_back"] = dict(avg_launch_us=hb["avg_launch_us"], achieved=hb["achieved"], frac=hb["frac"],
+                                               note="this run, this box: back-to-back graph replays, HIP events")
+                hb["in_graph_profile"] = dict(avg_launch_us=round(ns * 1e-3, 2), achieved=round(Bh / ns, 1),
+                                              frac=round(Bh / ns / HBM_PEAK_GBS, 4),
+                                              note="profiles/%s: mean of %s launches inside the S5 solves, rocprofv3 --kernel-trace, "
+                                                   "the box the profile was taken on; profile of this source tree: %s"
+                                                   % (cand, pj.get("spmv_kernel_trace_launches"), pj.get("source_hash") == tree_hash))
             break
         line["roofline_hbm"] = hb
+        from tools import bench_stages
+        log("[bench] stages ...")
+        st = dict(workload=wl["name"])
+        st["knn"] = bench_stages.knn_stage(wl["x"], wl["k"], knn=wl["knn"])
+        st.update(bench_stages.graph_laplacian_stage(wl["knn"], wl["x"], wl["k"], wl["eps"]))
+        kern = wl["mgp"].kernels.RiemannMaternKernel(nu=wl["nu"], x=wl["x"], nearest_neighbors=wl["k"], laplacian_normalization=wl["norm"],
+                                                     num_modes=100, bump_scale=3.0, bump_decay=0.01).to(dev)
+        st.update(bench_stages.spectral_stage(kern, wl["x"], wl["eps"], wl["hp"]["lengthscale"], spmm_bytes))
+        del kern
+        st["train_epoch_supervised"] = bench_stages.training_stage(wl["x"], wl["y"], wl["hp"], dev, semisup=False, epochs=4)
+        st["train_epoch_semisupervised"] = bench_stages.training_stage(wl["x"], wl["y"], wl["hp"], dev, semisup=True, epochs=3)
+        for key, rx in (("train_epoch_supervised", r"r\d+_training_supervised\.json"),
+                        ("train_epoch_semisupervised", r"r\d+_training_semisupervised\.json")):
+            ps = bench_stages.profile_share(rx)
+            if ps is not None:
+                ps["profile_of_this_source_tree"] = ps.get("source_hash") == tree_hash
+                st[key]["kernel_time_profile"] = ps
+        line["stages"] = st
+        log("[bench] reference shape ...")
+        line["reference_bench"] = bench_stages.reference_bench(dev)
+        log("[bench] manifold_784 ...")
+        line["manifold_784"] = bench_stages.manifold784_block(dev, spmm_bytes, n_all=(args.nodes + 600) if args.nodes else 60600)
+        torch.cuda.empty_cache()
     if not args.no_cpu_baseline:
         cb, xs = cpu_baseline(wl, its)
+        rb = line.get("reference_bench")
+        if rb:       # the reference benchmark's three legs on the host cores (benchmark/bench_sparse_laplacian.py:15-34 at its shape)
+            cb["reference_shape"] = dict(shape=rb["shape"], mv_ms=rb.get("cpu_matvec_ms"), mv_first_call_ms=rb.get("cpu_matvec_first_call_ms"),
+                                         grad_ms=rb.get("cpu_grad_backward_ms"), eigen_ms=rb.get("cpu_dense_symeig_ms"),
+                                         threads=rb.get("cpu_threads"), kind="port")
         line["cpu_baseline"] = cb
         err = float((out.view(-1).cpu() - xs).abs().max() / xs.abs().max())
         line["config"]["max_rel_diff_vs_cpu_solution"] = err

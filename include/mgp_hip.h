@@ -238,17 +238,10 @@ int mgp_spmm_set_dict_mode(int on);
  * the [N, 100] right-hand sides of precision_matern_operator.py:50-53. */
 int mgp_spmm_set_mt_mode(int on);
 /* which kernel mgp_spmm_fused would launch for this CSR / width (tests, docs): 0 = gather, 1 = C == 1 tile kernel, 2 = small-C
- * tile kernel, 3 = matrix-core tiles, 4 = 8-lanes-per-row dictionary, 5 = lanes-over-columns dictionary, 6 = chunked dictionary */
+ * tile kernel, 3 = matrix-core tiles, 5 = lanes-over-columns dictionary, 6 = chunked dictionary (4 was a round-4 kernel, removed) */
 int mgp_spmm_kernel_choice(const mgp_csr_t* L, int C, int with_dot, int64_t row_offset);
 int mgp_spmm_mt_fill(int64_t n, const int32_t* rowptr, const float* vals, const uint16_t* lid16, const int32_t* tile_ptr16,
                      const int32_t* tile_cols16, const int32_t* sptr, int64_t steps, int32_t* dcol, float* img, void* stream);
-/* 16 < C <= 128 with C % 4 == 0 on 64-row tiles in row order (round 4): the dictionary kernel as ONE persistent 512-thread
- * workgroup per CU, 8 lanes per row, the dictionary slices in a two-buffer LDS ring filled by LDS-DMA across tile boundaries, the
- * matrix stream decoded once per tile into (value, slice, LDS offset), the walk of a slice a counted loop
- * (csrc/spmm.hip spmm_dict8_kernel).  Built, bit-identical to the dictionary kernel above, NOT faster: 151 us against 91 us
- * per launch at C = 128 on the 60k graph (a barrier per slice makes every stage as long as its longest row run; docs/kernels/
- * spmm.md).  Default 0 = never; 1 = wherever the shape allows (tests, lab runs); returns the previous setting. */
-int mgp_spmm_set_dict8_mode(int on);
 /* Measurement hook (bench.py `roofline`): between begin and end every EAGER launch of the C == 1 tile kernel carries
  * its own start / stop event pair (hipExtLaunchKernelGGL: the dispatch's begin / end timestamps); end returns the sum of
  * the kernel durations and the number of launches timed (at most max_launches).  No effect on results. */
@@ -347,15 +340,21 @@ typedef struct {
 } mgp_cg_params_t;
 
 size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);
-/* C == 1, tile SpMV, nu >= 2, no preconditioner: fold the vector update into launch 0 of the next
- * operator apply (one kernel less per step).  Experiment, default 0 (no gain measured at N = 60k);
- * affects plans created afterwards. */
-int mgp_cg_set_fuse(int on);
+/* ---- Lab-only switches (mgp_*_set_*): process-wide std::atomic<int> words for A/B measurements and tests, each read ONCE per
+ * call (or once at plan creation where the comment says so).  They are not part of the path's contract and are not meant to be
+ * flipped while another thread is inside a call of the same family: two calls that size and launch the same product
+ * (mgp_spmm_dot_blocks_csr, then mgp_spmm_fused) must see the same setting. */
 /* C == 1 plans: the LAST update launch of a plan's first graph also takes the stopping decision of the step behind it and
- * leaves the end-of-graph mark (the workgroup whose dot-product partials arrive last does both: agent-scope release /
- * atomic arrive / acquire inside the launch), instead of a single-workgroup decision launch + a marker launch behind it.
- * Same sums in the same order, same rule, same flags.  Default 1; 0 = the separate launches (A/B measurements, tests);
- * returns the previous setting; affects graphs captured afterwards. */
+ * leaves the end-of-graph mark, instead of a single-workgroup decision launch + a marker launch behind it.  Hand-off inside the
+ * launch (no release / acquire fence -- a fence writes back every dirty L2 line of the vectors the launch has just stored, measured
+ * +3.4 us per solve): lane 0 of every workgroup stores its ||r||^2 partial with a write-through (sc1) relaxed agent-scope atomic
+ * store, drains it (s_waitcnt vmcnt(0)) and makes one returning relaxed agent-scope atomic add on its group's arrival counter
+ * (two levels: eight groups, one top word); the workgroup whose add completes the count reads all partials with sc1 relaxed
+ * agent-scope atomic loads, sums them in the decision kernel's order and takes the decision (MI355X_MICROARCH.md, inter-workgroup
+ * visibility: sc1 stores reach the shared level before vmcnt retires them, sc1 loads miss the non-coherent levels).  Same sums in
+ * the same order, same rule, same flags: bit-identical to the separate launches (tests/test_gpu_parity.py::
+ * test_cg_decide_in_update_matches_separate_launches).  Default 1; 0 = the separate launches; returns the previous setting; read
+ * at plan creation. */
 int mgp_cg_set_decide_in_update(int on);
 /* Plans with more than 16 columns sum the dot-product partials of a step ONCE (cg_reduce_kernel, one small launch
  * ahead of the update) instead of in every workgroup of the update kernel.  Default 1; 0 = the every-workgroup

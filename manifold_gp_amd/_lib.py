@@ -87,14 +87,12 @@ SIGNATURES = {
     "mgp_spmm_set_tile_small_mode": (c_int, [c_int]),
     "mgp_spmm_set_tile_wide_mode": (c_int, [c_int]),
     "mgp_spmm_set_dict_mode": (c_int, [c_int]),
-    "mgp_spmm_set_dict8_mode": (c_int, [c_int]),
     "mgp_spmm_set_mt_mode": (c_int, [c_int]),
     "mgp_spmm_kernel_choice": (c_int, [POINTER(CsrT), c_int, c_int, c_int64]),
     "mgp_spmm_mt_fill": (c_int, [c_int64, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     "mgp_spmm_timing_begin": (c_int, [c_int]),
     "mgp_spmm_timing_end": (c_int, [POINTER(c_float), POINTER(c_int)]),
     "mgp_spmm_set_v4_mode": (c_int, [c_int]),
-    "mgp_cg_set_fuse": (c_int, [c_int]),
     "mgp_cg_set_decide_in_update": (c_int, [c_int]),
     "mgp_cg_set_reduce_once": (c_int, [c_int]),
     "mgp_cg_set_poll_spin": (c_int, [c_int]),

@@ -25,6 +25,7 @@
 #include <new>
 #include <vector>
 #include <string.h>
+#include <atomic>
 #include "mgp_common.h"
 #include "mgp_internal.h"
 
@@ -33,7 +34,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxC = 256;
 constexpr int kMaxGridVec = 512;
-constexpr int kMaxPartials = 4096;   // capacity of the gamma / rr partial arrays (fused step: one slot per SpMV workgroup)
+constexpr int kMaxPartials = 4096;   // capacity of the gamma / rr partial arrays
 
 struct CgArgs {
   int64_t n;
@@ -57,7 +58,6 @@ struct CgArgs {
   float tol;
   int max_iter, min_iter, stop_mode;
   int64_t rows_per_block;
-  float *rn, *sn;     // fused step only (else NULL): scratch for the new r / s, committed by the chain's last SpMV
   // init-free solve (C == 1, tile SpMV, no preconditioner): there is no cg_init launch -- the first apply read the
   // right-hand side itself, copied it to r and left the partials of ||b||^2 here (one slot per SpMV workgroup);
   // at iteration 1 the update takes gamma = ||r||^2 from them and treats p, s, x as zero.  NULL: classic start.
@@ -124,7 +124,6 @@ __global__ __launch_bounds__(kBlock) void cg_init_kernel(CgArgs a, const float* 
       const float u = a.minv ? a.minv[r] * b : b;
       a.x[i] = 0.f; a.p[i] = 0.f; a.s[i] = 0.f;
       a.r[i] = b;
-      if (a.rn) { a.rn[i] = b; a.sn[i] = 0.f; }
       if (a.minv) a.u[i] = u;
       if (a.us) a.us[i] = a.pre[r] * u;
       g = fmaf(b, u, g);
@@ -560,7 +559,9 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
     a.gamma_old[par] = gamma;
     a.alpha_old[par] = alpha;
     if (it == 1) a.bb[0] = bb;
-    a.resid[0] = rel;
+    // DECIDE and not done: the last arriver of this launch writes the residual of step it + 1 to the same word, possibly
+    // through another XCD's L2 -- one writer per launch, so that the device value is defined
+    if (!DECIDE || done) a.resid[0] = rel;
     if (done) {
       a.state[2] = status; a.state[1] = 1;
       a.host_resid[0] = rel;
@@ -686,8 +687,8 @@ __global__ __launch_bounds__(kBlock) void cg_update_c1_kernel(CgArgs a) {
     // run_cg clears the record before every solve and unpacks it into the words the other deciding kernels write.
     const int c = a.state[5] + 1;
     a.state[5] = c;
+    a.resid[0] = reln;                        // the only writer of this word in a deciding launch that goes on (see above)
     if (dn) {
-      a.resid[0] = reln;
       a.state[2] = stn; a.state[1] = 1;
       const unsigned long long rec = (unsigned long long)__builtin_bit_cast(unsigned, reln) |
                                      ((unsigned long long)(unsigned)((itn << 8) | (stn << 4) | 3) << 32);
@@ -756,279 +757,6 @@ __global__ void cg_marker_kernel(int* state, int* host_state) {
   state[5] = c;
   __threadfence_system();
   host_state[4] = c;
-}
-
-// ---- Fused CG step (C == 1, tile SpMV, single-chain operator with nu >= 2, no preconditioner).
-// update_k and the FIRST SpMV of apply_{k+1} in one launch: one launch floor (~2.7 us) and the update
-// kernel's own load chain less per step.  A workgroup owns the same 64-row tiles as spmv_tile_kernel.
-//   * decision: the gamma / rr / delta partials (one slot per workgroup of this grid) are re-reduced by
-//     every workgroup exactly as in cg_update_c1_kernel -> alpha, beta, stop;
-//   * the SpMV input u_new = r - alpha (w + beta s) is NOT read from memory: for every column of the
-//     tile's dictionary it is recomputed from the OLD r, w, s with the same two fmas the owner of that
-//     row uses, so the staged values are bit-identical to what the owner commits;
-//   * own rows: p, x are updated in place (nobody else reads them); the new r and s go to scratch
-//     (rn, sn) because other workgroups still gather the old ones -- the chain's last SpMV, which runs
-//     behind a kernel boundary, copies them back in its epilogue (MgpCommit);
-//   * output: t0 = tau xs + L xs (launch 0 of the operator chain) and the gamma = rr partials of r_new.
-typedef float cgf_v4f __attribute__((ext_vector_type(4)));
-typedef unsigned short cgf_v4h __attribute__((ext_vector_type(4)));
-
-struct CgFuse {
-  const int32_t* rowptr;
-  const float* vals;
-  const float* diag;
-  const int32_t* tile_ptr;
-  const uint32_t* tile_cols;
-  const uint16_t* lid;
-  int64_t ntiles;
-  int tiles_per_block;
-  int max_cols;
-  float tau;
-  const float* pre;   // nullable (op->pre)
-  float* t0;          // output of the chain's launch 0
-  int nb;             // partial slots = workgroups of this grid
-  const float* rws;   // [n][4] = {r, w, s, pre} per row, published by the previous apply's last SpMV
-  const int32_t* rowid;   // nullable: tiles over a row order (rowptr / vals are then the tile-order arrays)
-};
-
-__global__ __launch_bounds__(kBlock, 4) void cg_fused_step_kernel(CgArgs a, CgFuse f) {   // <= 128 VGPRs: 4 workgroups per CU, the 60k grid (938) in one round
-  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
-  __shared__ float sh_w[kBlock / 64][5];
-  __shared__ float sh_o[kBlock / 64];
-  __shared__ int sh_state[2];
-  constexpr int TR = kBlock / 4, NQ = 4, BS = kBlock;
-  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = tid & 3;
-  float* __restrict__ xl = tile_lds;
-  float* __restrict__ part = tile_lds + f.max_cols;
-  const cgf_v4f* __restrict__ rws = reinterpret_cast<const cgf_v4f*>(f.rws);
-
-  // ---- round trip 1: state, scalars, partials (batches of 4 slots per lane, both parities)
-  const CgScalars sc = *reinterpret_cast<const CgScalars*>(a.gamma_old);
-  const int st_it = sc.it, st_done = sc.done;
-  const float go0 = sc.go0, go1 = sc.go1, ao0 = sc.ao0, ao1 = sc.ao1;
-  const float bb_old = sc.bb;
-  float t5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  float gv0[4], gv1[4], rv0[4], rv1[4], dv[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int b = tid + q * kBlock;
-    const int bc = b < f.nb ? b : f.nb - 1;
-    gv0[q] = a.pd_gamma[bc]; gv1[q] = a.pd_gamma[f.nb + bc];
-    rv0[q] = a.pd_rr[bc];    rv1[q] = a.pd_rr[f.nb + bc];
-    dv[q] = a.pd_delta[bc];
-  }
-
-  float alpha = 0.f, beta = 0.f;
-  int par = 0;
-  float nrr = 0.f;
-  const int64_t t0i = (int64_t)lb * f.tiles_per_block;
-  const int64_t t1i = t0i + f.tiles_per_block < f.ntiles ? t0i + f.tiles_per_block : f.ntiles;
-  for (int64_t tile = t0i; tile < t1i; ++tile) {
-    const bool lead = tile == t0i;
-    const int64_t r0 = tile * TR;
-    const int64_t r1 = r0 + TR < a.n ? r0 + TR : a.n;
-    const int e0 = f.rowptr[r0], e1 = f.rowptr[r1];
-    const int dp = f.tile_ptr[tile];
-    const int D = f.tile_ptr[tile + 1] - dp;
-    const int qb = e0 >> 2, Q = (e1 - e0) >> 2;
-    // own row operands (round trip 1 as well: the row index needs no metadata)
-    const int64_t row = r0 + (tid >> 2);
-    const bool valid = row < r1;
-    const int64_t pr_ = valid ? row : r0;                                  // position in the tile order
-    const int64_t rr_ = f.rowid ? (int64_t)f.rowid[pr_] : pr_;             // row of the vectors
-    const cgf_v4f o_rec = rws[rr_];
-    const float o_p = a.p[rr_], o_x = a.x[rr_], o_diag = f.diag[rr_];
-    const int rs = f.rowptr[pr_], re = f.rowptr[pr_ + 1];
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- round trip 2: dictionary ids + first half of the matrix stream
-    unsigned c[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-      const int j = tid + k * BS;
-      c[k] = f.tile_cols[j < D ? dp + j : 0];
-    }
-    cgf_v4f v[NQ];
-    cgf_v4h l[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ / 2; ++k) {
-      const int q = tid + k * BS;
-      const int qi = q < Q ? qb + q : 0;
-      v[k] = *reinterpret_cast<const cgf_v4f*>(f.vals + 4 * (int64_t)qi);
-      l[k] = *reinterpret_cast<const cgf_v4h*>(f.lid + 4 * (int64_t)qi);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (lead) {
-      // consume the partials while round trip 2 is in flight (more than 1024 slots: further batches).
-      // The empty asm pins the sums inside the loop body: they only depend on loop-invariant loads and
-      // would otherwise be hoisted above the tile's own loads, i.e. waited for first.
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        asm volatile("" : "+v"(gv0[q]), "+v"(gv1[q]), "+v"(rv0[q]), "+v"(rv1[q]), "+v"(dv[q]));
-        const bool on = tid + q * kBlock < f.nb;
-        t5[0] += on ? gv0[q] : 0.f; t5[1] += on ? gv1[q] : 0.f;
-        t5[2] += on ? rv0[q] : 0.f; t5[3] += on ? rv1[q] : 0.f;
-        t5[4] += on ? dv[q] : 0.f;
-      }
-      for (int b0 = 4 * kBlock; b0 < f.nb; b0 += 4 * kBlock) {
-        float g0[4], g1[4], q0[4], q1[4], d4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int b = b0 + tid + q * kBlock;
-          const int bc = b < f.nb ? b : f.nb - 1;
-          g0[q] = a.pd_gamma[bc]; g1[q] = a.pd_gamma[f.nb + bc];
-          q0[q] = a.pd_rr[bc];    q1[q] = a.pd_rr[f.nb + bc];
-          d4[q] = a.pd_delta[bc];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const bool on = b0 + tid + q * kBlock < f.nb;
-          t5[0] += on ? g0[q] : 0.f; t5[1] += on ? g1[q] : 0.f;
-          t5[2] += on ? q0[q] : 0.f; t5[3] += on ? q1[q] : 0.f;
-          t5[4] += on ? d4[q] : 0.f;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 5; ++k) t5[k] = mgp_wave_sum(t5[k]);
-      if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) sh_w[wave][k] = t5[k];
-      }
-      if (tid == 0) { sh_state[0] = st_it; sh_state[1] = st_done; }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- round trip 3: {r, w, s, pre} records of the dictionary columns (one 16-byte gather per
-    // column); second half of the stream
-    cgf_v4f g4[NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) g4[k] = rws[c[k]];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int k = NQ / 2; k < NQ; ++k) {
-      const int q = tid + k * BS;
-      const int qi = q < Q ? qb + q : 0;
-      v[k] = *reinterpret_cast<const cgf_v4f*>(f.vals + 4 * (int64_t)qi);
-      l[k] = *reinterpret_cast<const cgf_v4h*>(f.lid + 4 * (int64_t)qi);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (lead) {
-      __syncthreads();
-      if (sh_state[1]) return;
-      const int it = sh_state[0];
-      par = it & 1;
-      const int prev = par ^ 1;
-      float tot[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) tot[k] = (sh_w[0][k] + sh_w[1][k]) + (sh_w[2][k] + sh_w[3][k]);
-      const float gamma = prev ? tot[1] : tot[0], rr2 = prev ? tot[3] : tot[2], delta = tot[4];
-      const float bb = (it == 1) ? rr2 : bb_old;
-      const float rel = (bb > 0.f) ? sqrtf(rr2 / bb) : 0.f;
-      const bool frozen = (a.stop_mode == 0) ? (rel < 1e-10f) : (rel <= a.tol);
-      if (!frozen) {
-        if (it == 1) {
-          alpha = (delta != 0.f) ? gamma / delta : 0.f;
-        } else {
-          const float go = prev ? go1 : go0, ao = prev ? ao1 : ao0;
-          beta = (go != 0.f) ? gamma / go : 0.f;
-          const float den = delta - ((ao != 0.f) ? beta * gamma / ao : 0.f);
-          alpha = (den != 0.f) ? gamma / den : 0.f;
-        }
-        if (!isfinite(alpha) || !isfinite(beta)) { alpha = 0.f; beta = 0.f; }
-      }
-      int done = 0, status = 0;
-      if (a.stop_mode == 0) {
-        if (it > a.min_iter && rel < a.tol) { done = 1; status = 1; }
-      } else if (rel <= a.tol) { done = 1; status = 1; }
-      if (!isfinite(rel)) { done = 1; status = 3; }
-      if (!done && it > a.max_iter) { done = 1; status = 2; }
-      if (blockIdx.x == 0 && tid == 0) {
-        a.gamma_old[par] = gamma;
-        a.alpha_old[par] = alpha;
-        if (it == 1) a.bb[0] = bb;
-        a.resid[0] = rel;
-        if (done) {
-          a.state[2] = status; a.state[1] = 1;
-          a.host_resid[0] = rel;
-          a.host_state[0] = it; a.host_state[2] = status;
-          __threadfence_system();
-          a.host_state[1] = 1;
-        }
-      }
-      if (done) return;
-    }
-    // ---- own rows: the vector update (same fma sequence as cg_update_c1_kernel)
-    const float p_new = fmaf(beta, o_p, o_rec.x);
-    const float s_new = fmaf(beta, o_rec.z, o_rec.y);
-    const float r_new = fmaf(-alpha, s_new, o_rec.x);
-    const float e_x = o_rec.w * r_new;
-    if (valid && sub == 0) {
-      a.p[rr_] = p_new;
-      a.x[rr_] = fmaf(alpha, p_new, o_x);
-      a.sn[rr_] = s_new;
-      a.rn[rr_] = r_new;
-      nrr = fmaf(r_new, r_new, nrr);
-    }
-    // ---- dictionary -> LDS
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-      const int j = tid + k * BS;
-      const float sN = fmaf(beta, g4[k].z, g4[k].y);
-      const float rN = fmaf(-alpha, sN, g4[k].x);
-      if (j < D) xl[j] = g4[k].w * rN;
-    }
-    for (int j = tid + NQ * BS; j < D; j += BS) {
-      const cgf_v4f gg = rws[f.tile_cols[dp + j]];
-      const float sN = fmaf(beta, gg.z, gg.y);
-      const float rN = fmaf(-alpha, sN, gg.x);
-      xl[j] = gg.w * rN;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-      const int q = tid + k * BS;
-      if (q < Q) {
-        float sq = v[k].x * xl[l[k].x];
-        sq = fmaf(v[k].y, xl[l[k].y], sq);
-        sq = fmaf(v[k].z, xl[l[k].z], sq);
-        sq = fmaf(v[k].w, xl[l[k].w], sq);
-        part[q] = sq;
-      }
-    }
-    for (int q = tid + NQ * BS; q < Q; q += BS) {
-      const cgf_v4f vv = *reinterpret_cast<const cgf_v4f*>(f.vals + 4 * (int64_t)(qb + q));
-      const cgf_v4h ll = *reinterpret_cast<const cgf_v4h*>(f.lid + 4 * (int64_t)(qb + q));
-      float sq = vv.x * xl[ll.x];
-      sq = fmaf(vv.y, xl[ll.y], sq);
-      sq = fmaf(vv.z, xl[ll.z], sq);
-      sq = fmaf(vv.w, xl[ll.w], sq);
-      part[q] = sq;
-    }
-    __syncthreads();
-    float acc = 0.f;
-    {
-      int i = (rs >> 2) - qb + sub;
-      const int e = (re >> 2) - qb;
-      for (; i + 12 < e; i += 16) {
-        const float a0 = part[i], a1 = part[i + 4], a2 = part[i + 8], a3 = part[i + 12];
-        acc += a0; acc += a1; acc += a2; acc += a3;
-      }
-      for (; i < e; i += 4) acc += part[i];
-    }
-    acc = mgp_quad_sum(acc);
-    if (valid && sub == 0) {
-      const float lx = o_diag * e_x - acc;
-      f.t0[rr_] = f.tau * e_x + lx;        // a = tau, b = 1, co = 1: launch 0 of q2_chain
-    }
-    if (tile + 1 < t1i) __syncthreads();
-  }
-  nrr = mgp_wave_sum(nrr);
-  if (lane == 0) sh_o[wave] = nrr;
-  __syncthreads();
-  if (tid == 0) {
-    const float tsum = (sh_o[0] + sh_o[1]) + (sh_o[2] + sh_o[3]);
-    a.pd_gamma[(int64_t)par * f.nb + lb] = tsum;    // no preconditioner: gamma = r . r
-    a.pd_rr[(int64_t)par * f.nb + lb] = tsum;
-  }
 }
 
 // ---- iterative refinement (stop_mode 1, max_refine > 0): the recurrence residual of a single-
@@ -1201,14 +929,9 @@ struct CgPlan {
   int marker_seq;             // first graphs launched so far = what cg_marker_kernel will have counted when the newest ends
   bool graphs_tried;
   bool init_free;             // no cg_init launch: the first apply reads the rhs itself (CgArgs::pd_bb)
+  bool decide_in_update;      // the first graph's last update decides + marks (mgp_cg_set_decide_in_update at plan creation)
   float* pd_bb;               // [nbs] partials of ||b||^2 written by the first apply
   char first_record[MGP_SPMM_RECORD_BYTES];   // launch arguments of the first graph's root SpMV (rhs patched per solve)
-  bool fused;                 // step = (chain tail, fused update + chain head) -- see cg_fused_step_kernel
-  CgFuse fuse;
-  int fgrid;
-  size_t flds;
-  float* t0;                  // output of the chain's launch 0 (first scratch buffer of op_work)
-  float* rws;                 // fused step: [n][4] row records {r, w, s, pre}
   int32_t* host_state;      // pinned
   float* host_resid;        // pinned
   float *xacc, *rbuf, *tbuf, *rpart;   // refinement: accumulated solution, residual rhs, A x, partials
@@ -1229,7 +952,6 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   size_t b = 10 * nc;                                  // x r u w p s us + refinement xacc rbuf tbuf
   b += 4 * nc + 256;                                   // operator chain scratch (global length)
   b += 4 * mgp_align((size_t)kMaxPartials * C * sizeof(float));  // pd_gamma[2], pd_rr[2]
-  b += 6 * nc;                                         // fused step: rn, sn, row records [n][4]
   b += 2 * mgp_align((size_t)nbs * C * sizeof(float));          // pd_delta, pd_bb
   b += mgp_align((6 * (size_t)C + 16 + 1024 + 8192) * sizeof(float));   // gamma_old[2] alpha_old[2] bb resid state (+ lab stamps)
   b += mgp_align(3 * (size_t)C * sizeof(float));                 // tot (cg_reduce_kernel)
@@ -1240,17 +962,14 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
 }
 
 constexpr int kReduceOnceAbove = 16;
-int g_cg_reduce_once = 1;   // mgp_cg_set_reduce_once(0): every update workgroup re-reduces the partials at any C (A/B, tests)
-int g_cg_poll_spin = 64;    // flag reads between two looks at the clock in the flag-only poll window; 0: no such window (mgp_cg_set_poll_spin)
-int g_cg_init_free = 1;   // C == 1 plans start without a cg_init launch (mgp_cg_set_init_free(0): classic start)
-int g_cg_decide_in_update = 1;   // the first graph's last update decides + marks (mgp_cg_set_decide_in_update(0): separate launches)
-int g_cg_fuse = 0;   // measured at N = 60k: step 16.3 us fused vs 16.3 us unfused -- off until it wins (docs/kernels/cg.md)
+std::atomic<int> g_cg_reduce_once{1};   // mgp_cg_set_reduce_once(0): every update workgroup re-reduces the partials at any C (A/B, tests)
+std::atomic<int> g_cg_poll_spin{64};    // flag reads between two looks at the clock in the flag-only poll window; 0: no such window (mgp_cg_set_poll_spin)
+std::atomic<int> g_cg_init_free{1};   // C == 1 plans start without a cg_init launch (mgp_cg_set_init_free(0): classic start)
+std::atomic<int> g_cg_decide_in_update{1};   // the first graph's last update decides + marks (mgp_cg_set_decide_in_update(0): separate launches)
 
 // one CG step = operator apply (w = A u, partials of u . w, ticks the iteration counter; skipped once
 // converged) followed by the fused update kernel, which also takes the stopping decision: every
 // graph therefore ends right behind a decision and a solve that needs k steps runs exactly k bodies.
-// Fused form: the update kernel also runs launch 0 of the NEXT apply, so a body is (launches 1..nu-1 of
-// the chain, fused step) and the solve opens with a plain launch 0 (enqueue_head).
 void launch_update_c1(CgPlan* pl, hipStream_t st, bool decide_last) {
   const dim3 grid(pl->args.nbv), block(kBlock);
   if (pl->args.nbs <= 4 * kBlock) {
@@ -1263,14 +982,6 @@ void launch_update_c1(CgPlan* pl, hipStream_t st, bool decide_last) {
 }
 
 int enqueue_body(CgPlan* pl, hipStream_t st, bool decide_last = false) {
-  if (pl->fused) {
-    const MgpCommit cm{pl->args.rn, pl->args.sn, pl->op.pre, pl->rws};
-    MGP_TRY(mgp_operator_apply_tail(&pl->op, pl->args.rn, 1, pl->args.w, pl->args.rn, pl->pd_delta, pl->args.state + 1,
-                                    pl->args.state, &cm, pl->op_work, pl->op_work_bytes, st));
-    hipLaunchKernelGGL(cg_fused_step_kernel, dim3(pl->fgrid), dim3(kBlock), pl->flds, st, pl->args, pl->fuse);
-    MGP_LAUNCH_CHECK();
-    return MGP_OK;
-  }
   MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
                                   pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, pl->args.state + 1,
                                   pl->args.state, pl->op_work, pl->op_work_bytes, st));
@@ -1298,15 +1009,6 @@ int enqueue_first_body(CgPlan* pl, hipStream_t st, const float* rhs, bool record
   return MGP_OK;
 }
 
-// behind cg_init (fused form only): launch 0 of the first apply, t0 = tau xs + L xs with xs = pre (.) b
-int enqueue_head(CgPlan* pl, hipStream_t st) {
-  if (!pl->fused) return MGP_OK;
-  const float tau = 2.0f * (float)pl->op.nu / (pl->op.kappa * pl->op.kappa);
-  const float* in = pl->args.us ? pl->args.us : pl->args.r;
-  return mgp_spmm_fused_part(&pl->op.L, 0, in, 1, pl->t0, tau, 1.0f, nullptr, nullptr, nullptr, 0.f, 1.0f, nullptr, nullptr,
-                             nullptr, nullptr, st);
-}
-
 // (re)build the first graph: cg_init + len bodies.  Leaves has_first = false on any failure (the
 // solve then launches cg_init eagerly and replays the continuation graph).
 void capture_first(CgPlan* pl, int len) {
@@ -1320,13 +1022,13 @@ void capture_first(CgPlan* pl, int len) {
   if (ok) {
     int rc = MGP_OK;
     // `len` = steps until the stopping rule fires: the last of them only detects (see cg_decide_c1_kernel)
-    const bool decide = len >= 2 && !pl->fused && !pl->is_dist && pl->C == 1 &&
+    const bool decide = len >= 2 && !pl->is_dist && pl->C == 1 &&
                         pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock;
     const int bodies = decide ? len - 1 : len;
     int done_bodies = 0;
     // decide: the graph's LAST update also takes the next step's decision and leaves the end-of-graph mark (g_cg_decide_in_update;
     // 0: the separate cg_decide_c1_kernel + cg_marker_kernel launches of rounds 1-3)
-    const bool in_update = decide && g_cg_decide_in_update;
+    const bool in_update = decide && pl->decide_in_update;
     if (pl->init_free) {
       // root node = launch 0 of the first apply, reading a placeholder rhs that is patched before every launch
       rc = enqueue_first_body(pl, pl->cap_stream, (const float*)pl->args.x, true, in_update && bodies == 1);
@@ -1335,7 +1037,6 @@ void capture_first(CgPlan* pl, int len) {
       hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, pl->cap_stream, pl->args,
                          (const float*)pl->args.x);   // placeholder rhs, patched before every launch
       rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
-      if (rc == MGP_OK) rc = enqueue_head(pl, pl->cap_stream);
     }
     for (int i = done_bodies; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream, in_update && i == bodies - 1);
     if (decide && !in_update && rc == MGP_OK) {
@@ -1458,7 +1159,9 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   // update kernel re-reduces ALL dot partials of ALL columns (nbv x (2 nbv + nbs) x C loads per launch),
   // so the grid is kept to one workgroup per CU (their loads go out in batches of 8 / 32 per lane)
   // C > 16: the partials are summed once by cg_reduce_kernel, the update grid is free to fill the chip
-  const bool reduce_once = g_cg_reduce_once && C > (g_cg_reduce_once == 2 ? 1 : kReduceOnceAbove);
+  const int reduce_mode = g_cg_reduce_once;      // (lab knobs: read once, at plan creation)
+  pl->decide_in_update = g_cg_decide_in_update != 0;
+  const bool reduce_once = reduce_mode && C > (reduce_mode == 2 ? 1 : kReduceOnceAbove);
   const int max_grid_vec = (C == 1) ? kMaxGridVec : (reduce_once ? 2048 : 256);
   int64_t rpb = a.TS;
   int64_t nbv = mgp_cdiv(n, rpb);
@@ -1494,35 +1197,12 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   pl->rpart64 = ar.take<double>((size_t)256 * C * 2);
   a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter;
   a.stop_mode = pl->prm.stop_mode;
-  a.rn = nullptr; a.sn = nullptr;
-  pl->fused = false;
-  {
-    int fg = 0, ftpb = 0;
-    size_t fl = 0;
-    if (g_cg_fuse && C == 1 && !dist && !minv && mgp_operator_tail_supported(op) && op->L.tile_rows == kBlock / 4 &&
-        mgp_tile_plan(&op->L, 1, &fg, &ftpb, &fl) && fg <= kMaxPartials) {
-      pl->fused = true;
-      pl->fgrid = fg;
-      pl->flds = fl;
-      a.rn = ar.take<float>(nc); a.sn = ar.take<float>(nc);
-      pl->rws = ar.take<float>(4 * nc);
-      // cg_init and the partial arrays follow the SpMV grid: one slot per workgroup of the fused kernel
-      a.nbv = fg; a.rows_per_block = (int64_t)ftpb * (kBlock / 4);
-      const float tau = 2.0f * (float)op->nu / (op->kappa * op->kappa);
-      pl->t0 = mgp_operator_first_out(op, 1, pl->op_work, pl->op_work_bytes);
-      pl->fuse = CgFuse{op->L.tile_rowptr ? op->L.tile_rowptr : op->L.rowptr, op->L.tile_vals ? op->L.tile_vals : op->L.vals,
-                        op->L.diag, op->L.tile_ptr, reinterpret_cast<const uint32_t*>(op->L.tile_cols), op->L.lid,
-                        mgp_cdiv(op->L.n, (int64_t)op->L.tile_rows), ftpb, op->L.tile_max_cols, tau, op->pre, pl->t0, fg, pl->rws,
-                        op->L.tile_rowid};
-      if (!pl->t0) pl->fused = false;
-    }
-  }
   pl->pd_bb = ar.take<float>((size_t)a.nbs * C);
   a.pd_bb = nullptr;
   a.arrive = ar.take<int>(9 * 32);
   if (a.arrive) MGP_HIP_TRY(hipMemsetAsync(a.arrive, 0, 9 * 32 * sizeof(int), pl->stream));
   pl->init_free = false;
-  if (g_cg_init_free && C == 1 && !dist && !minv && !pl->fused && (op->form == 0 || op->form == 2) &&
+  if (g_cg_init_free && C == 1 && !dist && !minv && (op->form == 0 || op->form == 2) &&
       mgp_tile_plan(&op->L, 1, nullptr, nullptr, nullptr) && a.nbv <= kC1GammaSlots * kBlock &&
       a.nbs <= kC1DeltaSlots * kBlock) {
     pl->init_free = true;
@@ -1567,11 +1247,6 @@ extern "C" int mgp_cg_set_decide_in_update(int on) {
   return prev;
 }
 
-extern "C" int mgp_cg_set_fuse(int on) {
-  g_cg_fuse = on ? 1 : 0;
-  return MGP_OK;
-}
-
 extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
                                   const mgp_cg_params_t* params, void* work, size_t work_bytes,
                                   void* stream, void** plan_out) {
@@ -1610,7 +1285,6 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
     } else {
       hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, rhs);
       MGP_LAUNCH_CHECK();
-      MGP_TRY(enqueue_head(pl, st));
     }
   }
   int guard = 0;
@@ -1657,7 +1331,8 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
       pl->host_state[1] = 1;
       return true;
     };
-    if (launched_first && g_cg_poll_spin > 0) {
+    const int poll_spin = g_cg_poll_spin;      // (lab knob: read once per chunk)
+    if (launched_first && poll_spin > 0) {
       // (not even one query every 20 us: two or three of them during a 55 us solve took the whole gain back.)  The
       // graph's last node (cg_marker_kernel) reports a first graph that ran to its end undecided; the time budget --
       // ten times the last decided solve, at least 2 ms -- is only the guard against a marker that never comes.
@@ -1665,7 +1340,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
       const auto t_spin = std::chrono::steady_clock::now();
       volatile int32_t* marker = pl->host_state + 4;
       while (!decided() && *marker != pl->marker_seq) {
-        for (int spin = 0; spin < g_cg_poll_spin && !decided() && *marker != pl->marker_seq; ++spin) __builtin_ia32_pause();
+        for (int spin = 0; spin < poll_spin && !decided() && *marker != pl->marker_seq; ++spin) __builtin_ia32_pause();
         if (std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_spin).count() > budget) break;
       }
     }

@@ -32,6 +32,7 @@
 #include <functional>
 #include <chrono>
 #include <cstdio>
+#include <atomic>
 #include "mgp_common.h"
 #include "mgp_internal.h"
 
@@ -642,7 +643,7 @@ double top_ritz(int kfull, int k, const std::vector<double>& G, const std::vecto
   return th[kept - 1];
 }
 
-int g_eig_bound_mode = 1;   // 1: the filter's upper end from a Krylov estimate of lambda_max; 0: Gershgorin;
+std::atomic<int> g_eig_bound_mode{1};   // 1: the filter's upper end from a Krylov estimate of lambda_max; 0: Gershgorin;
                             // 2 (tests): HALF the estimate, a bound that is certainly short -- the fallback must catch it
 
 struct EigWork {
@@ -697,7 +698,7 @@ size_t eig_bytes(int64_t n, int m, const mgp_lanczos_params_t* p) {
 }
 
 // 1 (default): the partial Gram blocks on the fp64 matrix cores; 0: fp64 vector FMAs (mgp_gram_set_mfma: A/B, tests)
-int g_gram_mfma = 1;
+std::atomic<int> g_gram_mfma{1};
 
 int launch_gram(const float* A, const float* B, int64_t n, int b, EigWork& w, double* out, hipStream_t st) {
   dim3 grid((unsigned)mgp_cdiv(b, 64), (unsigned)mgp_cdiv(b, 64), (unsigned)w.chunks);

@@ -6,6 +6,7 @@
 // manifold_gp/operators/graph_laplacian_operator.py:146-157, manifold_gp/utils/torch_utils.py:38-41.
 #include <math.h>
 #include <type_traits>
+#include <atomic>
 #include "mgp_common.h"
 
 namespace {
@@ -939,7 +940,7 @@ constexpr int kPpBlocks = 256;     // one 512-thread workgroup per CU, two tile 
 // general one; 1 = lean one tile per workgroup where the operands allow it, 2 = the two-half walk where they allow it,
 // 3 = as 2 with every store dropped (timing), 4 = the general kernel always (kernel_block_mfma: any shape, any alignment)
 // 5 = as 0 (the resident-operand kernel, kernel_block_res, where the operands allow it), 6 = as 5 with every store dropped (timing)
-int g_kblock_pipe = 0;
+std::atomic<int> g_kblock_pipe{0};
 constexpr int kResMinModes = 16, kResMaxModes = 128;
 constexpr int kResWaves = 2048;    // 256 CUs x 4 SIMDs x 2 waves: every wave of kernel_block_res is resident from the start
 
@@ -947,20 +948,21 @@ constexpr int kResWaves = 2048;    // 256 CUs x 4 SIMDs x 2 waves: every wave of
 int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2, int m, float scale, float* K,
                         int64_t ldk, void* stream) {
   if (!Z1 || !Z2 || !K || n1 <= 0 || n2 <= 0 || m <= 0 || ldk < n2) return MGP_ERR_ARG;
+  const int kb_pipe = g_kblock_pipe;       // (lab knob: read once per call)
   dim3 grid((unsigned)mgp_cdiv(n2, kKB), (unsigned)mgp_cdiv(n1, kKB));
   const bool vec = (m % 4 == 0) && ((reinterpret_cast<uintptr_t>(Z1) | reinterpret_cast<uintptr_t>(Z2)) & 15) == 0;
   const bool x4 = vec && n2 % 4 == 0 && ldk % 4 == 0 && (reinterpret_cast<uintptr_t>(K) & 15) == 0;
   const int64_t ntiles = (int64_t)grid.x * grid.y;
   // the lean kernels: 16-byte stores, edge tiles moved back, 32-bit staging offsets, a 31-bit tile extent
-  const bool lean = x4 && g_kblock_pipe != 4 && n1 >= kKB && n2 >= kKB && ldk * 512 < (int64_t(1) << 31) &&
+  const bool lean = x4 && kb_pipe != 4 && n1 >= kKB && n2 >= kKB && ldk * 512 < (int64_t(1) << 31) &&
                     ntiles < (int64_t(1) << 30) && n1 * m < (int64_t(1) << 29) && n2 * m < (int64_t(1) << 29);
-  const bool walk = g_kblock_pipe == 2 || g_kblock_pipe == 3;
+  const bool walk = kb_pipe == 2 || kb_pipe == 3;
   // the resident-operand kernel: 16 <= m <= 128 (4..32 quads: Z1's 64-row group in 4 ceil(Q / 2) x 2 registers, 245 VGPRs at m = 128),
   // n1 >= 64, n2 >= 32
   const int64_t G = mgp_cdiv(n1, 64), nblk = mgp_cdiv(n2, 32);
   const bool res_ok = x4 && m >= kResMinModes && m <= kResMaxModes && n1 >= 64 && n2 >= 32 && 2 * G <= kResWaves && ldk * 512 < (int64_t(1) << 31) &&
                       n1 * m < (int64_t(1) << 29) && n2 * m < (int64_t(1) << 29);
-  const bool res = res_ok && (g_kblock_pipe == 0 || g_kblock_pipe == 5 || g_kblock_pipe == 6);
+  const bool res = res_ok && (kb_pipe == 0 || kb_pipe == 5 || kb_pipe == 6);
   if (res) {
     // a last group of 32 rows or fewer is one row block (n1 >= 64: it is moved back to end at n1)
     const int short_last = (n1 - (G - 1) * 64 <= 32 && G > 1) ? 1 : 0;
@@ -969,7 +971,7 @@ int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2
     // by their stores)
     const int64_t S = std::max<int64_t>(1, std::min<int64_t>((nblk + 1) / 2, kResWaves / WT));
     const int64_t nwg = (mgp_cdiv(WT * S, kBlock / 64) + 7) / 8 * 8;
-    const int records = g_kblock_pipe == 6 ? 0 : 1;
+    const int records = kb_pipe == 6 ? 0 : 1;
 #define MGP_KB_LAUNCH(Q)                                                                                                    \
   case Q:                                                                                                                   \
     hipLaunchKernelGGL(kernel_block_res<Q>, dim3((unsigned)nwg), dim3(kBlock), 0, mgp_stream(stream), Z1, n1, Z2, n2, scale, K, ldk, \
@@ -990,7 +992,7 @@ int mgp_kernel_block_ld(const float* Z1, int64_t n1, const float* Z2, int64_t n2
   if (lean && walk) {
     // tile id = column tile * row tiles + row tile, so the tiles in flight together share their Z2 rows
     const int64_t nb = (ntiles + 1) / 2 < kPpBlocks ? (ntiles + 1) / 2 : kPpBlocks;
-    const int records = g_kblock_pipe == 3 ? 0 : 0x7fffffff;   // 3: a descriptor of zero bytes drops every store (timing only)
+    const int records = kb_pipe == 3 ? 0 : 0x7fffffff;   // 3: a descriptor of zero bytes drops every store (timing only)
     const int ts = (m - (m - 1) / kKC * kKC) / 2;      // 2-mode steps of the last 16-mode stage: 2, 4, 6 or 8
 #define MGP_KB_LAUNCH(TS)                                                                                                   \
   hipLaunchKernelGGL(kernel_block_pp<TS>, dim3((unsigned)nb), dim3(kPpThreads), 0, mgp_stream(stream), Z1, n1, Z2, n2, m, scale, K, \

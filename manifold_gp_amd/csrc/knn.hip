@@ -29,6 +29,7 @@
 #include <math.h>
 #include <limits.h>
 #include <vector>
+#include <atomic>
 #include "mgp_common.h"
 #include "mgp_internal.h"
 
@@ -608,9 +609,9 @@ constexpr int kExactBatch = 16;
 
 // candidate distances on the matrix cores (knn_mfma.hip) from 32 features up; mgp_knn_set_mfma(0) forces
 // the direct-difference tiles
-int g_knn_mfma = 1;
-int g_knn_sym = 1;        // self-search: upper-triangle key tiles only (mgp_knn_set_symmetric(0): every tile)
-int64_t g_last_direct_chunks = 0;
+std::atomic<int> g_knn_mfma{1};
+std::atomic<int> g_knn_sym{1};        // self-search: upper-triangle key tiles only (mgp_knn_set_symmetric(0): every tile)
+std::atomic<int64_t> g_last_direct_chunks{0};
 // (the centring + split of the points is a fixed ~1 ms at 60k x 784: it pays from ~1000 queries on)
 bool use_mfma(int d, int64_t n) { return g_knn_mfma && d >= 32 && n >= 1024; }
 

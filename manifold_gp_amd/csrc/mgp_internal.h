@@ -15,20 +15,6 @@ int mgp_spmm_fused_part(const mgp_csr_t* L, int64_t row_offset, const float* X, 
                         const float* pre, const float* post, const float* base, float cb, float co,
                         const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream);
 
-// Row packing that rides in the epilogue of a C == 1 tile SpMV (fused CG step, cg.hip): the update
-// folded into the previous launch leaves the new r / s in scratch; the chain's last SpMV, which runs
-// behind a kernel boundary, publishes pack4[row] = {r_new, y (= w = A u), s_new, pre} as ONE 16-byte
-// store, so that the next fused step fetches everything it needs about a column with one gather.
-struct MgpCommit {
-  const float* src0;   // r_new [n]
-  const float* src1;   // s_new [n]
-  const float* pre;    // nullable: 1.0 is stored
-  float* pack4;        // [n][4]
-};
-int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
-                          const float* pre, const float* post, const float* base, float cb, float co,
-                          const float* dotw, float* dot_partials, const int* skip, int* tick,
-                          const MgpCommit* commit, void* stream);
 // Init-free CG solve (cg.hip): the FIRST operator apply of a solve reads the caller's right-hand side directly
 // (no cg_init launch).  Launch 0 of the chain stores its raw input rows to copy_x (r = b); the chain's last launch
 // also writes per-workgroup partials of sum dotw^2 (||b||^2) and resets the iteration state to {1, 0, 0}.
@@ -43,7 +29,7 @@ struct MgpFirst {
 int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
                          const float* pre, const float* post, const float* base, float cb, float co,
                          const float* dotw, float* dot_partials, const int* skip, int* tick,
-                         const MgpCommit* commit, const MgpFirst* first, void* stream);
+                         const MgpFirst* first, void* stream);
 int mgp_spmm_patch_node(void* exec, void* node, const void* record, const float* old_ptr, const float* new_ptr);
 // first apply of an init-free solve: launch 0 reads `rhs` (pre-scaled in the kernel by op->pre) and copies it to
 // r_copy; later launches take r_copy as base / dot weight; partials of r . A r and ||r||^2; state reset
@@ -79,14 +65,6 @@ int mgp_operator_apply_dist(const mgp_operator_t* op, const MgpDist* d, const fl
                             float* Y, const float* dotw, float* dot_partials, int nb_loc, const int* skip, int* tick,
                             void* work, size_t work_bytes, void* stream);
 int mgp_dist_allgather_f32(const MgpDist* d, float* buf, int64_t count_per_rank, void* stream);
-
-// fused CG step (cg.hip): run launches 1..nu-1 of a single-chain operator whose launch 0 was done by
-// the caller into mgp_operator_first_out(); hooks as in mgp_operator_apply_ex + row copies
-int mgp_operator_tail_supported(const mgp_operator_t* op);
-float* mgp_operator_first_out(const mgp_operator_t* op, int C, void* work, size_t work_bytes);
-int mgp_operator_apply_tail(const mgp_operator_t* op, const float* X, int C, float* Y, const float* dotw,
-                            float* dot_partials, const int* skip, int* tick, const MgpCommit* commit, void* work,
-                            size_t work_bytes, void* stream);
 
 // k-NN internals (knn.hip / knn_lowd.hip)
 int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,

@@ -21,8 +21,6 @@ struct Hooks {
   float* dot_partials;
   const int* skip;
   int* tick;
-  const MgpCommit* commit;   // nullable: row copies in the epilogue of the chain's last launch
-  int first;                 // first launch of the chain to run (1: launch 0 was done by the caller into t0)
   // init-free CG solve: launch 0 copies its raw input rows to copy_x and leaves its launch record; the last launch
   // writes the sum dotw^2 partials and resets the iteration state (all nullable / 0)
   float* copy_x;
@@ -48,9 +46,8 @@ namespace {
 int q2_chain(const mgp_operator_t* op, const MgpDist* d, int nb_loc, const float* X, const float* Xs, int C,
              float* Y, const float* base, float cb, float co, float* t0, float* t1, const Hooks* hk, void* stream) {
   const float tau = 2.0f * (float)op->nu / (op->kappa * op->kappa);
-  const int s0 = hk ? hk->first : 0;
-  const float* in = s0 > 0 ? (((s0 - 1) & 1) ? t1 : t0) : (Xs ? Xs : X);
-  for (int s = s0; s < op->nu; ++s) {
+  const float* in = Xs ? Xs : X;
+  for (int s = 0; s < op->nu; ++s) {
     const bool first = (s == 0), last = (s == op->nu - 1);
     float* out = last ? Y : ((s & 1) ? t1 : t0);
     // (x + delta L x) / delta == tau x + L x  with delta = 1/tau (precision_matern_operator.py:31-33)
@@ -63,8 +60,7 @@ int q2_chain(const mgp_operator_t* op, const MgpDist* d, int nb_loc, const float
                                  (first && !Xs) ? op->pre : nullptr, last ? op->post : nullptr,
                                  last ? base : nullptr, cb, last ? co * op->scale : 1.0f,
                                  (last && hk) ? hk->dotw : nullptr, dp, hk ? hk->skip : nullptr,
-                                 (last && hk) ? hk->tick : nullptr, (last && hk) ? hk->commit : nullptr,
-                                 use_fst ? &fst : nullptr, stream));
+                                 (last && hk) ? hk->tick : nullptr, use_fst ? &fst : nullptr, stream));
     if (d) {
       // the collectives run unconditionally (also after convergence) so that every rank issues
       // the same sequence; a skipped launch leaves stale but finite data behind them
@@ -130,8 +126,8 @@ int mgp_operator_apply_dist(const mgp_operator_t* op, const MgpDist* d, const fl
   float* ua = ar.take<float>(nc);
   float* ub = ar.take<float>(nc);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
-  Hooks hk{dotw, dot_partials, skip, tick, nullptr, 0, nullptr, nullptr, nullptr, 0};
-  Hooks hk_mid{nullptr, nullptr, skip, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0};
+  Hooks hk{dotw, dot_partials, skip, tick, nullptr, nullptr, nullptr, 0};
+  Hooks hk_mid{nullptr, nullptr, skip, nullptr, nullptr, nullptr, nullptr, 0};
   switch (op->form) {
     case 0:
       return q2_chain(op, d, nb_loc, X, Xs, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
@@ -144,36 +140,6 @@ int mgp_operator_apply_dist(const mgp_operator_t* op, const MgpDist* d, const fl
       return q2_chain(op, d, nb_loc, ub, nullptr, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
   }
   return MGP_ERR_ARG;
-}
-
-// Fused CG step support (cg.hip): the FIRST launch of the chain is done by the caller's own kernel,
-// which writes where launch 0 of q2_chain would (mgp_operator_first_out); this runs launches 1..nu-1
-// with the usual hooks on the last one plus the row copies of `commit`.  Single-chain forms only.
-int mgp_operator_tail_supported(const mgp_operator_t* op) {
-  return check_op(op) == MGP_OK && op->nu >= 2 && (op->form == 0 || op->form == 2);
-}
-
-float* mgp_operator_first_out(const mgp_operator_t* op, int C, void* work, size_t work_bytes) {
-  if (!mgp_operator_tail_supported(op) || !work) return nullptr;
-  MgpArena ar(work, work_bytes);
-  float* t0 = ar.take<float>((size_t)op->L.n * C);
-  return ar.ok() ? t0 : nullptr;
-}
-
-int mgp_operator_apply_tail(const mgp_operator_t* op, const float* X, int C, float* Y, const float* dotw,
-                            float* dot_partials, const int* skip, int* tick, const MgpCommit* commit, void* work,
-                            size_t work_bytes, void* stream) {
-  if (!mgp_operator_tail_supported(op)) return MGP_ERR_UNSUPPORTED;
-  if (!X || !Y || X == Y || C <= 0) return MGP_ERR_ARG;
-  if (!work || work_bytes < 4 * mgp_align((size_t)op->L.n * C * sizeof(float))) return MGP_ERR_WORKSPACE;
-  MgpArena ar(work, work_bytes);
-  const size_t nc = (size_t)op->L.n * C;
-  float* t0 = ar.take<float>(nc);
-  float* t1 = ar.take<float>(nc);
-  if (!ar.ok()) return MGP_ERR_WORKSPACE;
-  Hooks hk{dotw, dot_partials, skip, tick, commit, 1, nullptr, nullptr, nullptr, 0};
-  if (op->form == 0) return q2_chain(op, nullptr, 0, X, nullptr, C, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
-  return q2_chain(op, nullptr, 0, X, nullptr, C, Y, X, 1.f, op->noise, t0, t1, &hk, stream);
 }
 
 // First operator apply of an init-free CG solve (cg.hip), C == 1, tile kernel, single-chain forms (0 and 2):
@@ -194,7 +160,7 @@ int mgp_operator_apply_first(const mgp_operator_t* op, const float* rhs, float* 
   float* t1 = ar.take<float>(nc);
   if (!ar.ok()) return MGP_ERR_WORKSPACE;
   const float* rv = op->nu == 1 ? rhs : r_copy;      // what the last launch reads as r
-  Hooks hk{rv, dot_partials, nullptr, state, nullptr, 0, r_copy, record, dot2_partials, 1};
+  Hooks hk{rv, dot_partials, nullptr, state, r_copy, record, dot2_partials, 1};
   if (op->form == 0) return q2_chain(op, nullptr, 0, rhs, nullptr, 1, Y, nullptr, 0.f, 1.f, t0, t1, &hk, stream);
   return q2_chain(op, nullptr, 0, rhs, nullptr, 1, Y, rv, 1.f, op->noise, t0, t1, &hk, stream);
 }

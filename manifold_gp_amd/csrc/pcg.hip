@@ -533,8 +533,7 @@ int chain_launch(PcgPlan* pl, int s, const float* in, float* out, const float* b
     if (op.form == 2) { bs = base; cb = 1.f; co = op.noise * op.scale; }
   }
   return mgp_spmm_fused_first(&L, 0, in, 1, out, tau, 1.0f, first ? op.pre : nullptr, last ? op.post : nullptr, bs, cb, co,
-                              last ? dotw : nullptr, last ? dot_partials : nullptr, skip, last ? tick : nullptr, nullptr,
-                              nullptr, st);
+                              last ? dotw : nullptr, last ? dot_partials : nullptr, skip, last ? tick : nullptr, nullptr, st);
 }
 
 // q (or w_0) = A v on this rank's rows; v gathered at the global length

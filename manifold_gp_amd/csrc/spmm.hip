@@ -22,6 +22,7 @@
 //   * grids are capped (<= 4096 workgroups, contiguous row ranges per workgroup) and remapped so
 //     that each XCD streams one contiguous slice of rows (mgp_xcd_block).
 #include <string.h>
+#include <atomic>
 #include "mgp_common.h"
 #include "mgp_internal.h"
 #include <hip/hip_ext.h>
@@ -53,7 +54,6 @@ struct SpmmArgs {
   int* tick;         // nullable: workgroup 0 adds 1 when the launch is not skipped
   int64_t goff;      // row partition: CSR rows are local [0, n), vectors are global -> row r is
                      // element r + goff of X / Y / pre / post / base / dotw (0 on one GPU)
-  MgpCommit commit;  // tile kernel only: packed row record written in the epilogue (fused CG step)
   // tile kernel only (init-free CG solve, cg.hip): the first apply of a solve reads the caller's right-hand side
   float* copy_x;          // nullable: the epilogue stores the row's raw input x[row] here (r = b)
   float* dot2_partials;   // nullable: per-workgroup partials of sum dotw[row]^2 (||b||^2)
@@ -339,8 +339,6 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
     const float e_post = p.post ? l_post : 1.f;
     const float e_base = p.base ? l_base : 0.f;
     const float e_dotw = p.dotw ? l_dotw : 0.f;
-    const float l_cp0 = (p.commit.pack4 ? p.commit.src0 : x)[grr], l_cp1 = (p.commit.pack4 ? p.commit.src1 : x)[grr];
-    const float l_cp2 = ((p.commit.pack4 && p.commit.pre) ? p.commit.pre : x)[grr];
     __builtin_amdgcn_sched_barrier(0);
     if (p.skip && skipl) return;          // CG converged: every load above went to a valid address, nothing is written
 #pragma unroll
@@ -397,11 +395,6 @@ __global__ __launch_bounds__(BS) void spmv_tile_kernel(SpmmArgs p, TileArgs t) {
       dsum = fmaf(e_dotw, y, dsum);
       dsum2 = fmaf(e_dotw, e_dotw, dsum2);
       if (p.copy_x) p.copy_x[grr] = raw_x;
-      if (p.commit.pack4) {
-        mgp_v4f rec;
-        rec.x = l_cp0; rec.y = y; rec.z = l_cp1; rec.w = p.commit.pre ? l_cp2 : 1.f;
-        *reinterpret_cast<mgp_v4f*>(p.commit.pack4 + 4 * grr) = rec;
-      }
     }
     if (tile + 1 < t1) __syncthreads();                // the next tile overwrites xl / part
   }
@@ -1335,395 +1328,6 @@ __global__ __launch_bounds__(kDictThreads) void spmm_dict_kernel(SpmmArgs p, Til
   if (p.tick && blockIdx.x == 0 && tid == 0) *p.tick = tickv + 1;
 }
 
-// ---------------------------------------------------------------- 16 < C <= 128 on tile dictionaries: 8 LANES PER ROW, PERSISTENT, LDS-DMA RING
-// (round 4).  What the counters said about spmm_dict_kernel above at C = 128 on the 60k graph (profiles/r03_pmc_spmm_wide.txt):
-// nothing saturated -- VALU 32 % busy, LDS 24 % -- but for ~31 % of the launch a CU had no resident wave (launch / teardown
-// of 1024-thread workgroups with ~150 KB of LDS, the 3.66 -> 4 round tail), a tile's prologue was 6-11 of its ~24 us (a
-// chain of dependent round trips with nothing else on the CU), and the walk spent 55 wave-instructions per quad step of which
-// 16 were the packed FMAs.  This kernel keeps the dictionary idea and changes the shape:
-//   * ONE persistent 512-thread workgroup per CU walks a contiguous range of tiles;
-//   * the dictionary is a RING of two LDS buffers of S slots filled by LDS-DMA (global_load_lds_dwordx4: a per-lane source
-//     address, no VGPR destination, no ds_write pass): the slice of stage s + 1 -- the next slice of this tile or slice 0 of
-//     the next one -- is requested at the top of stage s and lands while stage s is walked; its column ids were requested
-//     one stage earlier.  One barrier per stage (a first version of this kernel staged through registers: 13 float4 per
-//     lane per stage, 1.5 us to issue the loads + 1.2 us of ds_write_b128 + two barriers per ~1 us walk: 130 us per launch);
-//   * 8 lanes per row (a wave owns 8 rows, 8 waves the tile's 64), a lane keeps NV4 float4 of its row: one wave-instruction
-//     of overhead serves 8 rows instead of 4, within a 256-VGPR budget;
-//   * the matrix stream is decoded ONCE per tile when it is copied to LDS: an entry becomes (value, slice << 24 | byte
-//     offset of its dictionary slot inside its slice) -- the walk does no subtraction / min / multiply per entry -- and a
-//     row's run of entries per slice is found once per tile (bnd[row][slice]: a row's columns ascend, so its slice tags do):
-//     the walk of a slice is a counted loop over a contiguous LDS range, two entries per iteration.  The raw stream of the
-//     NEXT tile travels in registers during the last stage of the current one;
-//   * zero-valued entries behind the first of a quad (the padding at a row's end: value exactly 0, column = the row
-//     itself) are redirected to a ZERO SLOT and inherit their predecessor's slice tag: they never break a run;
-//   * LDS reads are conflict free: a slot is NV4 x 128 bytes; lane l8 of a row reads bytes [16 l8, 16 l8 + 16) of piece
-//     j ^ swap at step j, swap = bit 1 of the row's position in its wave -- ds_read_b128 serves the lane groups
-//     {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X_MICROARCH.md, LDS table): four rows contribute a 64-byte half
-//     each, and with that swap the four halves fall into the four quarters of the 256-byte bank window.
-// Input pre-scaling (PRE) is applied to the VALUES when a tile's stream is fetched (a DMA cannot scale what it moves).  Pieces
-// of a slot beyond C hold copies of the row's first 16 bytes and feed accumulators nobody stores.
-// Summation order per row: entries in storage order (slices ascending, within a slice ascending) -- the same as
-// spmm_dict_kernel and independent of the grid.
-constexpr int kD8Threads = 512;
-constexpr int kD8MaxU = 12;          // LDS-DMA instructions (1 KiB each) per wave and stage
-constexpr int kD8MaxSlices = 16;     // bnd[row][0 .. 16]
-constexpr int kD8BndStride = 18;
-constexpr int kD8QPT = 4;            // quads of the next tile's raw stream a thread carries (512 x 4 x 4 = 8192 entries)
-
-#ifdef MGP_D8_STAMP   // lab build (tools/lab/stamp_d8.py): wave 0 of workgroup 0 records (phase, wall clock) pairs in an explicit buffer
-unsigned long long* g_d8_stamps = nullptr;     // device buffer of 2 * 4096 words, set by mgp_d8_set_stamp_buffer
-#define D8_STAMP(code)                                                                                           \
-  do {                                                                                                           \
-    if (stamps && blockIdx.x == 0 && tid == 0 && nstamp < 4095) {                                                \
-      stamps[2 * nstamp] = (unsigned long long)(code);                                                           \
-      stamps[2 * nstamp + 1] = wall_clock64();                                                                   \
-      ++nstamp;                                                                                                  \
-      stamps[2 * 4095] = (unsigned long long)nstamp;                                                             \
-    }                                                                                                            \
-  } while (0)
-#else
-#define D8_STAMP(code) do { } while (0)
-#endif
-
-typedef const __attribute__((address_space(1))) void* d8_gptr_t;
-typedef __attribute__((address_space(3))) void* d8_lptr_t;
-
-// One stage of spmm_dict8_kernel: request the NEXT stage's slice (LDS-DMA into `dnext`), then walk this row's run of the
-// current slice out of `dcur` / `strm`.  A function of its own with __restrict__ parameters on purpose: hipcc puts
-// s_waitcnt vmcnt(0) in front of every ds_read that may alias an LDS-DMA in flight (seen in the .s: inside the walk's inner
-// loop, i.e. the walk waited for the very slice it was meant to overlap), and only scoped-noalias information -- which
-// clang derives from restrict-qualified PARAMETERS of an inlined function, not from local pointers -- tells it that the
-// ring buffer being filled is not the one being read.
-template <int NV4>
-__device__ __forceinline__ void d8_stage(char* __restrict__ dnext, const char* __restrict__ dcur, const uint2* __restrict__ strm,
-                                         int i, const int b1, const mgp_v4f* const (&src)[kD8MaxU], const int U, const bool fill,
-                                         const unsigned laneA, const unsigned laneB, const unsigned zoff, mgp_v4f (&acc)[NV4]) {
-  if (fill) {
-#pragma unroll
-    for (int u = 0; u < kD8MaxU; ++u)
-      if (u < U) __builtin_amdgcn_global_load_lds((d8_gptr_t)src[u], (d8_lptr_t)(dnext + u * 1024), 16, 0, 0);   // (C-style casts change the address space)
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // two entries per iteration (four per iteration, all sixteen X pieces requested before the first FMA, was measured too: 181
-  // against 151 us per launch at C = 128 -- the runs are short, 11 entries per row and slice on average, and the padding
-  // up to a multiple of four costs more than the shorter dependency chain gives)
-  while (i < b1) {
-    const uint2 pa = strm[i];
-    const uint2 pb = strm[i + 1];
-    const bool two = i + 1 < b1;
-    const unsigned off0 = pa.y & 0xffffffu;
-    const unsigned off1 = two ? (pb.y & 0xffffffu) : zoff;
-    const unsigned bits0 = pa.x, bits1 = pb.x;
-    mgp_v2f vv;
-    vv.x = __uint_as_float(bits0);
-    vv.y = two ? __uint_as_float(bits1) : 0.f;
-    const char* a0 = dcur + off0;
-    const char* a1 = dcur + off1;
-    mgp_v4f x0[NV4], x1[NV4];
-#pragma unroll
-    for (int j = 0; j < NV4; ++j) {
-      const unsigned lo = ((j & 1) ? laneB : laneA) + (unsigned)(j >> 1) * 256u;
-      x0[j] = *reinterpret_cast<const mgp_v4f*>(a0 + lo);
-      x1[j] = *reinterpret_cast<const mgp_v4f*>(a1 + lo);
-    }
-    i += 2;
-#pragma unroll
-    for (int j = 0; j < NV4; ++j) {
-      mgp_v2f lo2 = mgp_v2f{acc[j].x, acc[j].y}, hi2 = mgp_v2f{acc[j].z, acc[j].w};
-      lo2 = pk_fma_lo(vv, mgp_v2f{x0[j].x, x0[j].y}, lo2); hi2 = pk_fma_lo(vv, mgp_v2f{x0[j].z, x0[j].w}, hi2);
-      lo2 = pk_fma_hi(vv, mgp_v2f{x1[j].x, x1[j].y}, lo2); hi2 = pk_fma_hi(vv, mgp_v2f{x1[j].z, x1[j].w}, hi2);
-      acc[j] = mgp_v4f{lo2.x, lo2.y, hi2.x, hi2.y};
-    }
-  }
-}
-
-template <int NV4, bool PRE>
-__global__ __launch_bounds__(kD8Threads) void spmm_dict8_kernel(SpmmArgs p, TileArgs t, int S, int stream_cap, unsigned tagmul) {
-  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
-  constexpr int TR = 64, SLOT4 = NV4 * 8, SLOTB = NV4 * 128;
-  constexpr int SPI = 1024 / SLOTB;                      // slots per DMA instruction (64 lanes x 16 bytes)
-  mgp_v4f* __restrict__ dict = reinterpret_cast<mgp_v4f*>(tile_lds);                          // ring [2][S + 1][SLOT4]: slot S of each buffer = zeros
-  uint2* __restrict__ strm = reinterpret_cast<uint2*>(dict + (size_t)(2 * (S + 1)) * SLOT4);  // [stream_cap + 8] (value bits, tag << 24 | offset)
-  int* __restrict__ bnd = reinterpret_cast<int*>(strm + stream_cap + 8);                     // [64][kD8BndStride]
-  if (p.skip && *p.skip) return;
-  const int tickv = (p.tick && blockIdx.x == 0) ? *p.tick : 0;
-  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
-  const int tid = threadIdx.x, g = tid >> 3, l8 = tid & 7;
-  const int lane = tid & 63, wave = tid >> 6;
-#ifdef MGP_D8_STAMP
-  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(const_cast<int32_t*>(t.rowptr_t));   // lab: explicit buffer
-  int nstamp = 0;
-#endif
-  D8_STAMP(0);
-  const int swap = (tid >> 4) & 1;
-  const int C = p.C, C4 = C >> 2;
-  const mgp_v4f* __restrict__ X4 = reinterpret_cast<const mgp_v4f*>(p.X);
-  const int32_t* __restrict__ rowptr = p.rowptr;
-  const float* __restrict__ vals = p.vals;
-  const uint32_t* __restrict__ tile_cols = reinterpret_cast<const uint32_t*>(t.tile_cols);
-  const int32_t* __restrict__ tile_ptr = t.tile_ptr;
-  const unsigned bufb = (unsigned)(S + 1) * SLOTB;       // bytes of one ring buffer (its zero slot included)
-  const unsigned zoff = (unsigned)S * SLOTB;              // the zero slot of either buffer, relative to the buffer
-  const unsigned laneA = (unsigned)(l8 * 16 + swap * 128), laneB = (unsigned)(l8 * 16 + (1 - swap) * 128);
-  const int U = S / (8 * SPI);                            // DMA instructions per wave and stage (S is a multiple of 8 SPI)
-  if (tid < 2 * SLOT4) dict[(tid < SLOT4 ? S : 2 * S + 1) * SLOT4 + (tid < SLOT4 ? tid : tid - SLOT4)] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
-  if (tid < 8) strm[stream_cap + tid] = make_uint2(0u, zoff);
-  mgp_v4f dsum[NV4];
-#pragma unroll
-  for (int v = 0; v < NV4; ++v) dsum[v] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
-
-  const int64_t ntiles = t.ntiles;
-  const int64_t t0 = (int64_t)lb * ntiles / gridDim.x;
-  const int64_t t1 = ((int64_t)lb + 1) * ntiles / gridDim.x;
-  if (t0 < t1) {
-    // dictionary offsets of this tile and the three behind it (look-ahead never goes further than two tiles)
-    auto tptr = [&](int64_t i) -> int { return tile_ptr[i < ntiles ? i : ntiles]; };
-    int tp0 = tptr(t0), tp1 = tptr(t0 + 1), tp2 = tptr(t0 + 2), tp3 = tptr(t0 + 3), tp4 = tptr(t0 + 4);
-    auto dp_of = [&](int o) -> int { return o == 0 ? tp0 : (o == 1 ? tp1 : tp2); };
-    auto D_of = [&](int o) -> int { return o == 0 ? tp1 - tp0 : (o == 1 ? tp2 - tp1 : tp3 - tp2); };
-    auto nsl_of = [&](int o) -> int { const int n = (D_of(o) + S - 1) / S; return n > 0 ? n : 1; };
-    // ---- ring fill: DMA instruction u of this wave moves slots (wave U + u) SPI .. + SPI - 1 of the slice; this lane's
-    // share is 16 bytes of slot (wave U + u) SPI + lane / SLOT4, piece lane % SLOT4
-    unsigned ids[kD8MaxU];
-    const int myslot0 = wave * U * SPI + lane / SLOT4, myf = lane % SLOT4;
-    const int myfc = myf < C4 ? myf : 0;
-    auto load_ids = [&](int o, int k) __attribute__((always_inline)) {
-      const int dp = dp_of(o), D = D_of(o);
-#pragma unroll
-      for (int u = 0; u < kD8MaxU; ++u) {
-        const int slot = k * S + myslot0 + u * SPI;
-        ids[u] = tile_cols[(u < U && slot < D) ? dp + slot : 0];
-      }
-    };
-    auto ring = [&](int b) -> char* { return reinterpret_cast<char*>(dict) + (size_t)b * bufb; };
-    // ---- per tile: this row group's row, the decoded stream, the run boundaries
-    int rs = 0, re = 0;
-    bool valid = false;
-    int64_t grr = 0, rr = 0;
-    float e_diag = 0.f, l_post = 1.f, e_pre = 1.f;
-    // the next tile's raw stream + row data, requested ahead and installed at the hand-over
-    mgp_v4f nsv[kD8QPT];
-    mgp_v4h nsl4[kD8QPT];
-    int n_e0 = 0, n_nq = 0, n_a0 = 0, n_a1 = 0;
-    bool n_valid = false;
-    int64_t n_rr = 0;
-    float n_diag = 0.f, n_post = 1.f, n_pre = 1.f;
-    auto fetch_tile = [&](int64_t tile) __attribute__((always_inline)) {
-      const int64_t r0 = tile * TR;
-      const int64_t r1 = r0 + TR < p.n ? r0 + TR : p.n;
-      const int e0 = rowptr[r0], e1 = rowptr[r1];
-      n_e0 = e0;
-      n_nq = (e1 - e0) >> 2;
-      const int64_t prow = r0 + g;
-      n_valid = prow < r1;
-      n_rr = n_valid ? prow : r0;
-      n_a0 = rowptr[n_rr];
-      n_a1 = rowptr[n_rr + 1];
-      n_diag = p.diag[n_rr];
-      n_post = p.post ? p.post[n_rr + p.goff] : 1.f;
-      n_pre = PRE ? p.pre[n_rr + p.goff] : 1.f;
-#pragma unroll
-      for (int m = 0; m < kD8QPT; ++m) {
-        const int q = tid + kD8Threads * m;
-        const int qc = q < n_nq ? q : 0;
-        nsv[m] = *reinterpret_cast<const mgp_v4f*>(vals + (int64_t)e0 + 4 * (int64_t)qc);
-        nsl4[m] = *reinterpret_cast<const mgp_v4h*>(t.lid + (int64_t)e0 + 4 * (int64_t)qc);
-      }
-      if (PRE) {
-        // input pre-scaling: the DMA cannot scale the X rows it moves, so the VALUES are scaled instead -- two dependent
-        // gathers per entry (dictionary id -> column -> pre), a stall of two round trips per tile that only launches with a
-        // `pre` operand pay (the first launch of a random-walk chain; not the eigensolver's or the factorised CG's loops)
-        const int dpn = tile_ptr[tile < ntiles ? tile : ntiles];
-#pragma unroll
-        for (int m = 0; m < kD8QPT; ++m) {
-          const unsigned c0 = tile_cols[dpn + nsl4[m].x], c1 = tile_cols[dpn + nsl4[m].y], c2 = tile_cols[dpn + nsl4[m].z], c3 = tile_cols[dpn + nsl4[m].w];
-          nsv[m].x *= p.pre[c0]; nsv[m].y *= p.pre[c1]; nsv[m].z *= p.pre[c2]; nsv[m].w *= p.pre[c3];
-        }
-      }
-    };
-    auto install_tile = [&]() __attribute__((always_inline)) {
-#pragma unroll
-      for (int m = 0; m < kD8QPT; ++m) {
-        const int q = tid + kD8Threads * m;
-        if (q < n_nq) {
-          const mgp_v4f vv = nsv[m];
-          const mgp_v4h ll = nsl4[m];
-          // slice of a dictionary id: id / S by a multiply (exact while id * S < 2^24)
-          const unsigned i0 = ll.x, i1 = ll.y, i2 = ll.z, i3 = ll.w;
-          const unsigned g0 = (i0 * tagmul) >> 24, g1 = (i1 * tagmul) >> 24, g2 = (i2 * tagmul) >> 24, g3 = (i3 * tagmul) >> 24;
-          // (scalars first: __builtin_bit_cast of a vector ELEMENT expression reads element 0 for every component with this
-          // compiler -- found in round 3, found again here as four entries carrying the quad's first value)
-          const float f0 = vv.x, f1 = vv.y, f2 = vv.z, f3 = vv.w;
-          const unsigned w0 = (g0 << 24) | ((i0 - g0 * (unsigned)S) * SLOTB);
-          // a zero-valued entry behind the first of its quad (padding): the zero slot, the predecessor's slice
-          const unsigned w1 = f1 == 0.f ? ((w0 & 0xff000000u) | zoff) : ((g1 << 24) | ((i1 - g1 * (unsigned)S) * SLOTB));
-          const unsigned w2 = f2 == 0.f ? ((w1 & 0xff000000u) | zoff) : ((g2 << 24) | ((i2 - g2 * (unsigned)S) * SLOTB));
-          const unsigned w3 = f3 == 0.f ? ((w2 & 0xff000000u) | zoff) : ((g3 << 24) | ((i3 - g3 * (unsigned)S) * SLOTB));
-          mgp_v4i o01, o23;
-          o01.x = __float_as_int(f0); o01.y = (int)w0; o01.z = __float_as_int(f1); o01.w = (int)w1;
-          o23.x = __float_as_int(f2); o23.y = (int)w2; o23.z = __float_as_int(f3); o23.w = (int)w3;
-          *reinterpret_cast<mgp_v4i*>(strm + 4 * q) = o01;
-          *reinterpret_cast<mgp_v4i*>(strm + 4 * q + 2) = o23;
-        }
-      }
-      valid = n_valid;
-      rr = n_rr;
-      grr = rr + p.goff;
-      e_diag = n_diag;
-      l_post = n_post;
-      e_pre = n_pre;
-      rs = n_a0 - n_e0;
-      re = valid ? n_a1 - n_e0 : rs;
-      // bnd[g][k] = first entry of the row with slice >= k: [0] = start, the rest = end until the scan below lowers them
-      bnd[g * kD8BndStride + 1 + l8] = re;
-      bnd[g * kD8BndStride + 9 + l8] = re;
-      if (l8 == 0) { bnd[g * kD8BndStride] = rs; bnd[g * kD8BndStride + 17] = re; }
-    };
-    // rows are quad aligned: lane l8 looks at quads l8, l8 + 8, ... of its row (two 16-byte reads + the word in front)
-    auto scan_runs = [&]() __attribute__((always_inline)) {
-      for (int i = rs + 4 * l8; i < re; i += 32) {
-        const mgp_v4i a = *reinterpret_cast<const mgp_v4i*>(strm + i);
-        const mgp_v4i b = *reinterpret_cast<const mgp_v4i*>(strm + i + 2);
-        const unsigned tprev = i > rs ? strm[i - 1].y >> 24 : 0u;
-        const unsigned tg0 = (unsigned)a.y >> 24, tg1 = (unsigned)a.w >> 24, tg2 = (unsigned)b.y >> 24, tg3 = (unsigned)b.w >> 24;
-        for (unsigned k = tprev + 1; k <= tg0; ++k) bnd[g * kD8BndStride + k] = i;
-        for (unsigned k = tg0 + 1; k <= tg1; ++k) bnd[g * kD8BndStride + k] = i + 1;
-        for (unsigned k = tg1 + 1; k <= tg2; ++k) bnd[g * kD8BndStride + k] = i + 2;
-        for (unsigned k = tg2 + 1; k <= tg3; ++k) bnd[g * kD8BndStride + k] = i + 3;
-      }
-    };
-
-    // ---- prologue of the first tile: ids -> DMA of stage 0, the tile's stream, ids of stage 1
-    int64_t tile = t0;
-    int k = 0;
-    load_ids(0, 0);
-    fetch_tile(tile);
-    {
-      const mgp_v4f* src[kD8MaxU];
-#pragma unroll
-      for (int u = 0; u < kD8MaxU; ++u) src[u] = X4 + (int64_t)ids[u] * C4 + myfc;
-      char* dst0 = ring(0) + (size_t)(wave * U) * 1024;
-#pragma unroll
-      for (int u = 0; u < kD8MaxU; ++u)
-        if (u < U) __builtin_amdgcn_global_load_lds((d8_gptr_t)src[u], (d8_lptr_t)(dst0 + u * 1024), 16, 0, 0);
-    }
-    int o1 = (1 < nsl_of(0)) ? 0 : 1, k1 = (1 < nsl_of(0)) ? 1 : 0;   // look-ahead stage 1 = (o1, k1), valid iff has1
-    bool has1 = (o1 == 0) || (tile + 1 < t1);
-    if (has1) load_ids(o1, k1);
-    install_tile();
-    D8_STAMP(1);
-    __syncthreads();
-    D8_STAMP(2);
-    scan_runs();
-    D8_STAMP(3);
-    mgp_v4f acc[NV4];
-#pragma unroll
-    for (int v = 0; v < NV4; ++v) acc[v] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
-    int buf = 0;
-
-    for (;;) {
-      const int nsl = nsl_of(0);
-      const bool last = k + 1 >= nsl;
-      // stage 2 = the one behind stage 1
-      int o2 = o1, k2 = k1 + 1;
-      bool has2 = false;
-      if (has1) {
-        if (k2 >= nsl_of(o1)) { o2 = o1 + 1; k2 = 0; }
-        has2 = (o2 == o1) || (tile + o2 < t1);
-      }
-      // every DMA of this stage's slice has landed (own: vmcnt, the others': the barrier), every wave is past the previous
-      // stage's walk (the other buffer is free), the run boundaries of a new tile are visible
-      __syncthreads();
-      D8_STAMP(10);
-      // the source addresses of stage 1's slice first (all of them, then the DMAs back to back inside d8_stage: with an
-      // LDS-DMA in flight hipcc waits vmcnt(0) at the next use of any ordinary load's result -- an id consumed between two
-      // DMAs serialised the whole fill, one round trip per KiB; and consuming the ids behind younger loads would wait for
-      // those too), then this stage's ordinary loads -- the tile's epilogue operands, the next tile's raw stream, stage 2's
-      // ids: all first used after the walk -- then the DMAs and the walk
-      const mgp_v4f* src[kD8MaxU];
-#pragma unroll
-      for (int u = 0; u < kD8MaxU; ++u) src[u] = X4 + (int64_t)ids[u] * C4 + myfc;
-      const int i0 = bnd[g * kD8BndStride + k];
-      const int b1 = bnd[g * kD8BndStride + k + 1];
-      mgp_v4f ex[NV4], lbv[NV4];
-      if (last) {
-#pragma unroll
-        for (int j = 0; j < NV4; ++j) {
-          const int f = l8 + 8 * (j ^ swap);
-          const int fc = f < C4 ? f : 0;
-          ex[j] = X4[grr * C4 + fc];
-          lbv[j] = *reinterpret_cast<const mgp_v4f*>((p.base ? p.base : p.X) + grr * C + 4 * fc);
-        }
-        if (has1) fetch_tile(tile + 1);                      // (stage 1 is then slice 0 of the next tile)
-      }
-      if (has2) load_ids(o2, k2);
-      __builtin_amdgcn_sched_barrier(0);
-      D8_STAMP(11);
-      d8_stage<NV4>(ring(buf ^ 1) + (size_t)(wave * U) * 1024, ring(buf), strm, i0, b1, src, U, has1, laneA, laneB, zoff, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      D8_STAMP(12);
-      if (last) {
-        // ---- epilogue of this lane's 4 NV4 columns
-#pragma unroll
-        for (int j = 0; j < NV4; ++j) {
-          const int f = l8 + 8 * (j ^ swap);
-          if (valid && f < C4) {
-            const float xs0 = ex[j].x * e_pre, xs1 = ex[j].y * e_pre, xs2 = ex[j].z * e_pre, xs3 = ex[j].w * e_pre;
-            mgp_v4f y;
-            y.x = p.co * ((p.a * xs0 + p.b * (e_diag * xs0 - acc[j].x)) * l_post) + (p.base ? p.cb * lbv[j].x : 0.f);
-            y.y = p.co * ((p.a * xs1 + p.b * (e_diag * xs1 - acc[j].y)) * l_post) + (p.base ? p.cb * lbv[j].y : 0.f);
-            y.z = p.co * ((p.a * xs2 + p.b * (e_diag * xs2 - acc[j].z)) * l_post) + (p.base ? p.cb * lbv[j].z : 0.f);
-            y.w = p.co * ((p.a * xs3 + p.b * (e_diag * xs3 - acc[j].w)) * l_post) + (p.base ? p.cb * lbv[j].w : 0.f);
-            *reinterpret_cast<mgp_v4f*>(p.Y + grr * C + 4 * f) = y;
-            if (p.dotw) {     // (the weights are fetched here: the last launch of a CG chain only, and 16 VGPRs the walk needs)
-              const mgp_v4f ldw = *reinterpret_cast<const mgp_v4f*>(p.dotw + grr * C + 4 * f);
-              dsum[j].x = fmaf(ldw.x, y.x, dsum[j].x); dsum[j].y = fmaf(ldw.y, y.y, dsum[j].y);
-              dsum[j].z = fmaf(ldw.z, y.z, dsum[j].z); dsum[j].w = fmaf(ldw.w, y.w, dsum[j].w);
-            }
-          }
-          acc[j] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      D8_STAMP(13);
-      if (!has1) break;
-      if (o1 == 1) {
-        // ---- next tile: every wave must be past its last read of this tile's stream before it is overwritten
-        __syncthreads();
-        D8_STAMP(14);
-        ++tile;
-        tp0 = tp1; tp1 = tp2; tp2 = tp3; tp3 = tp4; tp4 = tptr(tile + 4);
-        install_tile();
-        k = 0;
-        D8_STAMP(15);
-        __syncthreads();
-        D8_STAMP(16);
-        scan_runs();
-        o2 -= 1;
-      } else {
-        k = k1;
-      }
-      D8_STAMP(17);
-      buf ^= 1;
-      o1 = o2; k1 = k2; has1 = has2;
-      // (stage 2's ids are in `ids`: its DMA is issued at the top of the next iteration, behind the barrier)
-    }
-  }
-  if (p.dot_partials) {
-    mgp_v4f* red = dict;                                   // red[row group][SLOT4] float4
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NV4; ++j) red[g * SLOT4 + l8 + 8 * (j ^ swap)] = dsum[j];
-    __syncthreads();
-    if (tid < C) {
-      const float* rf = reinterpret_cast<const float*>(red);
-      float sacc = 0.f;
-      for (int gg = 0; gg < TR; ++gg) sacc += rf[gg * (SLOT4 * 4) + tid];
-      p.dot_partials[(int64_t)lb * C + tid] = sacc;
-    }
-  }
-  if (p.tick && blockIdx.x == 0 && tid == 0) *p.tick = tickv + 1;
-}
-
 // ---------------------------------------------------------------- 16 < C <= 256 on the MATRIX CORES: dense 16-row tiles
 // The gather kernels above move one X row through the vector memory path per ENTRY (3.6 M x 512 bytes at N = 60k, C = 128:
 // 91 us, bound by the L1 miss path); the LDS dictionary kernels move it once per 64-row tile but pay for it in barriers and
@@ -1978,8 +1582,8 @@ Plan make_plan(int64_t n, int rows_per_pass) {
 // C == 1 shape: lanes per row (4 entries per lane per pass) and rows in flight per lane group.
 // The host wrapper sets the lanes from the mean padded row length of the graph it built
 // (mgp_spmm_set_group_hint); measured best on the 60k and 500k graphs: 8 lanes x 1 row (tools/tune_spmv.py).
-int g_row_group_hint = 16;
-int g_rows_in_flight = 1;
+std::atomic<int> g_row_group_hint{16};
+std::atomic<int> g_rows_in_flight{1};
 
 }  // namespace
 
@@ -2016,10 +1620,10 @@ static int spmm_rows_per_pass(int C) {
 }
 
 #ifdef MGP_STAMP
-int g_stamp_enable = 0;
+std::atomic<int> g_stamp_enable{0};
 extern "C" int mgp_stamp_enable(int on) { g_stamp_enable = on ? 1 : 0; return 0; }
 #endif
-int g_tile_mode = 1;
+std::atomic<int> g_tile_mode{1};
 
 extern "C" int mgp_spmm_set_tile_mode(int on) {
   g_tile_mode = on ? 1 : 0;
@@ -2055,7 +1659,7 @@ int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, si
 }
 
 // C in {4, 8, 12, 16} on 64-row tiles whose staged data (dictionary rows + matrix stream) fits the LDS budget
-int g_tile_small_mode = 1;
+std::atomic<int> g_tile_small_mode{1};
 // quads of partial sums staged at once: what is left of a quarter of the CU's LDS (160 KB, four workgroups) behind the
 // dictionary, in steps of 256, at least 1024 (the quads a workgroup holds in registers), at most the largest tile
 static int tile_small_window(const mgp_csr_t* L) {
@@ -2082,8 +1686,8 @@ static bool use_tiles_small(const mgp_csr_t* L, int C) {
 }
 
 // 16 < C <= 256, C % 4 == 0 on 64-row tiles: the wide tile kernel (mgp_spmm_set_tile_wide_mode(0): spmm_kernel)
-int g_tile_wide_mode = 1;
-int g_spmm_v4_mode = 1;     // float4-lane gather kernel for 16 < C <= 256 (mgp_spmm_set_v4_mode(0): spmm_kernel)
+std::atomic<int> g_tile_wide_mode{1};
+std::atomic<int> g_spmm_v4_mode{1};     // float4-lane gather kernel for 16 < C <= 256 (mgp_spmm_set_v4_mode(0): spmm_kernel)
 static int tile_wide_cap(const mgp_csr_t* L) {
   int cap = (L->tile_max_cols + 63) / 64 * 64;
   if (cap > kWideCap) cap = kWideCap;
@@ -2130,7 +1734,7 @@ extern "C" int mgp_spmm_set_tile_small_mode(int on) {
 // gather):  60k graph  C = 64: 52 | 84 | 54 | 63   C = 128: 90 | 160 | 101 | 91   C = 256: 176 | 319 | 204 | 186
 //           1M graph   C = 64: 704 | 777 | 1020 | 1188   C = 128: 1201 | 1458 | 2084 | 3037   C = 256: 2380 | 2871 | 6515 | 6828
 // -> taken from 64 columns up when the X block (n x C floats) is 96 MB or more, i.e. does not sit in the caches.
-int g_dict_mode = 1;
+std::atomic<int> g_dict_mode{1};
 static int dict_nv(int C) { return (C + 63) / 64; }
 static int dict_stream_cap(const mgp_csr_t* L) { return (L->tile_max_entries + 7) / 8 * 8; }
 static int dict_slots(const mgp_csr_t* L, int C) {
@@ -2164,63 +1768,6 @@ static bool dict_shape_ok(const mgp_csr_t* L, int C) {
   if (g_dict_mode == 2) return true;
   return C >= 64 && (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20);
 }
-// 16 < C <= 256 on 64-row tiles in row order: the persistent 8-lanes-per-row dictionary kernel (spmm_dict8_kernel).
-// mgp_spmm_set_dict8_mode: 0 (default) never, 1 wherever the shape allows.  NOT taken by default: measured 151 us per launch at
-// C = 128 on the 60k graph against 91 us for the gather / dictionary kernels above (docs/kernels/spmm.md, round 4).
-int g_dict8_mode = 0;
-static int d8_nv4(int C) { const int n = (C + 31) / 32; return n < 2 ? 2 : (n + 1) / 2 * 2; }
-static int d8_stream_cap(const mgp_csr_t* L) { return (L->tile_max_entries + 7) / 8 * 8; }
-static int d8_slots(const mgp_csr_t* L, int C) {
-  const long slotb = d8_nv4(C) * 128L;
-  const long spi = 1024 / slotb;                                        // slots per DMA instruction
-  const long left = 160L * 1024 - 64L * kD8BndStride * 4 - ((long)d8_stream_cap(L) + 8) * 8 - 2 * slotb;      // (two zero slots)
-  long s = left / (2 * slotb);                                          // two ring buffers
-  const long cap = (long)kD8MaxU * 8 * spi;                             // DMA instructions per wave and stage <= kD8MaxU
-  if (s > cap) s = cap;
-  const long need = ((long)L->tile_max_cols + 8 * spi - 1) / (8 * spi) * (8 * spi);   // no slices larger than the largest dictionary
-  if (s > need) s = need;
-  s = s / (8 * spi) * (8 * spi);                                        // 8 waves x whole instructions
-  if (s < 64) s = need >= 64 ? 0 : 64;                                  // (the dot-partial reduction reuses 64 slots)
-  return (int)s;
-}
-static size_t d8_lds_bytes(const mgp_csr_t* L, int C) {
-  return (size_t)(2 * (d8_slots(L, C) + 1)) * d8_nv4(C) * 128 + ((size_t)d8_stream_cap(L) + 8) * 8 + (size_t)64 * kD8BndStride * 4;
-}
-static int d8_grid(const mgp_csr_t* L) {
-  static int cus[16] = {0};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16) dev = 0;
-  if (cus[dev] == 0) {
-    int v = 0;
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cus[dev] = v;
-  }
-  const int64_t ntiles = mgp_cdiv(L->n, L->tile_rows);
-  return (int)(ntiles < cus[dev] ? ntiles : cus[dev]);
-}
-static bool d8_shape_ok(const mgp_csr_t* L, int C) {
-  if (!g_tile_mode || !g_dict8_mode || C <= 16 || C > 128 || (C & 3) != 0) return false;   // (NV4 = 6 / 8: not built yet)
-  if (L->tile_rowptr || L->tile_vals || L->tile_rowid) return false;      // tiles in row order only (the solvers relabel)
-  if (!L->lid || !L->tile_ptr || !L->tile_cols || L->tile_rows != 64) return false;
-  if ((L->tile_max_entries & 3) != 0 || L->tile_max_entries > kD8QPT * kD8Threads * 4) return false;
-  const int S = d8_slots(L, C);
-  if (S < 64 || d8_lds_bytes(L, C) > 160u * 1024u) return false;
-  if (((long)L->tile_max_cols + S - 1) / S > kD8MaxSlices) return false;
-  return (long)L->tile_max_cols * S < (1L << 24);                          // the multiply that replaces id / S stays exact
-}
-#ifdef MGP_D8_STAMP
-extern "C" int mgp_d8_set_stamp_buffer(void* buf) {
-  g_d8_stamps = static_cast<unsigned long long*>(buf);
-  return MGP_OK;
-}
-#endif
-extern "C" int mgp_spmm_set_dict8_mode(int on) {
-  const int prev = g_dict8_mode;
-  g_dict8_mode = on ? 1 : 0;
-  return prev;
-}
-
 // the kernel moves 16 bytes per lane: X, Y, base and dotw rows must be 16-byte aligned (C % 4 == 0 makes every row so
 // once the block is); the planned kernel (dot-partial blocks) and the launched one must never disagree, so a
 // misaligned operand is an argument error at launch instead of a silent fall-through to another kernel
@@ -2232,7 +1779,7 @@ static bool aligned16(const void* a, const void* b, const void* c, const void* d
 // 48 <= C <= 256 on the matrix cores (spmm_mt_kernel): taken when the CSR carries the dense 16-row tile image (mgp_spmm_mt_fill;
 // the host wrapper builds it for graphs in natural row order whose tiles are at least 1/8 full) and the call has no row offset
 // (weighted dot-product partials included: one row of partials per workgroup).  mgp_spmm_set_mt_mode(0) = never (A/B runs, tests).
-int g_mt_mode = 1;
+std::atomic<int> g_mt_mode{1};
 constexpr int kMtMinCols = 48;
 static bool mt_shape_ok(const mgp_csr_t* L, int C) {
   if (!g_mt_mode || !L->mt_img || !L->mt_sptr || !L->mt_dcol || L->mt_tiles <= 0 || L->mt_steps <= 0) return false;
@@ -2272,15 +1819,14 @@ int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (!L) return MGP_ERR_ARG;
   if (use_tiles(L, C) || use_tiles_small(L, C)) return tile_grid(L, nullptr);
   if (mt_shape_ok(L, C)) return (int)mgp_cdiv((int64_t)L->mt_tiles * ((C + 63) / 64), kBlock / 64);
-  if (d8_shape_ok(L, C)) return d8_grid(L);
   if (dict_shape_ok(L, C)) return dict_grid(L);
   if (use_tiles_wide(L, C)) return tile_grid(L, nullptr);
   return mgp_spmm_dot_blocks(L->n, C);
 }
 
 // which kernel a call of mgp_spmm_fused with this CSR / width would launch (tests, docs): 0 = gather (C == 1: row groups),
-// 1 = C == 1 tile kernel, 2 = small-C tile kernel, 3 = matrix-core tiles, 4 = 8-lanes-per-row dictionary, 5 = lanes-over-columns
-// dictionary, 6 = chunked dictionary
+// 1 = C == 1 tile kernel, 2 = small-C tile kernel, 3 = matrix-core tiles, 5 = lanes-over-columns dictionary, 6 = chunked
+// dictionary (4 was round 4's persistent 8-lanes-per-row dictionary kernel: measured slower, removed in round 5)
 extern "C" int mgp_spmm_kernel_choice(const mgp_csr_t* L, int C, int with_dot, int64_t row_offset) {
   if (!L || L->n <= 0 || C <= 0 || C > 256) return MGP_ERR_ARG;
   static const float one = 1.f;
@@ -2288,7 +1834,6 @@ extern "C" int mgp_spmm_kernel_choice(const mgp_csr_t* L, int C, int with_dot, i
   if (use_tiles_small(L, C)) return 2;
   (void)with_dot; (void)one;
   if (mt_shape_ok(L, C) && row_offset == 0) return 3;
-  if (d8_shape_ok(L, C)) return 4;
   if (dict_shape_ok(L, C)) return 5;
   if (use_tiles_wide(L, C)) return 6;
   return 0;
@@ -2341,15 +1886,7 @@ int mgp_spmm_fused_ex(const mgp_csr_t* L, const float* X, int C, float* Y, float
 int mgp_spmm_fused_part(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
                         const float* pre, const float* post, const float* base, float cb, float co,
                         const float* dotw, float* dot_partials, const int* skip, int* tick, void* stream) {
-  return mgp_spmm_fused_commit(L, row_offset, X, C, Y, a, b, pre, post, base, cb, co, dotw, dot_partials, skip, tick,
-                               nullptr, stream);
-}
-
-int mgp_spmm_fused_commit(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
-                          const float* pre, const float* post, const float* base, float cb, float co,
-                          const float* dotw, float* dot_partials, const int* skip, int* tick,
-                          const MgpCommit* commit, void* stream) {
-  return mgp_spmm_fused_first(L, row_offset, X, C, Y, a, b, pre, post, base, cb, co, dotw, dot_partials, skip, tick, commit,
+  return mgp_spmm_fused_first(L, row_offset, X, C, Y, a, b, pre, post, base, cb, co, dotw, dot_partials, skip, tick,
                               nullptr, stream);
 }
 
@@ -2385,21 +1922,16 @@ int mgp_spmm_patch_node(void* exec, void* node, const void* record, const float*
 int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X, int C, float* Y, float a, float b,
                          const float* pre, const float* post, const float* base, float cb, float co,
                          const float* dotw, float* dot_partials, const int* skip, int* tick,
-                         const MgpCommit* commit, const MgpFirst* first, void* stream) {
+                         const MgpFirst* first, void* stream) {
   if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !X || !Y) return MGP_ERR_ARG;
   if (L->n <= 0 || C <= 0 || C > 256) return C > 256 ? MGP_ERR_UNSUPPORTED : MGP_ERR_ARG;
   if (X == Y) return MGP_ERR_ARG;  // rows gather other rows of X: never in place
   hipStream_t st = mgp_stream(stream);
   SpmmArgs p{L->n, L->rowptr, L->col, L->vals, L->diag, X, Y, C, a, b, pre, post, base, cb, co,
-             dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset, MgpCommit{nullptr, nullptr, nullptr, nullptr},
-             nullptr, nullptr, 0};
+             dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset, nullptr, nullptr, 0};
 #ifdef MGP_STAMP
   p.stamp_on = g_stamp_enable;
 #endif
-  if (commit) {
-    if (!use_tiles(L, C)) return MGP_ERR_UNSUPPORTED;   // the row records ride in the tile kernel only
-    p.commit = *commit;
-  }
   if (first) {
     if (!use_tiles(L, C)) return MGP_ERR_UNSUPPORTED;
     p.copy_x = first->copy_x;
@@ -2459,34 +1991,6 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     const int grid = (int)mgp_cdiv((int64_t)ma.T * ma.NCB, kBlock / 64);
     if (pre) hipLaunchKernelGGL((spmm_mt_kernel<true>), dim3(grid), dim3(kBlock), 0, st, p, ma);
     else hipLaunchKernelGGL((spmm_mt_kernel<false>), dim3(grid), dim3(kBlock), 0, st, p, ma);
-  } else if (d8_shape_ok(L, C)) {
-    if (!aligned16(X, Y, base, dotw)) return MGP_ERR_ARG;   // (the plan counted this kernel's dot-partial blocks)
-    TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,
-                nullptr, nullptr, nullptr, L->tile_max_entries, 0};
-    const int grid = d8_grid(L);
-    const size_t lds = d8_lds_bytes(L, C);
-    const int S = d8_slots(L, C), cap = d8_stream_cap(L);
-    const unsigned tagmul = (unsigned)((1u << 24) / (unsigned)S + 1u);
-#ifdef MGP_D8_STAMP
-    ta.rowptr_t = reinterpret_cast<const int32_t*>(g_d8_stamps);
-#endif
-#define MGP_D8_LAUNCH(NV4)                                                                                          \
-  do {                                                                                                              \
-    if (pre) {                                                                                                      \
-      MGP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_dict8_kernel<NV4, true>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                     \
-      hipLaunchKernelGGL((spmm_dict8_kernel<NV4, true>), dim3(grid), dim3(kD8Threads), lds, st, p, ta, S, cap, tagmul);  \
-    } else {                                                                                                        \
-      MGP_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&spmm_dict8_kernel<NV4, false>),                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                     \
-      hipLaunchKernelGGL((spmm_dict8_kernel<NV4, false>), dim3(grid), dim3(kD8Threads), lds, st, p, ta, S, cap, tagmul); \
-    }                                                                                                               \
-  } while (0)
-    switch (d8_nv4(C)) {
-      case 2: MGP_D8_LAUNCH(2); break;
-      default: MGP_D8_LAUNCH(4); break;
-    }
-#undef MGP_D8_LAUNCH
   } else if (dict_shape_ok(L, C)) {
     if (!aligned16(X, Y, base, dotw)) return MGP_ERR_ARG;   // (the plan counted this kernel's dot-partial blocks)
     TileArgs ta{L->tile_ptr, L->tile_cols, L->lid, mgp_cdiv(L->n, L->tile_rows), 1, L->tile_max_cols,

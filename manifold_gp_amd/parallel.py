@@ -524,7 +524,7 @@ def distributed_cg_reference(local_matvec, b_pad, part, rank, tol=1e-10, max_ite
 
 
 # ------------------------------------------------------------------------------ bench (N > 1)
-def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_peak, emit=print):
+def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_peak, emit=print, cpu_baseline=None):
     """bench.py body for world > 1 (also reachable at world == 1 with MGP_FORCE_DIST=1).
 
     --scaling strong (default; BASELINE.json's metric is the N = 60k graph on 1/2/4/8 GPUs): the SAME graph on every
@@ -638,6 +638,28 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
                        how="columns [rank::world] solved with the single-GPU plan on the replicated graph, one all-gather of "
                            "the solutions; time = max over ranks, barriers on both sides")
     rccl = comm_info(comm, world)          # (collective: every rank takes part)
+    # ---- the same solve with the single-GPU plan (cg.hip: one hipGraph per solve) on this rank's replica of the graph, in this
+    # process: what the partitioned plan's chunked loop + collectives cost against it is then visible in the record itself
+    from .solvers import CgPlan
+    single = None
+    if strong:
+        refine1 = args.refine if getattr(args, "refine", -1) >= 0 else (0 if args.workload == "c3" else 3)
+        sp = CgPlan(wl["desc"], 1, tol=args.tol, max_iter=5000, stop_mode=1, check_every=8, refine=refine1)
+        y1 = wl["y"].view(-1, 1).contiguous()
+        for _ in range(max(args.warmup, 2)):
+            sp.solve(y1, copy=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            sp.solve(y1, copy=False)
+        torch.cuda.synchronize()
+        single = dict(ms_per_step=round((time.perf_counter() - t1) / args.steps * 1e3, 4), iterations=sp.iters,
+                      rel_residual=float(max(sp.resid)), refine=refine1,
+                      note="rank 0, same process, same graph: solvers.CgPlan (what `bench.py --gpus 1` times)")
+        sp.close()
+    cb = None
+    if rank == 0 and cpu_baseline is not None:
+        cb, _ = cpu_baseline(wl, its)          # the N = 1 line's port (oracle/ref_torch.py), rank 0's host cores
     if rank == 0:
         how = ("rows AND vectors partitioned over %d ranks, %s, %d ghost rows on rank 0"
                % (world, "Chronopoulos-Gear recurrence: two RCCL collectives per iteration (gathered vector + gamma partials; "
@@ -663,6 +685,11 @@ def bench_distributed(args, dev, rank, world, build_workload, spmm_bytes, hbm_pe
                                   note="per-GPU share of the whole-job rate (includes collectives and vector "
                                        "kernels); the kernel-only figure is the N=1 line"))
         line["rccl_ranks"] = rccl
+        if single is not None:
+            line["ms_per_step_single_gpu_plan"] = single["ms_per_step"]
+            line["single_gpu_plan"] = single
+        if cb is not None:
+            line["cpu_baseline"] = cb
         if sharded is not None:
             line["cg_multi_rhs_sharded"] = sharded
         line["unmeasured_note"] = ("the partitioned solver has run with more than one RCCL rank only in the driver's scale "

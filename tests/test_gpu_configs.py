@@ -675,3 +675,91 @@ def test_bench_line_contract(dev):
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1
     assert line["value"] > 0 and line["ms_per_step"] > 0
     assert line["config"]["cg_true_residual_fp32_apply"] < 1e-5 and line["config"]["max_rel_diff_vs_cpu_solution"] < 1e-4
+
+
+def _run_bench(args, env_extra=None, timeout=900):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(args), capture_output=True, text=True,
+                       timeout=timeout, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_stages_contract(dev):
+    """The N = 1 line carries every stage of the path beside the headline (round 5): k-NN, graph + Laplacian build, eigensolve,
+    the wide SpMM, features in / out of sample, the kernel block, one supervised and one semi-supervised training epoch
+    (`stages`), the reference benchmark's mv / grad / eigen legs at its own shape on the GPU and on the host cores
+    (`reference_bench`, `cpu_baseline.reference_shape`; benchmark/bench_sparse_laplacian.py:15-34), the S5 k-NN
+    (`roofline_hbm.knn`) and the conditioned 60k-shape workload (`manifold_784`).  Reduced sizes here (--nodes 8000
+    --force-extras); the full-size line is the driver's."""
+    line = _run_bench(["--steps", "3", "--warmup", "1", "--nodes", "8000", "--force-extras"])
+    st = line["stages"]
+    for key in ("knn", "graph_symmetrise_csr_tiles", "laplacian_build", "eigensolve", "spmm_wide_C128", "spmm_wide_C100",
+                "features_insample", "features_oos", "kernel_block", "train_epoch_supervised", "train_epoch_semisupervised"):
+        assert key in st, key
+    assert st["knn"]["ms"] > 0 and st["knn"]["effective_fp32_tflops"] > 0 and st["knn"]["stats"]["rows_redone_exact"] == 0
+    assert st["laplacian_build"]["bytes"] == 24 * 2 * line["config"]["edges"] + 16 * line["config"]["nodes"]
+    assert st["eigensolve"]["ms"] > 0 and st["eigensolve"]["spmm_applies"] > 0 and st["eigensolve"]["modes"] == 100
+    for c in (128, 100):
+        w = st["spmm_wide_C%d" % c]
+        assert w["us"] > 0 and abs(w["frac"] - w["gbs"] / 8000.0) < 1e-3
+    kb = st["kernel_block"]
+    assert kb["tflops"] > 0 and abs(kb["frac"] - kb["tflops"] / kb["peak"]) < 2e-3
+    for key in ("train_epoch_supervised", "train_epoch_semisupervised"):
+        ep = st[key]
+        assert ep["epoch_ms"] > 0 and np.isfinite(ep["first_loss"]) and np.isfinite(ep["last_loss"])
+    assert st["train_epoch_semisupervised"]["labelled"] == 800
+    rb = line["reference_bench"]
+    for key in ("gpu_matvec_ms", "cpu_matvec_ms", "gpu_grad_backward_ms", "cpu_grad_backward_ms", "gpu_dense_symeig_ms",
+                "gpu_block_eigensolver_100_modes_ms", "cpu_dense_symeig_ms"):
+        assert rb[key] > 0, key
+    assert rb["matvec_max_rel_diff"] < 1e-5 and rb["grad_rel_diff"] < 1e-3 and rb["eig_100_max_abs_diff"] < 1e-3
+    rs = line["cpu_baseline"]["reference_shape"]
+    assert rs["mv_ms"] == rb["cpu_matvec_ms"] and rs["grad_ms"] == rb["cpu_grad_backward_ms"] and rs["eigen_ms"] == rb["cpu_dense_symeig_ms"]
+    hb = line["roofline_hbm"]
+    assert hb["knn"]["pair_distances_per_s"] > 0 and hb["measured"].startswith("live_back_to_back")
+    pc = hb["cg_solve"]["preconditioner"]
+    for key in ("none", "jacobi"):
+        assert pc[key]["iterations"] > 0 and pc[key]["ms"] > 0
+    assert any(k.startswith("chebyshev_") for k in pc)
+    m7 = line["manifold_784"]
+    assert m7["posterior_test_rmse"] < 0.5 and m7["precision_cg"]["rel_residual"] <= 1e-6 and m7["eval_eigensolve_ms"] > 0
+
+
+@pytest.mark.parametrize("workload", ["c3", "s5"])
+def test_bench_distributed_world1_line_contract(dev, workload):
+    """What `bench.py --gpus N` runs for N > 1 (parallel.bench_distributed: graph padding, row partition, RCCL communicator,
+    partitioned plan, sharded columns) in a fresh process at world 1 (MGP_FORCE_DIST=1), so that the first multi-rank run
+    cannot fail on plumbing: the N > 1 line's contract -- driver keys, `roofline`, `cpu_baseline`, `rccl_ranks.consistent`,
+    `cg_multi_rhs_sharded` (C3), the single-GPU plan's time in the same process -- and a converged solve.  c3: the pipelined
+    recurrence in chunks of 4; s5: Chronopoulos-Gear + refinement on the true residual."""
+    args = ["--steps", "3", "--warmup", "1", "--workload", workload, "--nodes", "8000" if workload == "c3" else "200000"]
+    line = _run_bench(args, env_extra={"MGP_FORCE_DIST": "1"})
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rccl_ranks", "ms_per_step_single_gpu_plan"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["scaling"] == "strong" and line["value"] > 0
+    roof = line["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    rc = line["rccl_ranks"]
+    assert rc["consistent"] is True and rc["comm_count"] == [1] and rc["user_rank"] == [0]
+    cb = line["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    cfg = line["config"]
+    assert cfg["cg_iters"] > 0 and cfg["cg_true_residual_fp32_apply"] < (1e-5 if workload == "c3" else 2e-3)
+    assert line["ms_per_step_single_gpu_plan"] > 0 and line["single_gpu_plan"]["iterations"] > 0
+    if workload == "c3":
+        sh = line["cg_multi_rhs_sharded"]
+        assert sh["columns"] == 100 and sh["solve_ms"] > 0 and sh["true_mean_rel_residual"] < 1e-2
+        assert "pipelined" in cfg["parallelism"]
+    else:
+        assert "Chronopoulos-Gear" in cfg["parallelism"] and cfg["cg_iters"] > 20
