@@ -359,6 +359,8 @@ def _main(quiet):
     ap.add_argument("--tol", type=float, default=1e-6)
     ap.add_argument("--s5-order", default="morton", choices=["random", "morton"])
     ap.add_argument("--refine", type=int, default=-1, help="CG refinement rounds (-1: 0 for c3, 3 for s5)")
+    ap.add_argument("--classic-cg", action="store_true",
+                    help="CG on A even where the complex-shift factorisation applies (the in-solve SpMV profile of --workload s5)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -391,6 +393,9 @@ def _main(quiet):
 
     wl = build_workload(args, dev, rank, world)
     from manifold_gp_amd.solvers import CgPlan
+    if args.classic_cg:
+        from manifold_gp_amd import _lib as _l
+        _l.lib().mgp_cg_set_complex_shift(0)
     g = wl["graph"]
     refine = args.refine if args.refine >= 0 else (0 if args.workload == "c3" else 3)
     plan = CgPlan(wl["desc"], 1, tol=args.tol, max_iter=5000, stop_mode=1, check_every=8, refine=refine)
@@ -424,7 +429,13 @@ def _main(quiet):
     # runs k of them once its graph ends in the decision-only launch, k + 1 before).  With refinement rounds the
     # fp32 applies of every round are iterations + 1.
     spmvs_per_solve = (applies / args.steps if refine == 0 else its + 1) * wl["nu"]
+    if plan.complex_shift:
+        # the plan solved through the complex factorisation (--workload s5): `its` products with B = tau I + L_sym in four
+        # columns (re, im, re, im) instead of (its + 1) * nu single-column products with L
+        spmvs_per_solve = its
+        B = spmm_bytes(g.n, g.M, 4)
     value = B * spmvs_per_solve * args.steps / dt / 1e9
+    B = spmm_bytes(g.n, g.M)
     resid = max(plan.resid)
     # residual re-check with one explicit operator apply
     r = wl["desc"].apply(out) - y
@@ -513,6 +524,8 @@ def _main(quiet):
                 scaling=args.scaling, vs_baseline=None, dtype="f32", data="synthetic",
                 config=dict(workload=wl["name"], nodes=g.n, edges=g.M, nnz_padded=g.nnz, rhs_columns=1,
                             system="A = I + noise*outputscale*Q, Q=(2nu/kappa^2 I + L)^nu x D",
+                            solver=("COCG on the complex factor I + i sigma B (A = I + c B^2): one 4-column SpMM per iteration"
+                                    if plan.complex_shift else "CG on A (Chronopoulos-Gear, one hipGraph per solve)"),
                             cg_tol=args.tol, cg_iters=its, cg_rel_residual=resid, cg_true_residual_fp32_apply=true_res,
                             spmv_per_solve=spmvs_per_solve, eps=wl["eps"], knn_graph_build_s=round(wl["t_graph"], 3)),
                 cg_solve_ms=round(dt / args.steps * 1e3, 4), roofline=roof)

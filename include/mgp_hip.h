@@ -356,6 +356,18 @@ size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);
  * test_cg_decide_in_update_matches_separate_launches).  Default 1; 0 = the separate launches; returns the previous setting; read
  * at plan creation. */
 int mgp_cg_set_decide_in_update(int on);
+/* Complex-shift solve (round 5).  C == 1 plans on A = I + s Q2 (form 2) with nu = 2 and no pre / post vectors (symmetric
+ * normalisation), stop_mode 1, no preconditioner: A = I + c B^2 = (I + i sigma B)(I - i sigma B) with B = tau I + L_sym,
+ * c = noise * scale, sigma = sqrt(c), and x = Re[(I + i sigma B)^-1 b].  The plan then runs COCG (the CG recurrences with the
+ * unconjugated bilinear form) on the complex symmetric system, whose condition is ~sqrt(cond(A)): ONE product with B (the
+ * 4-column tile SpMM over (re, im, re, im)) per iteration and about the square root of CG's iteration count -- 1M-node swiss
+ * roll: 58 iterations against 688 of two SpMVs each.  `iters` counts COCG iterations, `resid` is the relative norm of the
+ * COMPLEX residual (refined solves report the true residual of A x = b as before).  The reference's call is the unpreconditioned
+ * linear_cg of precision_matern_operator.py:53 / riemann_gp.py:45-75 on the same system.
+ * mgp_cg_set_complex_shift(0): CG on A as in rounds 1-4 (A/B runs, tests, the in-solve SpMV profile); returns the previous
+ * setting; read at plan creation.  mgp_cg_plan_is_complex_shift: 1 when the plan took that form. */
+int mgp_cg_set_complex_shift(int on);
+int mgp_cg_plan_is_complex_shift(void* plan);
 /* Plans with more than 16 columns sum the dot-product partials of a step ONCE (cg_reduce_kernel, one small launch
  * ahead of the update) instead of in every workgroup of the update kernel.  Default 1; 0 = the every-workgroup
  * scheme at any C (A/B measurements, tests); affects plans created afterwards. */

@@ -94,6 +94,8 @@ SIGNATURES = {
     "mgp_spmm_timing_end": (c_int, [POINTER(c_float), POINTER(c_int)]),
     "mgp_spmm_set_v4_mode": (c_int, [c_int]),
     "mgp_cg_set_decide_in_update": (c_int, [c_int]),
+    "mgp_cg_set_complex_shift": (c_int, [c_int]),
+    "mgp_cg_plan_is_complex_shift": (c_int, [_P]),
     "mgp_cg_set_reduce_once": (c_int, [c_int]),
     "mgp_cg_set_poll_spin": (c_int, [c_int]),
     "mgp_cg_set_init_free": (c_int, [c_int]),

@@ -36,6 +36,8 @@ constexpr int kMaxC = 256;
 constexpr int kMaxGridVec = 512;
 constexpr int kMaxPartials = 4096;   // capacity of the gamma / rr partial arrays
 
+typedef float mgp_cg_v4f __attribute__((ext_vector_type(4)));
+
 struct CgArgs {
   int64_t n;
   int C, TC, TS;
@@ -759,6 +761,221 @@ __global__ void cg_marker_kernel(int* state, int* host_state) {
   host_state[4] = c;
 }
 
+// ---- Complex-shift solve of the (K + s I) system in precision form, symmetric normalisation, nu = 2 (round 5).
+// A = I + c B^2 with B = tau I + L_sym and c = noise * scale factorises over the complex numbers: 1 + c b^2 =
+// (1 + i sigma b)(1 - i sigma b), sigma = sqrt(c), and 1 / (1 + c b^2) = Re[1 / (1 + i sigma b)], so
+//     x = Re[(I + i sigma B)^-1 y].
+// M = I + i sigma B is complex SYMMETRIC (not Hermitian) with its spectrum on the segment {1 + i sigma b}: its condition is
+// ~sqrt(cond(A)), and COCG -- the CG recurrences with the unconjugated bilinear form z . w = sum z_j w_j -- needs about the
+// square root of CG's iterations on A.  Measured on the 1M-node swiss roll (cond(A) = 1.4e4): 58 iterations of ONE product with
+// B against 688 iterations of two for CG on A, the same solution to 2e-7 (tools/lab/cocg_s5.py).  The reference's call site is the
+// unpreconditioned linear_cg of precision_matern_operator.py:53; this is the north star's "preconditioned CG" taken to its
+// end for the systems that factorise: an exact algebraic split instead of an approximate inverse.
+//   * vectors z, r, p, s are [n] complex (float2); the product B u runs on the 4-column tile SpMM (spmm_tile_q_kernel) over
+//     u4 = (u_re, u_im, u_re, u_im) with dot weights w4 = (u_re, u_im, u_im, u_re): its per-workgroup partials are exactly the
+//     four real sums of u . B u = (d0 - d1) + i (d2 + d3); w = M u = u + i sigma B u is formed in the update;
+//   * single-reduction (Chronopoulos-Gear) form as cg_update_kernel: gamma = r . r, delta = u . M u = gamma + i sigma u . B u
+//     (u = r: no preconditioner), beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old), all complex;
+//   * stop: ||r||_2 <= tol ||b||_2 on the COMPLEX residual (an upper bound for the residual of the real system's solution
+//     Re z up to the factor |I - i sigma B|; callers that need a certified true residual use the refinement rounds, which
+//     evaluate b - A x in fp64 on the original operator);
+//   * state words, host flags, skip / tick and the chunked hipGraph replay are those of the real solver.
+constexpr int kCxDeltaSlots = 16;    // nbs4 <= 4096
+
+struct CxArgs {
+  float2 *z, *r, *p, *s;     // [n] complex
+  mgp_cg_v4f *u4, *w4;       // SpMM input (u_re, u_im, u_re, u_im), dot weights (u_re, u_im, u_im, u_re)
+  const mgp_cg_v4f* y4;      // B u4
+  const float* pd4;          // [nbs4][4] partials of w4 . y4 per column
+  int nbs4;
+  float sigma;
+  float* pd_g;               // [2][nbv][4]: gamma_re, gamma_im, ||r||^2, 0
+  float* sc;                 // [2][4] {gamma_old re, im, alpha_old re, im} per parity, then [8] = ||b||^2
+};
+
+__device__ __forceinline__ float2 cx_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cx_div(float2 a, float2 b) {
+  const float d = b.x * b.x + b.y * b.y;
+  if (!(d > 0.f)) return make_float2(0.f, 0.f);
+  return make_float2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+
+__global__ __launch_bounds__(kBlock) void cx_init_kernel(CgArgs a, CxArgs c, const float* __restrict__ B) {
+  __shared__ float sh_o[kBlock / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int64_t r0 = (int64_t)lb * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.n) r1 = a.n;
+  if (blockIdx.x == 0 && tid == 0) { a.state[0] = 0; a.state[1] = 0; a.state[2] = 0; }   // the first product ticks it to 1
+  float g = 0.f;
+  for (int64_t r = r0 + tid; r < r1; r += kBlock) {
+    const float b = B[r];
+    c.z[r] = make_float2(0.f, 0.f);
+    c.r[r] = make_float2(b, 0.f);
+    c.p[r] = make_float2(0.f, 0.f);
+    c.s[r] = make_float2(0.f, 0.f);
+    c.u4[r] = mgp_cg_v4f{b, 0.f, b, 0.f};
+    c.w4[r] = mgp_cg_v4f{b, 0.f, 0.f, b};
+    a.x[r] = 0.f;
+    g = fmaf(b, b, g);
+  }
+  g = mgp_wave_sum(g);
+  if (lane == 0) sh_o[wave] = g;
+  __syncthreads();
+  if (tid == 0) {
+    const float t = (sh_o[0] + sh_o[1]) + (sh_o[2] + sh_o[3]);
+    float* dst = c.pd_g + 4 * (int64_t)lb;            // parity slot 0 = "previous" of iteration 1
+    dst[0] = t; dst[1] = 0.f; dst[2] = t; dst[3] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void cx_update_kernel(CgArgs a, CxArgs c) {
+  __shared__ float sh_w[kBlock / 64][7];
+  __shared__ float sh_o[kBlock / 64][3];
+  __shared__ int sh_state[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int st_it = a.state[0], st_done = a.state[1];
+  const int lb = mgp_xcd_block(blockIdx.x, gridDim.x);
+  const int64_t r0 = (int64_t)lb * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.n) r1 = a.n;
+  // ---- one round trip: the partials of both parities, the four-column partials of u . B u, the scalars
+  float t[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // gamma re/im, rr (parity 0), gamma re/im, rr (parity 1) -> selected below
+  mgp_cg_v4f gv[2][kC1GammaSlots];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < kC1GammaSlots; ++q) {
+      const int b = tid + q * kBlock;
+      const int bc = b < a.nbv ? b : a.nbv - 1;
+      gv[h][q] = *reinterpret_cast<const mgp_cg_v4f*>(c.pd_g + 4 * ((int64_t)h * a.nbv + bc));
+    }
+  }
+  mgp_cg_v4f dv[kCxDeltaSlots];
+#pragma unroll
+  for (int q = 0; q < kCxDeltaSlots; ++q) {
+    const int b = tid + q * kBlock;
+    const int bc = b < c.nbs4 ? b : c.nbs4 - 1;
+    dv[q] = *reinterpret_cast<const mgp_cg_v4f*>(c.pd4 + 4 * (int64_t)bc);
+  }
+  const float go_r0 = c.sc[0], go_i0 = c.sc[1], ao_r0 = c.sc[2], ao_i0 = c.sc[3];
+  const float go_r1 = c.sc[4], go_i1 = c.sc[5], ao_r1 = c.sc[6], ao_i1 = c.sc[7];
+  const float bb_old = c.sc[8];
+  float g0[3] = {0.f, 0.f, 0.f}, g1[3] = {0.f, 0.f, 0.f}, d4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < kC1GammaSlots; ++q) {
+    const bool on = tid + q * kBlock < a.nbv;
+    g0[0] += on ? gv[0][q].x : 0.f; g0[1] += on ? gv[0][q].y : 0.f; g0[2] += on ? gv[0][q].z : 0.f;
+    g1[0] += on ? gv[1][q].x : 0.f; g1[1] += on ? gv[1][q].y : 0.f; g1[2] += on ? gv[1][q].z : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < kCxDeltaSlots; ++q) {
+    const bool on = tid + q * kBlock < c.nbs4;
+    d4[0] += on ? dv[q].x : 0.f; d4[1] += on ? dv[q].y : 0.f; d4[2] += on ? dv[q].z : 0.f; d4[3] += on ? dv[q].w : 0.f;
+  }
+  if (tid == 0) { sh_state[0] = st_it; sh_state[1] = st_done; }
+  __syncthreads();
+  if (sh_state[1]) return;
+  const int it = sh_state[0];
+  const int par = it & 1, prev = par ^ 1;
+  t[0] = prev ? g1[0] : g0[0]; t[1] = prev ? g1[1] : g0[1]; t[2] = prev ? g1[2] : g0[2];
+  t[3] = d4[0]; t[4] = d4[1]; t[5] = d4[2]; t[6] = d4[3];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) t[k] = mgp_wave_sum(t[k]);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sh_w[wave][k] = t[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 7; ++k) t[k] = (sh_w[0][k] + sh_w[1][k]) + (sh_w[2][k] + sh_w[3][k]);
+  const float2 gamma = make_float2(t[0], t[1]);
+  const float rr2 = t[2];
+  const float2 uBu = make_float2(t[3] - t[4], t[5] + t[6]);
+  const float2 delta = make_float2(gamma.x - c.sigma * uBu.y, gamma.y + c.sigma * uBu.x);     // u . (u + i sigma B u)
+  const float bb = (it == 1) ? rr2 : bb_old;
+  const float rel = (bb > 0.f) ? sqrtf(rr2 / bb) : 0.f;
+  float2 alpha = make_float2(0.f, 0.f), beta = make_float2(0.f, 0.f);
+  if (rel > a.tol) {
+    if (it == 1) {
+      alpha = cx_div(gamma, delta);
+    } else {
+      const float2 go = prev ? make_float2(go_r1, go_i1) : make_float2(go_r0, go_i0);
+      const float2 ao = prev ? make_float2(ao_r1, ao_i1) : make_float2(ao_r0, ao_i0);
+      beta = cx_div(gamma, go);
+      const float2 corr = cx_div(cx_mul(beta, gamma), ao);
+      alpha = cx_div(gamma, make_float2(delta.x - corr.x, delta.y - corr.y));
+    }
+    if (!isfinite(alpha.x) || !isfinite(alpha.y) || !isfinite(beta.x) || !isfinite(beta.y)) {
+      alpha = make_float2(0.f, 0.f); beta = make_float2(0.f, 0.f);
+    }
+  }
+  int done = 0, status = 0;
+  if (rel <= a.tol) { done = 1; status = 1; }
+  if (!isfinite(rel)) { done = 1; status = 3; }
+  if (!done && it > a.max_iter) { done = 1; status = 2; }
+  if (blockIdx.x == 0 && tid == 0) {
+    c.sc[4 * par + 0] = gamma.x; c.sc[4 * par + 1] = gamma.y;
+    c.sc[4 * par + 2] = alpha.x; c.sc[4 * par + 3] = alpha.y;
+    if (it == 1) c.sc[8] = bb;
+    a.resid[0] = rel;
+    if (done) {
+      a.state[2] = status; a.state[1] = 1;
+      a.host_resid[0] = rel;
+      a.host_state[0] = it; a.host_state[2] = status;
+      __threadfence_system();
+      a.host_state[1] = 1;
+    }
+  }
+  if (done) return;
+  // ---- vector update over this workgroup's rows, four rows per lane in flight
+  float ngr = 0.f, ngi = 0.f, nrr = 0.f;
+  constexpr int U = 4;
+  const int64_t rf = r0 + tid;
+  for (int64_t rb = rf; rb < r1; rb += (int64_t)U * kBlock) {
+    float2 uo[U], po[U], so[U], zo[U];
+    mgp_cg_v4f yo[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t r = rb + (int64_t)k * kBlock;
+      const int64_t rc = r < r1 ? r : rf;
+      uo[k] = c.r[rc]; po[k] = c.p[rc]; so[k] = c.s[rc]; zo[k] = c.z[rc]; yo[k] = c.y4[rc];
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int64_t r = rb + (int64_t)k * kBlock;
+      if (r < r1) {
+        const float2 u = uo[k];
+        const float2 w = make_float2(u.x - c.sigma * yo[k].y, u.y + c.sigma * yo[k].x);       // M u = u + i sigma B u
+        const float2 bp = cx_mul(beta, po[k]), bs = cx_mul(beta, so[k]);
+        const float2 pn = make_float2(u.x + bp.x, u.y + bp.y);
+        const float2 sn = make_float2(w.x + bs.x, w.y + bs.y);
+        const float2 ap = cx_mul(alpha, pn), as = cx_mul(alpha, sn);
+        const float2 zn = make_float2(zo[k].x + ap.x, zo[k].y + ap.y);
+        const float2 rn = make_float2(u.x - as.x, u.y - as.y);
+        c.p[r] = pn; c.s[r] = sn; c.z[r] = zn; c.r[r] = rn;
+        a.x[r] = zn.x;                                             // the real system's solution: Re z
+        c.u4[r] = mgp_cg_v4f{rn.x, rn.y, rn.x, rn.y};
+        c.w4[r] = mgp_cg_v4f{rn.x, rn.y, rn.y, rn.x};
+        ngr += rn.x * rn.x - rn.y * rn.y;
+        ngi += 2.f * rn.x * rn.y;
+        nrr += rn.x * rn.x + rn.y * rn.y;
+      }
+    }
+  }
+  ngr = mgp_wave_sum(ngr); ngi = mgp_wave_sum(ngi); nrr = mgp_wave_sum(nrr);
+  if (lane == 0) { sh_o[wave][0] = ngr; sh_o[wave][1] = ngi; sh_o[wave][2] = nrr; }
+  __syncthreads();
+  if (tid == 0) {
+    float* dst = c.pd_g + 4 * ((int64_t)par * a.nbv + lb);
+    dst[0] = (sh_o[0][0] + sh_o[1][0]) + (sh_o[2][0] + sh_o[3][0]);
+    dst[1] = (sh_o[0][1] + sh_o[1][1]) + (sh_o[2][1] + sh_o[3][1]);
+    dst[2] = (sh_o[0][2] + sh_o[1][2]) + (sh_o[2][2] + sh_o[3][2]);
+    dst[3] = 0.f;
+  }
+}
+
 // ---- iterative refinement (stop_mode 1, max_refine > 0): the recurrence residual of a single-
 // reduction CG drifts from the true residual on ill-conditioned systems in fp32; the true residual
 // R = B - A x is formed explicitly and, if it misses the tolerance, A d = R is solved and x += d.
@@ -930,6 +1147,13 @@ struct CgPlan {
   bool graphs_tried;
   bool init_free;             // no cg_init launch: the first apply reads the rhs itself (CgArgs::pd_bb)
   bool decide_in_update;      // the first graph's last update decides + marks (mgp_cg_set_decide_in_update at plan creation)
+  bool cx;                    // complex-shift solve (cx_update_kernel): form 2, nu = 2, symmetric normalisation, C = 1
+  CxArgs cxa;
+  mgp_operator_t opB;         // B = tau I + L_sym (one launch of the 4-column SpMM per iteration)
+  float* pd4;                 // [nb4][4] partials of u . B u
+  int nb4;
+  void* op_work4;
+  size_t op_work4_bytes;
   float* pd_bb;               // [nbs] partials of ||b||^2 written by the first apply
   char first_record[MGP_SPMM_RECORD_BYTES];   // launch arguments of the first graph's root SpMV (rhs patched per solve)
   int32_t* host_state;      // pinned
@@ -958,10 +1182,17 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
   b += mgp_align(9 * 32 * sizeof(int));                         // arrival counters (cg_update_c1_kernel<true>)
   b += mgp_align((size_t)256 * C * 2 * sizeof(float));          // refinement partials
   b += 6 * 2 * nc + mgp_align((size_t)256 * C * 2 * sizeof(double));   // fp64 refinement: xacc, A x, 4 chain buffers
+  if (C == 1 && world == 1) {
+    // complex-shift solve: z r p s (float2), u4 w4 y4 (float4), the 4-column chain scratch, partials, scalars
+    const size_t n = (size_t)op->L.n;
+    b += 4 * mgp_align(n * 8) + 3 * mgp_align(n * 16) + 4 * mgp_align(n * 16) + 256;
+    b += mgp_align((size_t)kCxDeltaSlots * kBlock * 4 * sizeof(float)) + mgp_align((size_t)2 * kMaxGridVec * 4 * sizeof(float)) + 256;
+  }
   return b + 1024;
 }
 
 constexpr int kReduceOnceAbove = 16;
+std::atomic<int> g_cg_complex_shift{1};   // form 2, nu = 2, symmetric normalisation, C = 1: the complex-shift solve (mgp_cg_set_complex_shift(0): CG on A)
 std::atomic<int> g_cg_reduce_once{1};   // mgp_cg_set_reduce_once(0): every update workgroup re-reduces the partials at any C (A/B, tests)
 std::atomic<int> g_cg_poll_spin{64};    // flag reads between two looks at the clock in the flag-only poll window; 0: no such window (mgp_cg_set_poll_spin)
 std::atomic<int> g_cg_init_free{1};   // C == 1 plans start without a cg_init launch (mgp_cg_set_init_free(0): classic start)
@@ -982,6 +1213,17 @@ void launch_update_c1(CgPlan* pl, hipStream_t st, bool decide_last) {
 }
 
 int enqueue_body(CgPlan* pl, hipStream_t st, bool decide_last = false) {
+  if (pl->cx) {
+    // B u on the 4-column tile SpMM (partials of u . B u ride along; skipped once decided; ticks the iteration), then the
+    // complex update
+    MGP_TRY(mgp_operator_apply_dist(&pl->opB, nullptr, reinterpret_cast<const float*>(pl->cxa.u4), nullptr, 4,
+                                    const_cast<float*>(reinterpret_cast<const float*>(pl->cxa.y4)),
+                                    reinterpret_cast<const float*>(pl->cxa.w4), pl->pd4, pl->nb4, pl->args.state + 1,
+                                    pl->args.state, pl->op_work4, pl->op_work4_bytes, st));
+    hipLaunchKernelGGL(cx_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, pl->cxa);
+    MGP_LAUNCH_CHECK();
+    return MGP_OK;
+  }
   MGP_TRY(mgp_operator_apply_dist(&pl->op, pl->is_dist ? &pl->dist : nullptr, pl->args.u, pl->args.us, pl->C,
                                   pl->args.w, pl->args.u, pl->pd_delta, pl->nb_loc, pl->args.state + 1,
                                   pl->args.state, pl->op_work, pl->op_work_bytes, st));
@@ -1114,7 +1356,7 @@ static void capture_graphs(CgPlan* pl) {
   }
   pl->has_graph = ok;
   (void)hipGetLastError();   // a failed capture falls back to eager launches
-  if (ok) {
+  if (ok && !pl->cx) {      // (the complex-shift solve runs tens of iterations: init launch + chunk graphs, no single-graph form)
     int len = pl->last_need >= 1 && pl->last_need <= 64 ? pl->last_need : (pl->chunk < 4 ? pl->chunk : 4);
     capture_first(pl, len);
   }
@@ -1197,12 +1439,42 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   pl->rpart64 = ar.take<double>((size_t)256 * C * 2);
   a.tol = pl->prm.tol; a.max_iter = pl->prm.max_iter; a.min_iter = pl->prm.min_iter;
   a.stop_mode = pl->prm.stop_mode;
+  pl->cx = false;
+  if (C == 1 && !dist) {
+    // the complex-shift solve's buffers (taken whenever the shape could use them: cg_bytes counts them)
+    const size_t nn = (size_t)n;
+    CxArgs& cx = pl->cxa;
+    cx.z = ar.take<float2>(nn); cx.r = ar.take<float2>(nn); cx.p = ar.take<float2>(nn); cx.s = ar.take<float2>(nn);
+    cx.u4 = ar.take<mgp_cg_v4f>(nn); cx.w4 = ar.take<mgp_cg_v4f>(nn);
+    cx.y4 = ar.take<mgp_cg_v4f>(nn);
+    pl->op_work4_bytes = 4 * mgp_align(nn * 16) + 256;
+    pl->op_work4 = ar.take<char>(pl->op_work4_bytes);
+    pl->pd4 = ar.take<float>((size_t)kCxDeltaSlots * kBlock * 4);
+    cx.pd_g = ar.take<float>((size_t)2 * kMaxGridVec * 4);
+    cx.sc = ar.take<float>(64);
+    cx.pd4 = pl->pd4;
+    const float cc = op->noise * op->scale;
+    if (g_cg_complex_shift && !minv && op->form == 2 && op->nu == 2 && !op->pre && !op->post && cc > 0.f && ar.ok() &&
+        a.nbv <= kC1GammaSlots * kBlock && pl->prm.stop_mode == 1) {
+      pl->opB = *op;
+      pl->opB.nu = 1;
+      pl->opB.kappa = op->kappa / sqrtf(2.0f);       // tau_B = 2 / kappa_B^2 = 2 nu / kappa^2
+      pl->opB.scale = 1.0f; pl->opB.form = 0; pl->opB.noise = 0.f;
+      pl->nb4 = mgp_spmm_dot_blocks_for(&pl->opB.L, 4);
+      if (pl->nb4 >= 1 && pl->nb4 <= kCxDeltaSlots * kBlock) {
+        cx.nbs4 = pl->nb4;
+        cx.sigma = sqrtf(cc);
+        MGP_HIP_TRY(hipMemsetAsync(cx.sc, 0, 64 * sizeof(float), pl->stream));
+        pl->cx = true;
+      }
+    }
+  }
   pl->pd_bb = ar.take<float>((size_t)a.nbs * C);
   a.pd_bb = nullptr;
   a.arrive = ar.take<int>(9 * 32);
   if (a.arrive) MGP_HIP_TRY(hipMemsetAsync(a.arrive, 0, 9 * 32 * sizeof(int), pl->stream));
   pl->init_free = false;
-  if (g_cg_init_free && C == 1 && !dist && !minv && (op->form == 0 || op->form == 2) &&
+  if (g_cg_init_free && C == 1 && !dist && !minv && !pl->cx && (op->form == 0 || op->form == 2) &&
       mgp_tile_plan(&op->L, 1, nullptr, nullptr, nullptr) && a.nbv <= kC1GammaSlots * kBlock &&
       a.nbs <= kC1DeltaSlots * kBlock) {
     pl->init_free = true;
@@ -1239,6 +1511,17 @@ extern "C" int mgp_cg_set_poll_spin(int spins) {
 extern "C" int mgp_cg_set_reduce_once(int on) {
   g_cg_reduce_once = on == 2 ? 2 : (on ? 1 : 0);      // 2: from two columns up (A/B runs)
   return MGP_OK;
+}
+
+extern "C" int mgp_cg_set_complex_shift(int on) {
+  const int prev = g_cg_complex_shift;
+  g_cg_complex_shift = on ? 1 : 0;
+  return prev;
+}
+
+extern "C" int mgp_cg_plan_is_complex_shift(void* plan) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  return pl && pl->cx ? 1 : 0;
 }
 
 extern "C" int mgp_cg_set_decide_in_update(int on) {
@@ -1279,7 +1562,10 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   if (pl->has_first && !patch_first_rhs(pl, rhs)) pl->has_first = false;
   int eager_done = 0;           // bodies of the first eager chunk already enqueued
   if (!pl->has_first) {
-    if (pl->init_free) {
+    if (pl->cx) {
+      hipLaunchKernelGGL(cx_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args, pl->cxa, rhs);
+      MGP_LAUNCH_CHECK();
+    } else if (pl->init_free) {
       MGP_TRY(enqueue_first_body(pl, st, rhs, false));
       eager_done = 1;
     } else {

@@ -74,6 +74,13 @@ class CgPlan:
     def resid(self):
         return list(self._resid)
 
+    @property
+    def complex_shift(self):
+        """True when the plan solves its system through the complex factorisation I + c B^2 = (I + i sigma B)(I - i sigma B)
+        (COCG on the complex symmetric factor, include/mgp_hip.h: mgp_cg_set_complex_shift): `iters` then counts COCG
+        iterations of ONE four-column product with B each."""
+        return bool(lib().mgp_cg_plan_is_complex_shift(self.handle))
+
     def solution_view(self):
         """The plan's own solution buffer as a tensor view (no copy; overwritten by the next solve)."""
         if self._xview is None:                 # the buffer never moves: one view for the life of the plan

@@ -11,7 +11,7 @@ fail=0
 bash tools/profile.sh "$tag" || fail=1
 [ $fail = 0 ] && python3 tools/summarize_profile.py "$tag" | tail -3
 [ $fail = 0 ] && python3 tools/trace_solve.py "gpurun_out/prof_${tag}/trace" > "$out/${tag}_trace_solve.txt"
-[ $fail = 0 ] && { bash tools/profile.sh "${tag}_s5" --workload s5 || fail=1; }
+[ $fail = 0 ] && { bash tools/profile.sh "${tag}_s5" --workload s5 --classic-cg || fail=1; }
 [ $fail = 0 ] && python3 tools/summarize_profile.py "${tag}_s5" | tail -3
 # the eigensolve's kernel mix (three 60k eigensolves of 100 pairs at the shipped tolerance)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
