@@ -201,8 +201,8 @@ typedef struct {
   const float* tile_vals;      /* [nnz] vals gathered through emap */
   const int32_t* tile_rowid;   /* [n] original row of every tile-order position (= row_order) */
   /* dense 16-row tiles for the matrix-core SpMM at 48 <= C <= 256 (mgp_spmm_mt_fill); all NULL / 0 = not built */
-  const int32_t* mt_sptr;      /* [mt_tiles + 1] steps (of four distinct columns) before tile t; multiples of 4 */
-  const int32_t* mt_dcol;      /* [4 mt_steps + 192] the tiles' distinct columns, padded per tile to whole blocks of 16 */
+  const int32_t* mt_sptr;      /* [mt_tiles + 1] steps (of four distinct columns) before tile t; multiples of 16 */
+  const int32_t* mt_dcol;      /* [4 mt_steps + 192] the tiles' distinct columns, padded per tile to whole bodies of 64 */
   const float* mt_img;         /* [64 (mt_steps + 32)] tile values in MFMA operand order */
   int32_t mt_tiles;            /* ceil(n / 16) */
   int32_t mt_steps;            /* mt_sptr[mt_tiles] */
@@ -233,7 +233,7 @@ int mgp_spmm_set_dict_mode(int on);
  * N = 60k, C = 128: 60 us against 94 for the gather kernel.  mgp_spmm_set_mt_mode(0) = never; returns the previous setting.
  * mgp_spmm_mt_fill builds mt_dcol / mt_img from a CSR in natural row order and its 16-row tile dictionaries
  * (mgp_graph_tiles with tile_rows = 16: tile_ptr16, tile_cols16, lid16) and the step offsets sptr (per tile
- * 4 ceil(D / 16) steps, exclusive prefix sum, `steps` = the total).
+ * 16 ceil(D / 64) steps -- whole bodies of four blocks --, exclusive prefix sum, `steps` = the total).
  * Replaces torch_sparse.spmm at manifold_gp/operators/graph_laplacian_operator.py:118-119 for the eigensolver's blocks and
  * the [N, 100] right-hand sides of precision_matern_operator.py:50-53. */
 int mgp_spmm_set_mt_mode(int on);

@@ -1361,7 +1361,16 @@ struct MtArgs {
   const float* img;      // [64 * (steps + 32)]
   int T, NCB;
   int img_bytes, dic_bytes;
+#ifdef MGP_MT_STAMP      // lab build (tools/lab/stamp_mt.py): per wave {start, loop entry, loop exit, end} wall clocks, blocks, HW_ID, XCC_ID
+  unsigned long long* stamps;
+#endif
 };
+#ifdef MGP_MT_STAMP
+unsigned long long* g_mt_stamps = nullptr;
+#define MT_STAMP(k) do { if (m.stamps && lane == 0) m.stamps[(size_t)w * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define MT_STAMP(k) do { } while (0)
+#endif
 
 template <bool PRE>
 struct MtBuf {
@@ -1378,7 +1387,10 @@ __device__ __forceinline__ void mt_request(MtBuf<PRE>& nb, int dq, int p0, int k
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int d = __builtin_amdgcn_ds_bpermute((4 * (p0 + p) + kq) * 4, dq);
-    off[p] = d * rowbytes + joff;
+    // (a 24-bit multiply: column ids and row bytes are below 2^24, the product below 2^31.  The plain `d * rowbytes + joff` became
+    // v_mad_u64_u32 with a 64-bit addend whose unused high half the compiler took from any register at hand -- in round 5 the
+    // destination of an operand load still in flight: harmless, but the stream check rightly flags every touch of such a register)
+    off[p] = (int)__umul24((unsigned)d, (unsigned)rowbytes) + joff;
     offp[p] = d * 4;
   }
 #pragma unroll
@@ -1405,16 +1417,36 @@ __device__ __forceinline__ void mt_wait(MtBuf<PRE>& cb) {
 }
 
 template <bool PRE>
-__device__ __forceinline__ void mt_mfma(const MtBuf<PRE>& cb, int s0, int S, mgp_v4f (&acc)[4]) {
+__device__ __forceinline__ void mt_mfma(const MtBuf<PRE>& cb, mgp_v4f (&acc)[4]) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
-    float av = s0 + p < S ? cb.a[p] : 0.f;       // a step past the tile's end holds the next tile's operands
+    float av = cb.a[p];
     if constexpr (PRE) av *= cb.pr[p];           // x[col] * pre[col]: the scale rides on the matrix value
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, cb.b[p][e], acc[e], 0, 0, 0);
   }
 }
 
+// Round 5, after per-wave stamps of the round-4 kernel (tools/lab/stamp_mt.py, C = 128 on the 60k graph, 66 us): a wave lived
+// 9-11 us + 0.5 us per block of four steps -- a 2.2 us prologue (tile offsets, column batches, first requests), the first
+// operands a memory latency later, a final drain that also waited for six blocks requested PAST the tile's end, then the
+// epilogue's own load round trip -- half the life of a mean tile of 18.6 blocks, 2.4 times per wave slot; while its waves were
+// in their loops a SIMD's matrix pipe was ~90 % busy (the launch is 29 us of pipe work).  The same launch with every image / X
+// request answered without memory traffic took 63 us (tools/lab/mt_bounds.sh): it was never bound by cache misses.
+// What changed:
+//   * every tile is a whole number of BODIES (four blocks = 64 distinct columns = one column batch; +7 % steps on the C3 graph),
+//     so the unrolled loop needs no masked steps and its LAST body is peeled: nothing is requested past the tile's end (30 % of
+//     the round-4 kernel's memory traffic) and the waits of that body count down to zero;
+//   * the epilogue's operands (the X block of the tile's own rows, the diagonal) are REQUESTED WITH THE FIRST BLOCKS -- inline-asm
+//     loads like the stream's; they depend on nothing the loop computes -- and have landed long before the loop ends.  Extra
+//     operations in the queue only make the counted waits conservative (they wait for all but the N youngest).  Operands the
+//     common callers do not pass at these widths (pre / post scalings, base, a dot weight other than X) are fetched with
+//     ordinary loads in the epilogue: correct, a round trip slower, rare.
+// Tried in between and dropped, both measured (docs/kernels/spmm.md, round 5): PERSISTENT waves over contiguous tile ranges of
+// equal block count with the operand pipeline carried across tile boundaries (pending accumulators, the epilogue a body later):
+// 38 us at C = 64 (one wave per tile: 41), but 77 us at C = 128 and 177 at C = 256 -- ranges of two or three whole tiles differ
+// by a tile (max 88 blocks against a mean of 49) -- and 493 us against 375 at 1M nodes / C = 64, where waves far apart in the
+// tile order no longer share X rows in L2.  The hardware's dispatch of one wave per tile balances and co-locates better.
 template <bool PRE>
 __global__ __launch_bounds__(kBlock) void spmm_mt_kernel(SpmmArgs p, MtArgs m) {
   constexpr int LR = PRE ? 12 : 8;      // loads per block request
@@ -1427,18 +1459,29 @@ __global__ __launch_bounds__(kBlock) void spmm_mt_kernel(SpmmArgs p, MtArgs m) {
   const int C = p.C;
   if (t >= m.T && !p.dot_partials) return;           // (with dot partials every wave of the workgroup meets at the barrier below)
   mgp_v4f ds = {0.f, 0.f, 0.f, 0.f};                 // this lane's share of sum_rows dotw * y for columns c0 .. c0 + 3
+  MT_STAMP(0);
   if (t < m.T) {
-  const int base = __builtin_amdgcn_readfirstlane(m.sptr[t]), S = __builtin_amdgcn_readfirstlane(m.sptr[t + 1]) - base;
-  const int blk0 = base >> 2, NB = S >> 2;
+  const int blk0 = __builtin_amdgcn_readfirstlane(m.sptr[t]) >> 2, blk1 = __builtin_amdgcn_readfirstlane(m.sptr[t + 1]) >> 2;
   const int64_t nx = p.n + p.goff;                   // rows of X the columns can name (host side: goff == 0)
+#if defined(MGP_MT_LAB) && (MGP_MT_LAB & 2)     // lab (tools/lab/mt_bounds.sh): every X request out of range -> zeros, no memory traffic
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), (short)0, 0, 0x00020000);
+#else
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), (short)0, (int)(nx * C * 4), 0x00020000);
+#endif
   const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(m.img), (short)0, m.img_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rdic = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(m.dcol), (short)0, m.dic_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rpre = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PRE ? p.pre : p.X), (short)0, (int)(nx * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdiag = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.diag), (short)0, (int)(p.n * 4), 0x00020000);
+#if defined(MGP_MT_LAB) && (MGP_MT_LAB & 4)     // lab: every X request goes to row 0 (always cached)
+  const int lane4 = lane * 4, rowbytes = 0, joff = cb * 256 + j * 16;
+#else
   const int lane4 = lane * 4, rowbytes = C * 4, joff = cb * 256 + j * 16;
-  mgp_v4f acc[4];
+#endif
+  const int c0 = 64 * cb + 4 * j;                    // acc[e][r]: row 16 t + 4 kq + r, column c0 + e
+  mgp_v4f acc[4], ex[4];
+  float ed[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) acc[e] = mgp_v4f{0.f, 0.f, 0.f, 0.f};
+  for (int e = 0; e < 4; ++e) { acc[e] = mgp_v4f{0.f, 0.f, 0.f, 0.f}; ex[e] = mgp_v4f{0.f, 0.f, 0.f, 0.f}; ed[e] = 0.f; }
   MtBuf<PRE> buf0, buf1, buf2, buf3;
   int dq0, dq1, dq2;          // column-list batches of the body in hand, of the next one, and the one in flight
   const int dic0 = blk0 * 64, img0 = blk0 * 1024;      // byte offsets of the tile's first block
@@ -1448,28 +1491,46 @@ __global__ __launch_bounds__(kBlock) void spmm_mt_kernel(SpmmArgs p, MtArgs m) {
   mt_request<PRE>(buf0, dq0, 0, kq, joff, rowbytes, img0, rimg, rx, rpre, lane4);
   mt_request<PRE>(buf1, dq0, 4, kq, joff, rowbytes, img0 + 1024, rimg, rx, rpre, lane4);
   mt_request<PRE>(buf2, dq0, 8, kq, joff, rowbytes, img0 + 2048, rimg, rx, rpre, lane4);
-  for (int k = 0; k < NB; k += 4) {
-    const int so = img0 + k * 1024, sd = dic0 + k * 64;
+  {
+    // the epilogue's operands: the X block of the tile's own rows (16 bytes per lane and row) and the diagonal
+    int offx[4], offd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * t + 4 * kq + r;
+      // (rows past n / columns past C: in range of the descriptor or answered with 0; 24-bit multiply as in mt_request)
+      offx[r] = (int)__umul24((unsigned)row, (unsigned)(C * 4)) + c0 * 4;
+      offd[r] = row * 4;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(ex[r]) : "v"(offx[r]), "s"(rx));
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "+v"(ed[r]) : "v"(offd[r]), "s"(rdiag));
+    }
+    asm volatile("" :: "v"(offx[0]), "v"(offx[1]), "v"(offx[2]), "v"(offx[3]), "v"(offd[0]), "v"(offd[1]), "v"(offd[2]), "v"(offd[3]));
+  }
+  MT_STAMP(1);
+  for (int k = blk0; k < blk1 - 4; k += 4) {
+    const int so = k * 1024, sd = k * 64;
     asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:512" : "=v"(dq2) : "v"(lane4), "s"(rdic), "s"(sd));
     mt_wait<2 * LR + 1, PRE>(buf0);
     mt_request<PRE>(buf3, dq0, 12, kq, joff, rowbytes, so + 3 * 1024, rimg, rx, rpre, lane4);
     __builtin_amdgcn_sched_barrier(0);      // requests stay in front of the block's MFMAs (left alone, the scheduler sinks them)
-    mt_mfma<PRE>(buf0, 4 * k, S, acc);
+    mt_mfma<PRE>(buf0, acc);
     __builtin_amdgcn_sched_barrier(0);
     mt_wait<2 * LR + 1, PRE>(buf1);
     mt_request<PRE>(buf0, dq1, 0, kq, joff, rowbytes, so + 4 * 1024, rimg, rx, rpre, lane4);
     __builtin_amdgcn_sched_barrier(0);
-    mt_mfma<PRE>(buf1, 4 * k + 4, S, acc);
+    mt_mfma<PRE>(buf1, acc);
     __builtin_amdgcn_sched_barrier(0);
     mt_wait<2 * LR + 1, PRE>(buf2);
     mt_request<PRE>(buf1, dq1, 4, kq, joff, rowbytes, so + 5 * 1024, rimg, rx, rpre, lane4);
     __builtin_amdgcn_sched_barrier(0);
-    mt_mfma<PRE>(buf2, 4 * k + 8, S, acc);
+    mt_mfma<PRE>(buf2, acc);
     __builtin_amdgcn_sched_barrier(0);
     mt_wait<2 * LR, PRE>(buf3);
     mt_request<PRE>(buf2, dq1, 8, kq, joff, rowbytes, so + 6 * 1024, rimg, rx, rpre, lane4);
     __builtin_amdgcn_sched_barrier(0);
-    mt_mfma<PRE>(buf3, 4 * k + 12, S, acc);
+    mt_mfma<PRE>(buf3, acc);
     __builtin_amdgcn_sched_barrier(0);
     dq0 = dq1;
     // the batch requested at the top of this body is older than R(k+3), which wait(k+3) has seen land: 3 LR = R(k+4..k+6)
@@ -1477,29 +1538,62 @@ __global__ __launch_bounds__(kBlock) void spmm_mt_kernel(SpmmArgs p, MtArgs m) {
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dq2) : "n"(3 * LR));
     dq1 = dq2;
   }
+  // ---- the tile's LAST body, peeled: in flight at the top R(k) R(k+1) R(k+2); behind the one request left, R(k+1) R(k+2) R(k+3)
+  {
+    const int so = (blk1 - 4) * 1024;
+    mt_wait<2 * LR, PRE>(buf0);
+    mt_request<PRE>(buf3, dq0, 12, kq, joff, rowbytes, so + 3 * 1024, rimg, rx, rpre, lane4);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_mfma<PRE>(buf0, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_wait<2 * LR, PRE>(buf1);
+    mt_mfma<PRE>(buf1, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_wait<LR, PRE>(buf2);
+    mt_mfma<PRE>(buf2, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    mt_wait<0, PRE>(buf3);
+    mt_mfma<PRE>(buf3, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(dq0), "+v"(dq1));
-  mt_wait<0, PRE>(buf0); mt_wait<0, PRE>(buf1); mt_wait<0, PRE>(buf2); mt_wait<0, PRE>(buf3);
-  // acc[e][r]: row 16 t + 4 kq + r, column c0 + e with c0 = 64 cb + 4 j
-  const int c0 = 64 * cb + 4 * j;
+  mt_wait<0, PRE>(buf0); mt_wait<0, PRE>(buf1); mt_wait<0, PRE>(buf2);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(ex[r]), "+v"(ed[r]));
+  MT_STAMP(2);
+#ifdef MGP_MT_STAMP
+  if (m.stamps && lane == 0) {
+    m.stamps[(size_t)w * 8 + 4] = (unsigned long long)(blk1 - blk0);
+    m.stamps[(size_t)w * 8 + 5] = (unsigned long long)__builtin_amdgcn_s_getreg(63492);     // HW_REG_HW_ID
+    m.stamps[(size_t)w * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(63508);     // HW_REG_XCC_ID
+  }
+#endif
   if (c0 < C) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t row = (int64_t)16 * t + 4 * kq + r;
       if (row < p.n) {
         const int64_t gr = row + p.goff;
-        mgp_v4f xs = *reinterpret_cast<const mgp_v4f*>(p.X + gr * C + c0);
+        mgp_v4f xs = ex[r];
         if (PRE) xs *= p.pre[gr];
         const mgp_v4f av = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
-        const mgp_v4f lx = p.diag[row] * xs - av;
+        const mgp_v4f lx = ed[r] * xs - av;
         mgp_v4f tt = p.a * xs + p.b * lx;
         if (p.post) tt *= p.post[gr];
         mgp_v4f y = p.co * tt;
         if (p.base) y += p.cb * *reinterpret_cast<const mgp_v4f*>(p.base + gr * C + c0);
         *reinterpret_cast<mgp_v4f*>(p.Y + gr * C + c0) = y;
-        if (p.dot_partials) ds += *reinterpret_cast<const mgp_v4f*>(p.dotw + gr * C + c0) * y;
+        if (p.dot_partials) {
+          const mgp_v4f dw = (p.dotw == p.X) ? ex[r] : *reinterpret_cast<const mgp_v4f*>(p.dotw + gr * C + c0);
+          ds += dw * y;
+        }
       }
     }
   }
+#ifdef MGP_MT_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  MT_STAMP(3);
   }   // t < m.T
   if (p.dot_partials) {
     // per workgroup and column: lanes kq = 1..3 onto kq = 0 (fixed order), then the workgroup's waves of the column's block in
@@ -1787,9 +1881,16 @@ static bool mt_shape_ok(const mgp_csr_t* L, int C) {
   if (C < kMtMinCols || C > 256 || (C & 3) != 0 || L->tile_rowid) return false;
   if (L->ncols != 0 && L->ncols != L->n) return false;        // a row slice of a partitioned operator never carries an image
   if ((int64_t)L->n * C * 4 >= (int64_t(1) << 31) || ((int64_t)L->mt_steps + 32) * 256 >= (int64_t(1) << 31)) return false;
+  if ((L->mt_steps & 15) != 0) return false;           // every tile a whole number of bodies of four blocks
   return L->mt_tiles == (int32_t)mgp_cdiv(L->n, 16);
 }
 
+#ifdef MGP_MT_STAMP
+extern "C" int mgp_mt_set_stamp_buffer(void* buf) {
+  g_mt_stamps = static_cast<unsigned long long*>(buf);
+  return MGP_OK;
+}
+#endif
 extern "C" int mgp_spmm_set_mt_mode(int on) {
   const int prev = g_mt_mode;
   g_mt_mode = on ? 1 : 0;
@@ -1799,7 +1900,7 @@ extern "C" int mgp_spmm_set_mt_mode(int on) {
 extern "C" int mgp_spmm_mt_fill(int64_t n, const int32_t* rowptr, const float* vals, const uint16_t* lid16,
                                 const int32_t* tile_ptr16, const int32_t* tile_cols16, const int32_t* sptr, int64_t steps,
                                 int32_t* dcol, float* img, void* stream) {
-  if (n <= 0 || !rowptr || !vals || !lid16 || !tile_ptr16 || !tile_cols16 || !sptr || !dcol || !img || steps <= 0 || (steps & 3))
+  if (n <= 0 || !rowptr || !vals || !lid16 || !tile_ptr16 || !tile_cols16 || !sptr || !dcol || !img || steps <= 0 || (steps & 15))
     return MGP_ERR_ARG;
   hipStream_t st = mgp_stream(stream);
   MGP_HIP_TRY(hipMemsetAsync(img, 0, (size_t)(steps + 32) * 256, st));
@@ -1989,6 +2090,12 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     MtArgs ma{L->mt_sptr, L->mt_dcol, L->mt_img, L->mt_tiles, (C + 63) / 64, (int)(((int64_t)L->mt_steps + 32) * 256),
               (int)(((int64_t)L->mt_steps * 4 + 192) * 4)};
     const int grid = (int)mgp_cdiv((int64_t)ma.T * ma.NCB, kBlock / 64);
+#if defined(MGP_MT_LAB) && (MGP_MT_LAB & 1)     // lab: every image request out of range -> zeros, no memory traffic
+    ma.img_bytes = 0;
+#endif
+#ifdef MGP_MT_STAMP
+    ma.stamps = g_mt_stamps;
+#endif
     if (pre) hipLaunchKernelGGL((spmm_mt_kernel<true>), dim3(grid), dim3(kBlock), 0, st, p, ma);
     else hipLaunchKernelGGL((spmm_mt_kernel<false>), dim3(grid), dim3(kBlock), 0, st, p, ma);
   } else if (dict_shape_ok(L, C)) {

@@ -87,7 +87,7 @@ class MtPlan:
             t = build_tiles(n, graph.rowptr, graph.col, nnz, tile_rows=16) if (MT_ENABLED[0] and n >= MT_MIN_NODES and nnz > 0) else None
             if t is not None:
                 D = (t["tile_ptr"][1:] - t["tile_ptr"][:-1]).long()
-                S = (D + 15) // 16 * 4                                     # steps per tile: whole blocks of four
+                S = (D + 63) // 64 * 16                                    # steps per tile: whole bodies of four blocks of four
                 sptr = torch.zeros(D.numel() + 1, dtype=torch.int64, device=graph.col.device)
                 torch.cumsum(S, 0, out=sptr[1:])
                 steps = int(sptr[-1])

@@ -2377,11 +2377,11 @@ def test_spmm_matrix_core_tiles(mgp, dev, shape):
         plan = data.mt_plan()
     assert isinstance(plan, MtPlan) and plan.fill >= (0.05 if shape == "thin" else 0.125) and plan.tiles == -(-n // 16)
     S = (plan.sptr[1:] - plan.sptr[:-1]).cpu().numpy() // 4
-    assert S.min() >= 1
+    assert S.min() >= 4 and (S % 4 == 0).all()                         # whole bodies of four blocks (round 5)
     if shape == "roll":
-        assert len(set((S % 4).tolist())) == 4 and S.max() >= 12       # every tail of the four-block loop body
+        assert len(set((S // 4).tolist())) >= 3 and S.max() >= 12       # one-body tiles (the peeled body alone) up to several
     if shape == "thin":
-        assert S.max() <= 3
+        assert S.max() <= 4
     g = data.graph
     rowptr, col = g.rowptr.cpu().numpy().astype(np.int64), g.col.cpu().numpy().astype(np.int64)
     A = sp.csr_matrix((data.vals.cpu().double().numpy(), col, rowptr), shape=(n, n))

@@ -31,14 +31,31 @@ def test_library_exports_every_header_symbol():
     assert _lib.lib().mgp_version() >= 100
 
 
-def test_struct_layouts_match_c_abi():
-    """mgp_csr_t / mgp_operator_t / params structs: sizes as the C compiler lays them out."""
+def test_struct_layouts_match_c_abi(tmp_path):
+    """mgp_csr_t / mgp_operator_t / params structs: the ctypes mirrors against what the C compiler makes of include/mgp_hip.h
+    (gcc compiles a probe that prints sizeof / offsetof)."""
+    import subprocess
     from manifold_gp_amd import _lib
-    assert ctypes.sizeof(_lib.CsrT) == 144
-    assert ctypes.sizeof(_lib.OperatorT) == 144 + 8 + 8 + 4 * 5 + 4     # + tail padding to 8
-    assert ctypes.sizeof(_lib.CgParamsT) == 28
-    assert ctypes.sizeof(_lib.LanczosParamsT) == 24
-    assert _lib.OperatorT.pre.offset == 144 and _lib.OperatorT.nu.offset == 160
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "probe.c"
+    src.write_text("""
+#include <stdio.h>
+#include <stddef.h>
+#include "mgp_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mgp_csr_t), sizeof(mgp_operator_t), sizeof(mgp_cg_params_t),
+         sizeof(mgp_lanczos_params_t), offsetof(mgp_operator_t, pre), offsetof(mgp_operator_t, nu), offsetof(mgp_csr_t, mt_sptr),
+         offsetof(mgp_csr_t, mt_tiles), offsetof(mgp_csr_t, mt_steps));
+  return 0;
+}
+""")
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    c = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
+    assert c == [ctypes.sizeof(_lib.CsrT), ctypes.sizeof(_lib.OperatorT), ctypes.sizeof(_lib.CgParamsT),
+                 ctypes.sizeof(_lib.LanczosParamsT), _lib.OperatorT.pre.offset, _lib.OperatorT.nu.offset, _lib.CsrT.mt_sptr.offset,
+                 _lib.CsrT.mt_tiles.offset, _lib.CsrT.mt_steps.offset], c
+    assert ctypes.sizeof(_lib.CsrT) == 144 and ctypes.sizeof(_lib.CgParamsT) == 28 and ctypes.sizeof(_lib.LanczosParamsT) == 24
 
 
 def test_argument_errors_without_gpu():

@@ -143,64 +143,105 @@ def check_res(asm, expect=29):
 
 def check_replay(asm, pattern, expect, what):
     """Kernels whose loads are inline asm waited for with `vmcnt(N)`, N > 0, and whose loop is ENTERED with loads in flight
-    (spmm_mt_kernel: three blocks of operands ahead): the whole function is replayed in text order against an in-order queue of
-    its vector memory operations, every loop body three times (loops side by side, not nested; forward branches fall through: the paths that skip code issue
-    fewer operations and wait for the same counts, i.e. for more).  No instruction may read or write a destination register of
-    a load still in the queue; at s_endpgm the queue must be empty of loads."""
+    (spmm_mt_kernel: three blocks of operands ahead): the whole function is replayed against an in-order queue of its vector
+    memory operations.  The stream is walked as one path: unconditional forward branches are followed, every loop (a backward
+    branch, conditional or not; loops side by side, not nested; a loop the compiler rotated, i.e. entered in its middle, too) runs
+    three times and is left through its exit.  Every loop body is replayed on TWO paths: with every conditional forward branch
+    that stays inside the body falling through (the optional code -- spmm_mt_kernel's tile boundary and pending epilogue -- runs in
+    every round: its loads must not be touched before the waits have retired them) and with every such branch taken (no optional
+    operation in the queue: the counted waits then retire the fewest operations, the case they are counted for).  No instruction
+    may read or write a destination register of a load still in the queue; at s_endpgm the queue must be empty of loads."""
     lines = asm.split("\n")
     starts = [i for i, l in enumerate(lines) if re.match(pattern, l)]
     problems = []
+    br = re.compile(r"s_c?branch\w* (\.LBB\d+_\d+)")
+    ubr = re.compile(r"s_branch (\.LBB\d+_\d+)")
+    cbr = re.compile(r"s_cbranch_\w+ (\.LBB\d+_\d+)")
     for a in starts:
         b = next(i for i in range(a, len(lines)) if ".end_amdhsa_kernel" in lines[i])
         name = what + " " + re.sub(r"^_ZN\d+_GLOBAL__N_1\d+", "", lines[a].split(":")[0])[:40]
         body = [lines[i].strip() for i in range(a + 1, b)]
         body = [t for t in body if t and not t.startswith(";") and (not t.startswith(".") or re.match(r"^\.LBB\d+_\d+:", t))]
         labels = {t.split(":")[0]: k for k, t in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", t)}
-        loops = {}
+        back = {}
         for k, t in enumerate(body):
-            m = re.match(r"s_cbranch_\w+ (\.LBB\d+_\d+)", t)
-            if m and m.group(1) in labels and labels[m.group(1)] < k:
-                loops[k] = labels[m.group(1)]
-        # every loop body three times (loops of these kernels are not nested: checked)
-        spans = sorted((head, tail) for tail, head in loops.items())
-        if not spans or any(a2 <= b1 for (a1, b1), (a2, b2) in zip(spans, spans[1:])):
-            problems.append("%s: %d loops, nested or none" % (name, len(spans)))
+            m = br.match(t)
+            if m and m.group(1) in labels and labels[m.group(1)] <= k:
+                back[labels[m.group(1)]] = k
+        if not back or any(h1 < h2 <= t1 for h1, t1 in back.items() for h2 in back if h2 != h1):
+            problems.append("%s: %d loops, nested or none" % (name, len(back)))
             continue
-        trace, pos = [], 0
-        for head, tail in spans:
-            trace += body[pos:tail + 1] + body[head:tail + 1] * 2
-            pos = tail + 1
-        trace += body[pos:]
-        queue, mfma = [], 0
-        for t in trace:
-            op = t.split()[0]
-            if op.startswith(".LBB"):
-                continue
-            m = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t)
-            if m:
-                n = int(m.group(1))
-                if len(queue) > n:
-                    queue = queue[len(queue) - n:]
-                continue
-            if op == "s_endpgm":
-                if any(r for r in queue):
-                    problems.append("%s: loads in flight at s_endpgm" % name)
-                queue = []
-                continue
-            inflight = set().union(*[r for r in queue if r]) if queue else set()
-            if regs_of(t) & inflight:
-                problems.append("%s: touches a register of a load still in flight: %s" % (name, t))
-            mfma += op.startswith("v_mfma")
-            m = re.match(r"(buffer|global)_load_dword(x(\d))? v(\[(\d+):(\d+)\]|(\d+))", t)
-            if m:
-                lo = int(m.group(5) or m.group(7)); hi = int(m.group(6) or m.group(7))
-                queue.append(set(range(lo, hi + 1)))
-            elif op.startswith(("buffer_load", "global_load", "flat_load", "scratch_")):
-                problems.append("%s: a load the check does not know: %s" % (name, t))
-            elif op.startswith(("buffer_store", "global_store", "flat_store", "global_atomic", "buffer_atomic")):
-                queue.append(None)
-        if mfma == 0:
-            problems.append("%s: no MFMA found" % name)
+
+        def linear(lo, hi, take):
+            out, k = [], lo
+            while k < hi:
+                t = body[k]
+                out.append(t)
+                mu, mc = ubr.match(t), cbr.match(t)
+                if mu and labels.get(mu.group(1), -1) > k:
+                    k = min(labels[mu.group(1)], hi)
+                elif take and mc and k < labels.get(mc.group(1), -1) < hi:
+                    k = labels[mc.group(1)]
+                else:
+                    k += 1
+            return out
+
+        def leave(head, tail):
+            if ubr.match(body[tail]):       # behind an unconditional back edge: the body's last conditional branch that leaves it
+                exits = [labels[m.group(1)] for m in (cbr.match(body[q]) for q in range(head, tail)) if m and labels.get(m.group(1), -1) > tail]
+                return exits[-1] if exits else tail + 1
+            return tail + 1
+
+        for take in (False, True):
+            trace, k = [], 0
+            while k < len(body):
+                if k in back:
+                    trace += linear(k, back[k] + 1, take) * 3
+                    k = leave(k, back[k])
+                    continue
+                t = body[k]
+                trace.append(t)
+                mu, mb = ubr.match(t), br.match(t)
+                if mu and labels.get(mu.group(1), -1) > k:
+                    k = labels[mu.group(1)]
+                elif mb and mb.group(1) in labels and labels[mb.group(1)] <= k and back.get(labels[mb.group(1)]) == k:
+                    head = labels[mb.group(1)]          # the back edge of a loop entered in its middle: two more rounds from its head
+                    trace += linear(head, k + 1, take) * 2
+                    k = leave(head, k)
+                else:
+                    k += 1
+            queue, mfma = [], 0
+            for t in trace:
+                op = t.split()[0]
+                if op.startswith(".LBB"):
+                    continue
+                m = re.match(r"s_waitcnt .*vmcnt\((\d+)\)", t)
+                if m:
+                    n = int(m.group(1))
+                    if len(queue) > n:
+                        queue = queue[len(queue) - n:]
+                    continue
+                if op == "s_endpgm":
+                    if any(r for r in queue):
+                        problems.append("%s: loads in flight at s_endpgm" % name)
+                    queue = []
+                    continue
+                inflight = set().union(*[r for r in queue if r]) if queue else set()
+                if regs_of(t) & inflight:
+                    problems.append("%s: touches a register of a load still in flight: %s" % (name, t))
+                mfma += op.startswith("v_mfma")
+                # (flat_load: the compiler's own loads of optional epilogue operands, which it waits for with vmcnt(0) lgkmcnt(0) before
+                # their first use: in the queue like the others, so that a touch of their destinations in flight is seen too)
+                m = re.match(r"(buffer|global|flat)_load_dword(x(\d))? v(\[(\d+):(\d+)\]|(\d+))", t)
+                if m:
+                    lo = int(m.group(5) or m.group(7)); hi = int(m.group(6) or m.group(7))
+                    queue.append(set(range(lo, hi + 1)))
+                elif op.startswith(("buffer_load", "global_load", "flat_load", "scratch_")):
+                    problems.append("%s: a load the check does not know: %s" % (name, t))
+                elif op.startswith(("buffer_store", "global_store", "flat_store", "global_atomic", "buffer_atomic")):
+                    queue.append(None)
+            if mfma == 0:
+                problems.append("%s: no MFMA found" % name)
     if len(starts) != expect:
         problems.append("expected %d instantiations of %s, found %d" % (expect, what, len(starts)))
     return problems
