@@ -239,6 +239,9 @@ int mgp_spmm_set_dict_mode(int on);
 int mgp_spmm_set_mt_mode(int on);
 /* which kernel mgp_spmm_fused would launch for this CSR / width (tests, docs): 0 = gather, 1 = C == 1 tile kernel, 2 = small-C
  * tile kernel, 3 = matrix-core tiles, 5 = lanes-over-columns dictionary, 6 = chunked dictionary (4 was a round-4 kernel, removed) */
+/* A CSR that carries the matrix-core image, called with a row offset: the other kernels run (the image is ignored) -- except
+ * with dot partials, whose count mgp_spmm_dot_blocks_csr sized for the matrix-core kernel: MGP_ERR_UNSUPPORTED from this
+ * function and from mgp_spmm_fused_rows alike (strip mt_* from the struct for such a call). */
 int mgp_spmm_kernel_choice(const mgp_csr_t* L, int C, int with_dot, int64_t row_offset);
 int mgp_spmm_mt_fill(int64_t n, const int32_t* rowptr, const float* vals, const uint16_t* lid16, const int32_t* tile_ptr16,
                      const int32_t* tile_cols16, const int32_t* sptr, int64_t steps, int32_t* dcol, float* img, void* stream);
@@ -340,10 +343,12 @@ typedef struct {
 } mgp_cg_params_t;
 
 size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C);
-/* ---- Lab-only switches (mgp_*_set_*): process-wide std::atomic<int> words for A/B measurements and tests, each read ONCE per
- * call (or once at plan creation where the comment says so).  They are not part of the path's contract and are not meant to be
- * flipped while another thread is inside a call of the same family: two calls that size and launch the same product
- * (mgp_spmm_dot_blocks_csr, then mgp_spmm_fused) must see the same setting. */
+/* ---- Lab-only switches (every mgp_*_set_* in this header): process-wide std::atomic<int> words for A/B measurements and tests.
+ * The SpMM family copies them once per call into a thread-local snapshot that all of the call's shape tests consult; the CG
+ * switches are read at plan creation; the kernel-block switch once per call; the k-NN / eigensolver switches where a call
+ * branches on them.  They are not part of the path's contract and are not meant to be flipped while another thread is inside a
+ * call of the same family: two calls that size and launch the same product (mgp_spmm_dot_blocks_csr, then mgp_spmm_fused; the
+ * k-NN workspace query, then the search) must see the same setting. */
 /* C == 1 plans: the LAST update launch of a plan's first graph also takes the stopping decision of the step behind it and
  * leaves the end-of-graph mark, instead of a single-workgroup decision launch + a marker launch behind it.  Hand-off inside the
  * launch (no release / acquire fence -- a fence writes back every dirty L2 line of the vectors the launch has just stored, measured

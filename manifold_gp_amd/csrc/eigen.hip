@@ -825,7 +825,8 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   // the next Rayleigh-Ritz step and is answered there (Gershgorin, fresh block).
   double ubf = ub;
   const int kk = 32;
-  if (g_eig_bound_mode && b >= kk && n >= 8 * kk) {
+  const int bound_mode = g_eig_bound_mode;      // (lab switch: read once per call)
+  if (bound_mode && b >= kk && n >= 8 * kk) {
     float* K = w.buf[0];
     float* LK = w.buf[1];
     float* y[3] = {w.buf[2], w.buf[3], w.buf[4]};
@@ -862,7 +863,7 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
     if (std::isfinite(th_full) && std::isfinite(th_half) && th_full > 0.0) {
       const double cand = th_full + std::max(0.03 * th_full, 2.0 * fabs(th_full - th_half));
       if (cand < ub) ubf = cand;
-      if (g_eig_bound_mode == 2) ubf = 0.5 * th_full;
+      if (bound_mode == 2) ubf = 0.5 * th_full;
     }
     if (getenv("MGP_EIG_TIMING"))
       fprintf(stderr, "[eig] upper end: Gershgorin %.5g, Krylov(32) theta %.5g (16: %.5g) -> filter bound %.5g\n", ub, th_full, th_half, ubf);

@@ -713,10 +713,11 @@ __device__ __forceinline__ void kb_res_walk(const float* __restrict__ Z1, int64_
   // loads every block began with `s_waitcnt vmcnt(1)` / `vmcnt(0)` -- the wait-count pass merges the loop's back edge with the
   // prologue's pending loads and takes the stricter count -- i.e. with a wait for the previous block's last load AND its
   // stores.  Quads go in groups of four (the loads of a group share cache lines and are issued together), the ragged last
-  // group first: a block's memory operations are then  L(g_0) ... L(g_last) S x 4 NRB,  each L(g) right behind the MFMAs that
-  // read g's registers for the last time, and in front of group g's MFMAs of the next block exactly J - |g| loads and 4 NRB
-  // stores are younger than L(g): `vmcnt(J - |g| + 4 NRB)` waits for L(g) and for nothing issued after it (the vector memory
-  // operations of one wave complete in order on gfx9, loads and stores alike: the compiler's own wait counts rely on it).
+  // group first: a block's memory operations are then  L(g_0) ... L(g_last) S x 16 NRB  (kKbResStores = 16 dword stores per
+  // row block),  each L(g) right behind the MFMAs that read g's registers for the last time, and in front of group g's MFMAs of
+  // the next block exactly J - |g| loads and 16 NRB stores are younger than L(g): `vmcnt(J - |g| + 16 NRB)` waits for L(g) and
+  // for nothing issued after it (the vector memory operations of one wave complete in order on gfx9, loads and stores alike:
+  // the compiler's own wait counts rely on it).  The largest count, J = 16 - 4 + 32 = 44, stays under vmcnt's 6-bit limit of 63.
 #ifdef MGP_KB_STORE_WINDOW
   const int row_k = records == 0 ? 128 : (int)ldk * 4;
 #else

@@ -1681,6 +1681,14 @@ std::atomic<int> g_rows_in_flight{1};
 
 }  // namespace
 
+// The lab switches below are process-wide atomics; a call reads them ONCE, at its entry point (knobs_snap), into a thread-local
+// snapshot that every helper of the call consults: a switch flipped by another thread in the middle of a call cannot make the
+// call's shape tests disagree with each other.  (Two CALLS -- sizing the dot partials, then launching -- can still see different
+// settings: the header says the switches are not to be flipped while another thread is inside this family of calls.)
+struct Knobs { int hint, rif, tile, tile_small, tile_wide, v4, dict, mt; };
+thread_local Knobs tl_knobs{16, 1, 1, 1, 1, 1, 1, 1};
+static void knobs_snap();
+
 extern "C" int mgp_spmm_set_group_hint(int lanes) {
   if (lanes != 4 && lanes != 8 && lanes != 16 && lanes != 32 && lanes != 64) return MGP_ERR_ARG;
   g_row_group_hint = lanes;
@@ -1694,8 +1702,8 @@ extern "C" int mgp_spmm_set_rows_in_flight(int rows) {
 }
 
 static int spmv_rows_in_flight() {
-  int r = g_rows_in_flight;
-  if (r > g_row_group_hint) r = g_row_group_hint;   // lane t finishes row t: needs R <= G
+  int r = tl_knobs.rif;
+  if (r > tl_knobs.hint) r = tl_knobs.hint;   // lane t finishes row t: needs R <= G
   return r;
 }
 
@@ -1708,7 +1716,7 @@ static int spmm_cols_group(int C) {
 // rows a workgroup covers per pass (the grid / dot-partial count follows from it).  C in {4,8,12,16}
 // uses 64 whichever kernel runs (the row16 kernel needs 16-byte aligned X, the generic one does not)
 static int spmm_rows_per_pass(int C) {
-  if (C == 1) return (kBlock / g_row_group_hint) * spmv_rows_in_flight();
+  if (C == 1) return (kBlock / tl_knobs.hint) * spmv_rows_in_flight();
   if (C <= 16 && (C & 3) == 0) return (kBlock / 16) * 4;
   return kBlock / spmm_cols_group(C) * 4;
 }
@@ -1733,7 +1741,7 @@ static size_t tile_lds_bytes(const mgp_csr_t* L) {
 static bool use_tiles(const mgp_csr_t* L, int C) {
   const int ord = (L->tile_rowptr != nullptr) + (L->tile_vals != nullptr) + (L->tile_rowid != nullptr);
   if (ord != 0 && ord != 3) return false;      // an ordered tile view is all three arrays or none
-  return C == 1 && g_tile_mode && L->lid && L->tile_ptr && L->tile_cols &&
+  return C == 1 && tl_knobs.tile && L->lid && L->tile_ptr && L->tile_cols &&
          (L->tile_rows == 32 || L->tile_rows == 64 || L->tile_rows == 128) && tile_lds_bytes(L) <= 65536 - 64;
 }
 
@@ -1745,6 +1753,7 @@ static int tile_grid(const mgp_csr_t* L, int* tiles_per_block) {
 }
 
 int mgp_tile_plan(const mgp_csr_t* L, int C, int* grid, int* tiles_per_block, size_t* lds_bytes) {
+  knobs_snap();
   if (!L || !use_tiles(L, C)) return 0;
   const int g = tile_grid(L, tiles_per_block);
   if (grid) *grid = g;
@@ -1773,7 +1782,7 @@ static size_t tile_small_lds_bytes(const mgp_csr_t* L, int C) {
 static bool use_tiles_small(const mgp_csr_t* L, int C) {
   const int ord = (L->tile_rowptr != nullptr) + (L->tile_vals != nullptr) + (L->tile_rowid != nullptr);
   if (ord != 0 && ord != 3) return false;
-  if (!(C == 4 || C == 8 || C == 12 || C == 16) || !g_tile_mode || !g_tile_small_mode) return false;
+  if (!(C == 4 || C == 8 || C == 12 || C == 16) || !tl_knobs.tile || !tl_knobs.tile_small) return false;
   if (!L->lid || !L->tile_ptr || !L->tile_cols || L->tile_rows != 64) return false;
   if ((L->tile_max_entries & 3) != 0) return false;
   return tile_small_lds_bytes(L, C) <= 65536 - 64;
@@ -1795,7 +1804,7 @@ static size_t tile_wide_lds_bytes(const mgp_csr_t* L) {
 static bool use_tiles_wide(const mgp_csr_t* L, int C) {
   const int ord = (L->tile_rowptr != nullptr) + (L->tile_vals != nullptr) + (L->tile_rowid != nullptr);
   if (ord != 0 && ord != 3) return false;
-  if (C <= 16 || C > 256 || (C & 3) != 0 || !g_tile_mode || !g_tile_wide_mode) return false;
+  if (C <= 16 || C > 256 || (C & 3) != 0 || !tl_knobs.tile || !tl_knobs.tile_wide) return false;
   if (!L->lid || !L->tile_ptr || !L->tile_cols || L->tile_rows != 64) return false;
   if ((L->tile_max_entries & 3) != 0) return false;
   // measured (tools/lab/time_spmm_wide.py): on the 60k graph the per-entry gather kernel reads its X rows out of L2 and
@@ -1803,7 +1812,7 @@ static bool use_tiles_wide(const mgp_csr_t* L, int C) {
   // the 1M graph, whose X block does not fit the caches, the dictionary kernel is 1.5-2.4x faster at every width
   // (1.48 vs 3.04 ms at C = 128).  mode 2 forces it at any size (tests, A/B).
   // (and up to 64 columns the float4-lane gather kernel beats both on a cache-resident X block: 33 us at C = 32)
-  if (g_tile_wide_mode == 2) return true;
+  if (tl_knobs.tile_wide == 2) return true;
   return (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20);
 }
 
@@ -1855,11 +1864,11 @@ static int dict_grid(const mgp_csr_t* L) {
 static bool dict_shape_ok(const mgp_csr_t* L, int C) {
   const int ord = (L->tile_rowptr != nullptr) + (L->tile_vals != nullptr) + (L->tile_rowid != nullptr);
   if (ord != 0 && ord != 3) return false;
-  if (C <= 16 || C > 256 || (C & 3) != 0 || !g_tile_mode || !g_dict_mode) return false;
+  if (C <= 16 || C > 256 || (C & 3) != 0 || !tl_knobs.tile || !tl_knobs.dict) return false;
   if (!L->lid || !L->tile_ptr || !L->tile_cols || L->tile_rows != 64) return false;
   if ((L->tile_max_entries & 3) != 0) return false;
   if (dict_slots(L, C) < 32) return false;
-  if (g_dict_mode == 2) return true;
+  if (tl_knobs.dict == 2) return true;
   return C >= 64 && (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20);
 }
 // the kernel moves 16 bytes per lane: X, Y, base and dotw rows must be 16-byte aligned (C % 4 == 0 makes every row so
@@ -1874,9 +1883,13 @@ static bool aligned16(const void* a, const void* b, const void* c, const void* d
 // the host wrapper builds it for graphs in natural row order whose tiles are at least 1/8 full) and the call has no row offset
 // (weighted dot-product partials included: one row of partials per workgroup).  mgp_spmm_set_mt_mode(0) = never (A/B runs, tests).
 std::atomic<int> g_mt_mode{1};
+static void knobs_snap() {
+  tl_knobs = Knobs{g_row_group_hint.load(), g_rows_in_flight.load(), g_tile_mode.load(), g_tile_small_mode.load(), g_tile_wide_mode.load(),
+                   g_spmm_v4_mode.load(), g_dict_mode.load(), g_mt_mode.load()};
+}
 constexpr int kMtMinCols = 48;
 static bool mt_shape_ok(const mgp_csr_t* L, int C) {
-  if (!g_mt_mode || !L->mt_img || !L->mt_sptr || !L->mt_dcol || L->mt_tiles <= 0 || L->mt_steps <= 0) return false;
+  if (!tl_knobs.mt || !L->mt_img || !L->mt_sptr || !L->mt_dcol || L->mt_tiles <= 0 || L->mt_steps <= 0) return false;
   // below 48 columns most lanes of a wave's 64-column block idle: the gather kernel is faster there (C = 32: 34 us against 41)
   if (C < kMtMinCols || C > 256 || (C & 3) != 0 || L->tile_rowid) return false;
   if (L->ncols != 0 && L->ncols != L->n) return false;        // a row slice of a partitioned operator never carries an image
@@ -1918,6 +1931,7 @@ extern "C" int mgp_spmm_set_dict_mode(int on) {
 
 int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
   if (!L) return MGP_ERR_ARG;
+  knobs_snap();
   if (use_tiles(L, C) || use_tiles_small(L, C)) return tile_grid(L, nullptr);
   if (mt_shape_ok(L, C)) return (int)mgp_cdiv((int64_t)L->mt_tiles * ((C + 63) / 64), kBlock / 64);
   if (dict_shape_ok(L, C)) return dict_grid(L);
@@ -1930,11 +1944,13 @@ int mgp_spmm_dot_blocks_for(const mgp_csr_t* L, int C) {
 // dictionary (4 was round 4's persistent 8-lanes-per-row dictionary kernel: measured slower, removed in round 5)
 extern "C" int mgp_spmm_kernel_choice(const mgp_csr_t* L, int C, int with_dot, int64_t row_offset) {
   if (!L || L->n <= 0 || C <= 0 || C > 256) return MGP_ERR_ARG;
+  knobs_snap();
   static const float one = 1.f;
   if (use_tiles(L, C)) return 1;
   if (use_tiles_small(L, C)) return 2;
-  (void)with_dot; (void)one;
+  (void)one;
   if (mt_shape_ok(L, C) && row_offset == 0) return 3;
+  if (mt_shape_ok(L, C) && with_dot) return MGP_ERR_UNSUPPORTED;      // (as mgp_spmm_fused_rows: partials were sized for kernel 3)
   if (dict_shape_ok(L, C)) return 5;
   if (use_tiles_wide(L, C)) return 6;
   return 0;
@@ -1947,6 +1963,7 @@ extern "C" int mgp_spmm_dot_blocks_csr(const mgp_csr_t* L, int C) {
 
 extern "C" int mgp_spmm_dot_blocks(int64_t n, int C) {
   if (n <= 0 || C <= 0) return MGP_ERR_ARG;
+  knobs_snap();
   return make_plan(n, spmm_rows_per_pass(C)).grid;
 }
 
@@ -2027,6 +2044,7 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
   if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !X || !Y) return MGP_ERR_ARG;
   if (L->n <= 0 || C <= 0 || C > 256) return C > 256 ? MGP_ERR_UNSUPPORTED : MGP_ERR_ARG;
   if (X == Y) return MGP_ERR_ARG;  // rows gather other rows of X: never in place
+  knobs_snap();
   hipStream_t st = mgp_stream(stream);
   SpmmArgs p{L->n, L->rowptr, L->col, L->vals, L->diag, X, Y, C, a, b, pre, post, base, cb, co,
              dotw, dotw ? dot_partials : nullptr, 0, skip, tick, row_offset, nullptr, nullptr, 0};
@@ -2084,8 +2102,11 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     else if (C == 12) MGP_TILE_SMALL_LAUNCH(3);
     else MGP_TILE_SMALL_LAUNCH(4);
 #undef MGP_TILE_SMALL_LAUNCH
-  } else if (mt_shape_ok(L, C)) {
-    if (row_offset != 0) return MGP_ERR_UNSUPPORTED;      // (the dot-partial block count was planned for this kernel)
+  } else if (mt_shape_ok(L, C) && row_offset != 0 && dotw && dot_partials) {
+    // a CSR that carries the tile image, a row offset AND dot partials: mgp_spmm_dot_blocks_csr sized them for the matrix-core
+    // kernel, which takes no row offset -- the one combination that is refused (mgp_spmm_kernel_choice reports it too)
+    return MGP_ERR_UNSUPPORTED;
+  } else if (mt_shape_ok(L, C) && row_offset == 0) {
     if (!aligned16(X, Y, base, dotw)) return MGP_ERR_ARG;
     MtArgs ma{L->mt_sptr, L->mt_dcol, L->mt_img, L->mt_tiles, (C + 63) / 64, (int)(((int64_t)L->mt_steps + 32) * 256),
               (int)(((int64_t)L->mt_steps * 4 + 192) * 4)};
@@ -2136,7 +2157,7 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     if (pre) hipLaunchKernelGGL((spmm_tile_wide_kernel<true>), dim3(grid), dim3(256), lds, st, p, ta, cap);
     else hipLaunchKernelGGL((spmm_tile_wide_kernel<false>), dim3(grid), dim3(256), lds, st, p, ta, cap);
   } else if (C == 1) {
-    const int G = g_row_group_hint;
+    const int G = tl_knobs.hint;
     const int R = spmv_rows_in_flight();
     Plan pl = make_plan(L->n, (kBlock / G) * R);
     p.rows_per_block = pl.rows_per_block;
@@ -2168,11 +2189,11 @@ int mgp_spmm_fused_first(const mgp_csr_t* L, int64_t row_offset, const float* X,
     else if (C == 12) MGP_ROW16_LAUNCH(3);
     else MGP_ROW16_LAUNCH(4);
 #undef MGP_ROW16_LAUNCH
-  } else if (g_spmm_v4_mode && C > 16 && C <= 256 && (C & 3) == 0 &&
+  } else if (tl_knobs.v4 && C > 16 && C <= 256 && (C & 3) == 0 &&
              // measured (tools/lab/time_spmm_wide.py): 33 vs 59 us at C = 32 and 54 vs 63 us at C = 64 on the 60k graph, but
              // 101 vs 91 us at C = 128 (the X block no longer sits in L2 and the per-column kernel's whole-line pieces use
              // the Infinity Cache path better); on the 1M graph, when the dictionaries are not there, it wins at every width
-             (g_spmm_v4_mode == 2 || C <= 64 || (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20)) &&
+             (tl_knobs.v4 == 2 || C <= 64 || (size_t)L->n * (size_t)C * sizeof(float) >= ((size_t)96 << 20)) &&
              ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(base) |
                reinterpret_cast<uintptr_t>(dotw) | reinterpret_cast<uintptr_t>(L->col) | reinterpret_cast<uintptr_t>(L->vals)) & 15) == 0 &&
              (L->tile_max_entries & 3) == 0 && L->lid != nullptr) {

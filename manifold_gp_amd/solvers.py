@@ -82,7 +82,10 @@ class CgPlan:
         return bool(lib().mgp_cg_plan_is_complex_shift(self.handle))
 
     def solution_view(self):
-        """The plan's own solution buffer as a tensor view (no copy; overwritten by the next solve)."""
+        """The plan's own solution buffer as a tensor view (no copy; overwritten by the next solve).  NOTE: when the plan iterates
+        on the relabelled matrix P A P^T (`self._rg` set: a graph handed over without locality), the rows of this view are in THAT
+        order -- row p is node `self._rg.order[p]` of the caller's -- ; `solve()` and `solution64_view()` return caller-order
+        copies."""
         if self._xview is None:                 # the buffer never moves: one view for the life of the plan
             off = int(lib().mgp_cg_plan_x(self.handle)) - self.work.data_ptr()
             nb = self.desc.n * self.C * 4

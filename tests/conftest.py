@@ -54,6 +54,9 @@ def ref_round_equal_or_boundary(a, b32, b64, decimals=5, count=10, ulp=1.5e-6):
         dist = abs(scaled - np.floor(scaled) - 0.5) / 10 ** decimals
         if dist < ulp and abs(x - y64) < ulp:
             boundary += 1
+            # the one builder-written exception to the reference's criterion: say which entry took it (pytest -s / -rA shows it)
+            print("ref_round_equal_or_boundary: entry %.9g (reference fp32 %.9g, float64 %.9g) rounds differently at %d decimals; "
+                  "float64 value %.2e from a rounding boundary: admitted" % (x, y32, y64, decimals, dist))
             continue
         return False, boundary
     return True, boundary

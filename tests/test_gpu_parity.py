@@ -2391,6 +2391,9 @@ def test_spmm_matrix_core_tiles(mgp, dev, shape):
         # (below 48 columns the gather kernel is faster and keeps the call; the comparison below then is gather against gather)
         assert (lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 0, 0) == 3) == (C >= 48)
         assert lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 0, 16) != 3
+        # image + row offset + dot partials (sized for the matrix-core kernel): the one combination that is refused, by the
+        # query and by the launch alike
+        assert (lib.mgp_spmm_kernel_choice(ctypes.byref(csr), C, 1, 16) == -3) == (C >= 48)
         X = torch.randn(n, C, device=dev)
         pre = torch.rand(n, device=dev) + 0.5
         post = torch.rand(n, device=dev) + 0.5

@@ -10,6 +10,19 @@ src, out = os.path.join(ROOT, "gpurun_out", "profiles_out"), os.path.join(ROOT, 
 for f in ("bench_trace.json", "kernel_stats.csv", "pmc_traffic.json", "trace_solve.txt", "s5_bench_trace.json", "s5_kernel_stats.csv",
           "s5_pmc_traffic.json", "eigensolve_kernel_stats.csv"):
     shutil.copy(os.path.join(src, "%s_%s" % (tag, f)), os.path.join(out, "%s_%s" % (tag, f)))
+# round 5 additions (copied when the retake produced them)
+for f in ("knn_kernel_stats.csv", "s5_complex_shift_kernel_stats.csv", "s5_complex_shift_bench.json", "training_supervised.json",
+          "training_semisupervised.json"):
+    if os.path.exists(os.path.join(src, "%s_%s" % (tag, f))):
+        shutil.copy(os.path.join(src, "%s_%s" % (tag, f)), os.path.join(out, "%s_%s" % (tag, f)))
+for raw, dst, head in (("pmc_knn_mfma_raw.txt", "pmc_knn_mfma.txt",
+                        "# tools/pmc_knn.sh: matrix-pipe counters of dist_mfma_kernel (k-NN candidate keys, 60k x 784 self-search, upper-triangle tile pairs),\n"
+                        "# one counter group per rocprofv3 --pmc pass, mean per launch.  SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs; SQ_BUSY_CU_CYCLES the CUs.\n"),
+                       ("pmc_knn_select_raw.txt", "pmc_knn_select.txt",
+                        "# tools/pmc_select.sh: HBM-side traffic of select_kernel (k-NN top-k + fp64 re-rank), FETCH_SIZE / WRITE_SIZE in separate passes (KB;\n"
+                        "# FETCH_SIZE to be doubled on gfx950 for wide coalesced reads, MI355X_MICROARCH.md), kernel-trace durations.\n")):
+    if os.path.exists(os.path.join(src, "%s_%s" % (tag, raw))):
+        open(os.path.join(out, "%s_%s" % (tag, dst)), "w").write(head + open(os.path.join(src, "%s_%s" % (tag, raw))).read())
 
 
 def parse(fn):
@@ -23,13 +36,11 @@ def parse(fn):
 
 mt, ga = parse(os.path.join(src, tag + "_pmc_spmm_mt_raw.txt")), parse(os.path.join(src, tag + "_pmc_spmm_gather_raw.txt"))
 wide = os.path.join(out, tag + "_pmc_spmm_wide.txt")
-head = open(wide).read().split("\n# ---- round 4, second half")[0].rstrip("\n")
-lines = [head, "",
-         "# ---- round 4, second half: the matrix-core tile kernel (spmm_mt_kernel<false>, `tools/pmc_kernel.sh mt spmm_mt tools/lab/spmm_one.py 128 2 0 0 0 1`)",
-         "# against the gather kernel (`... gather128 'spmm_kernel<64' tools/lab/spmm_one.py 128 0 0 0 0 0`), same box, same recipe, C = 128, 60k C3 graph, per launch.",
-         "# Reading (docs/kernels/spmm.md, round 4): every distinct X row of a 16-row tile crosses L1 once instead of once per entry -- ~2.2x fewer L1 accesses,",
-         "# ~2.2x fewer L2 read requests, TA busy ~2.3x lower -- on 3x fewer VALU and 8x fewer SALU instructions (the dense tiles run on the matrix pipe); launch",
-         "# cycles (GRBM_GUI_ACTIVE / 8) ~0.75x under the profiler's serialised launches (61.7 against 91.1 us back to back, tools/lab/time_mt.py).",
+lines = ["# rocprofv3 --pmc passes (tools/pmc_kernel.sh, one counter group per pass) over tools/lab/spmm_one.py, per launch, C = 128 on the 60k C3 graph.",
+         "# _sum counters add all CUs / channels; GRBM_GUI_ACTIVE adds the 8 XCDs (cycles of the launch = value / 8); TCP accesses are 64-byte units;",
+         "# TCC requests / misses are 128-byte units; SQ_* cycle counters are in units of 4 clocks.",
+         "# matrix-core tile kernel (spmm_mt_kernel<false>, `tools/pmc_kernel.sh mt spmm_mt tools/lab/spmm_one.py 128 2 0 0 0 1`) against the gather kernel",
+         "# (`... gather128 'spmm_kernel<64' tools/lab/spmm_one.py 128 0 0 0 0 0`), same box, same recipe.  Reading: docs/kernels/spmm.md, round 5.",
          "counter                                     matrix-core tiles           gather    ratio"]
 for k in sorted(set(mt) & set(ga)):
     lines.append("%-40s %18.1f %16.1f %8.2f" % (k, mt[k], ga[k], mt[k] / ga[k] if ga[k] else float("nan")))
@@ -50,7 +61,7 @@ def busy(k):
     return c[(k, "SQ_VALU_MFMA_BUSY_CYCLES")] / 1024 / (c[(k, "GRBM_GUI_ACTIVE")] / 8)
 
 
-hdr = """# Matrix-pipe counters of mgp_kernel_block, round 4 (taken on the tree that ships the resident-operand kernel, kernel_block_res).
+hdr = """# Matrix-pipe counters of mgp_kernel_block (kernel_block_res, unchanged since round 4; retaken on the tree of this tag).
 # (1) 600 x 60000 x 100, the C3 posterior block (tools/lab/pmc_kbres.sh, one counter group per pass over tools/lab/kblock_one.py, 50 launches each;
 #     k0 = knob 0 = the default = kernel_block_res; k1 = knob 1 = the lean LDS kernel kernel_block_one that was the default until this round):
 #       kernel_block_res: SQ_VALU_MFMA_BUSY_CYCLES %.2f M / 1024 SIMDs = %.1f k cycles per pipe; launch = GRBM_GUI_ACTIVE %d / 8 XCDs = %.1f k

@@ -7,11 +7,15 @@ f = max(glob.glob(base + "/**/*kernel_trace.csv", recursive=True), key=os.path.g
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # (round 4: a solve's first graph ends in the deciding update launch, cg_update_c1_kernel<true, ..>; older traces: cg_decide)
 dec = [i for i, r in enumerate(rows) if "cg_update_c1_kernel<true" in r["Kernel_Name"] or "cg_decide" in r["Kernel_Name"]]
-end = dec[-1] if dec else max(i for i, r in enumerate(rows) if "cg_update" in r["Kernel_Name"])
-# walk back to the start of that solve: the gap before its first kernel is a host round trip (>= 8 us)
-start = end
-while start > 0 and int(rows[start]["Start_Timestamp"]) - int(rows[start - 1]["End_Timestamp"]) < 8000:
-    start -= 1
+cands = dec[::-1] if dec else [max(i for i, r in enumerate(rows) if "cg_update" in r["Kernel_Name"])]
+# walk back to the start of that solve: the gap before its first kernel is a host round trip (>= 8 us).  Under the profiler a
+# replay now and then shows such a gap INSIDE a solve: take the last solve that comes out whole (five kernels or more)
+for end in cands:
+    start = end
+    while start > 0 and int(rows[start]["Start_Timestamp"]) - int(rows[start - 1]["End_Timestamp"]) < 8000:
+        start -= 1
+    if end - start + 1 >= 5:
+        break
 t0 = int(rows[start]["Start_Timestamp"])
 prev_end = t0
 total = 0
