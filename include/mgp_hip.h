@@ -460,6 +460,14 @@ int mgp_lanczos_block_size(int m, const mgp_lanczos_params_t* p);
 int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs,
                             float* resid, int32_t* info, float* block_evals, float* block_evecs, float* block_resid,
                             void* work, size_t work_bytes, void* stream);
+/* Warm start (round 5).  The reference re-runs the whole eigendecomposition on every eval() (riemann_kernel.py:117-130); while
+ * the graph bandwidth moves a little per training step the previous Rayleigh-Ritz block is already close.  warm_block [n, b]
+ * (device: the block_evecs of an earlier call on the SAME sparsity pattern and row order) replaces the random start, warm_evals
+ * [b] (host: its block_evals) set the first round's filter, so that the first round is already a full-strength one.  Same
+ * outputs, return values and tolerances as mgp_lanczos_smallest_ex. */
+int mgp_lanczos_smallest_warm(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs, float* resid,
+                              int32_t* info, float* block_evals, float* block_evecs, float* block_resid, const float* warm_block,
+                              const float* warm_evals, void* work, size_t work_bytes, void* stream);
 /* Upper end of the eigensolver's Chebyshev filter: 1 (default) = lambda_max estimated from a 32-dimensional Krylov space
  * (+ 3 % or more), checked against the Ritz values of every round, with the Gershgorin bound as the fallback; 0 = the
  * Gershgorin bound (rigorous; about twice lambda_max on k-NN graph Laplacians, i.e. ~40 % more filter applies).  The residual

@@ -164,6 +164,9 @@ SIGNATURES = {
     "mgp_lanczos_smallest_ex": (c_int, [POINTER(CsrT), c_int, POINTER(LanczosParamsT), POINTER(c_float), _P,
                                         POINTER(c_float), POINTER(c_int32), POINTER(c_float), _P, POINTER(c_float), _P,
                                         c_size_t, _P]),
+    "mgp_lanczos_smallest_warm": (c_int, [POINTER(CsrT), c_int, POINTER(LanczosParamsT), POINTER(c_float), _P,
+                                          POINTER(c_float), POINTER(c_int32), POINTER(c_float), _P, POINTER(c_float), _P,
+                                          POINTER(c_float), _P, c_size_t, _P]),
     "mgp_lanczos_tridiag_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int]),
     "mgp_lanczos_tridiag": (c_int, [POINTER(OperatorT), _P, c_int, POINTER(c_float), POINTER(c_float), _P, _P,
                                     c_size_t, _P]),

@@ -773,9 +773,34 @@ extern "C" int mgp_lanczos_smallest(const mgp_csr_t* L, int m, const mgp_lanczos
   return mgp_lanczos_smallest_ex(L, m, p, evals, evecs, resid, info, nullptr, nullptr, nullptr, work, work_bytes, stream);
 }
 
+static int lanczos_smallest_impl(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs, float* resid,
+                                 int32_t* info, float* block_evals, float* block_evecs, float* block_resid, const float* warm_block,
+                                 const float* warm_evals, void* work, size_t work_bytes, void* stream);
+
 extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals,
                                        float* evecs, float* resid, int32_t* info, float* block_evals, float* block_evecs,
                                        float* block_resid, void* work, size_t work_bytes, void* stream) {
+  return lanczos_smallest_impl(L, m, p, evals, evecs, resid, info, block_evals, block_evecs, block_resid, nullptr, nullptr, work,
+                               work_bytes, stream);
+}
+
+// Warm start (round 5): the reference re-runs the whole eigendecomposition on every eval() (riemann_kernel.py:117-130); while the
+// hyper-parameters move a little per step the previous Rayleigh-Ritz block is already close.  warm_block [n, b] (device, the
+// block_evecs of an earlier call on the SAME sparsity pattern and row order, b = mgp_lanczos_block_size) replaces the random
+// start, warm_evals [b] (host, its Ritz values, ascending) set the first round's filter: damping interval from the block's
+// largest Ritz value, degree from the gap behind mode m -- i.e. the first round is already a full-strength round.
+extern "C" int mgp_lanczos_smallest_warm(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs,
+                                         float* resid, int32_t* info, float* block_evals, float* block_evecs, float* block_resid,
+                                         const float* warm_block, const float* warm_evals, void* work, size_t work_bytes,
+                                         void* stream) {
+  if (!warm_block || !warm_evals) return MGP_ERR_ARG;
+  return lanczos_smallest_impl(L, m, p, evals, evecs, resid, info, block_evals, block_evecs, block_resid, warm_block, warm_evals, work,
+                               work_bytes, stream);
+}
+
+static int lanczos_smallest_impl(const mgp_csr_t* L, int m, const mgp_lanczos_params_t* p, float* evals, float* evecs, float* resid,
+                                 int32_t* info, float* block_evals, float* block_evecs, float* block_resid, const float* warm_block,
+                                 const float* warm_evals, void* work, size_t work_bytes, void* stream) {
   if (!L || !L->rowptr || !L->col || !L->vals || !L->diag || !evals || !evecs || !work) return MGP_ERR_ARG;
   const int64_t n = L->n;
   if (n <= 0 || m <= 0 || m > n) return MGP_ERR_ARG;
@@ -785,7 +810,9 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   if (work_bytes < eig_bytes(n, m, p)) return MGP_ERR_WORKSPACE;
   hipStream_t st = mgp_stream(stream);
   const float tol = (p && p->tol > 0.f) ? p->tol : 1e-5f;
-  const int max_outer = (p && p->max_restarts > 0) ? p->max_restarts : 40;
+  // a warm start that has not converged within four rounds was not close enough (the matrix moved too far, or the wanted block
+  // sits in a cluster that no start resolves): the solve is then repeated from a cold start, with its own floor exits
+  const int max_outer = warm_block ? 4 : ((p && p->max_restarts > 0) ? p->max_restarts : 40);
   const uint64_t seed = p ? p->seed : 1337;
 
   EigWork w;
@@ -870,8 +897,12 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   }
 
   const int rgrid = (int)std::min<int64_t>(4096, mgp_cdiv(n * b, kBlock));
-  hipLaunchKernelGGL(random_cols_kernel, dim3(rgrid), dim3(kBlock), 0, st, w.buf[0], n, b, 0, b, seed);
-  MGP_LAUNCH_CHECK();
+  if (warm_block) {
+    MGP_HIP_TRY(hipMemcpyAsync(w.buf[0], warm_block, (size_t)n * b * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    hipLaunchKernelGGL(random_cols_kernel, dim3(rgrid), dim3(kBlock), 0, st, w.buf[0], n, b, 0, b, seed);
+    MGP_LAUNCH_CHECK();
+  }
 
   // Buffers: bV / bLV hold the current block V and L V (full width b); three more serve the filter.
   // Soft locking: the leading run of converged Ritz vectors (a multiple of 4 columns) is no longer filtered --
@@ -887,6 +918,18 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   double a = ubf / 4.0, a0 = 0.0;
   double top_prev = 1e300;      // largest Ritz value of the previous round's block (they only come down)
   int deg = (p && p->degree > 0) ? p->degree : 10;
+  if (warm_block && warm_evals && b > m) {
+    // the warm block's own Ritz values stand in for a first Rayleigh-Ritz round (a little margin on the interval's lower end: the
+    // matrix has moved since they were computed)
+    const double top = (double)warm_evals[b - 1], thm = (double)warm_evals[m - 1];
+    if (std::isfinite(top) && top > 0.0 && top < ubf && std::isfinite(thm) && thm < top) {
+      a = std::min(0.5 * (top + ubf), 1.02 * top);
+      a0 = std::min((double)warm_evals[0], 0.0);
+      const double gap = std::max(a - thm, 1e-12 * ub);
+      const int dnew = (int)ceil(3.0 / (2.0 * sqrt(gap / (ubf - a))));
+      if (!(p && p->degree > 0)) deg = std::min(std::max(dnew, 8), kCap);
+    }
+  }
   HostPool pool(host_pool_workers());      // lives for this call: joined on every return path
   std::vector<double> G((size_t)b * b), H((size_t)b * b), th, S, lam, U;
   std::vector<float> wt((size_t)b * b), thf(b);
@@ -1136,6 +1179,12 @@ extern "C" int mgp_lanczos_smallest_ex(const mgp_csr_t* L, int m, const mgp_lanc
   for (int j = 0; j < b; ++j) {
     if (block_evals) block_evals[j] = j < kept ? (float)th[j] : 0.f;
     if (block_resid) block_resid[j] = (float)res[j];
+  }
+  if (warm_block && nconv != m) {
+    const int rc = lanczos_smallest_impl(L, m, p, evals, evecs, resid, info, block_evals, block_evecs, block_resid, nullptr, nullptr, work,
+                                         work_bytes, stream);
+    if (info) { info[0] += outer; info[1] += nspmm; }       // rounds / block products of the abandoned warm attempt included
+    return rc;
   }
   if (info) { info[0] = outer; info[1] = nspmm; info[2] = nconv; info[3] = b; }
   if (nconv == m) return MGP_OK;

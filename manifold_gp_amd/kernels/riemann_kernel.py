@@ -70,6 +70,7 @@ class RiemannKernel(Kernel):
         # fp32 cannot reach it the solver stops at its residual floor (include/mgp_hip.h)
         self.eigen_tol = 1e-6
         self.keep_eigen_block = False     # True: eval() keeps the solver's whole Rayleigh-Ritz block (guard columns) in .eigen_block
+        self.warm_start = True            # eval() starts from the previous eval()'s block while the graph is the same object
 
         if graphbandwidth_constraint is None:
             graphbandwidth_constraint = Positive()
@@ -142,7 +143,16 @@ class RiemannKernel(Kernel):
             data = self.laplacian_operator.data
             n = self.laplacian_operator.operator_dimension
             m = min(self.num_modes, n)
-            out = lanczos_smallest(data, m, tol=self.eigen_tol, return_block=self.keep_eigen_block)
+            # warm start (round 5): the reference recomputes the whole decomposition on every eval() (:117-130); with the graph
+            # unchanged and the bandwidth moved a little, the previous Rayleigh-Ritz block is a far better start than a random one
+            gid = id(self.knn.knn_graph)
+            warm = getattr(self, "_eigen_warm", None)
+            warm = warm[1] if (self.warm_start and warm is not None and warm[0] == (gid, m)) else None
+            out = lanczos_smallest(data, m, tol=self.eigen_tol, return_block=self.keep_eigen_block, warm=warm, keep_warm=self.warm_start)
+            self.eigen_info = list(lanczos_smallest.last_info)
+            # (a block that ended at the fp32 residual floor -- fewer than m pairs under the tolerance: the wanted modes sit in a
+            # cluster -- is no better a start than a random one and keeps the solver from its floor exits: not kept)
+            self._eigen_warm = ((gid, m), lanczos_smallest.last_warm) if (self.warm_start and self.eigen_info[2] >= m) else None
             evals, evecs, resid = out[:3]
             self.eigen_block = out[3] if self.keep_eigen_block else None
             self.eigen_residuals = resid

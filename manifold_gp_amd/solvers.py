@@ -441,11 +441,14 @@ class EigenFloorWarning(UserWarning):
     """mgp_lanczos_smallest returned MGP_OK with info[2] < m (residual floor / unseparable guards)."""
 
 
-def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=60, seed=1337, return_block=False):
+def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=60, seed=1337, return_block=False, warm=None,
+                     keep_warm=False):
     """m smallest eigenpairs of L_sym (CSR in `lap_data`) by the HIP filtered block iteration.
     Returns (evals[m] device, evecs[n,m] device, resid[m] host list); with return_block=True a fourth item
     dict(evals [b] device, evecs [n, b] device, resid [b] list): the whole Rayleigh-Ritz block the solver ended with,
-    guard columns included (what the independent float64 check of the spectral stage starts from)."""
+    guard columns included (what the independent float64 check of the spectral stage starts from).
+    warm: the `lanczos_smallest.last_warm` of an earlier call on the same graph (same sparsity pattern, same m): the solve starts
+    from that block instead of a random one (mgp_lanczos_smallest_warm).  keep_warm=True leaves this call's block there."""
     g = lap_data.graph
     dev = g.device
     check(lib().mgp_spmm_set_group_hint(g.spmv_lanes), "mgp_spmm_set_group_hint")
@@ -467,13 +470,24 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
     resid = (ctypes.c_float * m)()
     info = (ctypes.c_int32 * 4)()
     evecs = torch.empty(g.n, m, dtype=torch.float32, device=dev)
-    b = int(lib().mgp_lanczos_block_size(int(m), ctypes.byref(prm))) if return_block else 0
+    b = int(lib().mgp_lanczos_block_size(int(m), ctypes.byref(prm))) if (return_block or keep_warm or warm is not None) else 0
     b = min(b, g.n)
     bev = (ctypes.c_float * b)() if b else None
     bres = (ctypes.c_float * b)() if b else None
     bvec = torch.empty(g.n, b, dtype=torch.float32, device=dev) if b else None
-    rc = lib().mgp_lanczos_smallest_ex(ctypes.byref(csr), int(m), ctypes.byref(prm), evals, ptr(evecs), resid, info,
-                                       bev, ptr(bvec) if b else None, bres, ptr(work), work.numel(), stream())
+    if warm is not None and (warm["block"].shape != (g.n, b) or warm["m"] != int(m) or warm["ordered"] != (order is not None)):
+        warm = None                                          # another shape / another row order: cold start
+    if warm is not None:
+        wev = (ctypes.c_float * b)(*warm["evals"])
+        rc = lib().mgp_lanczos_smallest_warm(ctypes.byref(csr), int(m), ctypes.byref(prm), evals, ptr(evecs), resid, info,
+                                             bev, ptr(bvec), bres, ptr(warm["block"]), wev, ptr(work), work.numel(), stream())
+    else:
+        rc = lib().mgp_lanczos_smallest_ex(ctypes.byref(csr), int(m), ctypes.byref(prm), evals, ptr(evecs), resid, info,
+                                           bev, ptr(bvec) if b else None, bres, ptr(work), work.numel(), stream())
+    if keep_warm and b:
+        # (in the SOLVER's row order -- the relabelled one when the graph has a locality order --: what the next call hands back)
+        lanczos_smallest.last_warm = dict(block=bvec.clone() if order is not None and return_block else bvec, evals=list(bev), m=int(m),
+                                          ordered=order is not None)
     if rc == -4:      # MGP_ERR_NOT_CONVERGED: the best block is returned, residuals say how good it is
         warnings.warn("eigensolver stopped after %d rounds with %d/%d pairs below tol (max residual %.3g)"
                       % (info[0], info[2], m, max(resid)))

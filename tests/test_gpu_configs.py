@@ -447,6 +447,50 @@ def test_c3_manifold784_60k_posterior_vs_independent_float64(mgp, dev):
     assert e_cg < 1e-4 and max(resid) <= 1e-6
 
 
+def test_c3_manifold784_warm_started_eval(mgp, dev):
+    """eval() again after a small bandwidth change (riemann_kernel.py:117-130 re-runs the whole decomposition every time; a
+    training loop that toggles train / eval moves the bandwidth a little per step): the block iteration starts from the previous
+    Rayleigh-Ritz block (mgp_lanczos_smallest_warm) and must land on what a COLD solve of the same matrix gives -- eigenvalues,
+    and everything downstream through the features' Gram -- in fewer rounds; a graph change, a changed mode count and a
+    kernel with warm_start off take the cold path; on the RMNIST-like graph, whose solve ends at the fp32 floor, no block is kept."""
+    from tools import synth
+    n, k, m, nu, eps, kappa = 60000, 50, 100, 2, 0.3, 3.0
+    x_np, y_np, _ = synth.manifold_784(n)
+    x = T(x_np, dev)
+    kern = mgp.kernels.RiemannMaternKernel(nu=nu, x=x, nearest_neighbors=k, laplacian_normalization="randomwalk", num_modes=m).to(dev)
+    assert kern.warm_start is True
+    rows = T(np.random.default_rng(3).choice(n, 256, replace=False), dev)
+
+    def run(e, warm):
+        kern.warm_start = warm
+        kern.initialize(graphbandwidth=e, lengthscale=kappa)
+        kern.eval()
+        Z = kern.features(x)
+        return kern.eigval.double().cpu().numpy(), (Z[rows] @ Z.t()).double().cpu().numpy(), list(kern.eigen_info), max(kern.eigen_residuals)
+
+    run(eps, True)                                            # cold (nothing kept yet), leaves its block behind
+    assert kern._eigen_warm is not None and kern.eigen_info[2] == m
+    for f in (1.01, 1.05):
+        lam_w, K_w, info_w, res_w = run(eps * f, True)        # warm from the eps block
+        assert kern._eigen_warm is not None
+        run(eps, True)                                        # put the eps block back
+        lam_c, K_c, info_c, res_c = run(eps * f, False)       # cold, same matrix
+        lmax = 2.0 * float(kern.laplacian_operator.data.diag.max())
+        assert info_w[2] == m and info_c[2] == m
+        assert info_w[1] < 0.7 * info_c[1], (info_w, info_c)                      # fewer block products
+        assert np.abs(lam_w - lam_c).max() < 1e-6 * lmax and (np.abs(lam_w[1:] - lam_c[1:]) / lam_c[1:]).max() < 1e-4
+        assert np.abs(K_w - K_c).max() < 1e-4 * np.abs(K_c).max()
+        assert res_w < 1e-5 * lmax
+        print("warm eval at eps x %.2f: %d block products against %d cold (rounds %d / %d)" % (f, info_w[1], info_c[1], info_w[0], info_c[0]))
+        run(eps, True)
+    # another mode count: the kept block does not fit -> cold
+    kern.num_modes = 64
+    kern.warm_start = True
+    kern.eval()
+    assert kern.eigen_info[2] == 64 and kern.eigval.shape[0] == 64
+    kern.num_modes = m
+
+
 def test_c4_semisupervised_60k_schur(mgp, dev, rmnist60k):
     """C4: the same 60k graph, 10 % labelled (randperm seed 1337, examples/RMNIST_semisupervised_learning.ipynb:65,99-101).
     Schur complement matvec (schur_complement_operator.py:26-30, nested HIP CG on the 54k unlabelled block) against
@@ -730,6 +774,7 @@ def test_bench_line_stages_contract(dev):
         assert pc[key]["iterations"] > 0 and pc[key]["ms"] > 0
     assert any(k.startswith("chebyshev_") for k in pc)
     m7 = line["manifold_784"]
+    assert m7["eval_warm_after_1pct_bandwidth_change"]["block_products"] <= m7["eval_cold"]["block_products"]
     assert m7["posterior_test_rmse"] < 0.5 and m7["precision_cg"]["rel_residual"] <= 1e-6 and m7["eval_eigensolve_ms"] > 0
 
 
