@@ -29,6 +29,13 @@ def bfs_order(n, rowptr, col):
     return order
 
 
+def chain_order(n, rowptr, col, d2):
+    """Nearest-neighbour chain order of the graph (mgp_graph_chain_order: a host walk over a copy of the CSR): int32 [n] permutation."""
+    order = torch.empty(n, dtype=torch.int32, device=col.device)
+    check(lib().mgp_graph_chain_order(n, ptr(rowptr), ptr(col), ptr(d2), ptr(order), stream()), "mgp_graph_chain_order")
+    return order
+
+
 def build_tiles(n, rowptr, col, nnz, tile_rows=None, order=None):
     """Row-tile column dictionaries for the C == 1 SpMV (mgp_graph_tiles).  Returns the dict that
     _lib.csr_struct takes, or None when the graph has no entries / a tile does not fit the LDS budget.
@@ -62,6 +69,10 @@ def build_tiles(n, rowptr, col, nnz, tile_rows=None, order=None):
     return None
 
 
+WIDE_CHAIN = [True]         # wide products on the chain-relabelled matrix where it pays (KnnGraph.wide_relabelled)
+WIDE_CHAIN_MIN_NODES = 4096
+WIDE_CHAIN_MAX_NODES = 400000
+WIDE_CHAIN_GAIN = 1.25
 MT_MIN_NODES = 4096         # below this a wide SpMM is a few microseconds whatever the kernel
 MT_MIN_FILL = 0.125         # non-zero share of the dense tiles below which the gather kernels are taken instead
 MT_ENABLED = [True]
@@ -179,6 +190,31 @@ class KnnGraph:
             self._relabelled = RelabelledGraph(self)
         return self._relabelled
 
+    def wide_relabelled(self):
+        """RelabelledGraph over the nearest-neighbour CHAIN order, for the wide products only (the eigensolver's blocks, the
+        100-column solves: csrc/spmm.hip spmm_mt_kernel, whose work is proportional to the distinct columns of a 16-row tile),
+        or None when it does not pay.  Tried for graphs in natural row order without low-dimensional coordinates (those get
+        the Z-curve), between WIDE_CHAIN_MIN_NODES and WIDE_CHAIN_MAX_NODES nodes (the walk is sequential, on the host); kept
+        when the dense 16-row tiles shrink by WIDE_CHAIN_GAIN or more.  The C = 1 / small-C paths keep the caller's order (a
+        relabelled solve permutes its right-hand side in and its solution out: two launches that a 55 us solve cannot afford,
+        a 3 ms one can).  Cached."""
+        if not hasattr(self, "_wide_relabelled"):
+            self._wide_relabelled = None
+            ordered = self.tiles is not None and self.tiles.get("rowid") is not None
+            if (WIDE_CHAIN[0] and not ordered and self.col.is_cuda and self.nnz > 0 and
+                    WIDE_CHAIN_MIN_NODES <= self.n <= WIDE_CHAIN_MAX_NODES):
+                base = MtPlan.structure(self)
+                order = chain_order(self.n, self.rowptr, self.col, self.d2)
+                t64 = build_tiles(self.n, self.rowptr, self.col, self.nnz, tile_rows=TILE_ROWS, order=order)
+                if t64 is not None:
+                    rg = RelabelledGraph(self, tiles=t64)
+                    rg.d2 = None
+                    st = MtPlan.structure(rg)
+                    if st is not None and (base is None or st["steps"] * WIDE_CHAIN_GAIN <= base["steps"]):
+                        rg.emap = t64["emap"]
+                        self._wide_relabelled = rg
+        return self._wide_relabelled
+
     @property
     def edge_index(self):
         """idx[2, M] int64, row<col, sorted -- what NearestNeighbors.graph returns."""
@@ -253,8 +289,8 @@ class RelabelledGraph:
     VECTORS of an iteration can live in this order too and every kernel (tile SpMV, vector updates, dictionaries) streams
     instead of gathering / scattering through `rowid` at 4-byte granularity.  Built once per graph, on demand."""
 
-    def __init__(self, g):
-        t = g.tiles
+    def __init__(self, g, tiles=None):
+        t = g.tiles if tiles is None else tiles         # (tiles: an ordered 64-row tile view of g over another order, see wide_relabelled)
         dev = g.device
         self.n, self.nnz, self.M, self.spmv_lanes = g.n, g.nnz, g.M, g.spmv_lanes
         self.device = dev
@@ -281,13 +317,16 @@ class RelabelledData:
     """LaplacianData of the relabelled graph (same eps): values = the tile-order copy the data already holds, node vectors
     permuted once.  Quacks like LaplacianData for Descriptor / the solvers."""
 
-    def __init__(self, data):
-        rg = data.graph.relabelled()
+    def __init__(self, data, rg=None):
+        """rg: None = the graph's own locality order (its tile view); else a RelabelledGraph over another order of the same graph
+        (KnnGraph.wide_relabelled: rg.emap maps its entries to the caller-order CSR's)."""
+        own = rg is None
+        rg = data.graph.relabelled() if own else rg
         self.graph = rg
         self.uid = LaplacianData._next_uid[0]
         LaplacianData._next_uid[0] += 1
         self.eps, self.self_loops = data.eps, data.self_loops
-        self.vals = data.vals_t
+        self.vals = data.vals_t if own else data.vals.index_select(0, rg.emap)
         for name in ("degree_unnorm", "degree", "diag", "dsqrt", "dinvsqrt"):
             setattr(self, name, rg.permute(getattr(data, name)).contiguous())
         self.vals_t = None
@@ -414,6 +453,14 @@ class LaplacianData:
         if getattr(self, "_relabelled", None) is None:
             self._relabelled = RelabelledData(self)
         return self._relabelled
+
+    def wide_relabelled(self):
+        """RelabelledData over the graph's chain order for the wide products (KnnGraph.wide_relabelled), else the graph's own
+        relabelled data (locality-ordered tiles), else None."""
+        if getattr(self, "_wide_rel", False) is False:
+            rg = self.graph.wide_relabelled() if hasattr(self.graph, "wide_relabelled") else None
+            self._wide_rel = RelabelledData(self, rg) if rg is not None else None
+        return self._wide_rel if self._wide_rel is not None else self.relabelled()
 
     def edge_values(self, which):
         """0: W (adjacency_unnorm_mat), 1: A (adjacency_mat), 2: S (laplacian_triu) in COO order."""

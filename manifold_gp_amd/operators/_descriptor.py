@@ -38,10 +38,12 @@ class Descriptor:
             post = row_mask if post is None else post * row_mask
         return replace(self, pre=pre, post=post)
 
-    def relabelled(self):
+    def relabelled(self, wide=False):
         """(descriptor of P A P^T, RelabelledGraph) when the graph's tiles follow a locality order -- the form the iterative
-        solvers run on: same operator on permuted vectors -- else (None, None)."""
-        rel = getattr(self.data, "relabelled", lambda: None)()
+        solvers run on: same operator on permuted vectors -- else (None, None).  wide: for products of 48 columns and more, the
+        chain-relabelled matrix where the graph has one (graph.LaplacianData.wide_relabelled)."""
+        name = "wide_relabelled" if wide else "relabelled"
+        rel = getattr(self.data, name, getattr(self.data, "relabelled", lambda: None))()
         if rel is None:
             return None, None
         return replace(self, data=rel, pre=rel.permuted(self.pre), post=rel.permuted(self.post)), rel.graph
@@ -66,6 +68,13 @@ class Descriptor:
         _lib.require_device(X)
         squeeze = X.dim() == 1
         X = _lib.f32c(X.unsqueeze(-1) if squeeze else X)
+        if X.shape[1] >= 48 and hasattr(self.data, "wide_relabelled"):
+            # 48 columns and more: the matrix-core tile SpMM, on the chain-relabelled matrix where the graph has one (half the tile
+            # image and the work, graph.KnnGraph.wide_relabelled): rows permuted in and out around the product
+            rg = self.data.graph.wide_relabelled() if hasattr(self.data.graph, "wide_relabelled") else None
+            if rg is not None:
+                rdesc, rg = self.relabelled(wide=True)
+                return rg.unpermute(rdesc.apply(rg.permute(X)))
         op = self.struct(wide=X.shape[1] >= 48)
         out = torch.empty_like(X)
         C = X.shape[1]

@@ -32,7 +32,8 @@ class CgPlan:
         # (graph_laplacian_operator.py:108-124).  RELABEL_SOLVES[0] = False: iterate in the caller's order (A/B, tests).
         self._rg = None
         if RELABEL_SOLVES[0]:
-            rdesc, rg = desc.relabelled()
+            # 48 columns and more run on the matrix-core tile SpMM: there the chain-relabelled matrix where it pays (round 5)
+            rdesc, rg = desc.relabelled(wide=int(C) >= 48)
             if rdesc is not None:
                 desc, self._rg = rdesc, rg
         self._xout = None
@@ -457,7 +458,9 @@ def lanczos_smallest(lap_data, m, tol=1e-5, max_basis=0, degree=0, max_restarts=
     # block of n x b floats (HBM-bound, 4.3 ms per 84-column SpMM at N = 1M); on the SAME matrix relabelled
     # by that order (P L P^T: same spectrum, eigenvectors permuted back below) they sit in cache.
     order = None
-    rel = getattr(lap_data, "relabelled", lambda: None)()      # graph.RelabelledData: built once per graph / bandwidth
+    # (round 5: for the block products the matrix relabelled by the graph's nearest-neighbour CHAIN order where that shrinks the
+    # dense 16-row tiles -- graph.KnnGraph.wide_relabelled --, else the graph's own locality order)
+    rel = getattr(lap_data, "wide_relabelled", getattr(lap_data, "relabelled", lambda: None))()
     if rel is not None:
         order = rel.graph.order
         csr = rel.csr(wide=True)

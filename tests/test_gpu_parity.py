@@ -2824,3 +2824,75 @@ def test_pcg_stagnation_guard_and_refinement_on_an_ill_conditioned_system(mgp, g
         assert true1 <= 3e-3 and abs(true1 - plan.resid) < 1e-3, (chunk, true1, plan.resid)
         assert float((x - xs).abs().max()) < 2e-2 * float(xs.abs().max())
         plan.close()
+
+
+def test_chain_order_and_wide_relabelling(mgp, dev):
+    """mgp_graph_chain_order (nearest-neighbour chain: a locality order for k-NN graphs whose given order keeps clusters together
+    but not the order inside them) and what the wide products do with it: a permutation, deterministic, consecutive positions
+    are graph neighbours for most of the chain; on an RMNIST-like graph (rotation orbits in random angle order) the dense 16-row
+    tiles of the relabelled matrix need well under the steps of the given order, graph.KnnGraph.wide_relabelled keeps it, and the
+    products / solves / eigenpairs computed on the relabelled matrix are those of the caller's order (float64 reference, rows
+    permuted in and out); a graph that gains nothing (already chain-like) keeps its own order."""
+    import ctypes
+    from manifold_gp_amd import _lib
+    from manifold_gp_amd.graph import LaplacianData, MtPlan, chain_order
+    from manifold_gp_amd.solvers import cg_solve, lanczos_smallest
+    from tools import synth
+    x, y = synth.rmnist_like(80, 100, seed=7, device=dev)
+    n = x.shape[0]
+    knn = mgp.utils.NearestNeighbors(x)
+    idx, val = knn.graph(30)
+    g = knn.knn_graph
+    o1 = chain_order(g.n, g.rowptr, g.col, g.d2).cpu().numpy()
+    o2 = chain_order(g.n, g.rowptr, g.col, g.d2).cpu().numpy()
+    assert np.array_equal(o1, o2) and np.array_equal(np.sort(o1), np.arange(n)) and o1[0] == 0
+    rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    adj = [set(col[rowptr[i]:rowptr[i + 1]].tolist()) - {i} for i in range(n)]
+    linked = sum(1 for a, b in zip(o1[:-1], o1[1:]) if b in adj[a])
+    assert linked > 0.9 * (n - 1), linked
+    rg = g.wide_relabelled()
+    assert rg is not None and np.array_equal(rg.order.cpu().numpy(), o1)
+    base, st = MtPlan.structure(g), MtPlan.structure(rg)
+    assert st["steps"] * 1.5 < base["steps"], (st["steps"], base["steps"])
+    data = LaplacianData(g, 0.3, True)
+    rel = data.wide_relabelled()
+    assert rel is not None and rel.graph is rg and data.relabelled() is None
+    # a wide product: caller-order Descriptor.apply (through the relabelled matrix) against float64 on the caller-order CSR
+    lap = mgp.operators.GraphLaplacianOperator(val, idx, n, torch.tensor([[0.3]], device=dev), "randomwalk", graph=g)
+    Q = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[1.5]], device=dev))
+    desc = Q._descriptor()
+    X = torch.randn(n, 64, device=dev)
+    Y = desc.apply(X).double().cpu().numpy()
+    vals = lap.data.vals.double().cpu().numpy()
+    rows = np.repeat(np.arange(n), np.diff(rowptr))
+    dsq, diag = lap.data.dsqrt.double().cpu().numpy(), lap.data.diag.double().cpu().numpy()
+    tau = 2.0 * 2 / 1.5 ** 2
+
+    def B(V):
+        S = np.zeros_like(V)
+        np.add.at(S, rows, vals[:, None] * V[col])
+        return tau * V + diag[:, None] * V - S
+    ref = dsq[:, None] * B(B(dsq[:, None] * X.double().cpu().numpy()))
+    assert np.abs(Y - ref).max() < 2e-5 * np.abs(ref).max()
+    csr = rel.csr(wide=True)
+    assert _lib.lib().mgp_spmm_kernel_choice(ctypes.byref(csr), 64, 0, 0) == 3
+    # a 64-column solve and the eigenpairs: relabelled under the hood, caller order at the surface
+    Bm = torch.randn(n, 64, device=dev)
+    Xs, its, res = cg_solve(desc, Bm, tol=1e-5, stop_mode=1, max_iter=4000)
+    assert float(((desc.apply(Xs) - Bm).norm(dim=0) / Bm.norm(dim=0)).max()) < 1e-4
+    ev, V, resid = lanczos_smallest(lap.data, 40, tol=1e-5)
+    LV = lap.data  # residual in the caller's order: L_sym V - V diag(ev) with the fused SpMM on the caller-order CSR
+    c0 = lap.data.csr()
+    out = torch.empty_like(V)
+    _lib.check(_lib.lib().mgp_spmm_fused(ctypes.byref(c0), _lib.ptr(V.contiguous()), 40, _lib.ptr(out), 0.0, 1.0, None, None, None, 0.0, 1.0,
+                                         None, None, _lib.stream()), "mgp_spmm_fused")
+    r = (out - V * ev.view(1, -1)).norm(dim=0)
+    lmax = 2.0 * float(lap.data.diag.max())
+    assert float(r.max()) < 5e-5 * lmax and float((V.t() @ V - torch.eye(40, device=dev)).abs().max()) < 1e-3
+    # an already chain-like graph (points on a curve in their own order): nothing to gain, the given order stays
+    t = torch.linspace(0, 60, 8000, device=dev)
+    xc = torch.stack([torch.cos(t) * (1 + 0.05 * t), torch.sin(t) * (1 + 0.05 * t), 0.1 * t, torch.zeros_like(t)], 1)
+    xc = torch.cat([xc, torch.zeros(8000, 28, device=dev)], 1).contiguous()       # d = 32: no Z-curve, natural order
+    k2 = mgp.utils.NearestNeighbors(xc)
+    k2.graph(16)
+    assert k2.knn_graph.wide_relabelled() is None

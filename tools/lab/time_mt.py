@@ -11,7 +11,7 @@ dev = torch.device("cuda:0")
 wl = bench.build_workload(argparse.Namespace(workload=sys.argv[1] if len(sys.argv) > 1 else "c3", nodes=0, s5_order="morton"), dev, 0, 1)
 g, lap = wl["graph"], wl["lap"]
 lib = _lib.lib(); lib.mgp_spmm_set_group_hint(g.spmv_lanes)
-data = lap.data.relabelled() or lap.data
+data = (lap.data.relabelled() if os.environ.get("MGP_NO_CHAIN") else lap.data.wide_relabelled()) or lap.data
 torch.cuda.synchronize(); t0 = time.perf_counter()
 plan = data.mt_plan()
 torch.cuda.synchronize()
