@@ -193,17 +193,18 @@ class KnnGraph:
     def wide_relabelled(self):
         """RelabelledGraph over the nearest-neighbour CHAIN order, for the wide products only (the eigensolver's blocks, the
         100-column solves: csrc/spmm.hip spmm_mt_kernel, whose work is proportional to the distinct columns of a 16-row tile),
-        or None when it does not pay.  Tried for graphs in natural row order without low-dimensional coordinates (those get
-        the Z-curve), between WIDE_CHAIN_MIN_NODES and WIDE_CHAIN_MAX_NODES nodes (the walk is sequential, on the host); kept
-        when the dense 16-row tiles shrink by WIDE_CHAIN_GAIN or more.  The C = 1 / small-C paths keep the caller's order (a
+        or None when it does not pay.  Tried between WIDE_CHAIN_MIN_NODES and WIDE_CHAIN_MAX_NODES nodes (the walk is sequential,
+        on the host); kept when the dense 16-row tiles shrink by WIDE_CHAIN_GAIN or more against what the wide products would
+        run on otherwise (the given order, or the graph's own breadth-first / Z-curve locality order).  The C = 1 / small-C paths keep the caller's order (a
         relabelled solve permutes its right-hand side in and its solution out: two launches that a 55 us solve cannot afford,
         a 3 ms one can).  Cached."""
         if not hasattr(self, "_wide_relabelled"):
             self._wide_relabelled = None
-            ordered = self.tiles is not None and self.tiles.get("rowid") is not None
-            if (WIDE_CHAIN[0] and not ordered and self.col.is_cuda and self.nnz > 0 and
-                    WIDE_CHAIN_MIN_NODES <= self.n <= WIDE_CHAIN_MAX_NODES):
-                base = MtPlan.structure(self)
+            ordered = self.has_locality_order()
+            if (WIDE_CHAIN[0] and self.col.is_cuda and self.nnz > 0 and WIDE_CHAIN_MIN_NODES <= self.n <= WIDE_CHAIN_MAX_NODES):
+                # what the wide products would run on otherwise: the graph as given, or relabelled by its own locality order
+                # (breadth-first / Z-curve: graph.build_tiles_auto)
+                base = MtPlan.structure(self.relabelled() if ordered else self)
                 order = chain_order(self.n, self.rowptr, self.col, self.d2)
                 t64 = build_tiles(self.n, self.rowptr, self.col, self.nnz, tile_rows=TILE_ROWS, order=order)
                 if t64 is not None:
