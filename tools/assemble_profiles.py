@@ -35,15 +35,19 @@ def parse(fn):
 
 
 mt, ga = parse(os.path.join(src, tag + "_pmc_spmm_mt_raw.txt")), parse(os.path.join(src, tag + "_pmc_spmm_gather_raw.txt"))
+given = parse(os.path.join(src, tag + "_pmc_spmm_mt_given_raw.txt")) if os.path.exists(os.path.join(src, tag + "_pmc_spmm_mt_given_raw.txt")) else {}
 wide = os.path.join(out, tag + "_pmc_spmm_wide.txt")
 lines = ["# rocprofv3 --pmc passes (tools/pmc_kernel.sh, one counter group per pass) over tools/lab/spmm_one.py, per launch, C = 128 on the 60k C3 graph.",
          "# _sum counters add all CUs / channels; GRBM_GUI_ACTIVE adds the 8 XCDs (cycles of the launch = value / 8); TCP accesses are 64-byte units;",
          "# TCC requests / misses are 128-byte units; SQ_* cycle counters are in units of 4 clocks.",
          "# matrix-core tile kernel (spmm_mt_kernel<false>, `tools/pmc_kernel.sh mt spmm_mt tools/lab/spmm_one.py 128 2 0 0 0 1`) against the gather kernel",
          "# (`... gather128 'spmm_kernel<64' tools/lab/spmm_one.py 128 0 0 0 0 0`), same box, same recipe.  Reading: docs/kernels/spmm.md, round 5.",
-         "counter                                     matrix-core tiles           gather    ratio"]
+         "# first column: on the matrix relabelled by the graph's nearest-neighbour chain order (what the wide products run on since round 5);",
+         "# second: the same kernel on the matrix in the given order (MGP_NO_CHAIN=1); third: the gather kernel (given order).",
+         "counter                                  mt, chain order   mt, given order           gather   chain / gather"]
 for k in sorted(set(mt) & set(ga)):
-    lines.append("%-40s %18.1f %16.1f %8.2f" % (k, mt[k], ga[k], mt[k] / ga[k] if ga[k] else float("nan")))
+    lines.append("%-40s %16.1f %17s %16.1f %12.2f" % (k, mt[k], ("%.1f" % given[k]) if k in given else "-", ga[k],
+                                                     mt[k] / ga[k] if ga[k] else float("nan")))
 open(wide, "w").write("\n".join(lines) + "\n")
 
 kb = open(os.path.join(src, tag + "_pmc_kbres_raw.txt")).read()

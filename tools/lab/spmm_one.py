@@ -9,7 +9,8 @@ wl = bench.build_workload(argparse.Namespace(workload="c3", nodes=0, s5_order="m
 g, lap = wl["graph"], wl["lap"]
 lib = _lib.lib(); lib.mgp_spmm_set_group_hint(g.spmv_lanes)
 mt = int(sys.argv[6]) if len(sys.argv) > 6 else 0
-csr = (lap.data.relabelled() or lap.data).csr(wide=True) if mt else lap.data.csr()
+# (mt: what the wide products run on -- the chain-relabelled matrix where the graph has such an order; MGP_NO_CHAIN=1: the given order)
+csr = ((lap.data.relabelled() if os.environ.get("MGP_NO_CHAIN") else lap.data.wide_relabelled()) or lap.data).csr(wide=True) if mt else lap.data.csr()
 lib.mgp_spmm_set_mt_mode(mt)
 C = int(sys.argv[1]); lib.mgp_spmm_set_v4_mode(int(sys.argv[2])); lib.mgp_spmm_set_tile_wide_mode(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
 lib.mgp_spmm_set_dict_mode(int(sys.argv[4]) if len(sys.argv) > 4 else 0)

@@ -31,6 +31,7 @@ fi
 # matrix-pipe counters of the kernel block, cache counters of the wide SpMM (matrix-core tiles against the gather kernel)
 [ $fail = 0 ] && { bash tools/pmc_mfma.sh > "$out/${tag}_pmc_mfma_raw.txt" 2>&1 || fail=1; }
 [ $fail = 0 ] && { bash tools/pmc_kernel.sh mt spmm_mt tools/lab/spmm_one.py 128 2 0 0 0 1 > "$out/${tag}_pmc_spmm_mt_raw.txt" 2>&1 || fail=1; }
+[ $fail = 0 ] && { MGP_NO_CHAIN=1 bash tools/pmc_kernel.sh mtgiven spmm_mt tools/lab/spmm_one.py 128 2 0 0 0 1 > "$out/${tag}_pmc_spmm_mt_given_raw.txt" 2>&1 || fail=1; }
 [ $fail = 0 ] && { bash tools/pmc_kernel.sh gather128 'spmm_kernel<64' tools/lab/spmm_one.py 128 0 0 0 0 0 > "$out/${tag}_pmc_spmm_gather_raw.txt" 2>&1 || fail=1; }
 # the kernel block at the C3 posterior shape: matrix-pipe counters and kernel-trace durations, default kernel against the lean one
 [ $fail = 0 ] && { KNOBS="0 1" bash tools/lab/pmc_kbres.sh > "$out/${tag}_pmc_kbres_raw.txt" 2>&1 || fail=1; }
@@ -69,7 +70,7 @@ fi
 [ $fail = 0 ] && { bash tools/profile_training.sh "$tag" > "$out/${tag}_training_log.txt" 2>&1 || fail=1; }
 rm -rf gpurun_out/pmc_kbres gpurun_out/trace_kbres gpurun_out/prof_knn gpurun_out/pmc_knn gpurun_out/pmc_select gpurun_out/prof_s5cx
 # gpurun copies at most 64 MiB of gpurun_out/ back: keep the summaries, drop the raw traces
-rm -rf gpurun_out/prof_"${tag}" gpurun_out/prof_"${tag}"_s5 gpurun_out/prof_eig gpurun_out/pmc_mfma gpurun_out/pmc_mt gpurun_out/pmc_gather128
+rm -rf gpurun_out/prof_"${tag}" gpurun_out/prof_"${tag}"_s5 gpurun_out/prof_eig gpurun_out/pmc_mfma gpurun_out/pmc_mt gpurun_out/pmc_mtgiven gpurun_out/pmc_gather128
 ls -la "$out"
 tail -n 12 "$out/${tag}_pmc_mfma_raw.txt"
 exit $fail
