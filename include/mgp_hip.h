@@ -383,6 +383,11 @@ int mgp_cg_plan_is_complex_shift(void* plan);
  * ahead of the update) instead of in every workgroup of the update kernel.  Default 1; 0 = the every-workgroup
  * scheme at any C (A/B measurements, tests); affects plans created afterwards. */
 int mgp_cg_set_reduce_once(int on);
+/* Plans whose column count is a multiple of four (the 12 probes, the 32 / 100 one-hot columns of training) run their vector update
+ * on float4 streams (cg_update_q_kernel: a lane owns a column QUAD of a row, every access a dwordx4; cg_update_kernel gives a lane
+ * one element and idles tile_cols(C) - C lanes of every row).  Default 1; 0 = the element form at every column count (A/B runs,
+ * tests); read at plan creation. */
+int mgp_cg_set_update_quads(int on);
 /* The host learns of the end of a solve from a host-mapped word the deciding kernel writes.  While the first graph of
  * a plan runs -- it is sized to end in the stopping decision -- the host reads only that word, for up to twice the
  * time the previous solve took (`spins` reads between two looks at the clock, default 64); hipStreamQuery, the guard
@@ -400,6 +405,14 @@ int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* minv,
                        void** plan_out);
 int mgp_cg_plan_solve(void* plan, const float* B, float* X, int32_t* iters, float* resid,
                       int32_t* status); /* status 1 converged, 2 max_iter, 3 breakdown (NaN) */
+/* Point an existing single-GPU plan at another operator of the SAME structure -- same sizes, tile / dense-tile layouts, nu, form,
+ * the same of pre / post / minv present --, e.g. the same graph at the next epoch's bandwidth and length scale (the reference
+ * rebuilds its operators every epoch, train_model.py:63-67; a fresh plan costs ~0.9 ms of host time between its creation, its
+ * first eager solve, the capture at its second and its destruction).  Pointers and scalars may all differ.  The workspace, the
+ * host-mapped flags and the executable graphs are kept: the next solve records its launches again and updates the graphs in
+ * place (hipGraphExecUpdate).  MGP_ERR_UNSUPPORTED when the structure differs (create a new plan), for distributed plans, and for a
+ * complex-shift plan whose new operator no longer factorises.  The old operator's arrays are not touched after this call. */
+int mgp_cg_plan_rebind(void* plan, const mgp_operator_t* op, const float* minv);
 float* mgp_cg_plan_x(void* plan);    /* device pointer of the plan's own solution buffer [n,C]; pass
                                          X = NULL to mgp_cg_plan_solve to skip the copy into X */
 /* refined solves (max_refine > 0, single GPU) accumulate the solution in float64 and form the true residual

@@ -98,6 +98,7 @@ SIGNATURES = {
     "mgp_cg_set_complex_shift": (c_int, [c_int]),
     "mgp_cg_plan_is_complex_shift": (c_int, [_P]),
     "mgp_cg_set_reduce_once": (c_int, [c_int]),
+    "mgp_cg_set_update_quads": (c_int, [c_int]),
     "mgp_cg_set_poll_spin": (c_int, [c_int]),
     "mgp_cg_set_init_free": (c_int, [c_int]),
     "mgp_host_symeig": (c_int, [c_int, _P, _P, _P]),
@@ -132,6 +133,7 @@ SIGNATURES = {
     "mgp_cg_plan_create": (c_int, [POINTER(OperatorT), c_int, _P, POINTER(CgParamsT), _P, c_size_t, _P,
                                    POINTER(c_void_p)]),
     "mgp_cg_plan_solve": (c_int, [_P, _P, _P, POINTER(c_int32), POINTER(c_float), POINTER(c_int32)]),
+    "mgp_cg_plan_rebind": (c_int, [_P, POINTER(OperatorT), _P]),
     "mgp_cg_plan_x": (c_void_p, [_P]),
     "mgp_cg_plan_x64": (c_void_p, [_P]),
     "mgp_cg_plan_last_applies": (c_int, [_P]),

@@ -67,6 +67,8 @@ struct CgArgs {
   // many columns (C > 16): cg_reduce_kernel has summed the partials of this step -> [3][C] gamma, ||r||^2, delta;
   // the update kernel reads 3 C floats instead of re-reducing (2 nbv + nbs) C of them in every workgroup.  NULL: off.
   float* tot;
+  // quad form of the update (cg_update_q_kernel, C % 4 == 0): CQ = C / 4 column quads, TSQ row slices per workgroup (CQ * TSQ active threads)
+  int CQ, TSQ;
   int* arrive;   // [9][32] arrival counters of the deciding update launch (8 groups + top, a 128-byte line each), zero between launches
 };
 
@@ -410,6 +412,201 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
   if (tid < a.TC && tid < C) {
     a.pd_gamma[((int64_t)par * a.nbv + blockIdx.x) * C + tid] = sh[0][tid];
     a.pd_rr[((int64_t)par * a.nbv + blockIdx.x) * C + tid] = sh[1][tid];
+  }
+}
+
+// ---- Quad form of the update for C % 4 == 0 (the column counts of training: 12 probes, 32, 100 one-hot columns).
+// cg_update_kernel gives a lane one (row, column) ELEMENT: dword loads and stores, tile_cols(C) - C lanes idle (12 of 16, 100 of 128),
+// a wave's stores covering 48-byte rows.  Here the [n, C] arrays are streams of float4: thread (slq, cq) owns column quad cq of the
+// rows slq, slq + TSQ, ... of its workgroup's contiguous row range -- CQ * TSQ of BLOCK threads active (255 of 256 at C = 12, 250
+// at C = 100), every load / store a dwordx4, a wave's accesses 1 KB contiguous.  Same arithmetic per element, same
+// single-reduction recurrence, same decision code as cg_update_kernel; the per-column sums run in a fixed order (rows of a slice in
+// order, slices in groups, groups left to right): bitwise reproducible, but not the order of cg_update_kernel.
+// Launched behind cg_reduce_kernel only (C > 16: the step's totals are 3 C floats).  Measured on the 60k graph, C = 100, Jacobi +
+// pre-scaling on (12 arrays, tools/lab/cg12.py): 57.7 -> 50.3 us per launch.  For 2 <= C <= 16, where every workgroup re-reduces
+// the partials itself, the same form was slower than cg_update_kernel (12.2 us: 15.4 in 1024-thread workgroups, 17.4 in 512) and
+// is not used.
+template <int K, int BLOCK>
+__device__ __forceinline__ void reduce_quads(mgp_cg_v4f (*shq)[BLOCK], float (*sh2)[BLOCK], float (*out)[kMaxC], const mgp_cg_v4f* v,
+                                             bool act, int C, int TSQ) {
+  // shq[k] as floats is P[slq][c] (flat slq * C + c): phase A every active thread stores its quad; phase B thread (g, c), g < G,
+  // sums the rows g, g + G, ... of column c; phase C thread c sums the G group values
+  const int tid = threadIdx.x;
+  if (act) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) shq[k][tid] = v[k];
+  }
+  __syncthreads();
+  int G = BLOCK / C;
+  if (G > 32) G = 32;
+  if (G > TSQ) G = TSQ;
+  const int g = tid / C, c = tid - g * C;
+  if (g < G) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float* P = reinterpret_cast<const float*>(shq[k]);
+      float t = 0.f;
+      for (int r = g; r < TSQ; r += G) t += P[r * C + c];
+      sh2[k][tid] = t;
+    }
+  }
+  __syncthreads();
+  if (tid < C) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float t = 0.f;
+      for (int q = 0; q < G; ++q) t += sh2[k][q * C + tid];
+      out[k][tid] = t;
+    }
+  }
+  __syncthreads();
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void cg_update_q_kernel(CgArgs a) {
+  __shared__ mgp_cg_v4f shq[2][BLOCK];
+  __shared__ float sh2[2][BLOCK];
+  __shared__ float sh_tot[2][kMaxC];
+  __shared__ __attribute__((aligned(16))) float sh_alpha[kMaxC];
+  __shared__ __attribute__((aligned(16))) float sh_beta[kMaxC];
+  __shared__ float sh_rel[kMaxC];
+  __shared__ int sh_done;
+  __shared__ int sh_state[2];
+  const int tid = threadIdx.x;
+  const int C = a.C, CQ = a.CQ, TSQ = a.TSQ;
+  const bool act = tid < CQ * TSQ;
+  const int slq = tid / CQ, cq = tid - slq * CQ;
+  // one round trip for everything the prologue needs (first touches of a line come from beyond L2): state, the partials of BOTH
+  // parities (or the step's totals), gamma_old / alpha_old of both parities -- the parity only selects among registers
+  const int st_it = a.state[0], st_done = a.state[1];
+  const int64_t r0 = (int64_t)blockIdx.x * a.rows_per_block;
+  int64_t r1 = r0 + a.rows_per_block;
+  if (r1 > a.n) r1 = a.n;
+  const int64_t rf = r0 + slq;
+  const mgp_cg_v4f z4 = {0.f, 0.f, 0.f, 0.f};
+  float go2[2] = {0.f, 0.f}, ao2[2] = {0.f, 0.f}, bb_old = 0.f, tg = 0.f, trr = 0.f, td = 0.f;
+  // (the step's totals come from cg_reduce_kernel: this form is only launched behind it)
+  if (tid < C) { tg = a.tot[tid]; trr = a.tot[C + tid]; td = a.tot[2 * C + tid]; }
+  if (tid < C) {
+    go2[0] = a.gamma_old[tid]; go2[1] = a.gamma_old[C + tid];
+    ao2[0] = a.alpha_old[tid]; ao2[1] = a.alpha_old[C + tid];
+    bb_old = a.bb[tid];
+  }
+  if (tid == 0) { sh_state[0] = st_it; sh_state[1] = st_done; }
+  __syncthreads();
+  if (sh_state[1]) return;
+  const int it = sh_state[0];
+  const int par = it & 1, prev = par ^ 1;
+  if (tid < C) {
+    const float gamma = tg, rrn = trr, delta = td;
+    const float bb = (it == 1) ? rrn : bb_old;
+    const float rel = (bb > 0.f) ? sqrtf(rrn / bb) : 0.f;
+    sh_rel[tid] = rel;
+    const bool frozen = (a.stop_mode == 0) ? (rel < 1e-10f) : (rel <= a.tol);
+    float alpha = 0.f, beta = 0.f;
+    if (!frozen) {
+      if (it == 1) {
+        alpha = (delta != 0.f) ? gamma / delta : 0.f;
+      } else {
+        const float go = prev ? go2[1] : go2[0], ao = prev ? ao2[1] : ao2[0];
+        beta = (go != 0.f) ? gamma / go : 0.f;
+        const float den = delta - ((ao != 0.f) ? beta * gamma / ao : 0.f);
+        alpha = (den != 0.f) ? gamma / den : 0.f;
+      }
+      if (!isfinite(alpha) || !isfinite(beta)) { alpha = 0.f; beta = 0.f; }
+    }
+    sh_alpha[tid] = alpha;
+    sh_beta[tid] = beta;
+    if (blockIdx.x == 0) {
+      a.gamma_old[par * C + tid] = gamma;
+      a.alpha_old[par * C + tid] = alpha;
+      if (it == 1) a.bb[tid] = bb;
+      a.resid[tid] = rel;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int done = 0, status = 0;
+    if (a.stop_mode == 0) {
+      float m = 0.f;
+      for (int c = 0; c < C; ++c) m += sh_rel[c];
+      m /= (float)C;
+      if (it > a.min_iter && m < a.tol) { done = 1; status = 1; }   // >= min_iter iterations done
+    } else {
+      int all = 1;
+      for (int c = 0; c < C; ++c) all &= (sh_rel[c] <= a.tol) ? 1 : 0;
+      if (all) { done = 1; status = 1; }
+    }
+    for (int c = 0; c < C; ++c) if (!isfinite(sh_rel[c])) { done = 1; status = 3; }
+    if (!done && it > a.max_iter) { done = 1; status = 2; }
+    sh_done = done;
+    if (done && blockIdx.x == 0) {
+      a.state[2] = status; a.state[1] = 1;
+      for (int c = 0; c < C; ++c) a.host_resid[c] = sh_rel[c];
+      a.host_state[0] = it; a.host_state[2] = status;
+      __threadfence_system();
+      a.host_state[1] = 1;
+    }
+  }
+  __syncthreads();
+  if (sh_done) return;
+
+  // ---- fused vector update: U row passes per batch, every load of a batch in flight before the first use
+  mgp_cg_v4f ng = z4, nrr = z4;
+  if (act) {
+    const mgp_cg_v4f alpha = *reinterpret_cast<const mgp_cg_v4f*>(&sh_alpha[4 * cq]);
+    const mgp_cg_v4f beta = *reinterpret_cast<const mgp_cg_v4f*>(&sh_beta[4 * cq]);
+    const mgp_cg_v4f *U4 = reinterpret_cast<const mgp_cg_v4f*>(a.u), *W4 = reinterpret_cast<const mgp_cg_v4f*>(a.w);
+    mgp_cg_v4f *P4 = reinterpret_cast<mgp_cg_v4f*>(a.p), *S4 = reinterpret_cast<mgp_cg_v4f*>(a.s), *X4 = reinterpret_cast<mgp_cg_v4f*>(a.x),
+               *R4 = reinterpret_cast<mgp_cg_v4f*>(a.r);
+    constexpr int U = 2;
+    for (int64_t rb = rf; rb < r1; rb += (int64_t)U * TSQ) {
+      mgp_cg_v4f un[U], po[U], so[U], wo[U], xo[U], ro[U];
+      float mo[U], pr[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int64_t r = rb + (int64_t)k * TSQ;
+        const int64_t rc = r < r1 ? r : rf;
+        const int64_t i = rc * CQ + cq;
+        un[k] = U4[i]; po[k] = P4[i]; so[k] = S4[i]; wo[k] = W4[i]; xo[k] = X4[i]; ro[k] = R4[i];
+        mo[k] = a.minv ? a.minv[rc] : 1.f;
+        pr[k] = a.us ? a.pre[rc] : 1.f;
+      }
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int64_t r = rb + (int64_t)k * TSQ;
+        if (r < r1) {
+          const int64_t i = r * CQ + cq;
+          mgp_cg_v4f p, sv, xn, rn, u2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            p[j] = fmaf(beta[j], po[k][j], un[k][j]);
+            sv[j] = fmaf(beta[j], so[k][j], wo[k][j]);
+            xn[j] = fmaf(alpha[j], p[j], xo[k][j]);
+            rn[j] = fmaf(-alpha[j], sv[j], ro[k][j]);
+            u2[j] = a.minv ? mo[k] * rn[j] : rn[j];
+            ng[j] = fmaf(rn[j], u2[j], ng[j]);
+            nrr[j] = fmaf(rn[j], rn[j], nrr[j]);
+          }
+          P4[i] = p; S4[i] = sv; X4[i] = xn; R4[i] = rn;
+          if (a.minv) reinterpret_cast<mgp_cg_v4f*>(a.u)[i] = u2;
+          if (a.us) {
+            mgp_cg_v4f us;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) us[j] = pr[k] * u2[j];
+            reinterpret_cast<mgp_cg_v4f*>(a.us)[i] = us;
+          }
+        }
+      }
+    }
+  }
+  {
+    const mgp_cg_v4f v[2] = {ng, nrr};
+    reduce_quads<2, BLOCK>(shq, sh2, sh_tot, v, act, C, TSQ);
+  }
+  if (tid < C) {
+    a.pd_gamma[((int64_t)par * a.nbv + blockIdx.x) * C + tid] = sh_tot[0][tid];
+    a.pd_rr[((int64_t)par * a.nbv + blockIdx.x) * C + tid] = sh_tot[1][tid];
   }
 }
 
@@ -1146,6 +1343,8 @@ struct CgPlan {
   int marker_seq;             // first graphs launched so far = what cg_marker_kernel will have counted when the newest ends
   bool graphs_tried;
   bool init_free;             // no cg_init launch: the first apply reads the rhs itself (CgArgs::pd_bb)
+  bool rebound;               // mgp_cg_plan_rebind since the last solve: the graphs are refreshed before they are launched again
+  int upd_quads;              // 0: cg_update_kernel; else the workgroup size of cg_update_q_kernel (C % 4 == 0)
   bool decide_in_update;      // the first graph's last update decides + marks (mgp_cg_set_decide_in_update at plan creation)
   bool cx;                    // complex-shift solve (cx_update_kernel): form 2, nu = 2, symmetric normalisation, C = 1
   CxArgs cxa;
@@ -1194,6 +1393,7 @@ size_t cg_bytes(const mgp_operator_t* op, int C, int world = 1) {
 constexpr int kReduceOnceAbove = 16;
 std::atomic<int> g_cg_complex_shift{1};   // form 2, nu = 2, symmetric normalisation, C = 1: the complex-shift solve (mgp_cg_set_complex_shift(0): CG on A)
 std::atomic<int> g_cg_reduce_once{1};   // mgp_cg_set_reduce_once(0): every update workgroup re-reduces the partials at any C (A/B, tests)
+std::atomic<int> g_cg_update_quads{1};   // C % 4 == 0 plans update through cg_update_q_kernel (mgp_cg_set_update_quads(0): the element form at every C)
 std::atomic<int> g_cg_poll_spin{64};    // flag reads between two looks at the clock in the flag-only poll window; 0: no such window (mgp_cg_set_poll_spin)
 std::atomic<int> g_cg_init_free{1};   // C == 1 plans start without a cg_init launch (mgp_cg_set_init_free(0): classic start)
 std::atomic<int> g_cg_decide_in_update{1};   // the first graph's last update decides + marks (mgp_cg_set_decide_in_update(0): separate launches)
@@ -1234,7 +1434,8 @@ int enqueue_body(CgPlan* pl, hipStream_t st, bool decide_last = false) {
       hipLaunchKernelGGL(cg_reduce_kernel, dim3((unsigned)mgp_cdiv(pl->C, 4), 3), dim3(kBlock), 0, st, pl->args);
       MGP_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(cg_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+    if (pl->upd_quads) hipLaunchKernelGGL(cg_update_q_kernel<kBlock>, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
+    else hipLaunchKernelGGL(cg_update_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, st, pl->args);
   }
   MGP_LAUNCH_CHECK();
   return MGP_OK;
@@ -1251,6 +1452,45 @@ int enqueue_first_body(CgPlan* pl, hipStream_t st, const float* rhs, bool record
   return MGP_OK;
 }
 
+// stream-capture the first graph (cg_init / init-free first apply + len bodies) into *out; false on any failure
+bool record_first(CgPlan* pl, int len, hipGraph_t* out) {
+  *out = nullptr;
+  if (!pl->cap_stream || len < 1) return false;
+  if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+  int rc = MGP_OK;
+  // `len` = steps until the stopping rule fires: the last of them only detects (see cg_decide_c1_kernel)
+  const bool decide = len >= 2 && !pl->is_dist && pl->C == 1 &&
+                      pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock;
+  const int bodies = decide ? len - 1 : len;
+  int done_bodies = 0;
+  // decide: the graph's LAST update also takes the next step's decision and leaves the end-of-graph mark (g_cg_decide_in_update;
+  // 0: the separate cg_decide_c1_kernel + cg_marker_kernel launches of rounds 1-3)
+  const bool in_update = decide && pl->decide_in_update;
+  if (pl->init_free) {
+    // root node = launch 0 of the first apply, reading a placeholder rhs that is patched before every launch
+    rc = enqueue_first_body(pl, pl->cap_stream, (const float*)pl->args.x, true, in_update && bodies == 1);
+    done_bodies = 1;
+  } else {
+    hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, pl->cap_stream, pl->args,
+                       (const float*)pl->args.x);   // placeholder rhs, patched before every launch
+    rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
+  }
+  for (int i = done_bodies; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream, in_update && i == bodies - 1);
+  if (decide && !in_update && rc == MGP_OK) {
+    hipLaunchKernelGGL(cg_decide_c1_kernel, dim3(1), dim3(kBlock), 0, pl->cap_stream, pl->args);
+    rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
+  }
+  if (!in_update && rc == MGP_OK) {
+    hipLaunchKernelGGL(cg_marker_kernel, dim3(1), dim3(1), 0, pl->cap_stream, pl->args.state, pl->args.host_state);
+    rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
+  }
+  hipGraph_t graph = nullptr;
+  const hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
+  if (rc == MGP_OK && e2 == hipSuccess && graph != nullptr) { *out = graph; return true; }
+  if (graph) (void)hipGraphDestroy(graph);
+  return false;
+}
+
 // (re)build the first graph: cg_init + len bodies.  Leaves has_first = false on any failure (the
 // solve then launches cg_init eagerly and replays the continuation graph).
 void capture_first(CgPlan* pl, int len) {
@@ -1259,41 +1499,7 @@ void capture_first(CgPlan* pl, int len) {
   pl->has_first = false;
   pl->patched_rhs = nullptr;
   pl->len_first = len;
-  if (!pl->cap_stream || len < 1) return;
-  bool ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-  if (ok) {
-    int rc = MGP_OK;
-    // `len` = steps until the stopping rule fires: the last of them only detects (see cg_decide_c1_kernel)
-    const bool decide = len >= 2 && !pl->is_dist && pl->C == 1 &&
-                        pl->args.nbv <= kC1GammaSlots * kBlock && pl->args.nbs <= kC1DeltaSlots * kBlock;
-    const int bodies = decide ? len - 1 : len;
-    int done_bodies = 0;
-    // decide: the graph's LAST update also takes the next step's decision and leaves the end-of-graph mark (g_cg_decide_in_update;
-    // 0: the separate cg_decide_c1_kernel + cg_marker_kernel launches of rounds 1-3)
-    const bool in_update = decide && pl->decide_in_update;
-    if (pl->init_free) {
-      // root node = launch 0 of the first apply, reading a placeholder rhs that is patched before every launch
-      rc = enqueue_first_body(pl, pl->cap_stream, (const float*)pl->args.x, true, in_update && bodies == 1);
-      done_bodies = 1;
-    } else {
-      hipLaunchKernelGGL(cg_init_kernel, dim3(pl->args.nbv), dim3(kBlock), 0, pl->cap_stream, pl->args,
-                         (const float*)pl->args.x);   // placeholder rhs, patched before every launch
-      rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
-    }
-    for (int i = done_bodies; i < bodies && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream, in_update && i == bodies - 1);
-    if (decide && !in_update && rc == MGP_OK) {
-      hipLaunchKernelGGL(cg_decide_c1_kernel, dim3(1), dim3(kBlock), 0, pl->cap_stream, pl->args);
-      rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
-    }
-    if (!in_update && rc == MGP_OK) {
-      hipLaunchKernelGGL(cg_marker_kernel, dim3(1), dim3(1), 0, pl->cap_stream, pl->args.state, pl->args.host_state);
-      rc = hipGetLastError() == hipSuccess ? MGP_OK : 1;
-    }
-    hipGraph_t graph = nullptr;
-    const hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
-    ok = (rc == MGP_OK && e2 == hipSuccess && graph != nullptr);
-    pl->graph_first = graph;
-  }
+  bool ok = record_first(pl, len, &pl->graph_first);
   if (ok) {
     size_t nroot = 1;
     hipGraphNode_t root = nullptr;
@@ -1336,6 +1542,62 @@ extern "C" size_t mgp_cg_workspace_bytes(const mgp_operator_t* op, int C) {
   return cg_bytes(op, C);
 }
 
+// stream-capture `chunk` bodies (the continuation graph) into *out
+static bool record_chunk(CgPlan* pl, hipGraph_t* out) {
+  *out = nullptr;
+  if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+  int rc = MGP_OK;
+  for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
+  hipGraph_t graph = nullptr;
+  const hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
+  if (rc == MGP_OK && e2 == hipSuccess && graph != nullptr) { *out = graph; return true; }
+  if (graph) (void)hipGraphDestroy(graph);
+  return false;
+}
+
+// After mgp_cg_plan_rebind: the captured graphs still hold the OLD operator's pointers and scalars.  Record the same launches
+// again with the new ones and update the executable graphs in place (hipGraphExecUpdate: same topology, same kernels, new
+// arguments -- tools/lab/graph_update.hip: record 15 us + update 20 us for 30 nodes, against instantiate 40-50 + the 210 us a
+// hipGraphExecDestroy costs); an update the runtime refuses falls back to destroy + instantiate.  The first graph keeps its ORIGINAL
+// hipGraph_t: the root node patched per solve (patch_first_rhs) is addressed through it, and the launch record it is patched from
+// was rewritten by the recording.
+static void refresh_graphs(CgPlan* pl) {
+  pl->rebound = false;
+  if (!pl->graphs_tried) return;          // nothing captured yet: the first capture will see the new operator
+  (void)hipGetLastError();
+  if (pl->has_graph) {
+    hipGraph_t g = nullptr;
+    bool ok = record_chunk(pl, &g);
+    if (ok) {
+      hipGraphNode_t err_node = nullptr;
+      hipGraphExecUpdateResult res;
+      if (hipGraphExecUpdate(pl->exec, g, &err_node, &res) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipGraphExecDestroy(pl->exec);
+        pl->exec = nullptr;
+        ok = hipGraphInstantiate(&pl->exec, g, nullptr, nullptr, 0) == hipSuccess;
+      }
+    }
+    if (g) (void)hipGraphDestroy(g);
+    if (!ok && pl->exec) { (void)hipGraphExecDestroy(pl->exec); pl->exec = nullptr; }
+    pl->has_graph = ok;
+    (void)hipGetLastError();
+  }
+  if (pl->has_first) {
+    hipGraph_t g = nullptr;
+    bool ok = record_first(pl, pl->len_first, &g);
+    if (ok) {
+      hipGraphNode_t err_node = nullptr;
+      hipGraphExecUpdateResult res;
+      ok = hipGraphExecUpdate(pl->exec_first, g, &err_node, &res) == hipSuccess;
+    }
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    pl->patched_rhs = nullptr;            // the update reset the root node to the placeholder right-hand side
+    if (!ok) capture_first(pl, pl->len_first);
+  }
+}
+
 // Graphs are captured at the SECOND solve of a plan: capture + instantiate cost ~0.3 ms (7 ms the first time in a
 // process; tools/lab/time_capture.py), as much as a short solve, and plans built for a one-off solve never earn it
 // back.  The first solve runs the same launches eagerly.
@@ -1344,13 +1606,9 @@ static void capture_graphs(CgPlan* pl) {
   if (!pl->prm.use_graph || pl->is_dist) return;   // collectives are enqueued eagerly (no capture)
   hipError_t e = hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking);
   bool ok = (e == hipSuccess);
-  if (ok) ok = hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
   if (ok) {
-    int rc = MGP_OK;
-    for (int i = 0; i < pl->chunk && rc == MGP_OK; ++i) rc = enqueue_body(pl, pl->cap_stream);
     hipGraph_t graph = nullptr;
-    hipError_t e2 = hipStreamEndCapture(pl->cap_stream, &graph);
-    ok = (rc == MGP_OK && e2 == hipSuccess && graph != nullptr);
+    ok = record_chunk(pl, &graph);
     if (ok) ok = hipGraphInstantiate(&pl->exec, graph, nullptr, nullptr, 0) == hipSuccess;
     if (graph) (void)hipGraphDestroy(graph);
   }
@@ -1404,10 +1662,22 @@ static int plan_create_impl(const mgp_operator_t* op, int C, const float* minv, 
   const int reduce_mode = g_cg_reduce_once;      // (lab knobs: read once, at plan creation)
   pl->decide_in_update = g_cg_decide_in_update != 0;
   const bool reduce_once = reduce_mode && C > (reduce_mode == 2 ? 1 : kReduceOnceAbove);
-  const int max_grid_vec = (C == 1) ? kMaxGridVec : (reduce_once ? 2048 : 256);
+  int max_grid_vec = (C == 1) ? kMaxGridVec : (reduce_once ? 2048 : 256);
   int64_t rpb = a.TS;
+  // C % 4 == 0 behind cg_reduce_kernel (C > 16): the quad form of the update (cg_update_q_kernel).  Up to 16 columns, where every
+  // workgroup re-reduces the partials, the element form stays: measured at 60k x 12 (tools/lab/cg12.py) 12.2 us against 15.4 for the
+  // quad form in 1024-thread workgroups and 17.4 in 512-thread ones (the kernel can do it: lab switch below)
+  pl->upd_quads = (C % 4 == 0 && reduce_once && g_cg_update_quads != 0) ? kBlock : 0;
+  a.CQ = C / 4; a.TSQ = 0;
+  if (pl->upd_quads) {
+    a.TSQ = pl->upd_quads / a.CQ;
+    rpb = a.TSQ;
+  }
   int64_t nbv = mgp_cdiv(n, rpb);
-  if (nbv > max_grid_vec) { rpb = mgp_cdiv(mgp_cdiv(n, max_grid_vec), a.TS) * a.TS; nbv = mgp_cdiv(n, rpb); }
+  {
+    const int64_t step = pl->upd_quads ? a.TSQ : a.TS;
+    if (nbv > max_grid_vec) { rpb = mgp_cdiv(mgp_cdiv(n, max_grid_vec), step) * step; nbv = mgp_cdiv(n, rpb); }
+  }
   a.rows_per_block = rpb; a.nbv = (int)nbv;
   a.pd_gamma = ar.take<float>(2 * (size_t)kMaxPartials * C);
   a.pd_rr = ar.take<float>(2 * (size_t)kMaxPartials * C);
@@ -1513,6 +1783,11 @@ extern "C" int mgp_cg_set_reduce_once(int on) {
   return MGP_OK;
 }
 
+extern "C" int mgp_cg_set_update_quads(int on) {
+  g_cg_update_quads = on ? 1 : 0;
+  return MGP_OK;
+}
+
 extern "C" int mgp_cg_set_complex_shift(int on) {
   const int prev = g_cg_complex_shift;
   g_cg_complex_shift = on ? 1 : 0;
@@ -1534,6 +1809,41 @@ extern "C" int mgp_cg_plan_create(const mgp_operator_t* op, int C, const float* 
                                   const mgp_cg_params_t* params, void* work, size_t work_bytes,
                                   void* stream, void** plan_out) {
   return plan_create_impl(op, C, minv, params, nullptr, work, work_bytes, stream, plan_out);
+}
+
+// see include/mgp_hip.h
+extern "C" int mgp_cg_plan_rebind(void* plan, const mgp_operator_t* op, const float* minv) {
+  CgPlan* pl = static_cast<CgPlan*>(plan);
+  if (!pl || !op) return MGP_ERR_ARG;
+  if (pl->poisoned || pl->is_dist) return MGP_ERR_UNSUPPORTED;
+  const mgp_operator_t& o = pl->op;
+  // the same STRUCTURE: everything that chose kernels, grids and buffer sizes at creation
+  const bool same = op->L.n == o.L.n && op->L.ncols == o.L.ncols && op->nu == o.nu && op->form == o.form &&
+                    (op->pre != nullptr) == (o.pre != nullptr) && (op->post != nullptr) == (o.post != nullptr) &&
+                    (minv != nullptr) == (pl->args.minv != nullptr) &&
+                    (op->L.tile_ptr != nullptr) == (o.L.tile_ptr != nullptr) && op->L.tile_rows == o.L.tile_rows &&
+                    op->L.tile_max_cols == o.L.tile_max_cols && op->L.tile_max_entries == o.L.tile_max_entries &&
+                    (op->L.tile_rowptr != nullptr) == (o.L.tile_rowptr != nullptr) &&
+                    (op->L.tile_vals != nullptr) == (o.L.tile_vals != nullptr) &&
+                    (op->L.tile_rowid != nullptr) == (o.L.tile_rowid != nullptr) &&
+                    (op->L.mt_img != nullptr) == (o.L.mt_img != nullptr) && op->L.mt_tiles == o.L.mt_tiles &&
+                    op->L.mt_steps == o.L.mt_steps && mgp_spmm_dot_blocks_for(&op->L, pl->C) == pl->nb_loc;
+  if (!same) return MGP_ERR_UNSUPPORTED;
+  if (pl->cx) {
+    const float cc = op->noise * op->scale;
+    if (!(cc > 0.f)) return MGP_ERR_UNSUPPORTED;
+    pl->opB = *op;
+    pl->opB.nu = 1;
+    pl->opB.kappa = op->kappa / sqrtf(2.0f);
+    pl->opB.scale = 1.0f; pl->opB.form = 0; pl->opB.noise = 0.f;
+    if (mgp_spmm_dot_blocks_for(&pl->opB.L, 4) != pl->nb4) return MGP_ERR_UNSUPPORTED;
+    pl->cxa.sigma = sqrtf(cc);
+  }
+  pl->op = *op;
+  pl->args.minv = minv;
+  pl->args.pre = op->pre;
+  pl->rebound = true;
+  return MGP_OK;
 }
 
 extern "C" size_t mgp_cg_dist_workspace_bytes(const mgp_operator_t* op_local, int C, int world) {
@@ -1558,6 +1868,7 @@ static int run_cg(CgPlan* pl, const float* rhs, float* Xcopy) {
   *reinterpret_cast<volatile uint64_t*>(pl->host_state + 8) = 0;     // the deciding update's 8-byte record
   bool first = true;
   const auto t_begin = std::chrono::steady_clock::now();
+  if (pl->rebound) refresh_graphs(pl);
   if (pl->solves++ >= 1 && !pl->graphs_tried) capture_graphs(pl);
   if (pl->has_first && !patch_first_rhs(pl, rhs)) pl->has_first = false;
   int eager_done = 0;           // bodies of the first eager chunk already enqueued

@@ -147,7 +147,11 @@ def build_tiles_auto(n, rowptr, col, nnz, points=None):
 
 
 class KnnGraph:
+    _next_uid = [1]
+
     def __init__(self, n, tri_row, tri_col, tri_val, rowptr, col, d2, eid, tiles="auto", points=None):
+        self.uid = KnnGraph._next_uid[0]          # never reused, unlike id(): what the solvers' plan cache keys on
+        KnnGraph._next_uid[0] += 1
         self.n = int(n)
         self.tri_row, self.tri_col, self.tri_val = tri_row, tri_col, tri_val
         self.rowptr, self.col, self.d2, self.eid = rowptr, col, d2, eid

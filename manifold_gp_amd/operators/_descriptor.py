@@ -38,10 +38,14 @@ class Descriptor:
             post = row_mask if post is None else post * row_mask
         return replace(self, pre=pre, post=post)
 
-    def relabelled(self, wide=False):
+    def relabelled(self, wide=False, chain_if_built=False):
         """(descriptor of P A P^T, RelabelledGraph) when the graph's tiles follow a locality order -- the form the iterative
         solvers run on: same operator on permuted vectors -- else (None, None).  wide: for products of 48 columns and more, the
-        chain-relabelled matrix where the graph has one (graph.LaplacianData.wide_relabelled)."""
+        chain-relabelled matrix where the graph has one (graph.LaplacianData.wide_relabelled).  chain_if_built: the same, but only
+        when the graph's chain order EXISTS already (a wide product built it: its host walk, 24 ms at 60k, is not worth starting
+        for a solve of a few columns)."""
+        if not wide and chain_if_built and getattr(getattr(self.data, "graph", None), "_wide_relabelled", None) is not None:
+            wide = True
         name = "wide_relabelled" if wide else "relabelled"
         rel = getattr(self.data, name, getattr(self.data, "relabelled", lambda: None))()
         if rel is None:

@@ -15,6 +15,14 @@ from ._lib import CgParamsT, LanczosParamsT, check, lib, ptr, stream
 
 # ------------------------------------------------------------------------------ CG
 RELABEL_SOLVES = [True]        # iterative solves on a graph with locality-ordered tiles run on P A P^T (CgPlan.__init__)
+# Column count from which a solve iterates on the CHAIN-relabelled matrix (graph.KnnGraph.wide_relabelled).  48 and more: the
+# matrix-core tile SpMM, whose work is the distinct columns of a 16-row tile -- these solves BUILD the chain order where it pays.
+# From CHAIN_SOLVE_MIN_C columns on the 64-row tile kernels gain too (their dictionaries shrink the same way: the 12-column SpMM on
+# the 60k graph 18.5 -> 15.9 us) and the two permutations of the right-hand side / the solution (~5 us each at 60k x 12) are a
+# fraction of one iteration: these solves USE the chain order when a wide product has built it (in training `_average_variance`
+# and `eval()` have) and never start the host walk themselves.  Below, a solve is too short to pay for the permutations
+# (tools/lab/chain_c1.py: C = 1 53 -> 69 us).
+CHAIN_SOLVE_MIN_C = [8]
 
 
 class CgPlan:
@@ -30,25 +38,18 @@ class CgPlan:
         # already is, node vectors permuted once per operator -- and permutes the right-hand side in and the solution out:
         # two gathers of n C floats per solve against hundreds of SpMVs.  Caller-order `rhs` in, caller-order result out
         # (graph_laplacian_operator.py:108-124).  RELABEL_SOLVES[0] = False: iterate in the caller's order (A/B, tests).
-        self._rg = None
-        if RELABEL_SOLVES[0]:
-            # 48 columns and more run on the matrix-core tile SpMM: there the chain-relabelled matrix where it pays (round 5)
-            rdesc, rg = desc.relabelled(wide=int(C) >= 48)
-            if rdesc is not None:
-                desc, self._rg = rdesc, rg
-        self._xout = None
-        self.desc = desc
         self.C = int(C)
+        self._xout = None
+        desc = self._bind(desc)
         dev = desc.data.graph.device
-        self.op = desc.struct(wide=self.C >= 48)       # 48 columns and more: the matrix-core tile SpMM (graph.MtPlan)
         stop_mode = settings.cg_stop_mode.value() if stop_mode is None else stop_mode
         self.params = CgParamsT(
             float(settings.cg_tolerance.value() if tol is None else tol),
             int(settings.max_cg_iterations.value() if max_iter is None else max_iter),
             int((10 if stop_mode == 0 else 0) if min_iter is None else min_iter),
             int(stop_mode), int(check_every), int(bool(use_graph)), int(refine))
-        jacobi = settings.cg_jacobi_preconditioner.value() if jacobi is None else jacobi
-        self.minv = desc.jacobi() if jacobi else None
+        self._jacobi = bool(settings.cg_jacobi_preconditioner.value() if jacobi is None else jacobi)
+        self.minv = desc.jacobi() if self._jacobi else None
         wb = lib().mgp_cg_workspace_bytes(ctypes.byref(self.op), self.C)
         if wb == 0:
             raise RuntimeError("mgp_cg_workspace_bytes: unsupported operator / column count %d" % C)
@@ -64,6 +65,36 @@ class CgPlan:
         self._resid = (ctypes.c_float * self.C)()
         self._solve_fn, self._applies_fn = lib().mgp_cg_plan_solve, lib().mgp_cg_plan_last_applies
         self.status = 0
+
+    def _bind(self, desc):
+        """The descriptor the plan iterates on (relabelled where that pays) + its C struct."""
+        self._rg = None
+        if RELABEL_SOLVES[0]:
+            # 48 columns and more run on the matrix-core tile SpMM: there the chain-relabelled matrix where it pays (round 5)
+            rdesc, rg = desc.relabelled(wide=self.C >= 48, chain_if_built=self.C >= CHAIN_SOLVE_MIN_C[0])
+            if rdesc is not None:
+                desc, self._rg = rdesc, rg
+        self.desc = desc
+        self.op = desc.struct(wide=self.C >= 48)       # 48 columns and more: the matrix-core tile SpMM (graph.MtPlan)
+        return desc
+
+    def rebind(self, desc):
+        """Point the plan at another operator of the same structure (mgp_cg_plan_rebind: the same graph at the next epoch's
+        hyper-parameters) instead of building a new plan: workspace, flags and executable graphs are kept.  False when the
+        library refuses (different structure): the caller builds a new plan."""
+        old = (self.desc, self.op, self.minv, self._rg)
+        had_rg = self._rg is not None
+        desc = self._bind(desc)
+        if (self._rg is not None) != had_rg:
+            self.desc, self.op, self.minv, self._rg = old
+            return False
+        minv = desc.jacobi() if self._jacobi else None
+        rc = lib().mgp_cg_plan_rebind(self.handle, ctypes.byref(self.op), ptr(minv))
+        if rc != 0:
+            self.desc, self.op, self.minv, self._rg = old
+            return False
+        self.minv = minv            # (the captured graphs still name the previous operator's arrays; they are re-recorded before
+        return True                 # their next launch and never read through the old pointers -- nothing to keep alive)
 
     # read on demand: a solve is ~60 us, every ctypes call / list conversion on its way back is a visible fraction
     @property
@@ -160,26 +191,41 @@ class CgPlan:
 
 _PLAN_CACHE = {}
 _PLAN_CACHE_MAX = 8
+REBIND_PLANS = [True]          # lab / test switch: False = a new plan for every new operator value (rounds 1-4)
 
 
 def _cached_plan(desc, C, kw):
-    """Plans own a captured hipGraph (~ms to build): reuse them for repeated solves with the same
-    operator (the nested CG of a Schur-complement matvec, _average_variance in a training loop)."""
+    """Plans own a workspace, host-mapped flags and captured hipGraphs (~0.9 ms of host time over a plan's life): they are
+    kept per operator STRUCTURE -- graph, nu, form, which of pre / post are present, column count, solver settings, stream --
+    and pointed at the current operator VALUES (bandwidth, length scale, scale, noise, the pre / post vectors) when those
+    changed since the plan's last use (CgPlan.rebind): the nested CG of a Schur-complement matvec and `_average_variance` reuse
+    one plan within an epoch, and the next epoch -- new hyper-parameters, same graph -- reuses it again."""
     # a plan is bound to the stream that was current when it was created (its launches, its graph replays and the
-    # copy of X are ordered there only): a solve issued under another torch.cuda.stream gets its own plan
-    # (keyed on the Laplacian data's monotonically assigned uid -- an id() could be reused by a new object once the old one
-    # is gone; the pre / post pointers are safe because a cached plan keeps its descriptor, hence those tensors, alive)
-    key = (getattr(desc.data, "uid", None) or id(desc.data), desc.nu, desc.kappa, desc.scale, desc.form, desc.noise,
-           desc.pre.data_ptr() if desc.pre is not None else 0, desc.post.data_ptr() if desc.post is not None else 0,
-           int(C), settings.cg_tolerance.value(), settings.max_cg_iterations.value(), settings.cg_stop_mode.value(),
-           settings.cg_jacobi_preconditioner.value(), tuple(sorted(kw.items())),
-           int(torch.cuda.current_stream(desc.data.graph.device).cuda_stream))
-    plan = _PLAN_CACHE.get(key)
+    # copy of X are ordered there only): a solve issued under another torch.cuda.stream gets its own plan.
+    # (graph / data uids are assigned monotonically -- an id() could be reused by a new object once the old one is gone; the
+    # pre / post pointers in the value key are safe because a plan keeps its descriptor, hence those tensors, alive)
+    g = getattr(desc.data, "graph", None)
+    skey = (getattr(g, "uid", None) or id(g), desc.nu, desc.form, desc.pre is not None, desc.post is not None,
+            int(C), settings.cg_tolerance.value(), settings.max_cg_iterations.value(), settings.cg_stop_mode.value(),
+            settings.cg_jacobi_preconditioner.value(), tuple(sorted(kw.items())),
+            int(torch.cuda.current_stream(desc.data.graph.device).cuda_stream))
+    vkey = (getattr(desc.data, "uid", None) or id(desc.data), desc.kappa, desc.scale, desc.noise,
+            desc.pre.data_ptr() if desc.pre is not None else 0, desc.post.data_ptr() if desc.post is not None else 0)
+    if not REBIND_PLANS[0]:
+        skey = skey + vkey
+    plan = _PLAN_CACHE.get(skey)
+    if plan is not None and plan._vkey != vkey:
+        if plan.rebind(desc):
+            plan._vkey = vkey
+        else:
+            _PLAN_CACHE.pop(skey).close()
+            plan = None
     if plan is None:
         if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
             _PLAN_CACHE.pop(next(iter(_PLAN_CACHE))).close()
         plan = CgPlan(desc, C, **kw)
-        _PLAN_CACHE[key] = plan
+        plan._vkey = vkey
+        _PLAN_CACHE[skey] = plan
     return plan
 
 

@@ -2826,6 +2826,81 @@ def test_pcg_stagnation_guard_and_refinement_on_an_ill_conditioned_system(mgp, g
         plan.close()
 
 
+def test_cg_plan_rebind_matches_fresh_plans(mgp, dev):
+    """mgp_cg_plan_rebind (round 5): a plan pointed at the same graph's operator at another bandwidth / length scale / scale /
+    noise -- what every training epoch does -- gives bit for bit what a fresh plan gives, solution, iterations and status, with
+    its graphs captured BEFORE the rebind (they are updated in place), at alternating right-hand-side addresses (the root node of
+    the first graph is patched through its original handle), for the init-free C = 1 plan, the Jacobi C = 1 plan with masked pre /
+    post vectors, the complex-shift plan, 12 columns (element update) and 100 columns (matrix-core SpMM + quad update); a
+    different structure is refused and the cache then builds a new plan."""
+    from manifold_gp_amd import solvers
+    from manifold_gp_amd.solvers import CgPlan
+    from tools import synth
+    x, _ = synth.rmnist_like(60, 100, seed=3, device=dev)
+    n = x.shape[0]
+    knn = mgp.utils.NearestNeighbors(x)
+    idx, val = knn.graph(20)
+    D1, _ = knn.search(x, 2)
+    e0 = float(D1[:, 1].median().sqrt()) * 1.5
+    g = knn.knn_graph
+    g.wide_relabelled()                                # (so that the 12-column plans take the chain order too)
+    mask = (torch.rand(n, generator=torch.Generator().manual_seed(3)) > 0.2).float().to(dev)
+
+    def descs(eps, kappa, scale, noise):
+        lap = mgp.operators.GraphLaplacianOperator(val, idx, n, torch.tensor([[eps]], device=dev), "randomwalk", graph=g)
+        lap_s = mgp.operators.GraphLaplacianOperator(val, idx, n, torch.tensor([[eps]], device=dev), "symmetric", graph=g)
+        q = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[kappa]], device=dev))._descriptor()
+        qs = mgp.operators.PrecisionMaternOperator(lap_s, 2, torch.tensor([[kappa]], device=dev))._descriptor()
+        return dict(c1=(q.with_(scale=scale, form=2, noise=noise), 1, dict(tol=1e-6, stop_mode=1)),
+                    c1_masked_jacobi=(q.masked(row_mask=mask, col_mask=mask), 1, dict(tol=1e-3, stop_mode=1, jacobi=True)),
+                    c1_complex=(qs.with_(scale=scale, form=2, noise=noise), 1, dict(tol=1e-6, stop_mode=1)),
+                    c12=(q.with_(nu=1, scale=1.0, pre=None, post=None), 12, dict(tol=1e-3, stop_mode=0)),
+                    c12_masked_jacobi=(q.masked(row_mask=mask, col_mask=mask), 12, dict(tol=1e-3, stop_mode=0, jacobi=True)),
+                    c100=(q.with_(nu=1, scale=1.0, pre=None, post=None), 100, dict(tol=1e-3, stop_mode=0)))
+    A, B = descs(e0, 3.0, 1.0, 1e-2), descs(1.07 * e0, 2.6, 1.3, 2e-2)
+    gen = torch.Generator().manual_seed(9)
+    for name in A:
+        (da, C, kw), (db, _, _) = A[name], B[name]
+        rhs = [torch.randn(n, C, generator=gen).to(dev) * (mask.view(-1, 1) if "masked" in name else 1.0) for _ in range(3)]
+        seq = [rhs[0], rhs[0], rhs[1], rhs[0].clone(), rhs[2]]
+
+        def run(plan):
+            out = []
+            for r in seq:
+                out.append((plan.solve(r).clone(), plan.iters, plan.status))
+            return out
+        fresh_b = CgPlan(db, C, max_iter=2000, **kw)
+        ref_b = run(fresh_b)
+        fresh_b.close()
+        plan = CgPlan(da, C, max_iter=2000, **kw)
+        ra = run(plan)                                 # graphs captured, first graph sized, on operator A
+        assert plan.complex_shift == (name == "c1_complex")
+        assert plan.rebind(db), name
+        rb = run(plan)
+        assert plan.rebind(da), name
+        ra2 = run(plan)
+        plan.close()
+        for (x1, i1, s1), (x2, i2, s2) in list(zip(rb, ref_b)) + list(zip(ra2, ra)):
+            assert (i1, s1) == (i2, s2) and s1 in (1, 2), (name, i1, s1, i2, s2)
+            assert torch.equal(x1, x2), (name, float((x1 - x2).abs().max()))
+        assert not torch.equal(ra[0][0], rb[0][0])
+    # a different structure (nu) is refused; the cache answers with a new plan and keeps serving both values
+    (da, C, kw), (db, _, _) = A["c12"], B["c12"]
+    plan = CgPlan(da, C, max_iter=2000, **kw)
+    assert not plan.rebind(A["c12_masked_jacobi"][0])
+    assert plan.desc.nu == 1 and plan.desc.pre is None
+    r = torch.randn(n, C, generator=gen).to(dev)
+    x_before = plan.solve(r).clone()
+    plan.close()
+    solvers.clear_plan_cache()
+    xa, _, _ = solvers.cg_solve(da, r, factorise=False, max_iter=2000, **kw)
+    xb, _, _ = solvers.cg_solve(db, r, factorise=False, max_iter=2000, **kw)
+    xa2, _, _ = solvers.cg_solve(da, r, factorise=False, max_iter=2000, **kw)
+    assert len(solvers._PLAN_CACHE) == 1              # one plan served all three
+    assert torch.equal(xa, x_before) and torch.equal(xa, xa2) and not torch.equal(xa, xb)
+    solvers.clear_plan_cache()
+
+
 def test_chain_order_and_wide_relabelling(mgp, dev):
     """mgp_graph_chain_order (nearest-neighbour chain: a locality order for k-NN graphs whose given order keeps clusters together
     but not the order inside them) and what the wide products do with it: a permutation, deterministic, consecutive positions
