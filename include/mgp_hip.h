@@ -507,6 +507,19 @@ int mgp_lanczos_set_bound_mode(int mode);
 size_t mgp_lanczos_tridiag_block_workspace_bytes(const mgp_operator_t* op, int P, int steps);
 int mgp_lanczos_tridiag_block(const mgp_operator_t* op, const float* Q0, int P, int steps, float* alpha, float* beta,
                               void* work, size_t work_bytes, void* stream);
+/* The same P runs for an operator the CALLER applies (round 5) -- the inverse of a Schur complement, every product of which is a CG
+ * solve of its own: the stochastic log-determinant of the semi-supervised loss (train_model.py:68 through
+ * schur_complement_operator.py:12-36).  mgp_blz_begin normalises the start block Q0 [n, P]; per step j = 0 .. steps - 1 the caller
+ * reads q_j (mgp_blz_q: device pointer of the [n, P] block inside `work`), applies its operator and hands W = A q_j [n, P] to
+ * mgp_blz_step (two passes of classical Gram-Schmidt against q_0 .. q_j, alpha_j, beta_j, q_j+1; W is overwritten);
+ * mgp_blz_end copies alpha / beta (host [steps][P]) and synchronises `stream` -- nothing before it synchronises or reads back.
+ * `work` (mgp_blz_workspace_bytes; 0 = unsupported shape: P <= 16, steps <= 47) is laid out identically at every call and must
+ * not be touched in between. */
+size_t mgp_blz_workspace_bytes(int64_t n, int P, int steps);
+int mgp_blz_begin(const float* Q0, int64_t n, int P, int steps, void* work, size_t work_bytes, void* stream);
+float* mgp_blz_q(int64_t n, int P, int steps, int j, void* work, size_t work_bytes);
+int mgp_blz_step(float* W, int64_t n, int P, int steps, int j, void* work, size_t work_bytes, void* stream);
+int mgp_blz_end(int64_t n, int P, int steps, float* alpha, float* beta, void* work, size_t work_bytes, void* stream);
 size_t mgp_lanczos_tridiag_workspace_bytes(const mgp_operator_t* op, int steps);
 int mgp_lanczos_tridiag(const mgp_operator_t* op, const float* q0, int steps, float* alpha,
                         float* beta, float* Q_out, void* work, size_t work_bytes, void* stream);

@@ -103,6 +103,11 @@ SIGNATURES = {
     "mgp_cg_set_init_free": (c_int, [c_int]),
     "mgp_host_symeig": (c_int, [c_int, _P, _P, _P]),
     "mgp_lanczos_set_bound_mode": (c_int, [c_int]),
+    "mgp_blz_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "mgp_blz_begin": (c_int, [_P, c_int64, c_int, c_int, _P, c_size_t, _P]),
+    "mgp_blz_q": (c_void_p, [c_int64, c_int, c_int, c_int, _P, c_size_t]),
+    "mgp_blz_step": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "mgp_blz_end": (c_int, [c_int64, c_int, c_int, POINTER(c_float), POINTER(c_float), _P, c_size_t, _P]),
     "mgp_lanczos_tridiag_block_workspace_bytes": (c_size_t, [POINTER(OperatorT), c_int, c_int]),
     "mgp_lanczos_tridiag_block": (c_int, [POINTER(OperatorT), _P, c_int, c_int, POINTER(c_float), POINTER(c_float), _P,
                                          c_size_t, _P]),

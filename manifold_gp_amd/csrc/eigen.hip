@@ -1414,17 +1414,108 @@ __global__ __launch_bounds__(kBlock) void blz_normalize_kernel(const float* __re
 
 }  // namespace
 
-extern "C" size_t mgp_lanczos_tridiag_block_workspace_bytes(const mgp_operator_t* op, int P, int steps) {
-  if (!op || steps <= 0 || steps + 1 > kBlzMaxNq || P <= 0 || P > kBlzMaxP || op->L.n <= 0) return 0;
-  const int64_t n = op->L.n;
+namespace {
+
+// Buffers of P independent Lanczos runs of `steps` steps on vectors of length n, laid out in one workspace the same way at
+// every call (the external-operator form below is stateless: begin / step / end recompute this layout).
+struct Blz {
+  int64_t n, blockf, nblk, rpb;
+  int P, steps, RL, egrid;
+  float *Q, *W, *dpart, *npart, *hsum, *nsum, *d_alpha, *d_beta;
+  bool ok;
+};
+
+size_t blz_bytes(int64_t n, int P, int steps) {
   size_t s = mgp_align((size_t)(steps + 1) * n * P * sizeof(float));   // Q
   s += mgp_align((size_t)n * P * sizeof(float));                       // W
-  s += mgp_operator_workspace_bytes(op, P);
   s += mgp_align((size_t)256 * (steps + 1) * P * sizeof(float));        // dot partials
   s += mgp_align((size_t)256 * P * sizeof(float));                      // norm partials
   s += 2 * mgp_align((size_t)(steps + 1) * P * sizeof(float));          // alpha, beta
   s += mgp_align((size_t)(steps + 1) * P * sizeof(float)) + mgp_align(kBlzMaxP * sizeof(float));   // reduced dots / norms
-  return s + 4096;
+  return s + 2048;
+}
+
+Blz blz_layout(MgpArena& ar, int64_t n, int P, int steps) {
+  Blz b;
+  b.n = n; b.P = P; b.steps = steps;
+  b.Q = ar.take<float>((size_t)(steps + 1) * n * P);
+  b.W = ar.take<float>((size_t)n * P);
+  b.dpart = ar.take<float>((size_t)256 * (steps + 1) * P);
+  b.npart = ar.take<float>((size_t)256 * P);
+  b.hsum = ar.take<float>((size_t)(steps + 1) * P);
+  b.nsum = ar.take<float>((size_t)kBlzMaxP);
+  b.d_alpha = ar.take<float>((size_t)(steps + 1) * P);
+  b.d_beta = ar.take<float>((size_t)(steps + 1) * P);
+  b.ok = ar.ok();
+  b.RL = kBlock / P;
+  b.nblk = std::min<int64_t>(256, mgp_cdiv(n, 4 * b.RL));
+  if (b.nblk < 1) b.nblk = 1;
+  b.rpb = mgp_cdiv(n, b.nblk);
+  b.nblk = mgp_cdiv(n, b.rpb);
+  b.egrid = (int)std::min<int64_t>(2048, mgp_cdiv(n * P, kBlock));
+  b.blockf = n * P;
+  return b;
+}
+
+void blz_reduce(const Blz& b, const float* part, int count, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(blz_reduce_kernel, dim3((unsigned)mgp_cdiv(count, kBlock / 4)), dim3(kBlock), 0, st, part, (int)b.nblk, count, out);
+}
+
+// q_0 = Q0 / column norms: one update launch with a zero coefficient gives the norm partials
+int blz_begin(const Blz& b, const float* Q0, hipStream_t st) {
+  const int P = b.P, steps = b.steps;
+  MGP_HIP_TRY(hipMemcpyAsync(b.W, Q0, b.blockf * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipMemcpyAsync(b.Q, Q0, b.blockf * sizeof(float), hipMemcpyDeviceToDevice, st));
+  MGP_HIP_TRY(hipMemsetAsync(b.dpart, 0, (size_t)256 * P * sizeof(float), st));
+  MGP_HIP_TRY(hipMemsetAsync(b.d_alpha, 0, (size_t)(steps + 1) * P * sizeof(float), st));
+  MGP_HIP_TRY(hipMemsetAsync(b.hsum, 0, (size_t)P * sizeof(float), st));
+  hipLaunchKernelGGL(blz_update_kernel, dim3((int)b.nblk), dim3(kBlock), (size_t)(P + b.RL * P) * sizeof(float), st, b.W, b.Q, b.n, P, 1,
+                     b.rpb, b.hsum, b.d_alpha + (size_t)steps * P, 0, b.npart);
+  MGP_LAUNCH_CHECK();
+  blz_reduce(b, b.npart, P, b.nsum, st);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(blz_normalize_kernel, dim3(b.egrid), dim3(kBlock), 0, st, b.W, b.Q, b.n, P, b.nsum, b.d_beta + (size_t)steps * P);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+// step j on W = A q_j (overwritten): classical Gram-Schmidt against q_0..q_j, twice; alpha_j, beta_j; q_{j+1}
+int blz_step(const Blz& b, float* W, int j, hipStream_t st) {
+  const int P = b.P, nq = j + 1;
+  for (int pass = 0; pass < 2; ++pass) {
+    hipLaunchKernelGGL(blz_dots_kernel, dim3((int)b.nblk), dim3(kBlock), (size_t)nq * b.RL * P * sizeof(float), st, W, b.Q, b.n, P,
+                       nq, b.rpb, b.dpart);
+    MGP_LAUNCH_CHECK();
+    blz_reduce(b, b.dpart, nq * P, b.hsum, st);
+    MGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(blz_update_kernel, dim3((int)b.nblk), dim3(kBlock), (size_t)(nq * P + b.RL * P) * sizeof(float), st, W,
+                       b.Q, b.n, P, nq, b.rpb, b.hsum, b.d_alpha + (size_t)j * P, pass, b.npart);
+    MGP_LAUNCH_CHECK();
+  }
+  blz_reduce(b, b.npart, P, b.nsum, st);
+  MGP_LAUNCH_CHECK();
+  hipLaunchKernelGGL(blz_normalize_kernel, dim3(b.egrid), dim3(kBlock), 0, st, W, b.Q + (int64_t)(j + 1) * b.blockf, b.n, P, b.nsum,
+                     b.d_beta + (size_t)j * P);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+int blz_end(const Blz& b, float* alpha, float* beta, hipStream_t st) {
+  MGP_HIP_TRY(hipMemcpyAsync(alpha, b.d_alpha, (size_t)b.steps * b.P * sizeof(float), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipMemcpyAsync(beta, b.d_beta, (size_t)b.steps * b.P * sizeof(float), hipMemcpyDeviceToHost, st));
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  return MGP_OK;
+}
+
+bool blz_shape_ok(int64_t n, int P, int steps) {
+  return n > 0 && steps > 0 && steps + 1 <= kBlzMaxNq && P > 0 && P <= kBlzMaxP;
+}
+
+}  // namespace
+
+extern "C" size_t mgp_lanczos_tridiag_block_workspace_bytes(const mgp_operator_t* op, int P, int steps) {
+  if (!op || !blz_shape_ok(op->L.n, P, steps)) return 0;
+  return blz_bytes(op->L.n, P, steps) + mgp_operator_workspace_bytes(op, P) + 2048;
 }
 
 // Q0 [n, P] start vectors (columns need not be normalised).  alpha / beta: host [steps][P].
@@ -1433,68 +1524,63 @@ extern "C" int mgp_lanczos_tridiag_block(const mgp_operator_t* op, const float* 
   if (!op || !Q0 || !alpha || !beta || !work || steps <= 0 || P <= 0) return MGP_ERR_ARG;
   if (P > kBlzMaxP || steps + 1 > kBlzMaxNq) return MGP_ERR_UNSUPPORTED;
   if (work_bytes < mgp_lanczos_tridiag_block_workspace_bytes(op, P, steps)) return MGP_ERR_WORKSPACE;
-  const int64_t n = op->L.n;
   hipStream_t st = mgp_stream(stream);
   MgpArena ar(work, work_bytes);
-  float* Q = ar.take<float>((size_t)(steps + 1) * n * P);
-  float* W = ar.take<float>((size_t)n * P);
+  const Blz b = blz_layout(ar, op->L.n, P, steps);
   const size_t owb = mgp_operator_workspace_bytes(op, P);
   void* ow = ar.take<char>(owb);
-  float* dpart = ar.take<float>((size_t)256 * (steps + 1) * P);
-  float* npart = ar.take<float>((size_t)256 * P);
-  float* hsum = ar.take<float>((size_t)(steps + 1) * P);
-  float* nsum = ar.take<float>((size_t)kBlzMaxP);
-  float* d_alpha = ar.take<float>((size_t)(steps + 1) * P);
-  float* d_beta = ar.take<float>((size_t)(steps + 1) * P);
-  if (!ar.ok()) return MGP_ERR_WORKSPACE;
-  const int RL = kBlock / P;
-  int64_t nblk = std::min<int64_t>(256, mgp_cdiv(n, 4 * RL));
-  if (nblk < 1) nblk = 1;
-  const int64_t rpb = mgp_cdiv(n, nblk);
-  nblk = mgp_cdiv(n, rpb);
-  const int egrid = (int)std::min<int64_t>(2048, mgp_cdiv(n * P, kBlock));
-  const int64_t blockf = n * P;
-
-  // q_0 = Q0 / column norms: one update launch with a zero coefficient gives the norm partials
-  MGP_HIP_TRY(hipMemcpyAsync(W, Q0, blockf * sizeof(float), hipMemcpyDeviceToDevice, st));
-  MGP_HIP_TRY(hipMemcpyAsync(Q, Q0, blockf * sizeof(float), hipMemcpyDeviceToDevice, st));
-  MGP_HIP_TRY(hipMemsetAsync(dpart, 0, (size_t)256 * P * sizeof(float), st));
-  MGP_HIP_TRY(hipMemsetAsync(d_alpha, 0, (size_t)(steps + 1) * P * sizeof(float), st));
-  auto reduce = [&](const float* part, int count, float* out) {
-    hipLaunchKernelGGL(blz_reduce_kernel, dim3((unsigned)mgp_cdiv(count, kBlock / 4)), dim3(kBlock), 0, st, part, (int)nblk, count, out);
-  };
-  MGP_HIP_TRY(hipMemsetAsync(hsum, 0, (size_t)P * sizeof(float), st));
-  hipLaunchKernelGGL(blz_update_kernel, dim3((int)nblk), dim3(kBlock), (size_t)(P + RL * P) * sizeof(float), st, W, Q, n, P, 1,
-                     rpb, hsum, d_alpha + (size_t)steps * P, 0, npart);
-  MGP_LAUNCH_CHECK();
-  reduce(npart, P, nsum);
-  MGP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(blz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, W, Q, n, P, nsum, d_beta + (size_t)steps * P);
-  MGP_LAUNCH_CHECK();
+  if (!b.ok || !ar.ok()) return MGP_ERR_WORKSPACE;
+  MGP_TRY(blz_begin(b, Q0, st));
   for (int j = 0; j < steps; ++j) {
-    float* qj = Q + (int64_t)j * blockf;
-    MGP_TRY(mgp_operator_apply_ex(op, qj, P, W, nullptr, nullptr, nullptr, nullptr, ow, owb, stream));
-    const int nq = j + 1;
-    for (int pass = 0; pass < 2; ++pass) {   // classical Gram-Schmidt against q_0..q_j, twice
-      hipLaunchKernelGGL(blz_dots_kernel, dim3((int)nblk), dim3(kBlock), (size_t)nq * RL * P * sizeof(float), st, W, Q, n, P,
-                         nq, rpb, dpart);
-      MGP_LAUNCH_CHECK();
-      reduce(dpart, nq * P, hsum);
-      MGP_LAUNCH_CHECK();
-      hipLaunchKernelGGL(blz_update_kernel, dim3((int)nblk), dim3(kBlock), (size_t)(nq * P + RL * P) * sizeof(float), st, W,
-                         Q, n, P, nq, rpb, hsum, d_alpha + (size_t)j * P, pass, npart);
-      MGP_LAUNCH_CHECK();
-    }
-    reduce(npart, P, nsum);
-    MGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(blz_normalize_kernel, dim3(egrid), dim3(kBlock), 0, st, W, Q + (int64_t)(j + 1) * blockf, n, P, nsum,
-                       d_beta + (size_t)j * P);
-    MGP_LAUNCH_CHECK();
+    MGP_TRY(mgp_operator_apply_ex(op, b.Q + (int64_t)j * b.blockf, P, b.W, nullptr, nullptr, nullptr, nullptr, ow, owb, stream));
+    MGP_TRY(blz_step(b, b.W, j, st));
   }
-  MGP_HIP_TRY(hipMemcpyAsync(alpha, d_alpha, (size_t)steps * P * sizeof(float), hipMemcpyDeviceToHost, st));
-  MGP_HIP_TRY(hipMemcpyAsync(beta, d_beta, (size_t)steps * P * sizeof(float), hipMemcpyDeviceToHost, st));
-  MGP_HIP_TRY(hipStreamSynchronize(st));
-  return MGP_OK;
+  return blz_end(b, alpha, beta, st);
+}
+
+// ---- the same P Lanczos runs for an operator the CALLER applies (a wrapper around a Schur complement: every product is a
+// CG solve of its own): begin normalises the start block, the caller reads q_j (mgp_blz_q), applies its operator and hands
+// W = A q_j to mgp_blz_step (W is overwritten), mgp_blz_end copies alpha / beta [steps][P] to the host and synchronises.
+// Nothing in between synchronises or reads anything back.  The workspace is laid out identically at every call.
+extern "C" size_t mgp_blz_workspace_bytes(int64_t n, int P, int steps) {
+  return blz_shape_ok(n, P, steps) ? blz_bytes(n, P, steps) : 0;
+}
+
+extern "C" int mgp_blz_begin(const float* Q0, int64_t n, int P, int steps, void* work, size_t work_bytes, void* stream) {
+  if (!Q0 || !work) return MGP_ERR_ARG;
+  if (!blz_shape_ok(n, P, steps)) return MGP_ERR_UNSUPPORTED;
+  if (work_bytes < blz_bytes(n, P, steps)) return MGP_ERR_WORKSPACE;
+  MgpArena ar(work, work_bytes);
+  const Blz b = blz_layout(ar, n, P, steps);
+  if (!b.ok) return MGP_ERR_WORKSPACE;
+  return blz_begin(b, Q0, mgp_stream(stream));
+}
+
+extern "C" float* mgp_blz_q(int64_t n, int P, int steps, int j, void* work, size_t work_bytes) {
+  if (!work || !blz_shape_ok(n, P, steps) || j < 0 || j > steps || work_bytes < blz_bytes(n, P, steps)) return nullptr;
+  MgpArena ar(work, work_bytes);
+  const Blz b = blz_layout(ar, n, P, steps);
+  return b.ok ? b.Q + (int64_t)j * b.blockf : nullptr;
+}
+
+extern "C" int mgp_blz_step(float* W, int64_t n, int P, int steps, int j, void* work, size_t work_bytes, void* stream) {
+  if (!W || !work || j < 0 || j >= steps) return MGP_ERR_ARG;
+  if (!blz_shape_ok(n, P, steps)) return MGP_ERR_UNSUPPORTED;
+  if (work_bytes < blz_bytes(n, P, steps)) return MGP_ERR_WORKSPACE;
+  MgpArena ar(work, work_bytes);
+  const Blz b = blz_layout(ar, n, P, steps);
+  if (!b.ok) return MGP_ERR_WORKSPACE;
+  return blz_step(b, W, j, mgp_stream(stream));
+}
+
+extern "C" int mgp_blz_end(int64_t n, int P, int steps, float* alpha, float* beta, void* work, size_t work_bytes, void* stream) {
+  if (!alpha || !beta || !work) return MGP_ERR_ARG;
+  if (!blz_shape_ok(n, P, steps)) return MGP_ERR_UNSUPPORTED;
+  if (work_bytes < blz_bytes(n, P, steps)) return MGP_ERR_WORKSPACE;
+  MgpArena ar(work, work_bytes);
+  const Blz b = blz_layout(ar, n, P, steps);
+  if (!b.ok) return MGP_ERR_WORKSPACE;
+  return blz_end(b, alpha, beta, mgp_stream(stream));
 }
 
 extern "C" size_t mgp_lanczos_tridiag_workspace_bytes(const mgp_operator_t* op, int steps) {

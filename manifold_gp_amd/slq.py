@@ -120,6 +120,9 @@ def _quadrature_log_sum(a, b, fun=None):
     return total
 
 
+HIP_GENERIC_LANCZOS = [True]   # False: the torch form of the step below at every shape (A/B runs, tests; it stays for P > 16)
+
+
 def _lanczos_block_generic(operator, Z, steps):
     """The same P independent Lanczos runs for an operator that is NOT one polynomial chain (wrappers around
     a Schur complement): torch vector algebra around `operator.matmul` on [n, P] blocks -- every matmul
@@ -130,6 +133,26 @@ def _lanczos_block_generic(operator, Z, steps):
     # each -- was 4 (j + 1) small launches per step, 840 per 20-step run, plus two host reads per step: ~9 ms of an
     # 80 ms semi-supervised epoch.)
     n, P = Z.shape
+    wb = lib().mgp_blz_workspace_bytes(n, P, int(steps)) if (HIP_GENERIC_LANCZOS[0] and Z.is_cuda) else 0
+    if wb:
+        # (round 5) the vector algebra of a step as ONE call of seven launches (mgp_blz_step: the kernels of the block Lanczos
+        # over a descriptor) instead of ~20 torch ops on [n, 12] blocks -- after every product, a CG solve that ends in a host
+        # wait, the device sat idle while the host issued them: ~2.5 ms of a 57 ms semi-supervised epoch
+        Z = _lib.f32c(Z)
+        work = _lib.workspace(wb, "blz_generic", Z.device)
+        wp, st = ptr(work), stream()
+        check(lib().mgp_blz_begin(ptr(Z), n, P, int(steps), wp, wb, st), "mgp_blz_begin")
+        off0 = int(lib().mgp_blz_q(n, P, int(steps), 0, wp, wb)) - work.data_ptr()
+        Qall = work[off0:off0 + (steps + 1) * n * P * 4].view(torch.float32).view(steps + 1, n, P)
+        for j in range(steps):
+            W = _lib.f32c(operator.matmul(Qall[j]))
+            if W.data_ptr() == Qall[j].data_ptr():
+                W = W.clone()
+            check(lib().mgp_blz_step(ptr(W), n, P, int(steps), j, wp, wb, st), "mgp_blz_step")
+        alpha = (ctypes.c_float * (steps * P))()
+        beta = (ctypes.c_float * (steps * P))()
+        check(lib().mgp_blz_end(n, P, int(steps), alpha, beta, wp, wb, st), "mgp_blz_end")
+        return (np.array(alpha, dtype=np.float64).reshape(steps, P), np.array(beta, dtype=np.float64).reshape(steps, P))
     Qt = torch.empty(P, steps + 1, n, dtype=Z.dtype, device=Z.device)
     Qt[:, 0, :] = (Z / Z.norm(dim=0, keepdim=True).clamp_min(1e-30)).t()
     A = torch.zeros(steps, P, dtype=Z.dtype, device=Z.device)

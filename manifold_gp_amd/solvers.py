@@ -173,6 +173,40 @@ class CgPlan:
             X = self._xout
         return rg.unpermute(self.solution_view(), out=X)
 
+    def solve_repeated(self, B, times):
+        """A^-times B: `times` solves in a row, each on the previous one's solution (the factors of Q = (tau I + L)^nu are the
+        same operator).  On a relabelled plan the right-hand side is permuted in ONCE and the result out once, and nothing but
+        the library calls sits between two solves (the host wait that ends a solve leaves the device idle until the next launch
+        arrives: two gathers and their Python less per factor).  Returns (X, total iterations, worst status)."""
+        if times == 1:
+            X = self.solve(B)
+            return X, self.iters, self.status
+        if B.device.type != "cuda":
+            _lib.require_device(B)
+        if B.dtype != torch.float32 or not B.is_contiguous():
+            B = _lib.f32c(B)
+        assert B.shape == (self.desc.n, self.C)
+        rg = self._rg
+        cur = rg.permute(B) if rg is not None else B
+        if getattr(self, "_chain_tmp", None) is None:
+            self._chain_tmp = (torch.empty_like(cur), torch.empty_like(cur))      # solve k lands in [k % 2], solve k + 1 reads it
+        its, worst = 0, 0
+        for k in range(times):
+            last = k == times - 1
+            dst = None if last else self._chain_tmp[k % 2].data_ptr()
+            rc = self._solve_fn(self.handle, cur.data_ptr(), dst, self._iters_ref, self._resid, self._status_ref)
+            if rc != 0:
+                check(rc, "mgp_cg_plan_solve")
+            its += self._iters.value
+            worst = max(worst, self._status.value)
+            if self._status.value == 3:
+                break
+            if not last:
+                cur = self._chain_tmp[k % 2]
+        self.iters, self.status = its, worst
+        X = self.solution_view()
+        return (rg.unpermute(X) if rg is not None else X.clone()), its, worst
+
     def close(self):
         if self.handle:
             if lib().mgp_cg_plan_poisoned(self.handle):
@@ -288,12 +322,11 @@ def _factorised_solve(desc, B, kw):
     for rnd in range(3):
         kw["tol"] = max(want, 1e-7) / ((div0 if rnd == 0 else 8.0) * nu)
         Y = R if dinv is None else (R * dinv).contiguous()
-        for _ in range(nu):
-            plan = _cached_plan(dB, Y.shape[1], kw)
-            Y = plan.solve(Y)                    # (a fresh tensor: copy=True)
-            its += plan.iters
-            if plan.status == 3:
-                raise RuntimeError("NaNs encountered in CG")
+        plan = _cached_plan(dB, Y.shape[1], kw)
+        Y, its_k, status = plan.solve_repeated(Y, nu)       # (a fresh tensor)
+        its += its_k
+        if status == 3:
+            raise RuntimeError("NaNs encountered in CG")
         if dinv is not None:
             Y = Y * dinv
         if desc.scale != 1.0:

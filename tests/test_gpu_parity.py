@@ -1945,6 +1945,59 @@ def test_lanczos_tridiag_block_matches_single_runs(mgp, golden, dev):
         np.testing.assert_allclose(B[:, p], b, rtol=2e-3, atol=2e-3 * np.abs(b).max())
 
 
+def test_blz_external_operator_matches_block_lanczos(mgp, golden, dev):
+    """mgp_blz_begin / _step / _end (round 5): the block Lanczos for an operator the caller applies -- the inverse of a Schur
+    complement in the semi-supervised log-determinant -- runs the kernels of mgp_lanczos_tridiag_block: with the operator
+    applied through the same descriptor the tridiagonals are identical bit for bit, and they agree with the torch form of the
+    step (batched Gram-Schmidt) that the library form replaces, on the descriptor and on a dense SPD matrix; the workspace layout
+    is the same at every call (q_j read back = the normalised vectors, orthonormal)."""
+    from manifold_gp_amd import slq
+    g = golden("dumbbell_k50_noloop")
+    lap = _operator(mgp, g, dev, "symmetric")
+    Q = mgp.operators.PrecisionMaternOperator(lap, 2, torch.tensor([[float(g["kappa"])]], device=dev))
+    desc = Q._descriptor()
+    n = lap.shape[0]
+    gen = torch.Generator(device="cpu").manual_seed(5)
+
+    class Op:
+        def __init__(self, fn):
+            self.fn, self.shape = fn, (n, n)
+
+        def matmul(self, V):
+            return self.fn(V)
+    for P, steps in ((12, 20), (4, 7), (16, 12)):
+        Z = (torch.randint(0, 2, (n, P), generator=gen).float() * 2 - 1).to(dev)
+        A0, B0 = slq.lanczos_tridiag_block(desc, Z, steps)
+        A1, B1 = slq._lanczos_block_generic(Op(desc.apply), Z, steps)
+        assert np.array_equal(A0, A1) and np.array_equal(B0, B1), (P, steps)
+        slq.HIP_GENERIC_LANCZOS[0] = False
+        try:
+            A2, B2 = slq._lanczos_block_generic(Op(desc.apply), Z, steps)
+        finally:
+            slq.HIP_GENERIC_LANCZOS[0] = True
+        np.testing.assert_allclose(A1, A2, rtol=2e-3, atol=2e-3 * np.abs(A2).max())
+        np.testing.assert_allclose(B1[:steps - 1], B2[:steps - 1], rtol=2e-3, atol=2e-3 * np.abs(B2).max())
+    # a dense SPD operator, and the basis the library kept
+    M = torch.randn(n, n, generator=gen).to(dev)
+    S = M @ M.t() / n + torch.eye(n, device=dev)
+    P, steps = 8, 10
+    Z = torch.randn(n, P, generator=gen).to(dev)
+    A1, B1 = slq._lanczos_block_generic(Op(lambda V: S @ V), Z, steps)
+    from manifold_gp_amd import _lib
+    wb = _lib.lib().mgp_blz_workspace_bytes(n, P, steps)
+    work = _lib.workspace(wb, "blz_generic", dev)
+    q0 = int(_lib.lib().mgp_blz_q(n, P, steps, 0, _lib.ptr(work), wb)) - work.data_ptr()
+    Qall = work[q0:q0 + (steps + 1) * n * P * 4].view(torch.float32).view(steps + 1, n, P).double()
+    for p in (0, 5):
+        Qp = Qall[:steps, :, p]                                        # [steps, n]
+        G = Qp @ Qp.t()
+        assert float((G - torch.eye(steps, device=dev, dtype=torch.float64)).abs().max()) < 1e-4
+        Tp = Qp @ S.double() @ Qp.t()
+        np.testing.assert_allclose(np.diag(Tp.cpu().numpy()), A1[:, p], rtol=1e-3, atol=1e-3)
+        np.testing.assert_allclose(np.diag(Tp.cpu().numpy(), 1), B1[:steps - 1, p], rtol=1e-3, atol=1e-3)
+    assert _lib.lib().mgp_blz_workspace_bytes(n, 17, steps) == 0 and _lib.lib().mgp_blz_workspace_bytes(n, 8, 48) == 0
+
+
 def test_knn_lowdim_few_queries_split_point_range(mgp, dev):
     """Few queries against many points (out-of-sample features of a small batch): the fused filter splits
     the point range over several workgroups that share the candidate lists; still bit-exact."""

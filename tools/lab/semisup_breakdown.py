@@ -11,6 +11,15 @@ from manifold_gp_amd.operators import _descriptor
 
 if os.environ.get("MGP_CHAIN_MIN_C"):
     solvers.CHAIN_SOLVE_MIN_C[0] = int(os.environ["MGP_CHAIN_MIN_C"])
+if os.environ.get("MGP_NO_REPEAT"):
+    def _rep(self, B, times):
+        its, worst = 0, 0
+        for _ in range(times):
+            B = self.solve(B); its += self.iters; worst = max(worst, self.status)
+        return B, its, worst
+    solvers.CgPlan.solve_repeated = _rep
+if os.environ.get("MGP_NO_REBIND"):
+    solvers.REBIND_PLANS[0] = False
 mode = sys.argv[1] if len(sys.argv) > 1 else "semisup"
 epochs = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 log = collections.Counter()
