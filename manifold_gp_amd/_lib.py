@@ -238,6 +238,23 @@ def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def host_scalar(owner, name):
+    """float(owner.<name>) for a hyper-parameter an operator holds, read from the device ONCE per (tensor object, version): an
+    operator asks for its length scale / scale / noise every time it describes itself (tens of times per training epoch), and every
+    `.item()` is a host wait that drains the queue.  The tensor is the operator's own attribute, so identity + `_version` say whether
+    the cached value still holds."""
+    t = getattr(owner, name)
+    if not torch.is_tensor(t):
+        return float(t)
+    cache = owner.__dict__.setdefault("_host_scalars", {})
+    hit = cache.get(name)
+    if hit is not None and hit[0] is t and hit[1] == t._version:
+        return hit[2]
+    v = float(t.reshape(-1)[0].item())
+    cache[name] = (t, t._version, v)
+    return v
+
+
 def f32c(t):
     """float32 + contiguous (the reference calls rhs.contiguous() at every _matmul)."""
     if t.dtype != torch.float32:

@@ -89,13 +89,18 @@ def _host_values(*ts):
 
 class _FusedSpmm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, eps, a, b, co, cb, pre, post, base, data):
+    def forward(ctx, X, eps, a, b, co, cb, pre, post, base, data, known=None):
         ctx.data = data
         ctx.save_for_backward(X, eps, a, b, co, cb,
                               pre if pre is not None else torch.empty(0), post if post is not None else torch.empty(0),
                               base if base is not None else torch.empty(0))
         ctx.has = (pre is not None, post is not None, base is not None)
-        av, bv, cov, cbv = ctx.vals = _host_values(a, b, co, cb)       # read once, reused by backward
+        # (known: host values the caller already holds for some of a, b, co, cb -- a device scalar derived from a hyper-parameter
+        # whose host copy exists, _lib.host_scalar -- so that the launch needs no read-back of its own)
+        kn = known or (None, None, None, None)
+        need = [t for t, k in zip((a, b, co, cb), kn) if k is None]
+        got = iter(_host_values(*need)) if need else iter(())
+        av, bv, cov, cbv = ctx.vals = tuple(float(k) if k is not None else next(got) for k in kn)   # read once, reused by backward
         return _spmm(data, X, av, bv, pre, post, base, cbv, cov)
 
     @staticmethod
@@ -140,15 +145,17 @@ class _FusedSpmm(torch.autograd.Function):
             gcb = ((g * base).sum() if base is not None else torch.zeros((), device=g.device)).reshape(cb.shape).to(cb.device)
         if need[8] and base is not None:
             gbase = g * cbv
-        return gX, geps, ga, gb, gco, gcb, gpre, gpost, gbase, None
+        return gX, geps, ga, gb, gco, gcb, gpre, gpost, gbase, None, None
 
 
-def fused_spmm(data, X, eps, a=0.0, b=1.0, co=1.0, cb=0.0, pre=None, post=None, base=None):
-    """Differentiable fused SpMM on the Laplacian held by `data` (built at the current eps)."""
+def fused_spmm(data, X, eps, a=0.0, b=1.0, co=1.0, cb=0.0, pre=None, post=None, base=None, a_value=None):
+    """Differentiable fused SpMM on the Laplacian held by `data` (built at the current eps).  a_value: the host value of `a` when
+    the caller has it (no read-back)."""
     squeeze = X.dim() == 1
     Xc = _lib.f32c(X.unsqueeze(-1) if squeeze else X)
     if base is not None and base.dim() == 1:
         base = base.unsqueeze(-1)
     eps = eps if torch.is_tensor(eps) else torch.tensor(float(eps), device=Xc.device)
-    out = _FusedSpmm.apply(Xc, eps, _as0(a, Xc), _as0(b, Xc), _as0(co, Xc), _as0(cb, Xc), pre, post, base, data)
+    known = None if a_value is None else (float(a_value), None, None, None)
+    out = _FusedSpmm.apply(Xc, eps, _as0(a, Xc), _as0(b, Xc), _as0(co, Xc), _as0(cb, Xc), pre, post, base, data, known)
     return out.squeeze(-1) if squeeze else out

@@ -3,6 +3,7 @@ Q (v - s Q (v - s Q v)) = (Q - s Q^2 + s^2 Q^3) v, the 2nd-order Neumann form of
 import torch
 
 from .._compat import LinearOperator
+from .._lib import host_scalar
 
 
 # When the wrapped operator is one polynomial chain the solve below can also run as HIP CG on the cubic polynomial itself
@@ -10,10 +11,6 @@ from .._compat import LinearOperator
 # ~100 such iterations per 12-probe solve, 600 SpMM launches, against ~30 iterations of the better conditioned wrapped
 # operator plus two or three series terms: 25 -> 18 ms per epoch.  False restores that CG (A/B runs).
 _NEUMANN_FOR_CHAINS = [True]
-
-
-def _scalar(t):
-    return float(t.reshape(-1)[0].item()) if torch.is_tensor(t) else float(t)
 
 
 class NoiseWrapperOperator(LinearOperator):
@@ -26,7 +23,7 @@ class NoiseWrapperOperator(LinearOperator):
         inner = getattr(self.operator, "_descriptor", lambda: None)()
         if inner is None or inner.form != 0:
             return None
-        return inner.with_(form=1, noise=_scalar(self.noise))
+        return inner.with_(form=1, noise=host_scalar(self, "noise"))
 
     def _hyper_tensors(self):
         return getattr(self.operator, "_hyper_tensors", lambda: [])() + [self.noise]
@@ -40,7 +37,7 @@ class NoiseWrapperOperator(LinearOperator):
         d = self._descriptor()
         if d is not None:
             return d.apply(rhs)
-        s = _scalar(self.noise)
+        s = host_scalar(self, "noise")
         Q = self.operator._matmul
         rhs = rhs.contiguous()
         return Q(rhs - s * Q(rhs - s * Q(rhs)))
@@ -69,7 +66,7 @@ class NoiseWrapperOperator(LinearOperator):
         from .. import _lib
         from .._compat import settings
         from ..solvers import generic_cg
-        s = _scalar(self.noise)
+        s = host_scalar(self, "noise")
         inner = self.operator
         tol = float(settings.cg_tolerance.value())
 

@@ -1,13 +1,11 @@
 """PrecisionMaternOperator: Q = (2 nu / kappa^2 I + L)^nu (x D for random walk), reference
 manifold_gp/operators/precision_matern_operator.py:10-53, applied as nu fused SpMM launches."""
+import numpy as np
 import torch
 
 from .._compat import LinearOperator
+from .._lib import host_scalar
 from ._descriptor import Descriptor
-
-
-def _scalar(t):
-    return float(t.reshape(-1)[0].item()) if torch.is_tensor(t) else float(t)
 
 
 class PrecisionMaternOperator(LinearOperator):
@@ -21,7 +19,7 @@ class PrecisionMaternOperator(LinearOperator):
         d = self.laplacian.data
         sq = d.dsqrt if self.laplacian.normalization == "randomwalk" else None
         # D (tau I + L_rw)^nu = D^1/2 (tau I + L_sym)^nu D^1/2   (precision_matern_operator.py:30-37)
-        return Descriptor(d, int(self.nu), _scalar(self.lengthscale), pre=sq, post=sq)
+        return Descriptor(d, int(self.nu), host_scalar(self, "lengthscale"), pre=sq, post=sq)
 
     def _hyper_tensors(self):
         return self.laplacian._hyper_tensors() + [self.lengthscale]
@@ -33,11 +31,15 @@ class PrecisionMaternOperator(LinearOperator):
         d, eps = lap.data, lap.graphbandwidth
         ls = self.lengthscale.reshape(()) if torch.is_tensor(self.lengthscale) else torch.tensor(float(self.lengthscale))
         tau = 2.0 * self.nu / ls.to(d.graph.device).square()
+        # the same value on the host, in the float32 steps torch takes on the device (scalar / tensor = reciprocal * scalar): the
+        # launches below take it by value, and reading `tau` back would be a host wait per launch
+        ls32 = np.float32(host_scalar(self, "lengthscale"))
+        tau_host = float((np.float32(1.0) / (ls32 * ls32)) * np.float32(2.0 * self.nu))
         sq = node_vector(eps, d, "dsqrt") if lap.normalization == "randomwalk" else None
         out = rhs
         for s in range(self.nu):
             out = fused_spmm(d, out, eps, a=tau, b=1.0, pre=sq if s == 0 else None,
-                             post=sq if s == self.nu - 1 else None)
+                             post=sq if s == self.nu - 1 else None, a_value=tau_host)
         return out
 
     def _matmul(self, rhs):

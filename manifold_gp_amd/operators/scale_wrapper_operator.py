@@ -3,10 +3,7 @@ When the wrapped operator is a polynomial chain the scale rides in the last SpMM
 import torch
 
 from .._compat import LinearOperator
-
-
-def _scalar(t):
-    return float(t.reshape(-1)[0].item()) if torch.is_tensor(t) else float(t)
+from .._lib import host_scalar
 
 
 class ScaleWrapperOperator(LinearOperator):
@@ -17,7 +14,7 @@ class ScaleWrapperOperator(LinearOperator):
         self.inverse_scale = inverse_scale
 
     def _factor(self):
-        s = _scalar(self.scale)
+        s = host_scalar(self, "scale")
         return 1.0 / s if self.inverse_scale else s
 
     def _descriptor(self):
