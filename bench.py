@@ -578,6 +578,10 @@ def _main(quiet):
             if ps is not None:
                 ps["profile_of_this_source_tree"] = ps.get("source_hash") == tree_hash
                 st[key]["kernel_time_profile"] = ps
+                # kernel-time share of the epoch: the profile's kernel time (rocprofv3 does not stretch kernel durations) over THIS
+                # run's epoch time; only quoted while the profile is of this source tree
+                if ps["profile_of_this_source_tree"] and ps.get("kernel_ms_per_epoch") and st[key].get("epoch_ms"):
+                    st[key]["kernel_share"] = round(min(1.0, ps["kernel_ms_per_epoch"] / st[key]["epoch_ms"]), 3)
         line["stages"] = st
         log("[bench] reference shape ...")
         line["reference_bench"] = bench_stages.reference_bench(dev)

@@ -32,6 +32,9 @@
 namespace {
 
 constexpr int kBlock = 256;
+#ifndef MGP_LAB_UPD
+#define MGP_LAB_UPD 0      // lab builds (tools/lab/upd_bounds.sh): 4 = never converge, alpha = beta = 0; | 1 skip the partial reads; | 2 skip the vector pass
+#endif
 constexpr int kMaxC = 256;
 constexpr int kMaxGridVec = 512;
 constexpr int kMaxPartials = 4096;   // capacity of the gamma / rr partial arrays
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
       rr2[0] = rr2[1] = a.tot[C + cc];
       d = a.tot[2 * C + cc];
     }
-  } else if (cc < C) {
+  } else if (cc < C && !(MGP_LAB_UPD & 1)) {
     // batches of 8 / 32 loads on clamped indices, masked afterwards: all in flight together (one round trip per
     // batch: with 256 workgroups and TS = 16 slices the gamma / rr partials are two batches, the ~940 delta
     // partials of a 12-column SpMM two as well)
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
       }
       if (!isfinite(alpha) || !isfinite(beta)) { alpha = 0.f; beta = 0.f; }
     }
+    if (MGP_LAB_UPD) { alpha = 0.f; beta = 0.f; }
     sh_alpha[tid] = alpha;
     sh_beta[tid] = beta;
     if (blockIdx.x == 0) {
@@ -352,6 +356,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
       if (all) { done = 1; status = 1; }
     }
     for (int c = 0; c < C; ++c) if (!isfinite(sh_rel[c])) { done = 1; status = 3; }
+    if (MGP_LAB_UPD) { done = 0; status = 0; }
     if (!done && it > a.max_iter) { done = 1; status = 2; }
     sh_done = done;
     if (done && blockIdx.x == 0) {
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_kernel(CgArgs a) {
 
   // ---- fused vector update over this workgroup's contiguous rows
   float ng = 0.f, nrr = 0.f;
-  if (cc < C) {
+  if (cc < C && !(MGP_LAB_UPD & 2)) {
     const float alpha = sh_alpha[cc], beta = sh_beta[cc];
     // eight row passes per batch, all their loads (clamped rows, masked afterwards) in flight before the
     // first use: with one pass at a time a workgroup's 30 passes were 30 dependent round trips (27 us per

@@ -4,7 +4,9 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
 import bench
-from manifold_gp_amd import solvers
+from manifold_gp_amd import solvers, _lib as _mlib
+if os.environ.get("MGP_LAB_LIB"):
+    _mlib.LIB_PATH = os.path.abspath(os.environ["MGP_LAB_LIB"])
 from manifold_gp_amd._lib import lib
 from manifold_gp_amd.operators._descriptor import Descriptor
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -23,7 +25,7 @@ mask = (torch.rand(data.graph.n, device=dev) > 0.1).float()
 desc = Descriptor(data=data, nu=2, kappa=3.0, pre=data.dsqrt * mask, post=data.dsqrt * mask)
 torch.manual_seed(0)
 B = torch.randn(data.graph.n, C, device=dev) * mask.view(-1, 1)
-plan = solvers.CgPlan(desc, C, tol=1e-4, max_iter=400, stop_mode=1, jacobi=jac)
+plan = solvers.CgPlan(desc, C, tol=1e-4, max_iter=int(os.environ.get("MGP_MAX_ITER", 400)), stop_mode=1, jacobi=jac)
 for _ in range(3):
     X = plan.solve(B)
 torch.cuda.synchronize()

@@ -45,7 +45,7 @@ def main(tag):
     res = {}
     pats = {"spmv_kernel (no pre-scaling)": r"spmv_kernel<\d+, \d+, false|spmv_tile_kernel<false",
             "spmv_kernel (pre-scaled input)": r"spmv_kernel<\d+, \d+, true|spmv_tile_kernel<true",
-            "cg_update_kernel": "cg_update_(c1_)?kernel", "cg_init_kernel": "cg_init_kernel"}
+            "cg_update_kernel": "cg_update_(c1_|q_)?kernel", "cg_init_kernel": "cg_init_kernel"}
     for label, k in pats.items():
         fs, n1 = med(f, "FETCH_SIZE", k)
         ws, _ = med(wv, "WRITE_SIZE", k)
