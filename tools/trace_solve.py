@@ -9,13 +9,16 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 dec = [i for i, r in enumerate(rows) if "cg_update_c1_kernel<true" in r["Kernel_Name"] or "cg_decide" in r["Kernel_Name"]]
 cands = dec[::-1] if dec else [max(i for i, r in enumerate(rows) if "cg_update" in r["Kernel_Name"])]
 # walk back to the start of that solve: the gap before its first kernel is a host round trip (>= 8 us).  Under the profiler a
-# replay now and then shows such a gap INSIDE a solve: take the last solve that comes out whole (five kernels or more)
-for end in cands:
+# replay now and then shows such a gap INSIDE a solve: among the last 200 solves take the last one of the most common length
+import collections
+spans = []
+for end in cands[:200]:
     start = end
     while start > 0 and int(rows[start]["Start_Timestamp"]) - int(rows[start - 1]["End_Timestamp"]) < 8000:
         start -= 1
-    if end - start + 1 >= 5:
-        break
+    spans.append((start, end))
+common = collections.Counter(e - s_ + 1 for s_, e in spans).most_common(1)[0][0]
+start, end = next((s_, e) for s_, e in spans if e - s_ + 1 == common)
 t0 = int(rows[start]["Start_Timestamp"])
 prev_end = t0
 total = 0
