@@ -2954,6 +2954,87 @@ def test_cg_plan_rebind_matches_fresh_plans(mgp, dev):
     solvers.clear_plan_cache()
 
 
+def test_solve_repeated_chain_if_built_and_host_scalar_cache(mgp, dev):
+    """Three host-side pieces of round 5.  (i) `CgPlan.solve_repeated(B, k)` -- the factors of a factorised solve back to back
+    behind one permutation -- equals k separate `solve` calls bit for bit (plans in the caller's order and on the relabelled
+    matrix, k = 2 and 3).  (ii) a 12-column plan
+    iterates on the chain-relabelled matrix only once a wide product has BUILT the chain order (it never starts the host walk
+    itself), with the same solution either way.  (iii) an operator's host copy of a hyper-parameter follows in-place updates of the
+    tensor (what an optimizer step does) and is not read again otherwise."""
+    from manifold_gp_amd import solvers
+    from manifold_gp_amd.solvers import CgPlan
+    from tools import synth
+    x, _ = synth.rmnist_like(50, 100, seed=11, device=dev)
+    n = x.shape[0]
+    knn = mgp.utils.NearestNeighbors(x)
+    idx, val = knn.graph(16)
+    D1, _ = knn.search(x, 2)
+    eps = torch.tensor([[float(D1[:, 1].median().sqrt()) * 1.5]], device=dev)
+    g = knn.knn_graph
+    lap = mgp.operators.GraphLaplacianOperator(val, idx, n, eps, "randomwalk", graph=g)
+    ls = torch.tensor([[2.5]], device=dev)
+    Q = mgp.operators.PrecisionMaternOperator(lap, 3, ls)
+    desc = Q._descriptor()
+    dB = desc.with_(nu=1, kappa=desc.kappa / 3 ** 0.5, scale=1.0, pre=None, post=None)
+    B = torch.randn(n, 12, generator=torch.Generator().manual_seed(4)).to(dev)
+    assert getattr(g, "_wide_relabelled", None) is None
+    solvers.clear_plan_cache()
+    # (ii) before any wide product: the caller's order
+    plan = CgPlan(dB, 12, tol=1e-6, max_iter=2000, stop_mode=1)
+    assert plan._rg is None
+    x_given = plan.solve(B).clone()
+    # (i) in the caller's order
+    for k in (2, 3):
+        Y = B
+        its = 0
+        for _ in range(k):
+            Y = plan.solve(Y).clone()
+            its += plan.iters
+        Z, its_r, status = plan.solve_repeated(B, k)
+        assert status == 1 and its_r == its and torch.equal(Z, Y), (k, its, its_r)
+    plan.close()
+    assert g.wide_relabelled() is not None                 # a wide product would have built it
+    plan = CgPlan(dB, 12, tol=1e-6, max_iter=2000, stop_mode=1)
+    assert plan._rg is not None and plan._rg is g.wide_relabelled()
+    x_chain = plan.solve(B).clone()
+    assert float((x_chain - x_given).abs().max() / x_given.abs().max()) < 2e-5
+    for k in (2, 3):
+        Y = B
+        for _ in range(k):
+            Y = plan.solve(Y).clone()
+        Z, _, status = plan.solve_repeated(B, k)
+        assert status == 1 and torch.equal(Z, Y), k
+    plan.close()
+    c1 = CgPlan(dB, 1, tol=1e-6, max_iter=2000, stop_mode=1)    # one column: never relabelled by the chain order
+    assert c1._rg is None
+    c1.close()
+    # (the factorised solves that run through solve_repeated are compared with CG on the whole chain and with dense float64 in
+    # test_factorised_chain_solve_vs_whole_chain_cg)
+    solvers.clear_plan_cache()
+    # (iii) host copies of hyper-parameters
+    noise = torch.tensor([1e-2], device=dev)
+    P = mgp.operators.NoiseWrapperOperator(mgp.operators.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev)), noise)
+    d1 = P._descriptor()
+    assert abs(d1.noise - 1e-2) < 1e-9 and abs(d1.kappa - 2.5) < 1e-7
+    calls = [0]
+    orig = torch.Tensor.item
+
+    def counting(self):
+        calls[0] += 1
+        return orig(self)
+    torch.Tensor.item = counting
+    try:
+        for _ in range(5):
+            d = P._descriptor()
+        assert calls[0] == 0 and d.noise == d1.noise and d.kappa == d1.kappa and d.scale == d1.scale
+        noise.mul_(3.0)
+        ls.add_(0.5)
+        d2 = P._descriptor()
+        assert calls[0] == 2 and abs(d2.noise - 3e-2) < 1e-8 and abs(d2.kappa - 3.0) < 1e-6
+    finally:
+        torch.Tensor.item = orig
+
+
 def test_chain_order_and_wide_relabelling(mgp, dev):
     """mgp_graph_chain_order (nearest-neighbour chain: a locality order for k-NN graphs whose given order keeps clusters together
     but not the order inside them) and what the wide products do with it: a permutation, deterministic, consecutive positions
