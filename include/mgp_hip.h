@@ -148,6 +148,10 @@ int mgp_morton_order(const float* x, int64_t n, int d, int32_t* order, void* wor
  * of their columns: 2.5 x fewer distinct columns per 16-row tile on the 60k RMNIST-like graph, which is what the matrix-core SpMM's
  * work is proportional to.  Sequential walk on the HOST over a copy of the CSR (one-off per graph); deterministic; synchronises. */
 int mgp_graph_chain_order(int64_t n, const int32_t* rowptr, const int32_t* col, const float* d2, int32_t* order, void* stream);
+/* dst[p, :] = src[order[p], :] for a row-major float32 block [n, C] (order: int32 [n], any row list with entries in [0, n_src);
+ * src != dst).  What the solvers that iterate on P A P^T (graph.RelabelledGraph) permute right-hand sides in and solutions out
+ * with; no counterpart in the reference. */
+int mgp_permute_rows(const float* src, const int32_t* order, int64_t n, int C, float* dst, void* stream);
 size_t mgp_graph_bfs_workspace_bytes(int64_t n);
 int mgp_graph_bfs_order(int64_t n, const int32_t* rowptr, const int32_t* col, int32_t* order, void* work,
                         size_t work_bytes, void* stream);

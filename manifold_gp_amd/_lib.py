@@ -81,6 +81,7 @@ SIGNATURES = {
     "mgp_morton_order_workspace_bytes": (c_size_t, [c_int64]),
     "mgp_morton_order": (c_int, [_P, c_int64, c_int, _P, _P, c_size_t, _P]),
     "mgp_graph_chain_order": (c_int, [c_int64, _P, _P, _P, _P, _P]),
+    "mgp_permute_rows": (c_int, [_P, _P, c_int64, c_int, _P, _P]),
     "mgp_graph_bfs_workspace_bytes": (c_size_t, [c_int64]),
     "mgp_graph_bfs_order": (c_int, [c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "mgp_spmm_dot_blocks_csr": (c_int, [POINTER(CsrT), c_int]),

@@ -643,6 +643,51 @@ extern "C" int mgp_graph_bfs_order(int64_t n, const int32_t* rowptr, const int32
   return MGP_OK;
 }
 
+// ---- row permutation of an [n, C] block: dst[p, :] = src[order[p], :].  The iterative solvers and the eigensolver run on
+// P A P^T (graph.RelabelledGraph): right-hand sides are permuted in and solutions out around every solve.  torch.index_select
+// takes 12 us for a 60 000 x 12 block (48-byte rows through a generic gather); here a lane moves a float4 of a row (C % 4 == 0)
+// or one element, destination coalesced.
+namespace {
+
+__global__ __launch_bounds__(kBlock) void permute_rows_q_kernel(const float4* __restrict__ src, const int32_t* __restrict__ order,
+                                                                 int64_t n, int CQ, float4* __restrict__ dst) {
+  const int64_t total = n * CQ;
+  for (int64_t e = blockIdx.x * (int64_t)kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t p = e / CQ;
+    const int q = (int)(e - p * CQ);
+    dst[e] = src[(int64_t)order[p] * CQ + q];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void permute_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ order,
+                                                               int64_t n, int C, float* __restrict__ dst) {
+  const int64_t total = n * C;
+  for (int64_t e = blockIdx.x * (int64_t)kBlock + threadIdx.x; e < total; e += (int64_t)gridDim.x * kBlock) {
+    const int64_t p = e / C;
+    const int c = (int)(e - p * C);
+    dst[e] = src[(int64_t)order[p] * C + c];
+  }
+}
+
+}  // namespace
+
+extern "C" int mgp_permute_rows(const float* src, const int32_t* order, int64_t n, int C, float* dst, void* stream) {
+  if (!src || !order || !dst || n < 0 || C <= 0 || src == dst) return MGP_ERR_ARG;
+  if (n == 0) return MGP_OK;
+  hipStream_t st = mgp_stream(stream);
+  const bool quads = (C & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+  const int64_t total = quads ? n * (C >> 2) : n * (int64_t)C;
+  const unsigned grid = (unsigned)std::min<int64_t>(mgp_cdiv(total, kBlock), 8192);
+  if (quads)
+    hipLaunchKernelGGL(permute_rows_q_kernel, dim3(grid), dim3(kBlock), 0, st, reinterpret_cast<const float4*>(src), order, n, C >> 2,
+                       reinterpret_cast<float4*>(dst));
+  else
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(grid), dim3(kBlock), 0, st, src, order, n, C, dst);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+
 // ---------------------------------------------------------------- nearest-neighbour chain order (round 5)
 // A locality order for k-NN graphs whose node order carries the CLUSTERS but not the order inside them (the RMNIST-like set: an
 // orbit's 100 rotations arrive in random angle order): walk the graph, always stepping to the nearest not-yet-numbered neighbour

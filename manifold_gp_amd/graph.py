@@ -309,13 +309,24 @@ class RelabelledGraph:
                           lid=t["lid"], rows=t["rows"], max_cols=t["max_cols"], max_entries=t["max_entries"],
                           reuse=t.get("reuse"))
 
+    @staticmethod
+    def _rows(v, idx32, idx64, out=None):
+        # float32 [n, C] blocks on the device (right-hand sides, solutions): mgp_permute_rows, a float4 of a row per lane;
+        # anything else (node vectors, float64 solutions, index tensors): torch
+        if v.dtype == torch.float32 and v.dim() == 2 and v.is_cuda and v.is_contiguous() and v.shape[0] == idx32.shape[0] \
+                and (out is None or (out.dtype == torch.float32 and out.is_contiguous() and out.shape == v.shape)):
+            dst = torch.empty_like(v) if out is None else out
+            check(lib().mgp_permute_rows(ptr(v), ptr(idx32), v.shape[0], v.shape[1], ptr(dst), stream()), "mgp_permute_rows")
+            return dst
+        return torch.index_select(v, 0, idx64, out=out)
+
     def permute(self, v):
         """caller's order -> this order, along dim 0"""
-        return v.index_select(0, self.order)
+        return self._rows(v, self.order32, self.order)
 
     def unpermute(self, v, out=None):
         """this order -> caller's order, along dim 0"""
-        return torch.index_select(v, 0, self.inv, out=out)
+        return self._rows(v, self.inv32, self.inv, out)
 
 
 class RelabelledData:

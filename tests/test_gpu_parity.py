@@ -3011,6 +3011,16 @@ def test_solve_repeated_chain_if_built_and_host_scalar_cache(mgp, dev):
     # (the factorised solves that run through solve_repeated are compared with CG on the whole chain and with dense float64 in
     # test_factorised_chain_solve_vs_whole_chain_cg)
     solvers.clear_plan_cache()
+    # the row permutations around a relabelled solve (mgp_permute_rows) against torch.index_select, both directions
+    rg = g.wide_relabelled()
+    for C in (1, 3, 12, 100):
+        V = torch.randn(n, C, generator=torch.Generator().manual_seed(C)).to(dev)
+        Pv = rg.permute(V)
+        assert torch.equal(Pv, V.index_select(0, rg.order)) and torch.equal(rg.unpermute(Pv), V)
+        out = torch.empty_like(V)
+        assert rg.unpermute(Pv, out=out) is out and torch.equal(out, V)
+    assert torch.equal(rg.permute(V.double()), V.double().index_select(0, rg.order))          # float64 / 1-D: the torch path
+    assert torch.equal(rg.permute(V[:, 0]), V[:, 0].index_select(0, rg.order))
     # (iii) host copies of hyper-parameters
     noise = torch.tensor([1e-2], device=dev)
     P = mgp.operators.NoiseWrapperOperator(mgp.operators.ScaleWrapperOperator(Q, torch.tensor(0.7, device=dev)), noise)
