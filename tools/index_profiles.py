@@ -55,7 +55,7 @@ library runs it by default (complex-shift COCG), the two training epochs, the wi
 
 | file | recipe | backs |
 |---|---|---|
-| `%(tag)s_kernel_stats.csv`, `%(tag)s_bench_trace.json`, `%(tag)s_pmc_traffic.json` | `tools/profile.sh %(tag)s` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras`, then the same command under `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes), `tools/summarize_profile.py` | `roofline.in_graph_profile` of the bench line: `spmv_tile_kernel<false,256>` %(ns).1f ns mean over %(nl)d launches -> %(mb).2f MB algorithmic / %(us).4f us = %(tbs).2f TB/s = %(frac).4f of 8 TB/s on the box of this pass (boxes of the pool: 5.5-6.2 us); `roofline.traffic` %(traffic)d bytes per launch (2 x FETCH_SIZE + WRITE_SIZE); the kernel mix of a solve |
+| `%(tag)s_kernel_stats.csv`, `%(tag)s_bench_trace.json`, `%(tag)s_pmc_traffic.json` | `tools/profile.sh %(tag)s` = `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras`, then the same command under `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes), `tools/summarize_profile.py` | `roofline.in_graph_profile` of the bench line: `spmv_tile_kernel<false,256>` %(ns).1f ns mean over %(nl)d launches -> %(mb).2f MB algorithmic / %(us).4f us = %(tbs).2f TB/s = %(frac).4f of 8 TB/s on the box of this pass (boxes of the pool: 5.4-6.2 us); `roofline.traffic` %(traffic)d bytes per launch (2 x FETCH_SIZE + WRITE_SIZE); the kernel mix of a solve |
 | `%(tag)s_trace_solve.txt` | `tools/trace_solve.py` over the same kernel trace (the last graph-replayed solve that came out whole under the profiler) | %(solve)s |
 | `%(tag)s_s5_kernel_stats.csv`, `%(tag)s_s5_bench_trace.json`, `%(tag)s_s5_pmc_traffic.json` | `tools/profile.sh %(tag)s_s5 --workload s5 --classic-cg` (the C = 1 streaming kernel is what `roofline_hbm` prices, so this pass keeps the classic CG that runs it twice per iteration) | `roofline_hbm`: %(ns5).1f ns mean over %(nl5)d launches -> %(frac5).3f of 8 TB/s in-graph under the profiler (%(mb5).0f MB algorithmic); counter traffic %(t5).1f MB per launch (the x dictionary hits in L2) |
 | `%(tag)s_s5_complex_shift_kernel_stats.csv`, `%(tag)s_s5_complex_shift_bench.json` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --workload s5 --steps 20 --warmup 3 --no-cpu-baseline --no-extras` (the default solver for I + s Q^2 systems: COCG on the complex factor I + i sigma B) | the S5 solve at %(cxms).1f ms under the profiler (round 4: 133 ms): `spmm_tile_q_kernel<1,false>` (4 interleaved columns: re, im of two products) %(cq1).1f us x %(cq0)d, `cx_update_kernel` %(cu1).1f us x %(cu0)d, the fp64 residual checks `spmv_f64_kernel` %(cf1).0f us x %(cf0)d; the bench line of that run |
