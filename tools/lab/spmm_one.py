@@ -5,7 +5,7 @@ import torch
 import bench
 from manifold_gp_amd import _lib
 dev = torch.device("cuda:0")
-wl = bench.build_workload(argparse.Namespace(workload="c3", nodes=0, s5_order="morton"), dev, 0, 1)
+wl = bench.build_workload(argparse.Namespace(workload="c3", nodes=int(os.environ.get("MGP_NODES", 0)), s5_order="morton"), dev, 0, 1)
 g, lap = wl["graph"], wl["lap"]
 lib = _lib.lib(); lib.mgp_spmm_set_group_hint(g.spmv_lanes)
 mt = int(sys.argv[6]) if len(sys.argv) > 6 else 0
