@@ -175,6 +175,15 @@ int mgp_laplacian_tangent(int64_t n, const int32_t* rowptr, const int32_t* col, 
                           float eps, int self_loops, const float* degree_unnorm, const float* degree,
                           const float* diag, float* d_degree_unnorm, float* d_degree, float* d_diag,
                           float* d_dsqrt, float* d_dinvsqrt, float* d_vals, void* stream);
+/* The reductions of the differentiable fused SpMM's backward pass in one launch (autograd through graph_laplacian_operator.py:108-124 /
+ * precision_matern_operator.py:26-37 wrt bandwidth, length scale and the node vectors; `_test_functions.py:59-104`).  Blocks are
+ * [n, C] row-major float32: h = cov post (.) g (upstream gradient), xs = pre (.) X, dlx = L' xs (tangent product), lx = L xs,
+ * gxs = a h + b L h.  Writes partial[mgp_spmm_backward_blocks(n)][2] = per-workgroup sums of <h, dlx> and <h, xs> (the caller adds
+ * them up), gpre[r] = sum_c gxs X and gpost[r] = cov sum_c g (a xs + b lx).  Null dlx / gpre / gpost switch that output off. */
+int mgp_spmm_backward_blocks(int64_t n);
+int mgp_spmm_backward_sums(int64_t n, int C, const float* h, const float* dlx, const float* xs, const float* gxs, const float* X,
+                           const float* g, const float* lx, float av, float bv, float cov, float* partial, float* gpre,
+                           float* gpost, void* stream);
 /* per-edge values in the reference's COO order: which = 0 W (adjacency_unnorm_mat :54-56),
  * 1 A (adjacency_mat :73-75), 2 S (laplacian_triu :104-106) */
 int mgp_edge_values(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val,

@@ -120,6 +120,8 @@ SIGNATURES = {
     "mgp_laplacian_build": (c_int, [c_int64, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "mgp_laplacian_tangent": (c_int, [c_int64, _P, _P, _P, c_float, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "mgp_edge_values": (c_int, [_P, _P, _P, c_int64, _P, _P, c_float, c_int, _P, _P]),
+    "mgp_spmm_backward_blocks": (c_int, [c_int64]),
+    "mgp_spmm_backward_sums": (c_int, [c_int64, c_int, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P, _P]),
     "mgp_spmm_dot_blocks": (c_int, [c_int64, c_int]),
     "mgp_spmm_set_group_hint": (c_int, [c_int]),
     "mgp_spmm_set_rows_in_flight": (c_int, [c_int]),

@@ -22,6 +22,9 @@ from . import _lib
 from ._lib import check, lib, ptr, stream
 
 
+FUSED_BACKWARD_SUMS = [True]     # False: the torch form of the backward pass's reductions (A/B runs, tests)
+
+
 def needs_grad(*tensors):
     return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in tensors)
 
@@ -119,28 +122,48 @@ class _FusedSpmm(torch.autograd.Function):
         if post is not None:
             h = h * post.view(-1, 1)
         gX = geps = ga = gb = gco = gcb = gpre = gpost = gbase = None
-        lx = None
-        if need[3] or need[4] or need[7]:
+        lx = gxs = dlx = None
+        want_pre = need[6] and pre is not None
+        want_post = need[7] and post is not None
+        if need[3] or need[4] or want_post:
             lx = _spmm(data, xs, 0.0, 1.0, None, None, None, 0.0, 1.0)          # L xs (recomputed)
-        if need[0] or need[6]:
+        if need[0] or want_pre:
             gxs = _spmm(data, h, av, bv, None, None, None, 0.0, 1.0)            # a h + b L h (L symmetric)
             if need[0]:
                 gX = gxs * pre.view(-1, 1) if pre is not None else gxs
-            if need[6] and pre is not None:
-                gpre = (gxs * X).sum(1)
         if need[1]:
             dlx = _spmm(data, xs, 0.0, 1.0, None, None, None, 0.0, 1.0, tangent=True)   # L' xs
-            geps = (bv * (h * dlx).sum()).reshape(eps.shape)
-        if need[2]:
-            ga = (h * xs).sum().reshape(a.shape).to(a.device)
+        if FUSED_BACKWARD_SUMS[0] and (need[1] or need[2] or want_pre or want_post):
+            # <h, L' xs>, <h, xs>, the row sums of gxs (.) X and of g (.) (a xs + b L xs) in ONE launch (mgp_spmm_backward_sums)
+            n, C = g.shape
+            nb = lib().mgp_spmm_backward_blocks(n)
+            part = torch.empty(nb, 2, dtype=torch.float32, device=g.device)
+            gpre = torch.empty(n, dtype=torch.float32, device=g.device) if want_pre else None
+            gpost = torch.empty(n, dtype=torch.float32, device=g.device) if want_post else None
+            Xc = _lib.f32c(X)
+            check(lib().mgp_spmm_backward_sums(n, C, ptr(h), ptr(dlx), ptr(xs if (need[2] or want_post) else None), ptr(gxs if want_pre else None),
+                                               ptr(Xc if want_pre else None), ptr(g if want_post else None), ptr(lx if want_post else None),
+                                               float(av), float(bv), float(cov), ptr(part), ptr(gpre), ptr(gpost), stream()),
+                  "mgp_spmm_backward_sums")
+            tot = part.sum(0)
+            if need[1]:
+                geps = (bv * tot[0]).reshape(eps.shape)
+            if need[2]:
+                ga = tot[1].reshape(a.shape).to(a.device)
+        else:
+            if want_pre:
+                gpre = (gxs * X).sum(1)
+            if need[1]:
+                geps = (bv * (h * dlx).sum()).reshape(eps.shape)
+            if need[2]:
+                ga = (h * xs).sum().reshape(a.shape).to(a.device)
+            if want_post:
+                gpost = (g * (av * xs + bv * lx)).sum(1) * cov
         if need[3]:
             gb = (h * lx).sum().reshape(b.shape).to(b.device)
-        if need[4] or need[7]:
+        if need[4]:
             t = av * xs + bv * lx
-            if need[4]:
-                gco = ((g * t * post.view(-1, 1)).sum() if post is not None else (g * t).sum()).reshape(co.shape).to(co.device)
-            if need[7] and post is not None:
-                gpost = (g * t).sum(1) * cov
+            gco = ((g * t * post.view(-1, 1)).sum() if post is not None else (g * t).sum()).reshape(co.shape).to(co.device)
         if need[5]:
             gcb = ((g * base).sum() if base is not None else torch.zeros((), device=g.device)).reshape(cb.shape).to(cb.device)
         if need[8] and base is not None:

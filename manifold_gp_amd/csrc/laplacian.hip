@@ -220,6 +220,68 @@ extern "C" int mgp_laplacian_build(int64_t n, const int32_t* rowptr, const int32
   return MGP_OK;
 }
 
+// ---- the reductions of the fused SpMM's backward pass (autograd._FusedSpmm.backward) in one launch.  With h = cov post (.) g the
+// upstream gradient and xs = pre (.) X the scaled input, the parameter gradients are inner products of [n, C] blocks:
+//     d/d eps  = b <h, L' xs>      d/d a = <h, xs>      d/d pre[r] = sum_c gxs[r, c] X[r, c]      d/d post[r] = cov sum_c g[r, c] (a xs + b L xs)[r, c]
+// -- as torch ops a product, a sum and a scalar fix-up each (a dozen small launches per differentiable SpMM, 12 of those per
+// supervised epoch, every one issued by a host that is the bottleneck of that epoch).  A thread owns a row; the two scalars are
+// block-reduced in a fixed order into partial[block][2] (the caller sums the few hundred partials).  Null inputs switch the
+// corresponding output off.
+namespace {
+
+__global__ __launch_bounds__(kBlock) void backward_sums_kernel(int64_t n, int C, const float* __restrict__ h, const float* __restrict__ dlx,
+                                                               const float* __restrict__ xs, const float* __restrict__ gxs,
+                                                               const float* __restrict__ X, const float* __restrict__ g,
+                                                               const float* __restrict__ lx, float av, float bv, float cov,
+                                                               float* __restrict__ partial, float* __restrict__ gpre,
+                                                               float* __restrict__ gpost) {
+  __shared__ float sh[2][kBlock / 64];
+  float s0 = 0.f, s1 = 0.f;
+  for (int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x; r < n; r += (int64_t)gridDim.x * kBlock) {
+    const int64_t o = r * C;
+    float p0 = 0.f, p1 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float hv = h ? h[o + c] : 0.f;
+      const float xv = xs ? xs[o + c] : 0.f;
+      if (dlx) s0 = fmaf(hv, dlx[o + c], s0);
+      if (h && xs) s1 = fmaf(hv, xv, s1);
+      if (gpre) p0 = fmaf(gxs[o + c], X[o + c], p0);
+      if (gpost) p1 = fmaf(g[o + c], fmaf(av, xv, bv * lx[o + c]), p1);
+    }
+    if (gpre) gpre[r] = p0;
+    if (gpost) gpost[r] = cov * p1;
+  }
+  for (int off = 32; off > 0; off >>= 1) { s0 += __shfl_xor(s0, off, 64); s1 += __shfl_xor(s1, off, 64); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s0; sh[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    partial[2 * blockIdx.x + 1] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+
+}  // namespace
+
+extern "C" int mgp_spmm_backward_blocks(int64_t n) {
+  if (n <= 0) return 0;
+  const int64_t b = mgp_cdiv(n, kBlock);
+  return (int)(b < 512 ? b : 512);
+}
+
+// see include/mgp_hip.h
+extern "C" int mgp_spmm_backward_sums(int64_t n, int C, const float* h, const float* dlx, const float* xs, const float* gxs,
+                                      const float* X, const float* g, const float* lx, float av, float bv, float cov,
+                                      float* partial, float* gpre, float* gpost, void* stream) {
+  if (n <= 0 || C <= 0 || !partial) return MGP_ERR_ARG;
+  if (gpre && (!gxs || !X)) return MGP_ERR_ARG;
+  if (gpost && (!g || !xs || !lx)) return MGP_ERR_ARG;
+  if (dlx && !h) return MGP_ERR_ARG;
+  hipLaunchKernelGGL(backward_sums_kernel, dim3(mgp_spmm_backward_blocks(n)), dim3(kBlock), 0, mgp_stream(stream), n, C, h, dlx, xs, gxs, X,
+                     g, lx, av, bv, cov, partial, gpre, gpost);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
 extern "C" int mgp_edge_values(const int32_t* tri_row, const int32_t* tri_col, const float* tri_val, int64_t M,
                                const float* degree_unnorm, const float* degree, float eps, int which,
                                float* out, void* stream) {

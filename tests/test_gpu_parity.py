@@ -983,6 +983,42 @@ def test_grad_and_marginal_likelihood_vs_reference_autograd(mgp, golden, dev, ca
     assert (np.abs(got - ref) < 5e-3 * np.abs(ref) + 1e-4 * np.abs(ref).max()).all(), (got, ref)
 
 
+@pytest.mark.parametrize("norm", ["symmetric", "randomwalk"])
+def test_backward_sums_kernel_vs_torch_reductions(mgp, golden, dev, norm):
+    """mgp_spmm_backward_sums (round 5): the reductions of the differentiable fused SpMM's backward pass -- <h, L' xs>, <h, xs>,
+    the row sums behind the gradients of the pre / post node vectors -- in one launch against the torch ops they replace
+    (autograd.FUSED_BACKWARD_SUMS = False), on the golden graph with 1 and 12 columns: gradients wrt bandwidth, length scale,
+    scale, noise and the right-hand side agree to float32 summation order."""
+    from manifold_gp_amd import autograd
+    g = golden("dumbbell_k10_loop")
+    O = mgp.operators
+    n = g["train_x"].shape[0]
+    idx, val = T(g["edge_index"].astype(np.int64), dev), T(g["edge_value"], dev)
+    def grads(C):
+        V = torch.randn(n, C, generator=torch.Generator().manual_seed(100 + C)).to(dev).requires_grad_(True)
+        W = torch.randn(n, C, generator=torch.Generator().manual_seed(200 + C)).to(dev)
+        eps_t = torch.tensor([[float(g["eps"])]], device=dev, requires_grad=True)
+        kap_t = torch.tensor([[float(g["kappa"])]], device=dev, requires_grad=True)
+        s_t = torch.tensor(0.7, device=dev, requires_grad=True)
+        z_t = torch.tensor(1e-3, device=dev, requires_grad=True)
+        lap = O.GraphLaplacianOperator(val, idx, n, eps_t, norm, bool(g["self_loops"]))
+        Q3 = O.NoiseWrapperOperator(O.ScaleWrapperOperator(O.PrecisionMaternOperator(lap, 2, kap_t), s_t), z_t)
+        loss = (W * Q3.matmul(V)).sum()
+        loss.backward()
+        return [t.grad.detach().double().reshape(-1).cpu().numpy() for t in (eps_t, kap_t, s_t, z_t, V)], float(loss.detach())
+    for C in (1, 12):
+        autograd.FUSED_BACKWARD_SUMS[0] = True
+        a, la = grads(C)
+        autograd.FUSED_BACKWARD_SUMS[0] = False
+        try:
+            b, lb = grads(C)
+        finally:
+            autograd.FUSED_BACKWARD_SUMS[0] = True
+        assert la == lb
+        for x, y in zip(a, b):
+            assert np.abs(x - y).max() <= 2e-5 * max(np.abs(y).max(), 1e-30), (C, x[:3], y[:3])
+
+
 def test_stochastic_gradients_large_n_branch(mgp, golden, dev):
     """N > max_cholesky_size branch of the marginal likelihood: SLQ value + surrogate gradients
     (d logdet = E[(A^-1 z)^T dA z]) against the float64 dense autograd golden, Monte-Carlo tolerance."""
