@@ -74,10 +74,22 @@ def node_vector(eps, data, name):
     return _NodeVector.apply(eps, data, name)
 
 
+_CONST0 = {}
+
+
 def _as0(t, like=None):
     # a python scalar becomes a CPU tensor: no host-to-device copy, and reading it back is free (the kernels take their
-    # coefficients by value; a device tensor here would be copied up only to be synchronised down again)
-    return t if torch.is_tensor(t) else torch.tensor(float(t))
+    # coefficients by value; a device tensor here would be copied up only to be synchronised down again).  The handful of
+    # constants the operators pass (0, 1) are made once: a tensor construction per coefficient per launch was 36 of them per epoch
+    if torch.is_tensor(t):
+        return t
+    v = float(t)
+    c = _CONST0.get(v)
+    if c is None:
+        if len(_CONST0) > 64:
+            _CONST0.clear()
+        c = _CONST0[v] = torch.tensor(v)
+    return c
 
 
 def _host_values(*ts):
