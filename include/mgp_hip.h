@@ -71,6 +71,18 @@ int64_t mgp_knn_last_direct_chunks(void);
  * tile pairs on and above the diagonal only and stores each off-diagonal tile twice (as it is and transposed): half the
  * MFMA work, the same selection, the same results bit for bit.  Default 1; 0 computes every tile (tests, A/B runs). */
 int mgp_knn_set_symmetric(int on);
+/* Candidate filter of the matrix-core searches (round 5).  A large search does not write its keys to an N x n slab for the
+ * select kernel to read back (60k x 60k: 14.4 GB each way): the keys of every row to a 1/stride sample of the points
+ * (stride 16 up to k = 64) give a per-row bound >= the row's K'-th smallest key, the key pass appends the ~stride K' keys
+ * under it to the row's candidate list (3840 entries of {key, index}; slots from per-row counters, two 256-byte atomic
+ * instructions per wave and tile pair), and the select kernel takes the exact K'-th smallest key, the candidates, the fp64
+ * re-rank and the sufficiency check from the list.  Rows whose list overflows or whose check fails are gathered and redone
+ * by the slab pipeline (which ends in the exact scan): the results are the oracle's bit for bit, as before.  Workspace at
+ * 60k x 784: 5.3 GB instead of 14.6.  mode 0: key slab (rounds 1-4); 1 (default): searches of >= 4096 queries against
+ * >= 16384 points; 2: every matrix-core search whose k the lists can serve (tests).  Lab / test switch: read once per call.
+ * mgp_knn_last_filter_failover: rows of the last search handed to the slab pipeline; -1 when the search ran on the slab. */
+int mgp_knn_set_filter(int mode);
+int64_t mgp_knn_last_filter_failover(void);
 /* Prepared index (d >= 32): the part of a search that depends on the points alone -- column means, the centred bf16 split
  * in the key kernel's tile layout, norms -- built once (faiss: index.train / index.add, nearest_neighbors.py:20-33) and
  * handed to every search.  Without it a search prepares the points itself (~1 ms at 60k x 784) and therefore keeps small

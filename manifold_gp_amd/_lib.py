@@ -69,6 +69,8 @@ SIGNATURES = {
                                POINTER(c_int64), _P]),
     "mgp_knn_set_mfma": (c_int, [c_int]),
     "mgp_knn_set_symmetric": (c_int, [c_int]),
+    "mgp_knn_set_filter": (c_int, [c_int]),
+    "mgp_knn_last_filter_failover": (c_int64, []),
     "mgp_knn_index_bytes": (c_size_t, [c_int64, c_int]),
     "mgp_knn_index_build": (c_int, [_P, c_int64, c_int, _P, c_size_t, _P]),
     "mgp_knn_search_indexed": (c_int, [_P, c_int64, c_int, _P, c_size_t, _P, c_int64, c_int, _P, _P, _P, c_size_t, _P, _P]),

@@ -222,6 +222,10 @@ struct SelectArgs {
   const float* qn2;          // |c_x|^2 per chunk row
   const unsigned* r2max;     // bits of R^2
   double alpha, beta;        // E = alpha |c_x| R + beta (|c_x| + R)^2
+  // candidate lists of the filtered key pass (knn_mfma.hip) instead of a slab row: dist == nullptr
+  const uint2* lists;        // [rows_in_chunk, list_cap] {key bits, point index}
+  const int* counts;         // entries drawn per row (may exceed list_cap: such a row fails over to the slab pipeline)
+  int list_cap;
 };
 
 // Visit every key of a slab row: 4 x 16-byte loads per lane are issued before the first key is used.
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
 
   const int tid = threadIdx.x;
   const int row = a.rows ? a.rows[blockIdx.x] : (int)blockIdx.x;
-  const uint32_t* keys = reinterpret_cast<const uint32_t*>(a.dist + (int64_t)row * a.ld);
+  const uint32_t* keys = a.lists ? nullptr : reinterpret_cast<const uint32_t*>(a.dist + (int64_t)row * a.ld);
   const int64_t N = a.N;
   const int Kp = a.Kp;
   const int cand = a.cand > 0 && a.cand < Kp ? a.cand : Kp;
@@ -352,7 +356,29 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   uint32_t T = 0xffffffffu;
   bool from_list = false;
   int n_list = 0;
-  if (want < N) {
+  if (a.lists) {
+    // the filtered key pass left every key of the row under the row's bound (>= its want-th smallest key: at least
+    // `want` of them) in the row's list: the exact T comes from the list, as from the one-pass list below.  A list that
+    // overflowed, or holds fewer than `want` keys (a retry wider than the filter was built for; keys of the sample and of
+    // the full pass that differ in the last bit at the bound), fails the row: the caller redoes it on a slab.
+    n_list = a.counts[row];
+    if (n_list > a.list_cap || n_list > kListCap || n_list < want || want >= N) {
+      if (tid == 0) {
+        const int slot = atomicAdd(a.fail_count, 1);
+        a.fail_list[slot] = row;
+      }
+      return;
+    }
+    const uint2* lrow = a.lists + (int64_t)row * a.list_cap;
+    for (int j = tid; j < n_list; j += kBlock) {
+      const uint2 e = lrow[j];
+      list_key[j] = e.x; list_idx[j] = (int)e.y;
+    }
+    __syncthreads();
+    T = radix_kth([&](auto f) { for (int j = tid; j < n_list; j += kBlock) f(list_key[j], (int64_t)list_idx[j]); },
+                  want, hist, sh_wave, &sh_bin, &sh_rank, &rank);
+    from_list = true;
+  } else if (want < N) {
     // sampling stride: the smallest power of two from 16 up whose sample (runs of 64 keys) fits the LDS list
     int S = 16;
     while (((N / kSampleBlock + S - 1) / S) * kSampleBlock > kListCap) S <<= 1;
@@ -563,6 +589,29 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ 2b. per-row bounds of the filtered key pass
+// One workgroup per query row: the want-th smallest of the row's keys to the S sampled points (a subset of the row:
+// its want-th smallest bounds the row's from above; two radix passes = the top 22 bits, rounded up) -> bounds[row],
+// widened by 2^-12 relative (the full pass recomputes these keys with the operands' roles swapped: last-bit
+// differences) and kept finite (keys that overflowed pass no finite bound: such rows fail over to the slab pipeline).
+__global__ __launch_bounds__(kBlock) void bound_kernel(const float* __restrict__ samp, int64_t ld, int S, int want,
+                                                       float* __restrict__ bounds) {
+  __shared__ int hist[2048];
+  __shared__ int sh_wave[4];
+  __shared__ int sh_bin, sh_rank;
+  const int tid = threadIdx.x;
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(samp + (int64_t)blockIdx.x * ld);
+  int dummy;
+  const uint32_t tau = radix_kth([&](auto f) { for (int j = tid; j < S; j += kBlock) f(keys[j], (int64_t)j); }, want, hist,
+                                 sh_wave, &sh_bin, &sh_rank, &dummy, 2);
+  if (tid == 0) {
+    float b = __uint_as_float(tau);
+    b = b < 3.0e38f ? b * (1.f + 0x1p-12f) : 3.0e38f;     // NaN bits (tau above the infinity pattern) land on the cap too
+    if (!(b < 3.0e38f)) b = 3.0e38f;
+    bounds[blockIdx.x] = b;
+  }
+}
+
 // ------------------------------------------------------------------ 3. exact fallback
 __global__ __launch_bounds__(kBlock) void exact_row_kernel(const float* __restrict__ db, int64_t N, int d,
                                                            const float* __restrict__ q, const int* __restrict__ rows,
@@ -615,6 +664,48 @@ std::atomic<int64_t> g_last_direct_chunks{0};
 // (the centring + split of the points is a fixed ~1 ms at 60k x 784: it pays from ~1000 queries on)
 bool use_mfma(int d, int64_t n) { return g_knn_mfma && d >= 32 && n >= 1024; }
 
+// first attempt: k + pad candidates (each costs a d-float row read in the fp64 re-rank: the selection's dominant traffic
+// at large d); MFMA keys carry an absolute error: a wider pad there keeps the retry launches rare
+int first_candidates(int k, bool mfma) { return mfma ? k + (k / 2 > 24 ? k / 2 : 24) : k + (k / 4 > 16 ? k / 4 : 16); }
+
+// Candidate filter (round 5): the matrix-core keys of a large search are not written to an N x n slab and read back by
+// the select kernel (60k x 60k: 14.4 GB each way, the key kernel's epilogue and the select pass were both bound by it);
+// the key pass keeps the ~stride K' keys per row that lie under a per-row bound from a 1/stride sample of the points.
+// 0: off; 1: searches of >= 4096 queries against >= 16384 points; 2: every matrix-core search the lists can serve (tests).
+std::atomic<int> g_knn_filter{1};
+std::atomic<int64_t> g_last_filter_failover{-1};
+
+struct FilterPlan {
+  bool on;
+  int stride;          // every stride-th point is sampled
+  int64_t S, ldS;      // sampled points, row pitch of their key slab
+  int64_t qc;          // query rows per chunk (the lists of a chunk: qc x kListCap x 8 bytes)
+  int64_t fr;          // rows per fail-over batch (slab pipeline)
+};
+
+FilterPlan filter_plan(int64_t N, int64_t n, int d, int k, bool indexed) {
+  FilterPlan f{};
+  const int mode = g_knn_filter;
+  if (!mode || !g_knn_mfma || d < 32) return f;
+  if (mode == 1 && (N < 16384 || n < 4096)) return f;
+  if (mode == 2 && !(indexed || use_mfma(d, n))) return f;
+  if (N < 1024) return f;
+  const int want = first_candidates(k, true);
+  int stride = 16;
+  while (stride > 4 && (int64_t)stride * want > kListCap * 2 / 5) stride >>= 1;   // expected list: stride x want keys
+  if ((int64_t)stride * want > kListCap * 2 / 5) return f;
+  const int64_t S = mgp_cdiv(N, stride);
+  if (S < 2 * want) return f;
+  f.on = true;
+  f.stride = stride;
+  f.S = S;
+  f.ldS = mgp_cdiv(S, 4) * 4;
+  const int64_t ncap = mgp_cdiv(n, kTile) * kTile;
+  f.qc = ncap < 262144 ? ncap : 262144;
+  f.fr = n < 2048 ? n : 2048;
+  return f;
+}
+
 int64_t chunk_rows(int64_t N, int64_t n, int d) {
   const int64_t ld = mgp_cdiv(N, 4) * 4;
   // fp32 distance slab: 2 GiB (8 192 query rows at N = 60k: 8 query tiles per XCD share a point tile in L2, and half
@@ -647,7 +738,7 @@ int next_pow2(int v) {
 
 }  // namespace
 
-static size_t bruteforce_bytes(int64_t N, int64_t n, int d, int k) {
+static size_t slab_bytes(int64_t N, int64_t n, int d, int k) {
   if (N <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
   const int64_t ld = mgp_cdiv(N, 4) * 4;
   const int64_t qc = chunk_rows(N, n, d);
@@ -662,13 +753,48 @@ static size_t bruteforce_bytes(int64_t N, int64_t n, int d, int k) {
   return b + 1024;
 }
 
+static size_t filter_bytes(int64_t N, int64_t n, int d, int k, const FilterPlan& f) {
+  size_t b = mgp_align(slab_bytes(N, f.fr, d, k));                       // fail-over batches
+  b += mgp_align(mgp_knn_mfma_index_bytes(N, d) + 256);                  // the points' split (a caller's index is used instead)
+  b += mgp_knn_mfma_sample_bytes(f.S, d) + mgp_knn_mfma_query_bytes(f.qc, d);
+  b += mgp_align((size_t)f.qc * f.ldS * sizeof(float));                  // keys to the sampled points
+  b += 4 * mgp_align((size_t)f.qc * sizeof(int)) + mgp_align(64);        // bounds, counters, two fail lists
+  b += mgp_align((size_t)f.qc * kListCap * sizeof(uint2));               // candidate lists
+  b += mgp_align((size_t)f.fr * d * sizeof(float)) + 2 * mgp_align((size_t)f.fr * k * sizeof(float));
+  return b + 1024;
+}
+
+static size_t bruteforce_bytes(int64_t N, int64_t n, int d, int k) {
+  if (N <= 0 || n <= 0 || d <= 0 || k <= 0) return 0;
+  // the workspace query does not see whether a prepared index comes with the search: a forced filter (mode 2) sizes for it
+  const FilterPlan f = filter_plan(N, n, d, k, true);
+  const size_t sb = slab_bytes(N, n, d, k);
+  if (!f.on) return sb;
+  const size_t fb = filter_bytes(N, n, d, k, f);
+  // a search the plan turns out not to serve (no index, few queries) still runs on the slab
+  return (g_knn_filter == 2 && !use_mfma(d, n)) ? (fb > sb ? fb : sb) : fb;
+}
+
 // the slab pipeline (any d): distance tiles -> radix select -> fp64 re-rank -> sufficiency check
+static int filtered_search(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D, int32_t* I, void* work,
+                           size_t work_bytes, int64_t* stats, void* stream, const void* index, size_t index_bytes,
+                           const FilterPlan& fp);
+
 int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
                        int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream, const void* index,
-                       size_t index_bytes) {
+                       size_t index_bytes, bool allow_filter) {
   if (!db || !q || !D || !I || !work) return MGP_ERR_ARG;
   if (N <= 0 || n <= 0 || d <= 0 || k <= 0 || k > N || k > 1024 || N > INT_MAX) return MGP_ERR_ARG;
-  if (work_bytes < bruteforce_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
+  if (allow_filter) {
+    const bool idx_ok = index != nullptr && g_knn_mfma && d >= 32;
+    const FilterPlan fp = filter_plan(N, n, d, k, idx_ok);
+    if (fp.on) {
+      if (work_bytes < filter_bytes(N, n, d, k, fp)) return MGP_ERR_WORKSPACE;
+      return filtered_search(db, N, d, q, n, k, D, I, work, work_bytes, stats, stream, idx_ok ? index : nullptr, index_bytes, fp);
+    }
+    g_last_filter_failover = -1;
+  }
+  if (work_bytes < slab_bytes(N, n, d, k)) return MGP_ERR_WORKSPACE;
   hipStream_t st = mgp_stream(stream);
   const int64_t ld = mgp_cdiv(N, 4) * 4;
   const int64_t qc = chunk_rows(N, n, d);
@@ -702,7 +828,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   // first attempt: k + pad candidates (each costs a d-float row read in the fp64 re-rank: the selection's
   // dominant traffic at large d), sorted in the next power of two; retries use the full sort width
   // (MFMA keys carry an absolute error: a wider pad there keeps the retry launches rare)
-  int cand0 = mfma ? k + (k / 2 > 24 ? k / 2 : 24) : k + (k / 4 > 16 ? k / 4 : 16);
+  int cand0 = first_candidates(k, mfma);
   int Kp0 = next_pow2(cand0);
   if (Kp0 < 64) Kp0 = 64;
   if (Kp0 > kMaxKp) Kp0 = kMaxKp;
@@ -717,7 +843,7 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
     ++n_chunks;
     dim3 grid((unsigned)mgp_cdiv(N, kTile), (unsigned)mgp_cdiv(rows, kTile));
     SelectArgs a{slab, ld, N, db, q + q0 * d, d, k, Kp0, cand0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, gamma,
-                 nullptr, nullptr, 0.0, 0.0};
+                 nullptr, nullptr, 0.0, 0.0, nullptr, nullptr, 0};
     int fails = 0;
     // pass 0: MFMA keys + absolute check; pass 1 (no MFMA, or too many rows of the chunk failed the
     // absolute check): exact fp32 direct-difference keys + relative check
@@ -772,6 +898,113 @@ int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_
   g_last_direct_chunks = n_direct;
   return MGP_OK;
 }
+
+// The filtered pipeline per chunk of query rows: keys to the sampled points -> per-row bounds -> ALL keys, the ones under
+// the bounds appended to the rows' lists -> select + fp64 re-rank + sufficiency check from the lists (the same kernel, the
+// same T: a list holds every key of its row up to a bound >= T) -> rows that fail (check, overflowing or short list) are
+// gathered and redone by the slab pipeline above, which ends in the exact fp64 scan.  The RESULT is the oracle's.
+static int filtered_search(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D, int32_t* I, void* work,
+                           size_t work_bytes, int64_t* stats, void* stream, const void* index, size_t index_bytes,
+                           const FilterPlan& fp) {
+  hipStream_t st = mgp_stream(stream);
+  MgpArena ar(work, work_bytes);
+  const size_t fb_bytes = slab_bytes(N, fp.fr, d, k);
+  void* fb_work = ar.take<char>(fb_bytes);
+  const size_t own_idx_bytes = mgp_knn_mfma_index_bytes(N, d) + 256;
+  void* own_idx = ar.take<char>(own_idx_bytes);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  if (index && index_bytes < mgp_knn_mfma_index_bytes(N, d)) return MGP_ERR_WORKSPACE;
+  const void* idx = index ? index : own_idx;
+  const size_t idx_bytes = index ? index_bytes : own_idx_bytes;
+  MgpKnnMfma mm{};
+  {
+    MgpArena ia(const_cast<void*>(idx), idx_bytes);
+    MGP_TRY(mgp_knn_mfma_index_take(ia, N, d, &mm));
+  }
+  if (!index) MGP_TRY(mgp_knn_mfma_prepare_points(db, N, d, mm, st));
+  MGP_TRY(mgp_knn_mfma_sample_take(ar, fp.S, d, &mm));
+  MGP_TRY(mgp_knn_mfma_query_take(ar, fp.qc, d, &mm));
+  float* samp = ar.take<float>((size_t)fp.qc * fp.ldS);
+  float* bounds = ar.take<float>(fp.qc);
+  int* cnt = ar.take<int>(fp.qc);
+  int* list_a = ar.take<int>(fp.qc);
+  int* list_b = ar.take<int>(fp.qc);
+  int* counter = ar.take<int>(16);
+  uint2* lists = ar.take<uint2>((size_t)fp.qc * kListCap);
+  float* qsub = ar.take<float>((size_t)fp.fr * d);
+  float* Dsub = ar.take<float>((size_t)fp.fr * k);
+  int32_t* Isub = ar.take<int32_t>((size_t)fp.fr * k);
+  if (!ar.ok()) return MGP_ERR_WORKSPACE;
+  MGP_TRY(mgp_knn_mfma_prepare_sample(db, fp.S, fp.stride, d, mm, st));
+  double alpha = 0.0, beta = 0.0;
+  mgp_knn_mfma_bound(mm.dpad, &alpha, &beta);
+  const bool sym = g_knn_sym && q == db && n == N && fp.qc >= n;
+  int cand0 = first_candidates(k, true);
+  int Kp0 = next_pow2(cand0);
+  if (Kp0 < 64) Kp0 = 64;
+  if (Kp0 > kMaxKp) Kp0 = kMaxKp;
+  if (cand0 > Kp0) cand0 = Kp0;
+  int64_t n_wide = 0, n_exact = 0, n_chunks = 0, n_failover = 0;
+  for (int64_t q0 = 0; q0 < n; q0 += fp.qc) {
+    const int64_t rows = (n - q0) < fp.qc ? (n - q0) : fp.qc;
+    ++n_chunks;
+    if (!sym) MGP_TRY(mgp_knn_mfma_prepare_queries(q + q0 * d, rows, d, mm, st));
+    MGP_TRY(mgp_knn_mfma_sample_tiles(mm, rows, fp.S, samp, fp.ldS, st, sym));
+    hipLaunchKernelGGL(bound_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, samp, fp.ldS, (int)fp.S, cand0, bounds);
+    MGP_LAUNCH_CHECK();
+    MGP_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)rows * sizeof(int), st));
+    MGP_TRY(mgp_knn_mfma_tiles_filtered(mm, rows, N, bounds, cnt, lists, kListCap, st, sym));
+    SelectArgs a{nullptr, 0, N, db, q + q0 * d, d, k, Kp0, cand0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, 0.0,
+                 sym ? mm.pn2 : mm.qn2, mm.r2max, alpha, beta, lists, cnt, kListCap};
+    int fails = 0;
+    MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
+    hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(kBlock), (size_t)a.Kp * 12, st, a);
+    MGP_LAUNCH_CHECK();
+    MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipStreamSynchronize(st));
+    int Kp = Kp0;
+    int* cur = list_a;
+    int* nxt = list_b;
+    // wider candidate sets from the same lists while they can hold them (a list has ~stride x K' keys)
+    while (fails > 0 && Kp < kMaxKp && Kp * 4 <= fp.stride * cand0) {
+      Kp = Kp * 4 > kMaxKp ? kMaxKp : Kp * 4;
+      n_wide += fails;
+      SelectArgs b = a;
+      b.Kp = Kp; b.cand = 0; b.rows = cur; b.fail_list = nxt;
+      MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
+      hipLaunchKernelGGL(select_kernel, dim3((unsigned)fails), dim3(kBlock), (size_t)b.Kp * 12, st, b);
+      MGP_LAUNCH_CHECK();
+      MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
+      MGP_HIP_TRY(hipStreamSynchronize(st));
+      int* t = cur; cur = nxt; nxt = t;
+    }
+    n_failover += fails;
+    for (int f0 = 0; f0 < fails; f0 += (int)fp.fr) {
+      const int64_t m = (fails - f0) < fp.fr ? (fails - f0) : fp.fr;
+      MGP_TRY(mgp_knn_gather_rows(q + q0 * d, cur + f0, m, d, qsub, stream));
+      int64_t s4[4] = {0, 0, 0, 0};
+      MGP_TRY(mgp_knn_bruteforce(db, N, d, qsub, m, k, Dsub, Isub, fb_work, fb_bytes, s4, stream, idx, idx_bytes, false));
+      MGP_TRY(mgp_knn_scatter_rows(Dsub, Isub, cur + f0, m, k, D + q0 * k, I + q0 * k, stream));
+      MGP_HIP_TRY(hipStreamSynchronize(st));
+      n_wide += s4[0]; n_exact += s4[1];
+    }
+  }
+  MGP_HIP_TRY(hipStreamSynchronize(st));
+  if (stats) { stats[0] = n_wide + n_failover; stats[1] = n_exact; stats[2] = n_chunks; stats[3] = cand0; }
+  g_last_direct_chunks = 0;
+  g_last_filter_failover = n_failover;
+  return MGP_OK;
+}
+
+// candidate filter of the matrix-core searches: 0 off (key slab), 1 default (large searches), 2 whenever it can serve
+extern "C" int mgp_knn_set_filter(int mode) {
+  if (mode < 0 || mode > 2) return MGP_ERR_ARG;
+  g_knn_filter = mode;
+  return MGP_OK;
+}
+
+// rows of the last search that the filtered pipeline handed to the slab pipeline; -1: the search ran on the slab
+extern "C" int64_t mgp_knn_last_filter_failover(void) { return g_last_filter_failover; }
 
 extern "C" int mgp_knn_set_symmetric(int on) {
   g_knn_sym = on ? 1 : 0;

@@ -78,9 +78,10 @@ __device__ __forceinline__ int64_t tiled_index(int64_t row, int k, int nst) {
 
 // One wave per row, 4 consecutive rows (same tile) per workgroup: the 4 x 64 bytes they write per stage are
 // contiguous -- whole 128-byte lines (one row per workgroup wrote half lines: 0.69 ms for 60k x 784).
+// stride > 1: output row i is source row i * stride (the sampled points of the candidate filter, knn.hip).
 __global__ __launch_bounds__(kBlock) void split_kernel(const float* __restrict__ x, int64_t n, int d, int dpad,
                                                        const float* __restrict__ mu, uint16_t* __restrict__ H,
-                                                       uint16_t* __restrict__ L, float* __restrict__ norm2) {
+                                                       uint16_t* __restrict__ L, float* __restrict__ norm2, int64_t stride) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nst = dpad / kBK;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kBlock) void split_kernel(const float* __restrict__
     }
     return;
   }
-  const float* xr = x + row * d;
+  const float* xr = x + row * stride * d;
   double s = 0.0;
   // a lane converts one 16-byte piece (8 features) at a time: two 16-byte stores instead of sixteen 2-byte ones
   const int rl = (int)(row & (kMT - 1));
@@ -143,12 +144,47 @@ __global__ __launch_bounds__(1024) void r2max_kernel(const float* __restrict__ n
 // other one is multiplied: one barrier per stage, no staging registers.  Fragment maps of
 // v_mfma_f32_16x16x32_bf16: lane (r = l & 15, g = l >> 4) holds A[row r][k = 8 g + 0..7] and
 // B[k = 8 g + 0..7][col r]; D[col = l & 15][row = 4 (l >> 4) + reg].
+//
+// FILTER (round 5): no key slab.  Every row x has a bound B(x) >= its K'-th smallest key (the K'-th smallest of its keys
+// to a 1/stride sample of the points, knn.hip); the epilogue appends the keys <= B(x) -- ~stride K' of a row's N -- to
+// that row's candidate list {key bits, point index}, `cap` entries per row, slots drawn from a per-row counter.  Per
+// wave and tile pair that is TWO atomic instructions whose 64 lanes address 64 consecutive counters (256 contiguous
+// bytes: the shape global atomics run at full rate for, they execute at the memory side): one for the wave's 64 query
+// rows, one (sym, off the diagonal) for its 64 point rows, whose mirrored keys go to THEIR lists.  A row's survivors in a
+// wave are counted with byte-packed counters: in-lane over the 4 column blocks, DPP row_shr scan over the 16 lanes that
+// hold the row's columns (direct), in-lane over the 16 row slots and a 4-lane exchange (mirrored).  A counter may run past
+// `cap`: the entries beyond it are dropped and the select kernel sends such a row to the slab pipeline.
+struct KnnFilterArgs {
+  const float* bq;       // [nq] bounds of the query rows (compare v <= b)
+  const float* bp;       // [N] bounds of the point rows (sym only: the same array)
+  int* cnt;              // [nq] list fill counters (zeroed by the caller)
+  uint2* lists;          // [nq, cap] {key bits, point index}
+  int cap;
+};
+
+template <int CTRL>
+__device__ __forceinline__ unsigned knn_dpp(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+// lane s of the caller's 16-lane row to all 16 (row_newbcast:s); s is a constant after unrolling, the switch folds
+__device__ __forceinline__ int knn_row_bcast(int v, int s) {
+  switch (s) {
+#define KNN_BC(S) case S: return __builtin_amdgcn_update_dpp(0, v, 0x150 + S, 0xf, 0xf, false);
+    KNN_BC(0) KNN_BC(1) KNN_BC(2) KNN_BC(3) KNN_BC(4) KNN_BC(5) KNN_BC(6) KNN_BC(7)
+    KNN_BC(8) KNN_BC(9) KNN_BC(10) KNN_BC(11) KNN_BC(12) KNN_BC(13) KNN_BC(14)
+#undef KNN_BC
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x15F, 0xf, 0xf, false);
+  }
+}
+
+template <bool FILTER>
 __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __restrict__ Qh, const uint16_t* __restrict__ Ql,
                                                            const float* __restrict__ qn2, int64_t nq,
                                                            const uint16_t* __restrict__ Ph, const uint16_t* __restrict__ Pl,
                                                            const float* __restrict__ pn2, int64_t N, int dpad,
                                                            float* __restrict__ out, int64_t ld, int ny_per_xcd, int nx,
-                                                           int sym) {
+                                                           int sym, KnnFilterArgs fa) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int kTileE = kMT * kBK;                 // bf16 elements of one operand tile (8 KB)
   __shared__ __attribute__((aligned(16))) uint16_t sm[2][4][kTileE];
@@ -227,6 +263,117 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
   // key = max(|c_x|^2 + |c_y|^2 - 2 S, +0): 16 consecutive points per 16 lanes and register.  The
   // query norms go through LDS (a global load per element would be 64 dependent round trips).
   float* qn_s = reinterpret_cast<float*>(&sm[0][0][0]);
+  if constexpr (FILTER) {
+    // rows / columns past the edge get an infinite norm (their keys pass no bound) and the bound -1
+    float* bq_s = qn_s + kMT;
+    if (tid < kMT) {
+      const bool in = q0 + tid < nq;
+      qn_s[tid] = in ? qn2[q0 + tid] : INFINITY;
+      bq_s[tid] = in ? fa.bq[q0 + tid] : -1.f;
+    }
+    __syncthreads();
+    float pn[4], bp[4];
+    knn_f32x4 qn[4], bq[4];
+    const bool mirror = sym && tx != qt;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t pcol = p0 + wn * 64 + j * 16 + r;
+      pn[j] = pcol < N ? pn2[pcol] : INFINITY;
+      bp[j] = (mirror && pcol < N) ? fa.bp[pcol] : -1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      qn[i] = *reinterpret_cast<const knn_f32x4*>(&qn_s[wm * 64 + i * 16 + g * 4]);
+      bq[i] = *reinterpret_cast<const knn_f32x4*>(&bq_s[wm * 64 + i * 16 + g * 4]);
+    }
+    // keys in place; predicate bits: direct (i, e, j) -> bit 16 i + 4 e + j, mirrored (j, i, e) -> bit 16 j + 4 i + e
+    unsigned pd[2] = {0u, 0u}, pm[2] = {0u, 0u};
+    unsigned cd[4] = {0u, 0u, 0u, 0u};     // cd[i], byte e: this lane's survivors of row (i, g, e) over its 4 columns
+    unsigned cm = 0u;                      // byte j: this lane's survivors of point row (j, r) over its 16 query rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = (qn[i][e] + pn[j]) - 2.f * acc[i][j][e];
+          v = v > 0.f ? v : 0.f;
+          acc[i][j][e] = v;
+          const unsigned a = v <= bq[i][e] ? 1u : 0u, b = v <= bp[j] ? 1u : 0u;
+          pd[i >> 1] |= a << (16 * (i & 1) + 4 * e + j);
+          pm[j >> 1] |= b << (16 * (j & 1) + 4 * i + e);
+          cd[i] += a << (8 * e);
+          cm += b << (8 * j);
+        }
+    // direct: inclusive scan over the 16 lanes of a row group (bytes stay under 64), lane 15's total to all of them
+    unsigned inc[4], tot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      unsigned x = cd[i];
+      x += knn_dpp<0x111>(x);
+      x += knn_dpp<0x112>(x);
+      x += knn_dpp<0x114>(x);
+      x += knn_dpp<0x118>(x);
+      inc[i] = x;
+      tot[i] = (unsigned)knn_row_bcast((int)x, 15);
+    }
+    // lane (g, r) draws the slots of row slot s = r = 4 i + e of its group: rows wm 64 + 16 (r >> 2) + 4 g + (r & 3),
+    // the wave's 64 lanes cover its 64 consecutive rows
+    const unsigned ts = (r >> 2) == 0 ? tot[0] : (r >> 2) == 1 ? tot[1] : (r >> 2) == 2 ? tot[2] : tot[3];
+    const int myd = (int)((ts >> (8 * (r & 3))) & 0xffu);
+    const int64_t rowd = q0 + wm * 64 + (r >> 2) * 16 + g * 4 + (r & 3);
+    int based = 0, basem = 0;
+    if (myd > 0) based = atomicAdd(fa.cnt + rowd, myd);
+    // mirrored: the 4 lanes r, r + 16, r + 32, r + 48 hold point row (j, r); lane (g, r) draws for j = g: row wn 64 + lane
+    unsigned exm = 0u;
+    if (mirror) {
+      const unsigned c0 = (unsigned)__shfl((int)cm, r, 64), c1 = (unsigned)__shfl((int)cm, r + 16, 64),
+                     c2 = (unsigned)__shfl((int)cm, r + 32, 64), c3 = (unsigned)__shfl((int)cm, r + 48, 64);
+      exm = (g > 0 ? c0 : 0u) + (g > 1 ? c1 : 0u) + (g > 2 ? c2 : 0u);
+      const unsigned tm = c0 + c1 + c2 + c3;
+      const int mym = (int)((tm >> (8 * g)) & 0xffu);
+      if (mym > 0) basem = atomicAdd(fa.cnt + p0 + wn * 64 + lane, mym);
+    }
+    // direct stores
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int bs = knn_row_bcast(based, 4 * i + e);   // the slot's base from the lane that drew it
+        const unsigned bits = (pd[i >> 1] >> (16 * (i & 1) + 4 * e)) & 0xfu;
+        if (bits) {
+          int slot = bs + (int)((inc[i] >> (8 * e)) & 0xffu) - (int)((cd[i] >> (8 * e)) & 0xffu);
+          const int64_t rowg = q0 + wm * 64 + i * 16 + g * 4 + e;
+          uint2* lrow = fa.lists + rowg * fa.cap;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (bits & (1u << j)) {
+              if (slot < fa.cap) lrow[slot] = make_uint2(__float_as_uint(acc[i][j][e]), (unsigned)(p0 + wn * 64 + j * 16 + r));
+              ++slot;
+            }
+        }
+      }
+    if (mirror) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int bs = __shfl(basem, j * 16 + r, 64);
+        const unsigned bits = (pm[j >> 1] >> (16 * (j & 1))) & 0xffffu;
+        if (bits) {
+          int slot = bs + (int)((exm >> (8 * j)) & 0xffu);
+          uint2* lrow = fa.lists + (p0 + wn * 64 + j * 16 + r) * fa.cap;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (bits & (1u << (4 * i + e))) {
+                if (slot < fa.cap) lrow[slot] = make_uint2(__float_as_uint(acc[i][j][e]), (unsigned)(q0 + wm * 64 + i * 16 + g * 4 + e));
+                ++slot;
+              }
+        }
+      }
+    }
+    return;
+  }
   if (tid < kMT) qn_s[tid] = qn2[q0 + tid < nq ? q0 + tid : nq - 1];
   __syncthreads();
   // every load first (4 point norms, 16 query norms as 4 x 16 bytes from LDS), then the 64 stores back to back: on
@@ -361,7 +508,7 @@ int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnM
   hipLaunchKernelGGL(colmean_kernel, dim3((unsigned)mgp_cdiv(d, 64)), dim3(kBlock), 0, st, m.partial, nblk, d, N, m.mu,
                      m.r2max);
   MGP_LAUNCH_CHECK();
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(N, kMT) * kMT / 4)), dim3(kBlock), 0, st, db, N, d, m.dpad, m.mu, m.Ph, m.Pl, m.pn2);
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(N, kMT) * kMT / 4)), dim3(kBlock), 0, st, db, N, d, m.dpad, m.mu, m.Ph, m.Pl, m.pn2, (int64_t)1);
   MGP_LAUNCH_CHECK();
   hipLaunchKernelGGL(r2max_kernel, dim3(1), dim3(1024), 0, st, m.pn2, N, m.r2max);
   MGP_LAUNCH_CHECK();
@@ -369,7 +516,64 @@ int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnM
 }
 
 int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpKnnMfma& m, hipStream_t st) {
-  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(rows, kMT) * kMT / 4)), dim3(kBlock), 0, st, q, rows, d, m.dpad, m.mu, m.Qh, m.Ql, m.qn2);
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(rows, kMT) * kMT / 4)), dim3(kBlock), 0, st, q, rows, d, m.dpad, m.mu, m.Qh, m.Ql, m.qn2, (int64_t)1);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+// the sampled points of the candidate filter: every stride-th point, split with the POINTS' column means
+size_t mgp_knn_mfma_sample_bytes(int64_t S, int d) {
+  const int dpad = mgp_knn_mfma_dpad(d);
+  return 2 * mgp_align((size_t)(mgp_cdiv(S, kMT) * kMT) * dpad * sizeof(uint16_t)) + mgp_align((size_t)S * sizeof(float));
+}
+
+int mgp_knn_mfma_sample_take(MgpArena& ar, int64_t S, int d, MgpKnnMfma* m) {
+  const int dpad = mgp_knn_mfma_dpad(d);
+  m->Sh = ar.take<uint16_t>((size_t)(mgp_cdiv(S, kMT) * kMT) * dpad);
+  m->Sl = ar.take<uint16_t>((size_t)(mgp_cdiv(S, kMT) * kMT) * dpad);
+  m->sn2 = ar.take<float>(S);
+  return ar.ok() ? MGP_OK : MGP_ERR_WORKSPACE;
+}
+
+int mgp_knn_mfma_prepare_sample(const float* db, int64_t S, int64_t stride, int d, const MgpKnnMfma& m, hipStream_t st) {
+  hipLaunchKernelGGL(split_kernel, dim3((unsigned)(mgp_cdiv(S, kMT) * kMT / 4)), dim3(kBlock), 0, st, db, S, d, m.dpad, m.mu, m.Sh, m.Sl, m.sn2, stride);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+namespace {
+struct TileGrid { int ny_per_xcd; int64_t blocks; int nx; };
+int tile_grid(int64_t rows, int64_t N, TileGrid* t) {
+  const int64_t nx = mgp_cdiv(N, kMT), ny = mgp_cdiv(rows, kMT);
+  t->ny_per_xcd = ny > 8 * MGP_NXCD ? 8 : (int)mgp_cdiv(ny, MGP_NXCD);
+  const int64_t groups = mgp_cdiv(ny, (int64_t)MGP_NXCD * t->ny_per_xcd);
+  t->blocks = groups * MGP_NXCD * t->ny_per_xcd * nx;
+  if (t->blocks > 0x7fffffff || nx > 0x7fffffff) return MGP_ERR_UNSUPPORTED;
+  t->nx = (int)nx;
+  return MGP_OK;
+}
+}  // namespace
+
+// keys of `rows` queries (sym: the points themselves) against the S sampled points into samp[rows, ld]
+int mgp_knn_mfma_sample_tiles(const MgpKnnMfma& m, int64_t rows, int64_t S, float* samp, int64_t ld, hipStream_t st, bool sym) {
+  TileGrid t;
+  MGP_TRY(tile_grid(rows, S, &t));
+  hipLaunchKernelGGL(dist_mfma_kernel<false>, dim3((unsigned)t.blocks), dim3(kBlock), 0, st, sym ? m.Ph : m.Qh, sym ? m.Pl : m.Ql,
+                     sym ? m.pn2 : m.qn2, rows, m.Sh, m.Sl, m.sn2, S, m.dpad, samp, ld, t.ny_per_xcd, t.nx, 0, KnnFilterArgs{});
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+// all keys, filtered into the rows' candidate lists (bounds[rows]; sym: rows == N, the bounds serve both sides)
+int mgp_knn_mfma_tiles_filtered(const MgpKnnMfma& m, int64_t rows, int64_t N, const float* bounds, int* cnt, void* lists, int cap,
+                                hipStream_t st, bool sym) {
+  TileGrid t;
+  MGP_TRY(tile_grid(rows, N, &t));
+  if (sym && rows != N) return MGP_ERR_ARG;
+  KnnFilterArgs fa{bounds, bounds, cnt, static_cast<uint2*>(lists), cap};
+  hipLaunchKernelGGL(dist_mfma_kernel<true>, dim3((unsigned)t.blocks), dim3(kBlock), 0, st, sym ? m.Ph : m.Qh, sym ? m.Pl : m.Ql,
+                     sym ? m.pn2 : m.qn2, rows, m.Ph, m.Pl, m.pn2, N, m.dpad, (float*)nullptr, (int64_t)0, t.ny_per_xcd, t.nx,
+                     sym ? 1 : 0, fa);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
@@ -384,8 +588,9 @@ int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab
   if (blocks > 0x7fffffff || nx > 0x7fffffff) return MGP_ERR_UNSUPPORTED;
   if (sym && rows != N) return MGP_ERR_ARG;
   // sym: the queries are the points -- their split and norms serve both sides
-  hipLaunchKernelGGL(dist_mfma_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, sym ? m.Ph : m.Qh, sym ? m.Pl : m.Ql,
-                     sym ? m.pn2 : m.qn2, rows, m.Ph, m.Pl, m.pn2, N, m.dpad, slab, ld, ny_per_xcd, (int)nx, sym ? 1 : 0);
+  hipLaunchKernelGGL(dist_mfma_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, st, sym ? m.Ph : m.Qh, sym ? m.Pl : m.Ql,
+                     sym ? m.pn2 : m.qn2, rows, m.Ph, m.Pl, m.pn2, N, m.dpad, slab, ld, ny_per_xcd, (int)nx, sym ? 1 : 0,
+                     KnnFilterArgs{});
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }

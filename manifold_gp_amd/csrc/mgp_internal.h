@@ -69,7 +69,7 @@ int mgp_dist_allgather_f32(const MgpDist* d, float* buf, int64_t count_per_rank,
 // k-NN internals (knn.hip / knn_lowd.hip)
 int mgp_knn_bruteforce(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D,
                        int32_t* I, void* work, size_t work_bytes, int64_t* stats, void* stream,
-                       const void* index = nullptr, size_t index_bytes = 0);
+                       const void* index = nullptr, size_t index_bytes = 0, bool allow_filter = true);
 int mgp_knn_lowd_eligible(int64_t N, int64_t n, int d, int k);
 size_t mgp_knn_lowd_workspace_bytes(int64_t N, int64_t n, int d, int k);
 int mgp_knn_lowd(const float* db, int64_t N, int d, const float* q, int64_t n, int k, float* D, int32_t* I, void* work,
@@ -86,6 +86,8 @@ struct MgpKnnMfma {
   float* mu;                     // [d] column means of the points
   float* partial;
   unsigned* r2max;               // bits of max |c_y|^2 over the points
+  uint16_t *Sh, *Sl;             // candidate filter: split of every stride-th point [S, dpad]
+  float* sn2;
 };
 int mgp_knn_mfma_dpad(int d);
 size_t mgp_knn_mfma_bytes(int64_t N, int64_t qc, int d);
@@ -98,6 +100,13 @@ int mgp_knn_mfma_prepare_points(const float* db, int64_t N, int d, const MgpKnnM
 int mgp_knn_mfma_prepare_queries(const float* q, int64_t rows, int d, const MgpKnnMfma& m, hipStream_t st);
 int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab, int64_t ld, hipStream_t st, bool sym = false);
 void mgp_knn_mfma_bound(int dpad, double* alpha, double* beta);
+// candidate filter (no key slab): sampled points, their keys, the filtered key pass
+size_t mgp_knn_mfma_sample_bytes(int64_t S, int d);
+int mgp_knn_mfma_sample_take(MgpArena& ar, int64_t S, int d, MgpKnnMfma* m);
+int mgp_knn_mfma_prepare_sample(const float* db, int64_t S, int64_t stride, int d, const MgpKnnMfma& m, hipStream_t st);
+int mgp_knn_mfma_sample_tiles(const MgpKnnMfma& m, int64_t rows, int64_t S, float* samp, int64_t ld, hipStream_t st, bool sym);
+int mgp_knn_mfma_tiles_filtered(const MgpKnnMfma& m, int64_t rows, int64_t N, const float* bounds, int* cnt, void* lists, int cap,
+                                hipStream_t st, bool sym);
 
 // fp64 operator apply from the fp32 matrix (true residual of the CG refinement); work64 = 4 n C doubles
 int mgp_operator_apply_f64(const mgp_operator_t* op, const double* X, int C, double* Y, double* work64, void* stream);

@@ -74,7 +74,8 @@ class NearestNeighbors():
             check(lib().mgp_knn_search(ptr(self._xc), N, d, ptr(q), n, k, ptr(D), ptr(I), ptr(work), work.numel(),
                                        stats, stream()), "mgp_knn_search")
         self.last_stats = dict(rows_redone_wide=stats[0], rows_redone_exact=stats[1], chunks=stats[2],
-                               candidates=stats[3], chunks_redone_direct=int(lib().mgp_knn_last_direct_chunks()))
+                               candidates=stats[3], chunks_redone_direct=int(lib().mgp_knn_last_direct_chunks()),
+                               filter_failover_rows=int(lib().mgp_knn_last_filter_failover()))
         return D, I.long()
 
     def graph(self, k, symmetric=True, self_loop=False, nprobe=1):
