@@ -73,13 +73,15 @@ int64_t mgp_knn_last_direct_chunks(void);
 int mgp_knn_set_symmetric(int on);
 /* Candidate filter of the matrix-core searches (round 5).  A large search does not write its keys to an N x n slab for the
  * select kernel to read back (60k x 60k: 14.4 GB each way): the keys of every row to a 1/stride sample of the points
- * (stride 16 up to k = 64) give a per-row bound >= the row's K'-th smallest key, the key pass appends the ~stride K' keys
- * under it to the row's candidate list (3840 entries of {key, index}; slots from per-row counters, two 256-byte atomic
- * instructions per wave and tile pair), and the select kernel takes the exact K'-th smallest key, the candidates, the fp64
+ * (stride 16 up to k = 64) give a per-row bound >= the row's K'-th smallest key; the key pass appends the ~stride K' keys
+ * per row under the bounds to a log (one returning atomic per WORKGROUP and tile pair draws its range; a self-search logs
+ * each key of an off-diagonal tile for both of its rows); regroup_kernel deals the log to per-row candidate lists (3840
+ * entries of {key, index}) with LDS counters; the select kernel takes the exact K'-th smallest key, the candidates, the fp64
  * re-rank and the sufficiency check from the list.  Rows whose list overflows or whose check fails are gathered and redone
- * by the slab pipeline (which ends in the exact scan): the results are the oracle's bit for bit, as before.  Workspace at
- * 60k x 784: 5.3 GB instead of 14.6.  mode 0: key slab (rounds 1-4); 1 (default): searches of >= 4096 queries against
- * >= 16384 points; 2: every matrix-core search whose k the lists can serve (tests).  Lab / test switch: read once per call.
+ * by the slab pipeline (which ends in the exact scan); a chunk whose log fills up is redone there whole: the results are
+ * the oracle's bit for bit, as before.  Workspace at 60k x 784: 6.4 GB instead of 14.6.  mode 0: key slab (rounds 1-4);
+ * 1 (default): searches of >= 4096 queries against >= 16384 points; 2: every matrix-core search whose k the lists can serve
+ * (tests).  Lab / test switch: read once per call.
  * mgp_knn_last_filter_failover: rows of the last search handed to the slab pipeline; -1 when the search ran on the slab. */
 int mgp_knn_set_filter(int mode);
 int64_t mgp_knn_last_filter_failover(void);

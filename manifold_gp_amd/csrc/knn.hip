@@ -346,7 +346,9 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   static_assert(kMaxDimLds * sizeof(float) <= sizeof(uint32_t) * 2 * kListCap, "query row staging");
 
   const int tid = threadIdx.x;
-  const int row = a.rows ? a.rows[blockIdx.x] : (int)blockIdx.x;
+  // consecutive rows to one XCD (blocks are dealt round-robin over the XCDs): neighbouring queries re-rank largely the same
+  // candidate rows, which then come from that XCD's L2 instead of being fetched into all eight
+  const int row = a.rows ? a.rows[blockIdx.x] : mgp_xcd_block((int)blockIdx.x, (int)gridDim.x);
   const uint32_t* keys = a.lists ? nullptr : reinterpret_cast<const uint32_t*>(a.dist + (int64_t)row * a.ld);
   const int64_t N = a.N;
   const int Kp = a.Kp;
@@ -673,6 +675,7 @@ int first_candidates(int k, bool mfma) { return mfma ? k + (k / 2 > 24 ? k / 2 :
 // the key pass keeps the ~stride K' keys per row that lie under a per-row bound from a 1/stride sample of the points.
 // 0: off; 1: searches of >= 4096 queries against >= 16384 points; 2: every matrix-core search the lists can serve (tests).
 std::atomic<int> g_knn_filter{1};
+constexpr int kLogPerRow = 2048;      // log entries per query row of a chunk (~stride K' = 1200 expected at k = 50)
 std::atomic<int64_t> g_last_filter_failover{-1};
 
 struct FilterPlan {
@@ -760,6 +763,8 @@ static size_t filter_bytes(int64_t N, int64_t n, int d, int k, const FilterPlan&
   b += mgp_align((size_t)f.qc * f.ldS * sizeof(float));                  // keys to the sampled points
   b += 4 * mgp_align((size_t)f.qc * sizeof(int)) + mgp_align(64);        // bounds, counters, two fail lists
   b += mgp_align((size_t)f.qc * kListCap * sizeof(uint2));               // candidate lists
+  b += mgp_align((size_t)f.qc * kLogPerRow * sizeof(uint2));             // the key pass's log
+  b += mgp_align(mgp_knn_mfma_table_entries(f.qc, N) * 16) + mgp_align((size_t)mgp_knn_mfma_log_shards() * 64 + 64);
   b += mgp_align((size_t)f.fr * d * sizeof(float)) + 2 * mgp_align((size_t)f.fr * k * sizeof(float));
   return b + 1024;
 }
@@ -931,6 +936,11 @@ static int filtered_search(const float* db, int64_t N, int d, const float* q, in
   int* list_b = ar.take<int>(fp.qc);
   int* counter = ar.take<int>(16);
   uint2* lists = ar.take<uint2>((size_t)fp.qc * kListCap);
+  uint2* klog = ar.take<uint2>((size_t)fp.qc * kLogPerRow);
+  uint4* table = ar.take<uint4>(mgp_knn_mfma_table_entries(fp.qc, N));
+  const int shards = mgp_knn_mfma_log_shards();
+  unsigned* cursor = ar.take<unsigned>((size_t)shards * 16 + 16);       // + the overflow flag
+  int* overflow = reinterpret_cast<int*>(cursor + (size_t)shards * 16);
   float* qsub = ar.take<float>((size_t)fp.fr * d);
   float* Dsub = ar.take<float>((size_t)fp.fr * k);
   int32_t* Isub = ar.take<int32_t>((size_t)fp.fr * k);
@@ -952,19 +962,33 @@ static int filtered_search(const float* db, int64_t N, int d, const float* q, in
     MGP_TRY(mgp_knn_mfma_sample_tiles(mm, rows, fp.S, samp, fp.ldS, st, sym));
     hipLaunchKernelGGL(bound_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, samp, fp.ldS, (int)fp.S, cand0, bounds);
     MGP_LAUNCH_CHECK();
-    MGP_HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)rows * sizeof(int), st));
-    MGP_TRY(mgp_knn_mfma_tiles_filtered(mm, rows, N, bounds, cnt, lists, kListCap, st, sym));
+    MGP_HIP_TRY(hipMemsetAsync(cursor, 0, ((size_t)shards * 16 + 16) * sizeof(unsigned), st));
+    const unsigned shard_cap = (unsigned)(((size_t)rows * kLogPerRow) / shards);
+    MGP_TRY(mgp_knn_mfma_tiles_filtered(mm, rows, N, bounds, klog, cursor, table, shard_cap, overflow, st, sym));
+    MGP_TRY(mgp_knn_mfma_regroup(table, klog, rows, N, lists, cnt, kListCap, st, sym));
     SelectArgs a{nullptr, 0, N, db, q + q0 * d, d, k, Kp0, cand0, nullptr, D + q0 * k, I + q0 * k, list_a, counter, 0.0,
                  sym ? mm.pn2 : mm.qn2, mm.r2max, alpha, beta, lists, cnt, kListCap};
     int fails = 0;
     MGP_HIP_TRY(hipMemsetAsync(counter, 0, sizeof(int), st));
     hipLaunchKernelGGL(select_kernel, dim3((unsigned)rows), dim3(kBlock), (size_t)a.Kp * 12, st, a);
     MGP_LAUNCH_CHECK();
+    int over = 0;
     MGP_HIP_TRY(hipMemcpyAsync(&fails, counter, sizeof(int), hipMemcpyDeviceToHost, st));
+    MGP_HIP_TRY(hipMemcpyAsync(&over, overflow, sizeof(int), hipMemcpyDeviceToHost, st));
     MGP_HIP_TRY(hipStreamSynchronize(st));
     int Kp = Kp0;
     int* cur = list_a;
     int* nxt = list_b;
+    if (over) {
+      // the log filled up (far more keys under the bounds than stride x K' per row): entries were dropped, every row of
+      // the chunk is redone on the slab
+      std::vector<int> all((size_t)rows);
+      for (int64_t i = 0; i < rows; ++i) all[(size_t)i] = (int)i;
+      MGP_HIP_TRY(hipMemcpyAsync(cur, all.data(), (size_t)rows * sizeof(int), hipMemcpyHostToDevice, st));
+      MGP_HIP_TRY(hipStreamSynchronize(st));
+      fails = (int)rows;
+      Kp = kMaxKp;
+    }
     // wider candidate sets from the same lists while they can hold them (a list has ~stride x K' keys)
     while (fails > 0 && Kp < kMaxKp && Kp * 4 <= fp.stride * cand0) {
       Kp = Kp * 4 > kMaxKp ? kMaxKp : Kp * 4;

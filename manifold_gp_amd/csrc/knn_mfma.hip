@@ -146,20 +146,31 @@ __global__ __launch_bounds__(1024) void r2max_kernel(const float* __restrict__ n
 // B[k = 8 g + 0..7][col r]; D[col = l & 15][row = 4 (l >> 4) + reg].
 //
 // FILTER (round 5): no key slab.  Every row x has a bound B(x) >= its K'-th smallest key (the K'-th smallest of its keys
-// to a 1/stride sample of the points, knn.hip); the epilogue appends the keys <= B(x) -- ~stride K' of a row's N -- to
-// that row's candidate list {key bits, point index}, `cap` entries per row, slots drawn from a per-row counter.  Per
-// wave and tile pair that is TWO atomic instructions whose 64 lanes address 64 consecutive counters (256 contiguous
-// bytes: the shape global atomics run at full rate for, they execute at the memory side): one for the wave's 64 query
-// rows, one (sym, off the diagonal) for its 64 point rows, whose mirrored keys go to THEIR lists.  A row's survivors in a
-// wave are counted with byte-packed counters: in-lane over the 4 column blocks, DPP row_shr scan over the 16 lanes that
-// hold the row's columns (direct), in-lane over the 16 row slots and a 4-lane exchange (mirrored).  A counter may run past
-// `cap`: the entries beyond it are dropped and the select kernel sends such a row to the slab pipeline.
+// to a 1/stride sample of the points, knn.hip); the epilogue keeps the keys <= B(x) -- ~stride K' of a row's N -- as
+// entries {key bits, (row in the wave's 64) << 6 | (column in the wave's 64)} of an append-only LOG: a workgroup draws
+// ONE range of it for all its survivors (one returning atomic per workgroup on one of 64 cursors, each with its own
+// region of the log) and every wave writes its entries side by side -- the DIRECT ones (key of query row x to point y,
+// for x's list) and, sym and off the diagonal, the MIRRORED ones (the same key, for y's list) -- and records
+// {offset, direct count, mirrored count} in a table indexed by (tile pair, wave).  regroup_kernel (below) then deals a
+// half tile's entries to its 64 rows' candidate lists with LDS counters.
+// (First version of this round: slots drawn per ROW from global counters, two 64-lane returning atomics per wave and tile
+// pair: 8.5 ms per 60k x 784 pass against 3.8 ms for the MFMA loop alone -- the atomics execute at the memory side and
+// 56 M of them per launch slowed every other request of the launch; tools/lab/knn_filter_bounds.sh.)
+#ifdef MGP_KNN_LAB
+__device__ unsigned long long g_knn_stamp[8];
+#define KNN_STAMP(K) do { if (MGP_KNN_LAB & 8) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && blockIdx.x % 61 == 0) atomicAdd(&g_knn_stamp[K], t_ - t_prev); t_prev = __builtin_readcyclecounter(); } } while (0)
+#else
+#define KNN_STAMP(K) do { } while (0)
+#endif
+constexpr int kLogShards = 64;
 struct KnnFilterArgs {
   const float* bq;       // [nq] bounds of the query rows (compare v <= b)
   const float* bp;       // [N] bounds of the point rows (sym only: the same array)
-  int* cnt;              // [nq] list fill counters (zeroed by the caller)
-  uint2* lists;          // [nq, cap] {key bits, point index}
-  int cap;
+  uint2* log;            // [kLogShards * shard_cap] entries
+  unsigned* cursor;      // [kLogShards * 16] fill of each shard's region (one word per 64-byte line; zeroed by the caller)
+  uint4* table;          // [query tiles * nx * 4 waves] {offset, direct count, mirrored count, 0}
+  unsigned shard_cap;    // entries per shard region
+  int* overflow;         // set when a region is full: the caller redoes the chunk on the slab
 };
 
 template <int CTRL>
@@ -190,6 +201,9 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
   __shared__ __attribute__((aligned(16))) uint16_t sm[2][4][kTileE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+#ifdef MGP_KNN_LAB
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
   // blocks are dealt round-robin over the 8 XCDs: XCD c takes the query tiles c, c + 8, ... and walks the
   // point tiles with its query tiles innermost, so that a point tile fetched into that XCD's L2 is used
   // by all its query tiles at about the same time and the few query tiles stay L2-resident.
@@ -260,10 +274,14 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
       }
   }
   __syncthreads();
+  KNN_STAMP(0);      // main loop
   // key = max(|c_x|^2 + |c_y|^2 - 2 S, +0): 16 consecutive points per 16 lanes and register.  The
   // query norms go through LDS (a global load per element would be 64 dependent round trips).
   float* qn_s = reinterpret_cast<float*>(&sm[0][0][0]);
   if constexpr (FILTER) {
+#ifdef MGP_KNN_LAB
+    if (MGP_KNN_LAB & 4) return;
+#endif
     // rows / columns past the edge get an infinite norm (their keys pass no bound) and the bound -1
     float* bq_s = qn_s + kMT;
     if (tid < kMT) {
@@ -286,10 +304,8 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
       qn[i] = *reinterpret_cast<const knn_f32x4*>(&qn_s[wm * 64 + i * 16 + g * 4]);
       bq[i] = *reinterpret_cast<const knn_f32x4*>(&bq_s[wm * 64 + i * 16 + g * 4]);
     }
-    // keys in place; predicate bits: direct (i, e, j) -> bit 16 i + 4 e + j, mirrored (j, i, e) -> bit 16 j + 4 i + e
+    // keys in place; predicate bits: direct and mirrored alike (i, e, j) -> bit 16 i + 4 e + j
     unsigned pd[2] = {0u, 0u}, pm[2] = {0u, 0u};
-    unsigned cd[4] = {0u, 0u, 0u, 0u};     // cd[i], byte e: this lane's survivors of row (i, g, e) over its 4 columns
-    unsigned cm = 0u;                      // byte j: this lane's survivors of point row (j, r) over its 16 query rows
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -299,79 +315,79 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
           float v = (qn[i][e] + pn[j]) - 2.f * acc[i][j][e];
           v = v > 0.f ? v : 0.f;
           acc[i][j][e] = v;
-          const unsigned a = v <= bq[i][e] ? 1u : 0u, b = v <= bp[j] ? 1u : 0u;
-          pd[i >> 1] |= a << (16 * (i & 1) + 4 * e + j);
-          pm[j >> 1] |= b << (16 * (j & 1) + 4 * i + e);
-          cd[i] += a << (8 * e);
-          cm += b << (8 * j);
+          pd[i >> 1] |= (v <= bq[i][e] ? 1u : 0u) << (16 * (i & 1) + 4 * e + j);
+          pm[i >> 1] |= (v <= bp[j] ? 1u : 0u) << (16 * (i & 1) + 4 * e + j);
         }
-    // direct: inclusive scan over the 16 lanes of a row group (bytes stay under 64), lane 15's total to all of them
-    unsigned inc[4], tot[4];
+    KNN_STAMP(1);    // bounds, keys, predicates
+    // this lane's entries, prefix over the wave (DPP: 16-lane rows, then row_bcast15 / row_bcast31), totals over the workgroup
+    const unsigned nd = __popc(pd[0]) + __popc(pd[1]), nm = __popc(pm[0]) + __popc(pm[1]);
+    unsigned x = nd | (nm << 16);                  // a wave holds at most 4096 entries of each kind
+    x += knn_dpp<0x111>(x);
+    x += knn_dpp<0x112>(x);
+    x += knn_dpp<0x114>(x);
+    x += knn_dpp<0x118>(x);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    const unsigned wt = (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+    unsigned* ws = reinterpret_cast<unsigned*>(bq_s + kMT);      // [4] wave totals, [4] base
+    if (lane == 0) ws[wave] = wt;
+    __syncthreads();
+    KNN_STAMP(2);    // scans
+    if (tid == 0) {
+      const unsigned t0 = ws[0], t1 = ws[1], t2 = ws[2], t3 = ws[3];
+      const unsigned n0 = (t0 & 0xffffu) + (t0 >> 16), n1 = (t1 & 0xffffu) + (t1 >> 16), n2 = (t2 & 0xffffu) + (t2 >> 16),
+                     n3 = (t3 & 0xffffu) + (t3 >> 16);
+      const unsigned total = n0 + n1 + n2 + n3;
+      // a multiplicative hash of the block index: blockIdx % 64 is the QUERY TILE within its group, whose tile pairs (and
+      // entries) a self-search deals unevenly (tile 0 has every pair, the last one a single pair)
+      const unsigned shard = (blockIdx.x * 2654435761u) >> 26;
+      static_assert(kLogShards == 64, "top 6 bits of the hash");
+      unsigned base = 0u;
+      bool ok = true;
+#ifdef MGP_KNN_LAB
+      if (!(MGP_KNN_LAB & 1))
+#endif
+      if (total) {
+        base = atomicAdd(fa.cursor + shard * 16, total);
+        if (base + total > fa.shard_cap) { ok = false; *fa.overflow = 1; }
+      }
+      base += shard * fa.shard_cap;
+      uint4* trow = fa.table + ((int64_t)qt * nx + tx) * 4;
+      const unsigned m = ok ? 0xffffffffu : 0u;
+      trow[0] = make_uint4(base, (t0 & 0xffffu) & m, (t0 >> 16) & m, 0u);
+      trow[1] = make_uint4(base + n0, (t1 & 0xffffu) & m, (t1 >> 16) & m, 0u);
+      trow[2] = make_uint4(base + n0 + n1, (t2 & 0xffffu) & m, (t2 >> 16) & m, 0u);
+      trow[3] = make_uint4(base + n0 + n1 + n2, (t3 & 0xffffu) & m, (t3 >> 16) & m, 0u);
+      ws[4] = base; ws[5] = base + n0; ws[6] = base + n0 + n1; ws[7] = base + n0 + n1 + n2;
+      ws[8] = ok ? 1u : 0u;
+    }
+    __syncthreads();
+    KNN_STAMP(3);    // the workgroup's range drawn
+    if (!ws[8]) return;
+#ifdef MGP_KNN_LAB
+    if (MGP_KNN_LAB & 2) return;
+#endif
+    const unsigned ex = x - (nd | (nm << 16));
+    uint2* od = fa.log + ws[4 + wave] + (ex & 0xffffu);
+    uint2* om = fa.log + ws[4 + wave] + (wt & 0xffffu) + (ex >> 16);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      unsigned x = cd[i];
-      x += knn_dpp<0x111>(x);
-      x += knn_dpp<0x112>(x);
-      x += knn_dpp<0x114>(x);
-      x += knn_dpp<0x118>(x);
-      inc[i] = x;
-      tot[i] = (unsigned)knn_row_bcast((int)x, 15);
-    }
-    // lane (g, r) draws the slots of row slot s = r = 4 i + e of its group: rows wm 64 + 16 (r >> 2) + 4 g + (r & 3),
-    // the wave's 64 lanes cover its 64 consecutive rows
-    const unsigned ts = (r >> 2) == 0 ? tot[0] : (r >> 2) == 1 ? tot[1] : (r >> 2) == 2 ? tot[2] : tot[3];
-    const int myd = (int)((ts >> (8 * (r & 3))) & 0xffu);
-    const int64_t rowd = q0 + wm * 64 + (r >> 2) * 16 + g * 4 + (r & 3);
-    int based = 0, basem = 0;
-    if (myd > 0) based = atomicAdd(fa.cnt + rowd, myd);
-    // mirrored: the 4 lanes r, r + 16, r + 32, r + 48 hold point row (j, r); lane (g, r) draws for j = g: row wn 64 + lane
-    unsigned exm = 0u;
-    if (mirror) {
-      const unsigned c0 = (unsigned)__shfl((int)cm, r, 64), c1 = (unsigned)__shfl((int)cm, r + 16, 64),
-                     c2 = (unsigned)__shfl((int)cm, r + 32, 64), c3 = (unsigned)__shfl((int)cm, r + 48, 64);
-      exm = (g > 0 ? c0 : 0u) + (g > 1 ? c1 : 0u) + (g > 2 ? c2 : 0u);
-      const unsigned tm = c0 + c1 + c2 + c3;
-      const int mym = (int)((tm >> (8 * g)) & 0xffu);
-      if (mym > 0) basem = atomicAdd(fa.cnt + p0 + wn * 64 + lane, mym);
-    }
-    // direct stores
+      const unsigned bd = (pd[i >> 1] >> (16 * (i & 1))) & 0xffffu, bm = (pm[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+      if (bd | bm) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int bs = knn_row_bcast(based, 4 * i + e);   // the slot's base from the lane that drew it
-        const unsigned bits = (pd[i >> 1] >> (16 * (i & 1) + 4 * e)) & 0xfu;
-        if (bits) {
-          int slot = bs + (int)((inc[i] >> (8 * e)) & 0xffu) - (int)((cd[i] >> (8 * e)) & 0xffu);
-          const int64_t rowg = q0 + wm * 64 + i * 16 + g * 4 + e;
-          uint2* lrow = fa.lists + rowg * fa.cap;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (bits & (1u << j)) {
-              if (slot < fa.cap) lrow[slot] = make_uint2(__float_as_uint(acc[i][j][e]), (unsigned)(p0 + wn * 64 + j * 16 + r));
-              ++slot;
-            }
-        }
-      }
-    if (mirror) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int bs = __shfl(basem, j * 16 + r, 64);
-        const unsigned bits = (pm[j >> 1] >> (16 * (j & 1))) & 0xffffu;
-        if (bits) {
-          int slot = bs + (int)((exm >> (8 * j)) & 0xffu);
-          uint2* lrow = fa.lists + (p0 + wn * 64 + j * 16 + r) * fa.cap;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (bits & (1u << (4 * i + e))) {
-                if (slot < fa.cap) lrow[slot] = make_uint2(__float_as_uint(acc[i][j][e]), (unsigned)(q0 + wm * 64 + i * 16 + g * 4 + e));
-                ++slot;
-              }
-        }
+          for (int j = 0; j < 4; ++j) {
+            const uint2 ent = make_uint2(__float_as_uint(acc[i][j][e]), (unsigned)(((i * 16 + g * 4 + e) << 6) | (j * 16 + r)));
+            if (bd & (1u << (4 * e + j))) *od++ = ent;
+            if (bm & (1u << (4 * e + j))) *om++ = ent;
+          }
       }
     }
+    KNN_STAMP(5);    // stores issued
+#ifdef MGP_KNN_LAB
+    if (MGP_KNN_LAB & 8) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); KNN_STAMP(7); }   // stores acknowledged
+#endif
     return;
   }
   if (tid < kMT) qn_s[tid] = qn2[q0 + tid < nq ? q0 + tid : nq - 1];
@@ -433,6 +449,74 @@ __global__ __launch_bounds__(kBlock) void dist_mfma_kernel(const uint16_t* __res
     }
   }
 #endif
+}
+
+// The log's entries of one half tile (64 rows) dealt to the rows' candidate lists {key bits, point index}: its direct
+// entries sit in the segments of the tile pairs (t, tx) (sym: tx >= t), waves (b, wn); its mirrored ones in those of
+// (qt < t, t), waves (wm, b).  Segments are taken 1024 at a time: their {offset, count} to LDS, a prefix over the counts, then
+// the batch's entries flat over the 1024 threads (binary search of the segment); slots from 64 LDS counters, which end
+// up as the rows' entry counts (a count past `cap` marks an overflowed list: the select kernel fails that row over).
+constexpr int kRgThreads = 1024;
+__global__ __launch_bounds__(kRgThreads) void regroup_kernel(const uint4* __restrict__ table, const uint2* __restrict__ log, int nx,
+                                                             int64_t nq, int sym, uint2* __restrict__ lists,
+                                                             int* __restrict__ counts, int cap) {
+  __shared__ unsigned seg_off[kRgThreads], seg_pre[kRgThreads + 1];
+  __shared__ int seg_base[kRgThreads];
+  __shared__ int cnt[64];
+  __shared__ unsigned wsum[kRgThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x >> 1, b = blockIdx.x & 1;
+  if (tid < 64) cnt[tid] = 0;
+  const int n_dir = (sym ? nx - t : nx) * 2, n_mir = (sym ? t : 0) * 2, nseg = n_dir + n_mir;
+  for (int s0 = 0; s0 < nseg; s0 += kRgThreads) {
+    __syncthreads();                       // the previous batch is consumed (first round: the counters are zero)
+    const int sg = s0 + tid;
+    unsigned c = 0, off = 0;
+    int base = 0;
+    if (sg < nseg) {
+      if (sg < n_dir) {
+        const int tx = (sym ? t : 0) + (sg >> 1), wn = sg & 1;
+        const uint4 e = table[((int64_t)t * nx + tx) * 4 + b * 2 + wn];
+        off = e.x; c = e.y; base = tx * kMT + wn * 64;
+      } else {
+        const int m = sg - n_dir, qt = m >> 1, wm = m & 1;
+        const uint4 e = table[((int64_t)qt * nx + t) * 4 + wm * 2 + b];
+        off = e.x + e.y; c = e.z; base = (qt * kMT + wm * 64) | (int)0x80000000;
+      }
+    }
+    unsigned inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned u = (unsigned)__shfl_up((int)inc, o, 64);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    unsigned wb = 0, total = 0;
+    for (int w = 0; w < kRgThreads / 64; ++w) { const unsigned v = wsum[w]; if (w < wave) wb += v; total += v; }
+    seg_off[tid] = off; seg_base[tid] = base; seg_pre[tid] = wb + inc - c;
+    if (tid == 0) seg_pre[kRgThreads] = total;
+    __syncthreads();
+    for (unsigned e = tid; e < total; e += kRgThreads) {
+      int lo = 0, hi = kRgThreads;         // seg_pre[lo] <= e < seg_pre[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_pre[mid] <= e) lo = mid; else hi = mid;
+      }
+      const uint2 ent = log[(size_t)seg_off[lo] + (e - seg_pre[lo])];
+      const int sb = seg_base[lo];
+      const int rl = (int)(ent.y >> 6) & 63, cl = (int)ent.y & 63;
+      const int rowl = sb < 0 ? cl : rl;
+      const unsigned idx = (unsigned)(sb & 0x7fffffff) + (unsigned)(sb < 0 ? rl : cl);
+      const int slot = atomicAdd(&cnt[rowl], 1);
+      if (slot < cap) lists[((int64_t)t * kMT + b * 64 + rowl) * cap + slot] = make_uint2(ent.x, idx);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int64_t row = (int64_t)t * kMT + b * 64 + tid;
+    if (row < nq) counts[row] = cnt[tid];
+  }
 }
 
 // Tried in round 2 and removed (docs/kernels/knn.md): a 256 x 128 tile shared by eight waves with a
@@ -564,16 +648,30 @@ int mgp_knn_mfma_sample_tiles(const MgpKnnMfma& m, int64_t rows, int64_t S, floa
   return MGP_OK;
 }
 
-// all keys, filtered into the rows' candidate lists (bounds[rows]; sym: rows == N, the bounds serve both sides)
-int mgp_knn_mfma_tiles_filtered(const MgpKnnMfma& m, int64_t rows, int64_t N, const float* bounds, int* cnt, void* lists, int cap,
-                                hipStream_t st, bool sym) {
+// all keys, the ones under the rows' bounds appended to the log (bounds[rows]; sym: rows == N, the bounds serve both
+// sides); cursor (kLogShards x 16 words) and *overflow zeroed by the caller
+size_t mgp_knn_mfma_table_entries(int64_t rows, int64_t N) { return (size_t)mgp_cdiv(rows, kMT) * (size_t)mgp_cdiv(N, kMT) * 4; }
+int mgp_knn_mfma_log_shards(void) { return kLogShards; }
+
+int mgp_knn_mfma_tiles_filtered(const MgpKnnMfma& m, int64_t rows, int64_t N, const float* bounds, void* log, unsigned* cursor,
+                                void* table, unsigned shard_cap, int* overflow, hipStream_t st, bool sym) {
   TileGrid t;
   MGP_TRY(tile_grid(rows, N, &t));
   if (sym && rows != N) return MGP_ERR_ARG;
-  KnnFilterArgs fa{bounds, bounds, cnt, static_cast<uint2*>(lists), cap};
+  KnnFilterArgs fa{bounds, bounds, static_cast<uint2*>(log), cursor, static_cast<uint4*>(table), shard_cap, overflow};
   hipLaunchKernelGGL(dist_mfma_kernel<true>, dim3((unsigned)t.blocks), dim3(kBlock), 0, st, sym ? m.Ph : m.Qh, sym ? m.Pl : m.Ql,
                      sym ? m.pn2 : m.qn2, rows, m.Ph, m.Pl, m.pn2, N, m.dpad, (float*)nullptr, (int64_t)0, t.ny_per_xcd, t.nx,
                      sym ? 1 : 0, fa);
+  MGP_LAUNCH_CHECK();
+  return MGP_OK;
+}
+
+// the log's entries dealt to the rows' candidate lists [rows, cap] and counts[rows]
+int mgp_knn_mfma_regroup(const void* table, const void* log, int64_t rows, int64_t N, void* lists, int* counts, int cap,
+                         hipStream_t st, bool sym) {
+  const int64_t nx = mgp_cdiv(N, kMT), ny = mgp_cdiv(rows, kMT);
+  hipLaunchKernelGGL(regroup_kernel, dim3((unsigned)(2 * ny)), dim3(kRgThreads), 0, st, static_cast<const uint4*>(table),
+                     static_cast<const uint2*>(log), (int)nx, rows, sym ? 1 : 0, static_cast<uint2*>(lists), counts, cap);
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
@@ -594,6 +692,14 @@ int mgp_knn_mfma_tiles(const MgpKnnMfma& m, int64_t rows, int64_t N, float* slab
   MGP_LAUNCH_CHECK();
   return MGP_OK;
 }
+
+#ifdef MGP_KNN_LAB
+extern "C" int mgp_knn_lab_stamps(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_knn_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_knn_stamp), z, sizeof(z)) != hipSuccess) return 1; }
+  return MGP_OK;
+}
+#endif
 
 // coefficients of E(x) = alpha |c_x| R + beta (|c_x| + R)^2 (header)
 void mgp_knn_mfma_bound(int dpad, double* alpha, double* beta) {

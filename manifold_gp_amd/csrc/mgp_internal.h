@@ -105,8 +105,12 @@ size_t mgp_knn_mfma_sample_bytes(int64_t S, int d);
 int mgp_knn_mfma_sample_take(MgpArena& ar, int64_t S, int d, MgpKnnMfma* m);
 int mgp_knn_mfma_prepare_sample(const float* db, int64_t S, int64_t stride, int d, const MgpKnnMfma& m, hipStream_t st);
 int mgp_knn_mfma_sample_tiles(const MgpKnnMfma& m, int64_t rows, int64_t S, float* samp, int64_t ld, hipStream_t st, bool sym);
-int mgp_knn_mfma_tiles_filtered(const MgpKnnMfma& m, int64_t rows, int64_t N, const float* bounds, int* cnt, void* lists, int cap,
-                                hipStream_t st, bool sym);
+int mgp_knn_mfma_tiles_filtered(const MgpKnnMfma& m, int64_t rows, int64_t N, const float* bounds, void* log, unsigned* cursor,
+                                void* table, unsigned shard_cap, int* overflow, hipStream_t st, bool sym);
+int mgp_knn_mfma_regroup(const void* table, const void* log, int64_t rows, int64_t N, void* lists, int* counts, int cap,
+                         hipStream_t st, bool sym);
+size_t mgp_knn_mfma_table_entries(int64_t rows, int64_t N);
+int mgp_knn_mfma_log_shards(void);
 
 // fp64 operator apply from the fp32 matrix (true residual of the CG refinement); work64 = 4 n C doubles
 int mgp_operator_apply_f64(const mgp_operator_t* op, const double* X, int C, double* Y, double* work64, void* stream);

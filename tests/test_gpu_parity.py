@@ -2601,6 +2601,63 @@ def test_knn_self_search_upper_triangle_tiles(mgp, dev, n, d, k):
     assert np.array_equal(I1[rows].cpu().numpy(), Ir) and np.array_equal(D1[rows].cpu().numpy(), Dr)
 
 
+@pytest.mark.parametrize("shape", ["ragged_self", "k100_stride8", "out_of_sample", "duplicates_overflow", "tight_clusters",
+                                   "far_from_origin", "default_mode_17k"])
+def test_knn_candidate_filter_matches_slab_and_oracle(mgp, dev, shape):
+    """The candidate filter of the matrix-core searches (mgp_knn_set_filter; round 5: per-row bounds from a sample of the
+    points, the key pass logs the keys under them, regroup_kernel deals them to per-row lists, the select kernel works from
+    the lists; no N x n key slab) against the slab pipeline (mode 0) bit for bit and against the oracle: ragged self-searches
+    (upper-triangle tile pairs, mirrored entries), k = 100 (sample stride 8), out-of-sample queries (direct entries only),
+    2001 copies of one point (their lists overflow: fail-over to the slab), tight clusters, data far from the origin
+    (absolute bound of the keys useless), and the default mode at a size where it switches itself on."""
+    from manifold_gp_amd import _lib
+    from oracle import knn as oknn
+    lib = _lib.lib()
+    rng = np.random.default_rng(len(shape))
+    mode, expect_failover = 2, None
+    if shape == "ragged_self":
+        x = rng.normal(size=(8323, 96)).astype(np.float32); q = None; k = 50
+        expect_failover = 0
+    elif shape == "k100_stride8":
+        x = rng.normal(size=(8323, 96)).astype(np.float32); q = None; k = 100
+    elif shape == "out_of_sample":
+        x = rng.normal(size=(8323, 96)).astype(np.float32); q = rng.normal(size=(1500, 96)).astype(np.float32); k = 32
+    elif shape == "duplicates_overflow":
+        x = rng.normal(size=(8323, 96)).astype(np.float32); x[1000:3001] = x[0]; q = None; k = 20
+    elif shape == "tight_clusters":
+        c = rng.normal(size=(40, 128)) * 5
+        x = (c[rng.integers(0, 40, 20000)] + 0.01 * rng.normal(size=(20000, 128))).astype(np.float32); q = None; k = 50
+    elif shape == "far_from_origin":
+        x = (rng.normal(size=(5000, 64)) * 1e-3 + 100.0).astype(np.float32); q = None; k = 16
+    else:
+        x = rng.normal(size=(17000, 48)).astype(np.float32); q = None; k = 12; mode = 1
+        expect_failover = 0
+    xt = T(x, dev)
+    qt = xt if q is None else T(q, dev)
+    nn = mgp.utils.NearestNeighbors(xt)
+    try:
+        lib.mgp_knn_set_filter(0)
+        D0, I0 = nn.search(qt, k)
+        assert nn.last_stats["filter_failover_rows"] == -1, nn.last_stats
+        lib.mgp_knn_set_filter(mode)
+        D1, I1 = nn.search(qt, k)
+        st = dict(nn.last_stats)
+    finally:
+        lib.mgp_knn_set_filter(1)
+    assert st["filter_failover_rows"] >= 0, st                      # the filtered pipeline ran
+    if expect_failover is not None:
+        assert st["filter_failover_rows"] == expect_failover, st
+    if shape == "duplicates_overflow":
+        assert st["filter_failover_rows"] >= 2001, st               # every copy's list holds the 2001 zero keys and more
+    assert torch.equal(I0, I1) and torch.equal(D0, D1), st
+    qn = x if q is None else q
+    rows = np.r_[0:30, len(qn) // 2:len(qn) // 2 + 30, len(qn) - 30:len(qn)]
+    if shape == "duplicates_overflow":
+        rows = np.r_[rows, 1000:1010]
+    Dr, Ir = oknn.knn_search(x, qn[rows], k)
+    assert np.array_equal(I1[rows].cpu().numpy(), Ir) and np.array_equal(D1[rows].cpu().numpy(), Dr), st
+
+
 def test_knn_prepared_index_small_batches_and_stale_snapshot(mgp, dev):
     """The prepared index (mgp_knn_index_build / mgp_knn_search_indexed; NearestNeighbors.train builds it): small
     query batches -- 1, 77, 600 rows, which a search without index keeps on the direct-difference tiles -- rank their
