@@ -79,7 +79,7 @@ int mgp_knn_set_symmetric(int on);
  * entries of {key, index}) with LDS counters; the select kernel takes the exact K'-th smallest key, the candidates, the fp64
  * re-rank and the sufficiency check from the list.  Rows whose list overflows or whose check fails are gathered and redone
  * by the slab pipeline (which ends in the exact scan); a chunk whose log fills up is redone there whole: the results are
- * the oracle's bit for bit, as before.  Workspace at 60k x 784: 6.4 GB instead of 14.6.  mode 0: key slab (rounds 1-4);
+ * the oracle's bit for bit, as before.  Workspace at 60k x 784: 4.9 GB instead of 14.8.  mode 0: key slab (rounds 1-4);
  * 1 (default): searches of >= 4096 queries against >= 16384 points; 2: every matrix-core search whose k the lists can serve
  * (tests).  Lab / test switch: read once per call.
  * mgp_knn_last_filter_failover: rows of the last search handed to the slab pipeline; -1 when the search ran on the slab. */

@@ -614,6 +614,45 @@ __global__ __launch_bounds__(kBlock) void bound_kernel(const float* __restrict__
   }
 }
 
+// The same bound with one WAVE per row and the row's sampled keys in registers (S <= 4096: up to ~65k points at stride 16):
+// the top 22 bits of the want-th smallest key bit by bit -- count the keys <= (prefix | ones below the bit), a DPP wave sum,
+// keep the bit clear when `want` of them are -- instead of two histogram passes with a dozen workgroup barriers (0.52 -> 
+// 0.2x ms at 60k rows of 3750 keys).  Same value as bound_kernel's.
+constexpr int kBoundRegs = 64;
+__global__ __launch_bounds__(kBlock) void bound_wave_kernel(const float* __restrict__ samp, int64_t ld, int S, int want,
+                                                            float* __restrict__ bounds, int64_t rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(samp + row * ld);
+  uint32_t kreg[kBoundRegs];
+#pragma unroll
+  for (int u = 0; u < kBoundRegs; ++u) {
+    const int i = u * 64 + lane;
+    kreg[u] = i < S ? keys[i] : 0xffffffffu;
+  }
+  uint32_t prefix = 0u;
+  for (int bit = 31; bit >= 10; --bit) {
+    const uint32_t c = prefix | ((1u << bit) - 1u);
+    int n = 0;
+#pragma unroll
+    for (int u = 0; u < kBoundRegs; ++u) n += kreg[u] <= c ? 1 : 0;
+    n += __builtin_amdgcn_update_dpp(0, n, 0x111, 0xf, 0xf, true);
+    n += __builtin_amdgcn_update_dpp(0, n, 0x112, 0xf, 0xf, true);
+    n += __builtin_amdgcn_update_dpp(0, n, 0x114, 0xf, 0xf, true);
+    n += __builtin_amdgcn_update_dpp(0, n, 0x118, 0xf, 0xf, true);
+    n += __builtin_amdgcn_update_dpp(0, n, 0x142, 0xa, 0xf, true);
+    n += __builtin_amdgcn_update_dpp(0, n, 0x143, 0xc, 0xf, true);
+    if (__builtin_amdgcn_readlane(n, 63) < want) prefix |= 1u << bit;
+  }
+  if (lane == 0) {
+    float b = __uint_as_float(prefix | 0x3ffu);
+    b = b < 3.0e38f ? b * (1.f + 0x1p-12f) : 3.0e38f;
+    if (!(b < 3.0e38f)) b = 3.0e38f;
+    bounds[row] = b;
+  }
+}
+
 // ------------------------------------------------------------------ 3. exact fallback
 __global__ __launch_bounds__(kBlock) void exact_row_kernel(const float* __restrict__ db, int64_t N, int d,
                                                            const float* __restrict__ q, const int* __restrict__ rows,
@@ -960,7 +999,11 @@ static int filtered_search(const float* db, int64_t N, int d, const float* q, in
     ++n_chunks;
     if (!sym) MGP_TRY(mgp_knn_mfma_prepare_queries(q + q0 * d, rows, d, mm, st));
     MGP_TRY(mgp_knn_mfma_sample_tiles(mm, rows, fp.S, samp, fp.ldS, st, sym));
-    hipLaunchKernelGGL(bound_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, samp, fp.ldS, (int)fp.S, cand0, bounds);
+    if (fp.S <= kBoundRegs * 64)
+      hipLaunchKernelGGL(bound_wave_kernel, dim3((unsigned)mgp_cdiv(rows, kBlock / 64)), dim3(kBlock), 0, st, samp, fp.ldS, (int)fp.S,
+                         cand0, bounds, rows);
+    else
+      hipLaunchKernelGGL(bound_kernel, dim3((unsigned)rows), dim3(kBlock), 0, st, samp, fp.ldS, (int)fp.S, cand0, bounds);
     MGP_LAUNCH_CHECK();
     MGP_HIP_TRY(hipMemsetAsync(cursor, 0, ((size_t)shards * 16 + 16) * sizeof(unsigned), st));
     const unsigned shard_cap = (unsigned)(((size_t)rows * kLogPerRow) / shards);

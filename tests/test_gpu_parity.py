@@ -2602,14 +2602,16 @@ def test_knn_self_search_upper_triangle_tiles(mgp, dev, n, d, k):
 
 
 @pytest.mark.parametrize("shape", ["ragged_self", "k100_stride8", "out_of_sample", "duplicates_overflow", "tight_clusters",
-                                   "far_from_origin", "default_mode_17k"])
+                                   "far_from_origin", "default_mode_17k", "histogram_bounds_70k"])
 def test_knn_candidate_filter_matches_slab_and_oracle(mgp, dev, shape):
     """The candidate filter of the matrix-core searches (mgp_knn_set_filter; round 5: per-row bounds from a sample of the
     points, the key pass logs the keys under them, regroup_kernel deals them to per-row lists, the select kernel works from
     the lists; no N x n key slab) against the slab pipeline (mode 0) bit for bit and against the oracle: ragged self-searches
     (upper-triangle tile pairs, mirrored entries), k = 100 (sample stride 8), out-of-sample queries (direct entries only),
     2001 copies of one point (their lists overflow: fail-over to the slab), tight clusters, data far from the origin
-    (absolute bound of the keys useless), and the default mode at a size where it switches itself on."""
+    (absolute bound of the keys useless), the default mode at a size where it switches itself on, and 70 000 points
+    (4 375 sampled keys per row: the bounds come from bound_kernel's histogram passes instead of the one-wave-per-row
+    kernel) with out-of-sample queries in the default mode."""
     from manifold_gp_amd import _lib
     from oracle import knn as oknn
     lib = _lib.lib()
@@ -2629,6 +2631,9 @@ def test_knn_candidate_filter_matches_slab_and_oracle(mgp, dev, shape):
         x = (c[rng.integers(0, 40, 20000)] + 0.01 * rng.normal(size=(20000, 128))).astype(np.float32); q = None; k = 50
     elif shape == "far_from_origin":
         x = (rng.normal(size=(5000, 64)) * 1e-3 + 100.0).astype(np.float32); q = None; k = 16
+    elif shape == "histogram_bounds_70k":
+        x = rng.normal(size=(70000, 32)).astype(np.float32); q = rng.normal(size=(4200, 32)).astype(np.float32); k = 10; mode = 1
+        expect_failover = 0
     else:
         x = rng.normal(size=(17000, 48)).astype(np.float32); q = None; k = 12; mode = 1
         expect_failover = 0
