@@ -323,6 +323,12 @@ __device__ uint32_t radix_kth(Scan scan, int rank, int* hist, int* sh_wave, int*
   return passes == 3 ? prefix : (prefix | 0x3ffu);
 }
 
+#ifdef MGP_SEL_LAB
+__device__ unsigned long long g_sel_stamp[8];
+#define SEL_STAMP(K) do { __syncthreads(); const unsigned long long t_ = __builtin_readcyclecounter(); if (threadIdx.x == 0 && blockIdx.x % 61 == 0) atomicAdd(&g_sel_stamp[K], t_ - t_prev); t_prev = __builtin_readcyclecounter(); } while (0)
+#else
+#define SEL_STAMP(K) do { } while (0)
+#endif
 // One workgroup per query row.  Rows of 8192+ keys are not radix-selected over the whole row: the K'-th
 // smallest of a 1/S sample of the row (runs of 64 keys, S = 16 up to ~61k keys) bounds the K'-th smallest
 // of the row from above, ONE pass over the row keeps the ~S K' keys under that bound in LDS, and the exact
@@ -346,6 +352,9 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   static_assert(kMaxDimLds * sizeof(float) <= sizeof(uint32_t) * 2 * kListCap, "query row staging");
 
   const int tid = threadIdx.x;
+#ifdef MGP_SEL_LAB
+  unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
   // consecutive rows to one XCD (blocks are dealt round-robin over the XCDs): neighbouring queries re-rank largely the same
   // candidate rows, which then come from that XCD's L2 instead of being fetched into all eight
   const int row = a.rows ? a.rows[blockIdx.x] : mgp_xcd_block((int)blockIdx.x, (int)gridDim.x);
@@ -377,9 +386,11 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
       list_key[j] = e.x; list_idx[j] = (int)e.y;
     }
     __syncthreads();
+    SEL_STAMP(0);    // list loaded
     T = radix_kth([&](auto f) { for (int j = tid; j < n_list; j += kBlock) f(list_key[j], (int64_t)list_idx[j]); },
                   want, hist, sh_wave, &sh_bin, &sh_rank, &rank);
     from_list = true;
+    SEL_STAMP(1);    // radix select
   } else if (want < N) {
     // sampling stride: the smallest power of two from 16 up whose sample (runs of 64 keys) fits the LDS list
     int S = 16;
@@ -449,12 +460,14 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
     for (int i = tid; i < want; i += kBlock) cand_idx[i] = i;
   }
   __syncthreads();   // the list is dead from here on
+  SEL_STAMP(2);      // candidates collected
   // query row to LDS (falls back to global reads for very wide features)
   const float* qrow = a.q + (int64_t)row * a.d;
   const bool q_lds = a.d <= kMaxDimLds;
   if (q_lds) for (int j = tid; j < a.d; j += kBlock) qrow_s[j] = qrow[j];
   __syncthreads();
 
+  SEL_STAMP(3);      // query row staged
   // ---- fp64 re-evaluation in the oracle's operation order
   // One thread per candidate running oracle_d2 (below, kept for wide retry sets and odd shapes) leaves 3/4 of the
   // workgroup idle and makes every load instruction touch 64 different rows.  (Measured, round 3: 22.3 -> 21.6 ms per
@@ -525,6 +538,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
     }
   }
   __syncthreads();
+  SEL_STAMP(4);      // re-rank
   // ---- order by (d64, index).  Up to 256 candidates: every candidate counts the candidates ahead of it
   // (all pairs are distinct, so the counts are the sorted positions; LDS reads are broadcasts) -- one
   // barrier instead of the 28+ of a bitonic network; wider retry sets: bitonic sort of Kp (pow2) entries.
@@ -533,12 +547,31 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
   double my_d = 0.0;
   int my_i = 0;
   if (by_rank) {
-    if (tid < want) {
-      my_d = cand_d[tid];
-      my_i = cand_idx[tid];
-      int ahead = 0;
+    // up to 64 candidates... 256: the counting is split over the workgroup -- `parts` threads per candidate, each over a
+    // slice of the others -- and the partial counts meet in LDS (the histogram is dead): with one thread per candidate
+    // a 75-candidate row kept two of the four waves busy for 75 dependent LDS round trips (18 % of the kernel, stamps)
+    const int parts = want <= 64 ? 4 : want <= 128 ? 2 : 1;
+    int* ahead_s = hist;
+    if (parts > 1) {
+      if (tid < want) ahead_s[tid] = 0;
+      __syncthreads();
+    }
+    const int c = tid % (kBlock / parts), part = tid / (kBlock / parts);
+    int ahead = 0;
+    if (c < want) {
+      my_d = cand_d[c];
+      my_i = cand_idx[c];
+      const int per = (want + parts - 1) / parts;
+      const int j0 = part * per, j1 = j0 + per < want ? j0 + per : want;
 #pragma unroll 8
-      for (int j = 0; j < want; ++j) ahead += cand_less(cand_d[j], cand_idx[j], my_d, my_i) ? 1 : 0;
+      for (int j = j0; j < j1; ++j) ahead += cand_less(cand_d[j], cand_idx[j], my_d, my_i) ? 1 : 0;
+      if (parts > 1) atomicAdd(&ahead_s[c], ahead);
+    }
+    if (parts > 1) {
+      __syncthreads();
+      if (c < want) ahead = ahead_s[c];
+    }
+    if (c < want && part == 0) {
       my_pos = ahead;
       if (ahead == a.k - 1) sh_dk = my_d;
     }
@@ -559,6 +592,7 @@ __global__ __launch_bounds__(kBlock) void select_kernel(SelectArgs a) {
       }
     }
   }
+  SEL_STAMP(5);      // ordered
   // ---- sufficiency check, then write or flag
   const double dk = by_rank ? sh_dk : cand_d[a.k - 1];
   bool ok = true;
@@ -1072,6 +1106,14 @@ extern "C" int mgp_knn_set_filter(int mode) {
 
 // rows of the last search that the filtered pipeline handed to the slab pipeline; -1: the search ran on the slab
 extern "C" int64_t mgp_knn_last_filter_failover(void) { return g_last_filter_failover; }
+
+#ifdef MGP_SEL_LAB
+extern "C" int mgp_sel_lab_stamps(unsigned long long* out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_sel_stamp), 8 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sel_stamp), z, sizeof(z)) != hipSuccess) return 1; }
+  return MGP_OK;
+}
+#endif
 
 extern "C" int mgp_knn_set_symmetric(int on) {
   g_knn_sym = on ? 1 : 0;

@@ -29,3 +29,15 @@ if os.environ.get("MGP_KNN_STAMPS"):
     tot = sum(out)
     for nme, v in zip(names, out):
         print("stamp %-24s %14d cycles  %5.1f %%   per wave %8.0f" % (nme, v, 100.0 * v / tot, v / (4 * 469 * 470 // 2 / 61)), flush=True)
+
+if os.environ.get("MGP_SEL_STAMPS"):
+    import ctypes
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    out = (ctypes.c_uint64 * 8)()
+    h.mgp_sel_lab_stamps(out, 1)
+    knn.search(x, 50); torch.cuda.synchronize()
+    h.mgp_sel_lab_stamps(out, 1)
+    names = ["list loaded", "radix select", "candidates collected", "query row staged", "re-rank", "ordered", "-", "-"]
+    tot = sum(out)
+    for nme, v in zip(names, out):
+        print("sel stamp %-24s %14d cycles  %5.1f %%   per row %8.0f" % (nme, v, 100.0 * v / max(tot, 1), v / (60000 / 61)), flush=True)
