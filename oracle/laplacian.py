@@ -66,12 +66,35 @@ class LaplacianOracle:
             vec = rhs
         out = vec * self.diag[:, None]
         # torch_sparse.spmm(idx, val, n, n, vec) = scatter_add(val * vec[col], row)
-        np.subtract.at(out, r, self.triu[:, None] * vec[c])
-        np.subtract.at(out, c, self.triu[:, None] * vec[r])
+        if vec.shape[1] > 64:
+            # wide right-hand sides (dense twins of the wrappers: identity blocks of ~1500 columns): the same updates in
+            # the same order per output row -- first the entries with this row as `r` in list order, then those with it as
+            # `c` -- through a CSR product that accumulates into `out` entry by entry (np.subtract.at takes a minute here)
+            out = self._wide_subtract(out, vec)
+        else:
+            np.subtract.at(out, r, self.triu[:, None] * vec[c])
+            np.subtract.at(out, c, self.triu[:, None] * vec[r])
         if self.normalization == "randomwalk":
             out = out * dsq if transposed else out / dsq
         out = out.astype(self.dtype)
         return out[:, 0] if squeeze else out
+
+    def _wide_subtract(self, out, vec):
+        from scipy.sparse import _sparsetools
+        if getattr(self, "_csr", None) is None:
+            r, c = self.idx[0].astype(np.int64), self.idx[1].astype(np.int64)
+            rows = np.concatenate([r, c])
+            cols = np.concatenate([c, r])
+            vals = np.concatenate([-self.triu, -self.triu]).astype(self.dtype)
+            order = np.argsort(rows, kind="stable")               # list order kept inside a row, `r` entries first
+            indptr = np.zeros(self.n + 1, np.int64)
+            np.add.at(indptr, rows + 1, 1)
+            self._csr = (np.cumsum(indptr).astype(np.int32), cols[order].astype(np.int32), np.ascontiguousarray(vals[order]))
+        ip, ix, vx = self._csr
+        y = np.ascontiguousarray(out, dtype=self.dtype)
+        x = np.ascontiguousarray(vec, dtype=self.dtype)
+        _sparsetools.csr_matvecs(self.n, self.n, x.shape[1], ip, ix, vx, x.ravel(), y.ravel())
+        return y
 
     def dense_symmetric(self):
         """Dense L_sym as assembled at manifold_gp/kernels/riemann_kernel.py:121-124."""

@@ -73,9 +73,22 @@ def knn_stage(x, k, knn=None):
         dpad = -(-d // 32) * 32
         tiles = -(-N // 128)
         pairs = tiles * (tiles + 1) // 2 * 128 * 128              # tile pairs on and above the diagonal (mgp_knn_set_symmetric)
+        filtered = knn.last_stats.get("filter_failover_rows", -1) >= 0
+        if filtered:
+            # + the keys of every row to the sampled points (every 16th point up to k = 64: mgp_knn_set_filter)
+            want = k + max(k // 2, 24)
+            stride = 16
+            while stride > 4 and stride * want > 1536:
+                stride //= 2
+            pairs += tiles * -(-(-(-N // stride)) // 128) * 128 * 128
+        from manifold_gp_amd import _lib as _l
+        out["pipeline"] = ("candidate filter: sampled bounds -> filtered key pass (log) -> regroup -> select from lists; no key slab"
+                           if filtered else "key slab: keys -> N x n slab -> select")
+        out["workspace_GB"] = round(_l.lib().mgp_knn_workspace_bytes(N, N, d, k) / 1e9, 2)
         out.update(effective_fp32_tflops=round(2.0 * N * N * d / t / 1e12, 1), fp32_peak_tflops=FP32_PEAK_TFLOPS,
                    frac_of_fp32_peak=round(2.0 * N * N * d / t / 1e12 / FP32_PEAK_TFLOPS, 3),
                    bf16_mfma_tflops_whole_search=round(3 * 2.0 * pairs * dpad / t / 1e12, 1), bf16_peak_tflops=BF16_PEAK_TFLOPS,
+                   frac_of_bf16_peak_whole_search=round(3 * 2.0 * pairs * dpad / t / 1e12 / BF16_PEAK_TFLOPS, 3),
                    note="effective = 2 N^2 d flops of the all-pairs GEMM form over the WHOLE search (keys + select + fp64 "
                         "re-rank); the key kernel executes 3 bf16 MFMA products per pair on the upper-triangle tile pairs only: "
                         "bf16_mfma_tflops_whole_search divides those flops by the whole search time (a lower bound of the key "
