@@ -16,10 +16,11 @@ for f in ("knn_kernel_stats.csv", "s5_complex_shift_kernel_stats.csv", "s5_compl
     if os.path.exists(os.path.join(src, "%s_%s" % (tag, f))):
         shutil.copy(os.path.join(src, "%s_%s" % (tag, f)), os.path.join(out, "%s_%s" % (tag, f)))
 for raw, dst, head in (("pmc_knn_mfma_raw.txt", "pmc_knn_mfma.txt",
-                        "# tools/pmc_knn.sh: matrix-pipe counters of dist_mfma_kernel (k-NN candidate keys, 60k x 784 self-search, upper-triangle tile pairs),\n"
-                        "# one counter group per rocprofv3 --pmc pass, mean per launch.  SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs; SQ_BUSY_CU_CYCLES the CUs.\n"),
+                        "# tools/pmc_knn.sh: matrix-pipe counters of dist_mfma_kernel (k-NN candidate keys, 60k x 784 self-search: <true> the filtered key pass over the\n"
+                        "# upper-triangle tile pairs, <false> the keys to the 3750 sampled points), one counter group per rocprofv3 --pmc pass, mean per launch.\n"
+                        "# SQ_VALU_MFMA_BUSY_CYCLES sums the 1024 SIMDs; SQ_BUSY_CU_CYCLES the CUs.\n"),
                        ("pmc_knn_select_raw.txt", "pmc_knn_select.txt",
-                        "# tools/pmc_select.sh: HBM-side traffic of select_kernel (k-NN top-k + fp64 re-rank), FETCH_SIZE / WRITE_SIZE in separate passes (KB;\n"
+                        "# tools/pmc_select.sh: HBM-side traffic of select_kernel (k-NN top-k from the candidate lists + fp64 re-rank, one launch per 60k-row search), FETCH_SIZE / WRITE_SIZE in separate passes (KB;\n"
                         "# FETCH_SIZE to be doubled on gfx950 for wide coalesced reads, MI355X_MICROARCH.md), kernel-trace durations.\n")):
     if os.path.exists(os.path.join(src, "%s_%s" % (tag, raw))):
         open(os.path.join(out, "%s_%s" % (tag, dst)), "w").write(head + open(os.path.join(src, "%s_%s" % (tag, raw))).read())

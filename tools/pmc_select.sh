@@ -1,5 +1,5 @@
 #!/usr/bin/env bash
-# HBM traffic counters of the k-NN select kernel (tools/time_knn.py at C3 size), FETCH_SIZE and WRITE_SIZE in separate passes
+# HBM traffic counters of the k-NN select kernel (tools/lab/knn_filter_time.py: 60k x 784 self-searches, candidate lists), FETCH_SIZE and WRITE_SIZE in separate passes
 # (MI355X_MICROARCH.md: they do not fit one pass; FETCH_SIZE is doubled for wide coalesced reads on gfx950).
 set -o pipefail
 failed=""
@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 250 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/p$i" -- python3 tools/time_knn.py > "$out/p$i.log" 2>&1 || { echo "pass $i FAILED (rc $?)"; tail -5 "$out/p$i.log"; failed="$failed $i"; rm -rf "$out/p$i"; }
+  timeout -k 10 250 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$out/p$i" -- python3 tools/lab/knn_filter_time.py 1 > "$out/p$i.log" 2>&1 || { echo "pass $i FAILED (rc $?)"; tail -5 "$out/p$i.log"; failed="$failed $i"; rm -rf "$out/p$i"; }
 done
 python3 - <<'PY'
 import csv, glob, collections, statistics
