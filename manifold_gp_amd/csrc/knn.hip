@@ -778,6 +778,10 @@ FilterPlan filter_plan(int64_t N, int64_t n, int d, int k, bool indexed) {
   f.ldS = mgp_cdiv(S, 4) * 4;
   const int64_t ncap = mgp_cdiv(n, kTile) * kTile;
   f.qc = ncap < 262144 ? ncap : 262144;
+  // the keys to the sampled points (qc x S floats) within 4 GiB: whole rounds of 8 XCDs x 128-row tiles (1M points: 16 384 rows)
+  const int64_t by_sample = (((int64_t)1 << 30) / f.ldS) / 1024 * 1024;
+  if (by_sample >= 1024 && f.qc > by_sample) f.qc = by_sample;
+  if (by_sample < 1024) { f.on = false; return f; }          // N beyond ~16 M points: the slab pipeline's chunks
   f.fr = n < 2048 ? n : 2048;
   return f;
 }

@@ -2602,7 +2602,7 @@ def test_knn_self_search_upper_triangle_tiles(mgp, dev, n, d, k):
 
 
 @pytest.mark.parametrize("shape", ["ragged_self", "k100_stride8", "out_of_sample", "duplicates_overflow", "tight_clusters",
-                                   "far_from_origin", "default_mode_17k", "histogram_bounds_70k"])
+                                   "far_from_origin", "default_mode_17k", "histogram_bounds_70k", "two_chunks_1M"])
 def test_knn_candidate_filter_matches_slab_and_oracle(mgp, dev, shape):
     """The candidate filter of the matrix-core searches (mgp_knn_set_filter; round 5: per-row bounds from a sample of the
     points, the key pass logs the keys under them, regroup_kernel deals them to per-row lists, the select kernel works from
@@ -2611,7 +2611,8 @@ def test_knn_candidate_filter_matches_slab_and_oracle(mgp, dev, shape):
     2001 copies of one point (their lists overflow: fail-over to the slab), tight clusters, data far from the origin
     (absolute bound of the keys useless), the default mode at a size where it switches itself on, and 70 000 points
     (4 375 sampled keys per row: the bounds come from bound_kernel's histogram passes instead of the one-wave-per-row
-    kernel) with out-of-sample queries in the default mode."""
+    kernel) with out-of-sample queries in the default mode; 20 000 queries against 1M points, where the keys to the 62 500
+    sampled points bound a chunk at 16 384 query rows (two chunks, each with its own bounds / log / lists)."""
     from manifold_gp_amd import _lib
     from oracle import knn as oknn
     lib = _lib.lib()
@@ -2631,6 +2632,9 @@ def test_knn_candidate_filter_matches_slab_and_oracle(mgp, dev, shape):
         x = (c[rng.integers(0, 40, 20000)] + 0.01 * rng.normal(size=(20000, 128))).astype(np.float32); q = None; k = 50
     elif shape == "far_from_origin":
         x = (rng.normal(size=(5000, 64)) * 1e-3 + 100.0).astype(np.float32); q = None; k = 16
+    elif shape == "two_chunks_1M":
+        x = rng.normal(size=(1000000, 32)).astype(np.float32); q = rng.normal(size=(20000, 32)).astype(np.float32); k = 10; mode = 1
+        expect_failover = 0
     elif shape == "histogram_bounds_70k":
         x = rng.normal(size=(70000, 32)).astype(np.float32); q = rng.normal(size=(4200, 32)).astype(np.float32); k = 10; mode = 1
         expect_failover = 0
@@ -2650,6 +2654,8 @@ def test_knn_candidate_filter_matches_slab_and_oracle(mgp, dev, shape):
     finally:
         lib.mgp_knn_set_filter(1)
     assert st["filter_failover_rows"] >= 0, st                      # the filtered pipeline ran
+    if shape == "two_chunks_1M":
+        assert st["chunks"] == 2, st
     if expect_failover is not None:
         assert st["filter_failover_rows"] == expect_failover, st
     if shape == "duplicates_overflow":
