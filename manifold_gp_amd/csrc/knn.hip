@@ -741,7 +741,23 @@ bool use_mfma(int d, int64_t n) { return g_knn_mfma && d >= 32 && n >= 1024; }
 
 // first attempt: k + pad candidates (each costs a d-float row read in the fp64 re-rank: the selection's dominant traffic
 // at large d); MFMA keys carry an absolute error: a wider pad there keeps the retry launches rare
-int first_candidates(int k, bool mfma) { return mfma ? k + (k / 2 > 24 ? k / 2 : 24) : k + (k / 4 > 16 ? k / 4 : 16); }
+int first_candidates(int k, bool mfma) {
+  int want = mfma ? k + (k / 2 > 24 ? k / 2 : 24) : k + (k / 4 > 16 ? k / 4 : 16);
+  // whole waves of candidates: the re-rank's ordered fp64 sums run one thread per candidate and a wave instruction costs the
+  // same with 11 active lanes as with 64 -- K' = 75 (k = 50) held two waves for 784 dependent adds, K' = 64 holds one and fills
+  // the product rounds exactly (64 x 8 float4 items = 2 x 256 threads).  Down to k + max(k / 4, 12) only; the few rows whose
+  // check then fails (RMNIST-like 60k: 148, Gaussian 60k x 784: 11) are redone with 4 K' candidates from the same lists
+  // (tools/lab/knn_pad.py: 12.5 -> 12.0 ms, identical lists).
+  if (mfma && want > 64) {
+    const int lo = k + (k / 4 > 12 ? k / 4 : 12);
+    const int w64 = want / 64 * 64;
+    if (w64 >= lo) want = w64;
+  }
+#ifdef MGP_KNN_PAD_LAB
+  if (const char* e = getenv("MGP_KNN_CAND")) return atoi(e);
+#endif
+  return want;
+}
 
 // Candidate filter (round 5): the matrix-core keys of a large search are not written to an N x n slab and read back by
 // the select kernel (60k x 60k: 14.4 GB each way, the key kernel's epilogue and the select pass were both bound by it);
