@@ -1144,11 +1144,31 @@ static int lanczos_smallest_impl(const mgp_csr_t* L, int m, const mgp_lanczos_pa
       a = th[kept - 1];
       a0 = std::min(th[0], 0.0);
       const double gap = std::max(a - th[m - 1], 1e-12 * ub);
-      int dnew = (int)ceil(3.0 / (2.0 * sqrt(gap / (ubf - a))));
+      // dunit: the filter degree per unit of damping exponent at the measured gap; dnew: the degree of an e^-3 round (rounds 1-4
+      // ran every round at it; the exits below are written in it).
+      const double dunit = 1.0 / (2.0 * sqrt(gap / (ubf - a)));
+      int dnew = (int)ceil(3.0 * dunit);
+      // Round 5: a Rayleigh-Ritz round costs ~2 ms of host + Gram + rotation at b = 128 -- as much as 57 block products at 60k -- so
+      // a round should do what the arithmetic allows, and the last one no more than is left to do.  The largest wanted residual falls
+      // by ~exp(-t / 2) in a round of exponent t (measured: t = 3 / 4.5 / 9 -> x 0.22 / 0.1 / 0.01), so t_fin = 2 ln(r_max / (0.3 tol
+      // ub)) would finish; inside the wanted block the filter lifts mode 1 over mode m by exp(t (sqrt(a - th_1) - sqrt(gap)) /
+      // sqrt(gap)), which float32 columns survive up to ~1e4 (t_safe; more and mode m drops under the round-off of mode 1), and 9
+      // at most.  Never less than the e^-3 round.  Conditioned 60k swiss roll: 7 rounds / 105 products / 18.3 ms -> 4 / ~120 /
+      // ~13.5 ms; RMNIST-like 60k (ends at the fp32 floor): 4 / 280 / 18.4 ms -> 3 / ~220 / ~14 ms.
+      double rmx_w = 0.0;
+      for (int j = 0; j < m; ++j) rmx_w = std::max(rmx_w, res[j]);
+      const double t_fin = 2.0 * log(std::max(rmx_w, 1e-300) / (0.3 * tol * ub));
+      const double s1 = sqrt(std::max(a - th[0], 0.0)), sm = sqrt(gap);
+      const double t_safe = s1 > sm ? log(1e4) * sm / (s1 - sm) : 9.0;
+      double target = std::min(std::max(t_fin, 3.0), std::min(9.0, std::max(t_safe, 3.0)));
+      if (const char* e = getenv("MGP_EIG_TARGET")) target = atof(e);       // lab: fixed per-round damping exponent
+      const int dask = (int)ceil(target * dunit);
       // degree cap 200 (80 until late in round 1: 8 rounds / 497 applies at m = 100 where 200 needs 4 / 343; the
       // scaled three-term recurrence is normalised at a0, so the block does not overflow at these degrees)
-      deg = std::min(std::max(dnew, 8), kCap);
-      if (getenv("MGP_EIG_TIMING")) fprintf(stderr, "[eig] round %d: a %.4e  theta_m %.4e  gap %.3e  degree asked %d\n", outer, a, th[m - 1], gap, dnew);
+      deg = std::min(std::max(dask, 8), kCap);
+      if (getenv("MGP_EIG_TIMING"))
+        fprintf(stderr, "[eig] round %d: a %.4e  theta_m %.4e  gap %.3e  exponent %.2f (finish %.2f, safe %.2f)  degree asked %d (e^-3: %d)\n",
+                outer, a, th[m - 1], gap, target, t_fin, t_safe, dask, dnew);
       if (p && p->degree > 0) deg = p->degree;
       // The same exit, predicted instead of observed.  A round of degree d multiplies the slowest wanted pair's error by
       // about exp(-3 d / dnew) (dnew = the degree that gives e^-3 at the measured gap between the wanted block and its
@@ -1156,7 +1176,11 @@ static int lanczos_smallest_impl(const mgp_csr_t* L, int m, const mgp_lanczos_pa
       // > 0.5: the wanted modes sit in a cluster with their guards -- on the 60k RMNIST-like graph 128 Ritz values lie
       // within 1e-6 lambda_max), every further 200-apply round would buy less than a factor 2: stop before running it
       // (C3 at tol 1e-6: 4 rounds / 50 ms instead of 5 / 67 ms, same residual 2.5e-4 as tol 1e-5 reaches).
-      if (!(p && p->degree > 0) && deg_used >= kCap && dnew > kCap && exp(-3.0 * kCap / (double)dnew) > 0.5) {
+      // (Round 5: 0.5 -> 0.36.  The largest RESIDUAL follows the square root of that factor -- see the exponent rule above -- so a
+      // cap round predicted at 0.36 improves it by less than 1.7 x for ~7 ms at 60k; and with the stronger early rounds the first
+      // cap round is reached a round sooner, at a gap that asks for ~3.8 caps instead of ~5.8: the same block quality -- RMNIST-like
+      // 60k: 2.4e-4 after 3 rounds / 249 products against 2.2e-4 after 4 / 280 -- must end the same way.)
+      if (!(p && p->degree > 0) && deg_used >= kCap && dnew > kCap && exp(-3.0 * kCap / (double)dnew) > 0.36) {
         double rmx = 0.0;
         for (int j = 0; j < m; ++j) rmx = std::max(rmx, res[j]);
         if (rmx <= floor_guard * ub) { floor_hit = true; ++outer; break; }
