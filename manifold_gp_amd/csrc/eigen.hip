@@ -1153,14 +1153,19 @@ static int lanczos_smallest_impl(const mgp_csr_t* L, int m, const mgp_lanczos_pa
       // by ~exp(-t / 2) in a round of exponent t (measured: t = 3 / 4.5 / 9 -> x 0.22 / 0.1 / 0.01), so t_fin = 2 ln(r_max / (0.3 tol
       // ub)) would finish; inside the wanted block the filter lifts mode 1 over mode m by exp(t (sqrt(a - th_1) - sqrt(gap)) /
       // sqrt(gap)), which float32 columns survive up to ~1e4 (t_safe; more and mode m drops under the round-off of mode 1), and 9
-      // at most.  Never less than the e^-3 round.  Conditioned 60k swiss roll: 7 rounds / 105 products / 18.3 ms -> 4 / ~120 /
+      // at most (t_cap, below).  Never less than the e^-3 round.  Conditioned 60k swiss roll: 7 rounds / 105 products / 18.3 ms -> 4 / ~120 /
       // ~13.5 ms; RMNIST-like 60k (ends at the fp32 floor): 4 / 280 / 18.4 ms -> 3 / ~220 / ~14 ms.
       double rmx_w = 0.0;
       for (int j = 0; j < m; ++j) rmx_w = std::max(rmx_w, res[j]);
       const double t_fin = 2.0 * log(std::max(rmx_w, 1e-300) / (0.3 * tol * ub));
       const double s1 = sqrt(std::max(a - th[0], 0.0)), sm = sqrt(gap);
       const double t_safe = s1 > sm ? log(1e4) * sm / (s1 - sm) : 9.0;
-      double target = std::min(std::max(t_fin, 3.0), std::min(9.0, std::max(t_safe, 3.0)));
+      // ... where rounds are expensive against block products: a round is ~57 products at n b = 7.7e6 (60k x 128) but ~5 at
+      // 6.4e7 (1M x 64), where the stronger rounds only add products (530 against 438, 229 against 225 ms): the cap goes from 9
+      // under n b = 1.6e7 to the e^-3 round at 6.4e7 (logarithmically in between; deterministic, no timing involved).
+      const double nb = (double)n * (double)b;
+      const double t_cap = nb <= 1.6e7 ? 9.0 : nb >= 6.4e7 ? 3.0 : 9.0 - 6.0 * log(nb / 1.6e7) / log(4.0);
+      double target = std::min(std::max(t_fin, 3.0), std::min(t_cap, std::max(t_safe, 3.0)));
       if (const char* e = getenv("MGP_EIG_TARGET")) target = atof(e);       // lab: fixed per-round damping exponent
       const int dask = (int)ceil(target * dunit);
       // degree cap 200 (80 until late in round 1: 8 rounds / 497 applies at m = 100 where 200 needs 4 / 343; the
