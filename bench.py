@@ -465,8 +465,8 @@ def _main(quiet):
     t_b2b = time_spmv_kernel(wl)
     t_in, n_in = time_spmv_in_solve(wl, args, refine, y)
     # (3) is quoted only from a profile taken on THIS source tree: tools/summarize_profile.py stores a hash of csrc/ + include/
-    # in the summary; a summary whose hash differs from the tree's, or whose mean differs from this run's back-to-back
-    # figure by more than 10 %, is stale -- `frac` then quotes the live in-solve figure and the line says so
+    # in the summary; a summary whose hash differs from the tree's, or whose mean is far from this run's back-to-back
+    # figure (band below), is stale -- `frac` then quotes the live in-solve figure and the line says so
     t_prof, prof_src, prof_hash, prof_file = None, None, None, None
     suffix = "_pmc_traffic.json" if args.workload == "c3" else "_s5_pmc_traffic.json"
     cands = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+" + suffix, f)), reverse=True) \
@@ -486,7 +486,9 @@ def _main(quiet):
         except Exception:
             pass
     tree_hash = source_hash()
-    profile_age_ok = bool(t_prof) and prof_hash == tree_hash and abs(t_prof - t_b2b) <= 0.10 * t_b2b
+    # (band: the in-graph mean sits ABOVE this run's back-to-back figure -- (1) <= (3) -- by 3-8 % on one box, and the boxes of the
+    # pool differ by up to 14 % in this kernel (5.4-6.2 us): a profile of this tree within -5 % / +25 % of the live figure is current)
+    profile_age_ok = bool(t_prof) and prof_hash == tree_hash and -0.05 * t_b2b <= t_prof - t_b2b <= 0.25 * t_b2b
     t_k = (t_prof if profile_age_ok else None) or t_in or t_b2b
     def fig(t, note):
         return dict(avg_launch_us=round(t * 1e6, 2), achieved=round(B / t / 1e9, 1), frac=round(B / t / 1e9 / HBM_PEAK_GBS, 4), note=note)
