@@ -1,6 +1,8 @@
 #!/usr/bin/env bash
 # Lab: what the filtered key pass (dist_mfma_kernel<true>) spends outside its MFMA loop: the same search with
-# (1) no counter atomics, (2) no list stores, (3) neither, (4) no epilogue at all.  Results are wrong in every variant (rows fail
+# (1) no range atomic, (2) no log stores, (3) neither, (4) no epilogue at all.  CAUTION (docs/kernels/knn.md): with nothing stored the
+# compiler drops the accumulators' MFMAs too -- variants 3 and 4 time the operand copies alone, not the MFMA loop; use the in-kernel
+# stamps (-DMGP_KNN_LAB=8, MGP_KNN_STAMPS=1 tools/lab/knn_filter_time.py) for the split between loop and epilogue.  Results are wrong in every variant (rows fail
 # over): only the key kernel's duration in the kernel trace is read.  Build: knn_filter_bounds.sh build (CPU box); run on the GPU box.
 set -uo pipefail
 cd "$(dirname "${BASH_SOURCE[0]}")/../.."
