@@ -280,6 +280,12 @@ def workspace(nbytes, tag, device):
     return buf
 
 
+def workspace_bytes(tag, device):
+    """Size of the cached scratch of (tag, device); 0 when there is none."""
+    buf = _WORK.get((tag, str(device)))
+    return 0 if buf is None else int(buf.numel())
+
+
 def release_workspace(tag, device=None):
     """Drop the cached scratch of `tag` (all devices when device is None): the 60k x 60k key slab of a graph build is
     ~18 GB that nothing needs once the lists exist (the allocator hands it to the next large request)."""

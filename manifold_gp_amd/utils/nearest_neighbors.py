@@ -81,8 +81,12 @@ class NearestNeighbors():
     def graph(self, k, symmetric=True, self_loop=False, nprobe=1):
         val, idx = self.search(self.x, k, nprobe)
         n = self.x.shape[0]
-        if n * n * 4 > (1 << 31):
-            _lib.release_workspace("knn", self.x.device)    # the self-search's whole-matrix key slab (up to 32 GiB)
+        # the self-search's scratch is dropped once the lists exist when it is the whole-matrix key slab (14.8 GB at 60k x 784, up to
+        # 32 GiB); the candidate filter's 4.9 GB stay cached: a later construction in the same process otherwise pays a fresh
+        # device allocation of that size (~100 ms against a 12 ms search; tools/lab/first_eval.py)
+        wb = _lib.workspace_bytes("knn", self.x.device)
+        if wb > (8 << 30):
+            _lib.release_workspace("knn", self.x.device)
         if symmetric and not self_loop:
             self.knn_graph = KnnGraph.from_knn(val, idx.to(torch.int32), points=self.x if self.x.shape[1] <= 3 else None)
             return self.knn_graph.edge_index, self.knn_graph.edge_value
