@@ -13,6 +13,7 @@
 #include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <vector>
+#include <mutex>
 #include "mgp_common.h"
 
 namespace {
@@ -696,8 +697,40 @@ extern "C" int mgp_permute_rows(const float* src, const int32_t* order, int64_t 
 // rotation orbit the chain runs along the angle -- and the rows of a tile share most of their columns: 16-row tiles of the 60k
 // RMNIST-like graph name 291 distinct columns in the given order, 233 in breadth-first order, ~115 in this one, which is what
 // the matrix-core SpMM's work and gathers are proportional to (docs/kernels/spmm.md, round 5).  No reference counterpart.
-// The walk is sequential: it runs on the HOST over a copy of the CSR (60k nodes, k = 50: 30 MB across PCIe + ~10 ms), once per
-// graph.  Deterministic.  Synchronises `stream`.
+// The walk is sequential: it runs on the HOST, once per graph.  Round 5 (second half): the device first orders every row's
+// neighbours by (d2, column) (chain_rank_kernel: one wave per row, every entry counts the entries ahead of it), so that the host
+// receives ONE int32 array through a pinned staging buffer (60k nodes, k = 50: 15 MB instead of 30 MB into pageable vectors) and
+// "the nearest unvisited neighbour" is the first unvisited entry of the row instead of a scan of all of it: 19.5 -> ~7 ms, the
+// same order entry for entry (same tie rule: smaller column).  Deterministic.  Synchronises `stream`.
+namespace {
+__global__ __launch_bounds__(256) void chain_rank_kernel(int64_t n, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                         const float* __restrict__ d2, int32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= n) return;
+  const int32_t b = rowptr[v], e = rowptr[v + 1];
+  for (int32_t i = b + lane; i < e; i += 64) {
+    const float di = d2[i];
+    const int32_t ci = col[i];
+    int32_t ahead = 0;
+    for (int32_t j = b; j < e; ++j) {
+      const float dj = d2[j];
+      const int32_t cj = col[j];
+      ahead += (dj < di || (dj == di && (cj < ci || (cj == ci && j < i)))) ? 1 : 0;
+    }
+    out[b + ahead] = ci;
+  }
+}
+
+// pinned staging for the sorted columns (kept for the life of the process; grown when a larger graph comes)
+struct ChainStage {
+  int32_t* p = nullptr;
+  size_t cap = 0;
+  std::mutex mu;
+};
+ChainStage g_chain_stage;
+}  // namespace
+
 extern "C" int mgp_graph_chain_order(int64_t n, const int32_t* rowptr, const int32_t* col, const float* d2, int32_t* order,
                                      void* stream) {
   if (!rowptr || !col || !d2 || !order || n <= 0 || n > 0x7fffffff) return MGP_ERR_ARG;
@@ -706,25 +739,34 @@ extern "C" int mgp_graph_chain_order(int64_t n, const int32_t* rowptr, const int
   MGP_HIP_TRY(hipMemcpyAsync(rp.data(), rowptr, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   MGP_HIP_TRY(hipStreamSynchronize(st));
   const size_t nnz = (size_t)rp[n];
-  std::vector<int32_t> cj(nnz);
-  std::vector<float> dj(nnz);
+  std::lock_guard<std::mutex> lock(g_chain_stage.mu);
+  if (g_chain_stage.cap < nnz + 1) {
+    if (g_chain_stage.p) (void)hipHostFree(g_chain_stage.p);
+    g_chain_stage.p = nullptr;
+    g_chain_stage.cap = 0;
+    MGP_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&g_chain_stage.p), (nnz + 1) * sizeof(int32_t), hipHostMallocDefault));
+    g_chain_stage.cap = nnz + 1;
+  }
+  const int32_t* cj = g_chain_stage.p;
   if (nnz) {
-    MGP_HIP_TRY(hipMemcpyAsync(cj.data(), col, nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    MGP_HIP_TRY(hipMemcpyAsync(dj.data(), d2, nnz * sizeof(float), hipMemcpyDeviceToHost, st));
-    MGP_HIP_TRY(hipStreamSynchronize(st));
+    int32_t* sorted = nullptr;
+    MGP_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sorted), nnz * sizeof(int32_t)));
+    hipLaunchKernelGGL(chain_rank_kernel, dim3((unsigned)mgp_cdiv(n, 4)), dim3(256), 0, st, n, rowptr, col, d2, sorted);
+    hipError_t le = hipGetLastError();
+    if (le == hipSuccess) le = hipMemcpyAsync(g_chain_stage.p, sorted, nnz * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (le == hipSuccess) le = hipStreamSynchronize(st);
+    (void)hipFree(sorted);
+    if (le != hipSuccess) return (int)le;
   }
   std::vector<uint8_t> seen((size_t)n, 0);
   std::vector<int32_t> ord((size_t)n);
-  auto nearest_free = [&](int32_t v) -> int32_t {
-    int32_t best = -1;
-    float bd = 0.f;
+  auto nearest_free = [&](int32_t v) -> int32_t {      // the row is in ascending (d2, column) order: the first unvisited entry
     for (int32_t e = rp[v]; e < rp[v + 1]; ++e) {
       const int32_t c = cj[e];
       if (c < 0 || c >= n || c == v || seen[c]) continue;        // (padding entries name the row itself)
-      const float d = dj[e];
-      if (best < 0 || d < bd || (d == bd && c < best)) { best = c; bd = d; }
+      return c;
     }
-    return best;
+    return -1;
   };
   int64_t scan = 0, cnt = 0;
   int32_t cur = 0;

@@ -3170,6 +3170,35 @@ def test_chain_order_and_wide_relabelling(mgp, dev):
     o2 = chain_order(g.n, g.rowptr, g.col, g.d2).cpu().numpy()
     assert np.array_equal(o1, o2) and np.array_equal(np.sort(o1), np.arange(n)) and o1[0] == 0
     rowptr, col = g.rowptr.cpu().numpy(), g.col.cpu().numpy()
+    # the rule restated (the library ranks the rows on the device and walks their sorted columns on the host): from the current
+    # node to its nearest unvisited neighbour by (d2, column); stuck: the same from the last 64 nodes of the chain, latest
+    # first; else the lowest unvisited index
+    d2 = g.d2.cpu().numpy()
+    seen, walk, cur, scan = np.zeros(n, bool), [], 0, 0
+
+    def nearest_free(v):
+        best = None
+        for e in range(rowptr[v], rowptr[v + 1]):
+            c = int(col[e])
+            if c == v or seen[c]:
+                continue
+            if best is None or (d2[e], c) < best:
+                best = (d2[e], c)
+        return -1 if best is None else best[1]
+    while len(walk) < n:
+        walk.append(cur); seen[cur] = True
+        if len(walk) == n:
+            break
+        nxt = nearest_free(cur)
+        back = len(walk) - 2
+        while nxt < 0 and back >= 0 and back >= len(walk) - 64:
+            nxt = nearest_free(walk[back]); back -= 1
+        if nxt < 0:
+            while seen[scan]:
+                scan += 1
+            nxt = scan
+        cur = nxt
+    assert np.array_equal(o1, np.asarray(walk)), int(np.argmax(o1 != np.asarray(walk)))
     adj = [set(col[rowptr[i]:rowptr[i + 1]].tolist()) - {i} for i in range(n)]
     linked = sum(1 for a, b in zip(o1[:-1], o1[1:]) if b in adj[a])
     assert linked > 0.9 * (n - 1), linked
