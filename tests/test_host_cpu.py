@@ -74,6 +74,37 @@ def test_argument_errors_without_gpu():
         _lib.check(-2, "x")
 
 
+def test_knn_workspace_sizing_follows_the_filter_switch():
+    """mgp_knn_workspace_bytes is host arithmetic (no device): the candidate filter's scratch (sampled keys, log, lists, a
+    fail-over slab) replaces the whole-matrix key slab for large matrix-core searches and nothing else; a chunk of the filtered
+    pipeline is bounded by its sampled-key slab; the switch itself validates its argument."""
+    from manifold_gp_amd import _lib
+    L = _lib.lib()
+    try:
+        assert L.mgp_knn_set_filter(3) != 0 and L.mgp_knn_set_filter(-1) != 0
+        L.mgp_knn_set_filter(0)
+        slab60 = L.mgp_knn_workspace_bytes(60000, 60000, 784, 50)
+        small0 = L.mgp_knn_workspace_bytes(60000, 600, 784, 50)
+        lowd0 = L.mgp_knn_workspace_bytes(1000000, 1000000, 3, 64)
+        L.mgp_knn_set_filter(1)
+        filt60 = L.mgp_knn_workspace_bytes(60000, 60000, 784, 50)
+        assert slab60 > 14e9 and 3e9 < filt60 < 6e9, (slab60, filt60)          # 60k x 60k x 4 bytes against ~4.9 GB
+        assert L.mgp_knn_workspace_bytes(60000, 600, 784, 50) == small0          # few queries: the slab pipeline either way
+        assert L.mgp_knn_workspace_bytes(1000000, 1000000, 3, 64) == lowd0       # d <= 3: the low-dimensional path
+        assert L.mgp_knn_workspace_bytes(8000, 8000, 784, 50) == L.mgp_knn_workspace_bytes(8000, 8000, 784, 50)
+        # k beyond what the lists serve at the smallest sampling stride (K' x 4 > 1536): the slab again
+        L.mgp_knn_set_filter(0)
+        big_k0 = L.mgp_knn_workspace_bytes(60000, 60000, 784, 400)
+        L.mgp_knn_set_filter(1)
+        assert L.mgp_knn_workspace_bytes(60000, 60000, 784, 400) == big_k0
+        # 1M points: chunks of 16 384 query rows (4 GiB of sampled keys), far below one list + log per query
+        w1m = L.mgp_knn_workspace_bytes(1000000, 1000000, 64, 20)
+        assert 8e9 < w1m < 20e9, w1m
+        assert L.mgp_knn_last_filter_failover() == -1                             # no search has run in this process
+    finally:
+        L.mgp_knn_set_filter(1)
+
+
 def test_product_path_refuses_cpu_tensors():
     import manifold_gp_amd as mgp
     x = torch.randn(50, 3)
