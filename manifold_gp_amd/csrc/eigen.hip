@@ -133,8 +133,13 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 __global__ __launch_bounds__(kBlock) void gram_mfma_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                            int64_t n, int b, int64_t rows_per_chunk,
                                                            double* __restrict__ partial) {
-  __shared__ float As[16][64 + 1];
-  __shared__ float Bs[16][64 + 1];
+  // Staging (round 5, second half): 32 rows x 64 columns of A and of B per stage, one 16-byte global load per thread, item and
+  // matrix (8 scalar loads per stage of 16 rows before), requested a stage ahead into registers and written to LDS behind the
+  // barrier; rows padded to 80 floats: the four k-groups of a ds_read_b32 (lanes 16 apart read rows one apart) then fall 16 banks
+  // apart (65 floats: one bank apart, SQ_LDS_BANK_CONFLICT 40 % of the LDS cycles).  Half the barriers per row of the chunk.
+  constexpr int kGR = 32, kGP = 64 + 16;
+  __shared__ __attribute__((aligned(16))) float As[kGR][kGP];
+  __shared__ __attribute__((aligned(16))) float Bs[kGR][kGP];
   const int ti = blockIdx.x, tj = blockIdx.y;
   const int64_t r0 = (int64_t)blockIdx.z * rows_per_chunk;
   int64_t r1 = r0 + rows_per_chunk;
@@ -147,17 +152,49 @@ __global__ __launch_bounds__(kBlock) void gram_mfma_kernel(const float* __restri
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int c = 0; c < 2; ++c) acc[a][c] = f64x4{0.0, 0.0, 0.0, 0.0};
-  for (int64_t rr = r0; rr < r1; rr += 16) {
-    for (int e = threadIdx.x; e < 16 * 64; e += kBlock) {
-      const int lr = e >> 6, lc = e & 63;
+  // thread -> (row lr, 4 columns from lc) of the stage, two such items per thread and matrix (32 x 64 floats = 512 float4)
+  const bool vec = (b & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+  float4 pa[2], pb[2];
+  auto fetch = [&](int64_t rr) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = threadIdx.x + u * kBlock;
+      const int lr = e >> 4, lc = (e & 15) * 4;
       const int64_t r = rr + lr;
       const int ci = ti * 64 + lc, cj = tj * 64 + lc;
-      As[lr][lc] = (r < r1 && ci < b) ? A[r * b + ci] : 0.f;
-      Bs[lr][lc] = (r < r1 && cj < b) ? B[r * b + cj] : 0.f;
+      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < r1) {
+        if (vec && ci + 3 < b) pa[u] = *reinterpret_cast<const float4*>(A + r * b + ci);
+        else {
+          if (ci < b) pa[u].x = A[r * b + ci];
+          if (ci + 1 < b) pa[u].y = A[r * b + ci + 1];
+          if (ci + 2 < b) pa[u].z = A[r * b + ci + 2];
+          if (ci + 3 < b) pa[u].w = A[r * b + ci + 3];
+        }
+        if (vec && cj + 3 < b) pb[u] = *reinterpret_cast<const float4*>(B + r * b + cj);
+        else {
+          if (cj < b) pb[u].x = B[r * b + cj];
+          if (cj + 1 < b) pb[u].y = B[r * b + cj + 1];
+          if (cj + 2 < b) pb[u].z = B[r * b + cj + 2];
+          if (cj + 3 < b) pb[u].w = B[r * b + cj + 3];
+        }
+      }
+    }
+  };
+  if (r0 < r1) fetch(r0);
+  for (int64_t rr = r0; rr < r1; rr += kGR) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = threadIdx.x + u * kBlock;
+      const int lr = e >> 4, lc = (e & 15) * 4;
+      *reinterpret_cast<float4*>(&As[lr][lc]) = pa[u];
+      *reinterpret_cast<float4*>(&Bs[lr][lc]) = pb[u];
     }
     __syncthreads();
+    if (rr + kGR < r1) fetch(rr + kGR);            // the next stage's rows are in flight during this stage's MFMAs
 #pragma unroll
-    for (int k0 = 0; k0 < 16; k0 += 4) {
+    for (int k0 = 0; k0 < kGR; k0 += 4) {
       double av[2], bv[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) av[a] = (double)As[k0 + kq][wi + 16 * a + l16];
