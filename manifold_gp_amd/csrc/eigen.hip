@@ -273,6 +273,22 @@ __global__ void copy_cols_kernel(const float* __restrict__ V, int64_t n, int ld,
     out[i] = V[(i / m) * ld + (i % m)];
 }
 
+// K[r, j] = KT[j, r] for kk <= 64 vectors of length n kept one after the other (the Krylov vectors of the lambda_max estimate: each is
+// written in place by its SpMV launch; one transpose instead of a strided column copy behind every launch)
+__global__ __launch_bounds__(256) void vecs_to_cols_kernel(const float* __restrict__ KT, int64_t n, int kk, float* __restrict__ K) {
+  __shared__ float tile[64][64 + 1];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int e = threadIdx.x; e < 64 * kk; e += 256) {
+    const int j = e >> 6, lr = e & 63;
+    tile[j][lr] = r0 + lr < n ? KT[(int64_t)j * n + r0 + lr] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * kk; e += 256) {
+    const int lr = e / kk, j = e - lr * kk;
+    if (r0 + lr < n) K[(r0 + lr) * kk + j] = tile[j][lr];
+  }
+}
+
 // ---------------------------------------------------------------- host: symmetric eigensolver (fp64)
 // Householder tridiagonalisation + implicit-shift QL, restated so that every O(n^3) loop walks a ROW of a row-major
 // array and the eigenvector update runs on host threads:
@@ -893,27 +909,20 @@ static int lanczos_smallest_impl(const mgp_csr_t* L, int m, const mgp_lanczos_pa
   if (bound_mode && b >= kk && n >= 8 * kk) {
     float* K = w.buf[0];
     float* LK = w.buf[1];
-    float* y[3] = {w.buf[2], w.buf[3], w.buf[4]};
+    float* KT = w.buf[2];          // the kk Krylov vectors one after the other (b >= kk columns of room): vector j at KT + j n
     const int g1 = (int)std::min<int64_t>(4096, mgp_cdiv(n, kBlock));
-    hipLaunchKernelGGL(random_cols_kernel, dim3(g1), dim3(kBlock), 0, st, y[0], n, 1, 0, 1, seed ^ 0x5bd1e995ULL);
+    hipLaunchKernelGGL(random_cols_kernel, dim3(g1), dim3(kBlock), 0, st, KT, n, 1, 0, 1, seed ^ 0x5bd1e995ULL);
     MGP_LAUNCH_CHECK();
     const double ce = ub / 2.0;     // centre = half width of [0, ub]
-    auto put = [&](const float* src, int j) {
-      hipLaunchKernelGGL(move_cols_kernel, dim3(g1), dim3(kBlock), 0, st, src, n, 1, 0, 1, K, kk, j);
-    };
-    put(y[0], 0);
     // T_1 = (L - c) / e
-    MGP_TRY(mgp_spmm_fused_ex(L, y[0], 1, y[1], (float)(-1.0), (float)(1.0 / ce), nullptr, nullptr, nullptr, 0.f, 1.f, nullptr,
+    MGP_TRY(mgp_spmm_fused_ex(L, KT, 1, KT + n, (float)(-1.0), (float)(1.0 / ce), nullptr, nullptr, nullptr, 0.f, 1.f, nullptr,
                               nullptr, nullptr, nullptr, stream));
-    put(y[1], 1);
-    int i0 = 0, i1 = 1, i2 = 2;
     for (int j = 2; j < kk; ++j) {
-      // T_j = 2 (L - c) / e T_{j-1} - T_{j-2}
-      MGP_TRY(mgp_spmm_fused_ex(L, y[i1], 1, y[i2], (float)(-2.0), (float)(2.0 / ce), nullptr, nullptr, y[i0], -1.f, 1.f, nullptr,
-                                nullptr, nullptr, nullptr, stream));
-      put(y[i2], j);
-      const int t = i0; i0 = i1; i1 = i2; i2 = t;
+      // T_j = 2 (L - c) / e T_{j-1} - T_{j-2}, written where it stays (round 5: no column copy behind every launch)
+      MGP_TRY(mgp_spmm_fused_ex(L, KT + (int64_t)(j - 1) * n, 1, KT + (int64_t)j * n, (float)(-2.0), (float)(2.0 / ce), nullptr, nullptr,
+                                KT + (int64_t)(j - 2) * n, -1.f, 1.f, nullptr, nullptr, nullptr, nullptr, stream));
     }
+    hipLaunchKernelGGL(vecs_to_cols_kernel, dim3((unsigned)mgp_cdiv(n, 64)), dim3(256), 0, st, KT, n, kk, K);
     MGP_LAUNCH_CHECK();
     MGP_TRY(mgp_spmm_fused_ex(L, K, kk, LK, 0.f, 1.f, nullptr, nullptr, nullptr, 0.f, 1.f, nullptr, nullptr, nullptr, nullptr,
                               stream));
