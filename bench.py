@@ -487,8 +487,9 @@ def _main(quiet):
             pass
     tree_hash = source_hash()
     # (band: the in-graph mean sits ABOVE this run's back-to-back figure -- (1) <= (3) -- by 3-8 % on one box, and the boxes of the
-    # pool differ by up to 14 % in this kernel (5.4-6.2 us): a profile of this tree within -5 % / +25 % of the live figure is current)
-    profile_age_ok = bool(t_prof) and prof_hash == tree_hash and -0.05 * t_b2b <= t_prof - t_b2b <= 0.25 * t_b2b
+    # pool differ by up to 14 % in this kernel (5.3-6.2 us in-graph): a profile of this tree -- the hash is the staleness test --
+    # within -15 % (a profile from a fast box read on a slow one) / +25 % of the live figure is current)
+    profile_age_ok = bool(t_prof) and prof_hash == tree_hash and -0.15 * t_b2b <= t_prof - t_b2b <= 0.25 * t_b2b
     t_k = (t_prof if profile_age_ok else None) or t_in or t_b2b
     def fig(t, note):
         return dict(avg_launch_us=round(t * 1e6, 2), achieved=round(B / t / 1e9, 1), frac=round(B / t / 1e9 / HBM_PEAK_GBS, 4), note=note)

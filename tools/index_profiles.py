@@ -51,7 +51,7 @@ miss = re.search(r"TCC_MISS_sum\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)", wide)
 sec = """Round 5 (`%(tag)s_*`), one MI355X.  Every file: `tools/retake_profiles.sh %(tag)s` on the GPU box, then `python tools/assemble_profiles.py %(tag)s` and
 `python tools/index_profiles.py %(tag)s` here (this section is generated from the files: every number below is read from them).  Source
 hash of the tree they were taken on: `%(hash)s` (`bench.py` quotes a profile in `roofline.frac` only while it matches and the live
-figure lies within -5 / +25 %% of it -- `profile_age_ok`).  New this round: the k-NN search (kernel mix + both counter passes; since the candidate filter: the filtered key pass, the sample keys, regroup and bounds), the S5 solve as the
+figure lies within -15 / +25 %% of it -- `profile_age_ok`).  New this round: the k-NN search (kernel mix + both counter passes; since the candidate filter: the filtered key pass, the sample keys, regroup and bounds), the S5 solve as the
 library runs it by default (complex-shift COCG), the two training epochs, the wide SpMM on the chain-relabelled matrix.
 
 | file | recipe | backs |
